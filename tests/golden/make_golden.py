@@ -1,0 +1,400 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (it imports /root/reference, which never travels to
+the GPU box).  Nothing of the reference's source is written anywhere: the outputs are
+data -- quantised inputs and the reference's fp32 outputs at every stage boundary.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Recipe: shim the transformers-4.36 names the reference imports, stub the
+unused heavy imports, build the reference modules at a tiny configuration, load OUR seeded
+state_dict (videotgb_amd.synth) with strict key checking (which also pins the state_dict
+layout of Appendix A), call .eval(), inject recorded Gumbel noise, and record.
+"""
+import inspect
+import os
+import sys
+import tempfile
+import textwrap
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+
+# ----------------------------------------------------------------------------- shim
+def install_shim():
+    import transformers  # noqa
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+    from transformers import PreTrainedModel
+    from transformers.pytorch_utils import apply_chunking_to_forward, prune_linear_layer
+
+    def find_pruneable_heads_and_indices(heads, n_heads, head_size, already_pruned_heads):
+        mask = torch.ones(n_heads, head_size)
+        heads = set(heads) - already_pruned_heads
+        for head in heads:
+            head = head - sum(1 if h < head else 0 for h in already_pruned_heads)
+            mask[head] = 0
+        mask = mask.view(-1).contiguous().eq(1)
+        return heads, torch.arange(len(mask))[mask].long()
+
+    for m in (mu, pu):
+        for n, f in (("apply_chunking_to_forward", apply_chunking_to_forward),
+                     ("prune_linear_layer", prune_linear_layer),
+                     ("find_pruneable_heads_and_indices", find_pruneable_heads_and_indices)):
+            if not hasattr(m, n):
+                setattr(m, n, f)
+    if not hasattr(PreTrainedModel, "get_head_mask"):
+        PreTrainedModel.get_head_mask = lambda self, head_mask, n, is_attention_chunked=False: [None] * n
+    PreTrainedModel.all_tied_weights_keys = {}
+    for name in ("sentence_transformers", "peft", "av", "cv2", "decord", "ffmpeg"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    st = sys.modules["sentence_transformers"]
+    st.SentenceTransformer = object
+    st.util = object
+    for n in ("get_peft_model", "LoraConfig", "TaskType"):
+        setattr(sys.modules["peft"], n, object)
+    dec = sys.modules["decord"]
+    dec.cpu = lambda *a, **k: None
+    dec.bridge = types.SimpleNamespace(set_bridge=lambda *a, **k: None)
+    sys.path.insert(0, REF)
+
+
+def q8(shape, gen, scale):
+    """int8 tensor + its exact fp32 dequantisation (value = q * scale)."""
+    q = torch.randint(-127, 128, shape, generator=gen, dtype=torch.int32).to(torch.int8)
+    return q, q.float() * scale
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e3:.0f} kB")
+
+
+# ----------------------------------------------------------------------------- models
+def build_reference(arch, cfg, sd):
+    """Reference eval-side module (eval/utils/model.py LSTP / LSTP_blip2) at the tiny config."""
+    from transformers import (Blip2Config, Blip2QFormerConfig, Blip2VisionConfig, InstructBlipConfig,
+                              InstructBlipQFormerConfig, InstructBlipVisionConfig, LlamaConfig)
+    import eval.utils.model as em
+    v, q, t = cfg.vit, cfg.qformer, cfg.tgb
+    vkw = dict(hidden_size=v.hidden, intermediate_size=v.mlp, num_hidden_layers=v.layers,
+               num_attention_heads=v.heads, image_size=v.image, patch_size=v.patch, layer_norm_eps=v.eps)
+    qkw = dict(hidden_size=q.hidden, num_hidden_layers=q.layers, num_attention_heads=q.heads,
+               intermediate_size=q.ffn, encoder_hidden_size=q.enc_hidden, vocab_size=q.vocab,
+               max_position_embeddings=q.max_pos, cross_attention_frequency=q.cross_freq)
+    tc = LlamaConfig(hidden_size=cfg.llm_hidden, intermediate_size=64, num_hidden_layers=2,
+                     num_attention_heads=2, num_key_value_heads=2, vocab_size=120,
+                     architectures=["LlamaForCausalLM"], bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    if arch == "instructblip":
+        c = InstructBlipConfig(vision_config=InstructBlipVisionConfig(**vkw).to_dict(),
+                               qformer_config=InstructBlipQFormerConfig(**qkw).to_dict(),
+                               text_config=tc.to_dict(), num_query_tokens=q.n_query)
+        cls = em.LSTP
+    else:
+        c = Blip2Config(vision_config=Blip2VisionConfig(**vkw).to_dict(),
+                        qformer_config=Blip2QFormerConfig(**qkw).to_dict(),
+                        text_config=tc.to_dict(), num_query_tokens=q.n_query)
+        cls = em.LSTP_blip2
+    d = tempfile.mkdtemp()
+    c.save_pretrained(d)
+    # the reference hard-codes BertConfig(fusion_layer=6, encoder_width=768) for the TGB
+    # (eval/utils/model.py:35); shrink it for the tiny fixture through the class it calls.
+    from transformers import BertConfig
+    orig = em.BertConfig
+    em.BertConfig = lambda **kw: BertConfig(hidden_size=t.hidden, num_hidden_layers=t.layers,
+                                            num_attention_heads=t.heads, intermediate_size=t.ffn,
+                                            vocab_size=t.vocab, max_position_embeddings=t.max_pos,
+                                            fusion_layer=t.fusion_layer, encoder_width=t.enc_width)
+    try:
+        ref = cls(d, "cpu")
+    finally:
+        em.BertConfig = orig
+    ref.eval()
+    # LLM weights: third-party on both sides; seed them through the same generator
+    from videotgb_amd.synth import synth_tensor
+    full = dict(sd)
+    for k, p in ref.model.language_model.state_dict().items():
+        full["model.language_model." + k] = synth_tensor("model.language_model." + k, tuple(p.shape))
+    ref_keys = set(ref.state_dict().keys())
+    missing = ref_keys - set(full)
+    extra = set(full) - ref_keys
+    assert not missing and not extra, f"state_dict layout mismatch: missing={sorted(missing)[:8]} extra={sorted(extra)[:8]}"
+    for k, p in ref.state_dict().items():
+        assert tuple(p.shape) == tuple(full[k].shape), (k, p.shape, full[k].shape)
+    ref.load_state_dict(full, strict=True)
+    llm_sd = {k: v for k, v in full.items() if k.startswith("model.language_model.")}
+    return ref, tc, llm_sd
+
+
+class NoiseQueue:
+    """Make F.gumbel_softmax draw recorded exponentials."""
+
+    def __init__(self, exps):
+        self.exps = list(exps)
+        self.used = 0
+
+    def __enter__(self):
+        self.orig = torch.Tensor.exponential_
+        q = self
+
+        def patched(t, *a, **k):
+            e = q.exps[q.used]
+            q.used += 1
+            return t.copy_(e.reshape(t.shape))
+        torch.Tensor.exponential_ = patched
+        return self
+
+    def __exit__(self, *a):
+        torch.Tensor.exponential_ = self.orig
+
+
+class BE(dict):
+    """HF BatchEncoding stand-in: both ["k"] and .k access (eval/inference.py:76-89)."""
+    __getattr__ = dict.__getitem__
+
+
+def e2e_fixture(arch):
+    from videotgb_amd.synth import path_state_dict, tiny_cfg
+    cfg = tiny_cfg(arch)
+    cfg.vit.image = 56
+    sd = path_state_dict(cfg, seed=0)
+    ref, tc, llm_sd = build_reference(arch, cfg, sd)
+    g = torch.Generator().manual_seed(7)
+    T, N, nframe, B = 4, 8, 4, 1
+    fq, frames = q8((N, 3, 56, 56), g, 1 / 48)
+    ffq, flow_frames = q8((B, T, 3, 224, 224), g, 1 / 48)
+    samp_ids = torch.randint(3, cfg.tgb.vocab, (B, 7), generator=g)
+    samp_mask = torch.ones_like(samp_ids)
+    qf_ids = torch.randint(3, cfg.qformer.vocab, (B, 6), generator=g)
+    qf_mask = torch.ones_like(qf_ids)
+    prompt = torch.randint(3, tc.vocab_size, (B, 5), generator=g)
+    pmask = torch.ones_like(prompt)
+    exps = [torch.empty(2 * B, T, 1).exponential_(generator=g) for _ in range(2)]
+    noise = torch.stack([-e.log().squeeze(-1) for e in exps])             # [draws, 2B, T]
+    cap = {}
+    hooks = [
+        ref.of_extractor.register_forward_hook(lambda m, i, o: cap.__setitem__("raft_flow", o)),
+        ref.temporal_encoder.register_forward_hook(lambda m, i, o: cap.update(tgb_seq=o[0], tgb_logits=o[1])),
+        ref.model.vision_model.register_forward_hook(lambda m, i, o: cap.__setitem__("image_embeds", o.last_hidden_state)),
+        ref.model.vision_model.register_forward_pre_hook(lambda m, a, k: cap.__setitem__("sampled", k["pixel_values"]), with_kwargs=True),
+        ref.model.qformer.register_forward_hook(lambda m, i, o: cap.__setitem__("qformer_seq", o[0])),
+        ref.model.language_projection.register_forward_hook(lambda m, i, o: cap.__setitem__("prefix", o)),
+    ]
+    lm = ref.model.language_model
+    orig_gen = lm.generate
+
+    def gen_spy(**kw):
+        cap["inputs_embeds"] = kw["inputs_embeds"]
+        cap["attention_mask"] = kw["attention_mask"]
+        out = orig_gen(**kw, output_scores=True, return_dict_in_generate=True)
+        cap["first_logits"] = out.scores[0]
+        return out.sequences
+    lm.generate = gen_spy
+    te = BE(input_ids=prompt, attention_mask=pmask)
+    if arch == "instructblip":
+        te["qformer_input_ids"] = qf_ids
+        te["qformer_attention_mask"] = qf_mask
+    with NoiseQueue(exps) as nq:
+        ids, cand = ref.generate(frames, flow_frames, nframe, te, BE(input_ids=samp_ids, attention_mask=samp_mask),
+                                 do_sample=False, temperature=None, max_new_tokens=6, use_cache=False)
+    assert nq.used == 2 and "tgb_logits" in cap, "reference took its bare-except fallback"
+    for h in hooks:
+        h.remove()
+    nq_tok = cfg.qformer.n_query
+    save(f"tiny_{arch}_e2e", frames_q8=fq, flow_frames_q8=ffq, q8_scale=np.float32(1 / 48),
+         sampler_ids=samp_ids, sampler_mask=samp_mask, qformer_ids=qf_ids, qformer_mask=qf_mask,
+         prompt_ids=prompt, prompt_mask=pmask, noise=noise, nframe=nframe,
+         raft_flow=cap["raft_flow"], tgb_seq=cap["tgb_seq"], tgb_logits=cap["tgb_logits"],
+         cand_index=cand, sampled=cap["sampled"], image_embeds=cap["image_embeds"],
+         query_out=cap["qformer_seq"][:, :nq_tok], prefix=cap["prefix"], inputs_embeds=cap["inputs_embeds"],
+         first_logits=cap["first_logits"], greedy_ids=ids)
+    return ref, cfg, sd
+
+
+def component_fixtures(ref_ib, cfg_ib, sd_ib, ref_b2, cfg_b2, sd_b2):
+    """Per-component vectors with batch > 1, ragged masks and both TGB modes."""
+    g = torch.Generator().manual_seed(11)
+    # --- TGB: B=2, lengths 12 and 9 (ragged of_mask), text padding, both modes
+    B, L = 2, 12
+    ofq, of = q8((B, L, 2, 224, 224), g, 1 / 127)
+    of_mask = torch.ones(B, L + 2, dtype=torch.long)
+    of_mask[1, 9 + 2:] = 0
+    tids = torch.randint(3, cfg_ib.tgb.vocab, (B, 8), generator=g)
+    tmask = torch.ones_like(tids)
+    tmask[1, 5:] = 0
+    outs = {}
+    with torch.no_grad():
+        for mode in ("multi_modal", "fusion", "vision"):
+            seq, logits = ref_ib.temporal_encoder(encoder_embeds=of.clone(), attention_mask=of_mask,
+                                                  encoder_hidden_states=tids, encoder_attention_mask=tmask, mode=mode)
+            outs[f"seq_{mode}"] = seq
+            outs[f"logits_{mode}"] = logits
+        flow_emb = ref_ib.temporal_encoder.temporal_embeddings(of.clone(), of_mask)
+        text_emb = ref_ib.temporal_encoder.embeddings(tids)
+    save("tiny_tgb", of_q8=ofq, q8_scale=np.float32(1 / 127), of_mask=of_mask, text_ids=tids, text_mask=tmask,
+         flow_embed=flow_emb, text_embed=text_emb, **outs)
+    # --- ViT: 3 frames, all hidden states
+    pq, pix = q8((3, 3, 56, 56), g, 1 / 48)
+    with torch.no_grad():
+        vo = ref_ib.model.vision_model(pixel_values=pix, output_hidden_states=True, return_dict=True)
+    save("tiny_vit", pixel_q8=pq, q8_scale=np.float32(1 / 48), last_hidden_state=vo.last_hidden_state,
+         hidden_0=vo.hidden_states[0], hidden_1=vo.hidden_states[1], hidden_2=vo.hidden_states[2])
+    # --- Q-Former InstructBLIP: 3 frames, padded text;  BLIP-2: queries only
+    img = vo.last_hidden_state
+    qids = torch.randint(3, cfg_ib.qformer.vocab, (3, 7), generator=g)
+    qmask = torch.ones_like(qids)
+    qmask[1, 4:] = 0
+    qmask[2, 6:] = 0
+    with torch.no_grad():
+        qt = ref_ib.model.query_tokens.expand(3, -1, -1)
+        am = torch.cat([torch.ones(3, qt.shape[1], dtype=torch.long), qmask], dim=1)
+        qo = ref_ib.model.qformer(input_ids=qids, attention_mask=am, query_embeds=qt, encoder_hidden_states=img,
+                                  encoder_attention_mask=torch.ones(img.shape[:2], dtype=torch.long), return_dict=True)
+        with torch.no_grad():
+            vo2 = ref_b2.model.vision_model(pixel_values=pix, return_dict=True).last_hidden_state
+        qt2 = ref_b2.model.query_tokens.expand(3, -1, -1)
+        qo2 = ref_b2.model.qformer(query_embeds=qt2, encoder_hidden_states=vo2,
+                                   encoder_attention_mask=torch.ones(vo2.shape[:2], dtype=torch.long))[0]
+        # pooling variants on the InstructBLIP queries (mean: eval/utils/model.py:186-191; concat: LSTP_module.py:477-478)
+        q32 = qo.last_hidden_state[:, : qt.shape[1]]
+        mean = ref_ib.model.language_projection(q32.mean(0, keepdim=True))
+        concat = ref_ib.model.language_projection(q32).reshape(1, -1, mean.shape[-1])
+    save("tiny_qformer", image_embeds=img, qformer_ids=qids, qformer_mask=qmask, seq_instructblip=qo.last_hidden_state,
+         image_embeds_blip2=vo2, seq_blip2=qo2, prefix_mean=mean, prefix_concat=concat)
+    # --- RAFT alone: 3 frames 128x128 -> 2 flows (64x64 would make the coarsest corr level 1x1: division by W-1 = 0)
+    rq, rf = q8((3, 3, 128, 128), g, 1.0)
+    with torch.no_grad():
+        fl = ref_ib.of_extractor(rf[:-1], rf[1:])
+        fl5 = ref_ib.of_extractor(rf[:-1], rf[1:], iters=5)
+    save("tiny_raft", frames_q8=rq, q8_scale=np.float32(1.0), flow_iters20=fl, flow_iters5=fl5)
+
+
+def index_map_code(cls):
+    """Compile the reference's own span->frame index-map lines (eval/utils/model.py:124-150 or
+    :337-366), sliced out of the live function at run time; nothing of them is stored."""
+    lines = textwrap.dedent(inspect.getsource(cls.generate)).split("\n")
+    lo = next(i for i, l in enumerate(lines) if l.strip().startswith("video_lengths = [flow_frames.size(1)]"))
+    hi = next(i for i, l in enumerate(lines) if l.strip().startswith("sampled_pixel_values[j] = torch.index_select"))
+    body = [l for l in lines[lo + 1:hi] if "sampled_pixel_values = torch.zeros" not in l and "pixel_shape" not in l]
+    body = [l.replace("device=pixel_values.device", "device='cpu'") for l in body]
+    return compile(textwrap.dedent("\n".join(body)), f"<reference index map {cls.__name__}>", "exec")
+
+
+def integer_tables():
+    """Known-answer tables for the integer stages, produced by executing the reference's own lines."""
+    import eval.utils.model as em
+    from src.data.components.util import sample_frames
+    rows, fb = [], []
+    rng = np.random.default_rng(5)
+    for vflag, cls in ((0, em.LSTP), (1, em.LSTP_blip2)):
+        code = index_map_code(cls)
+        for V in (4, 8, 32, 34, 64, 96, 100, 255, 256):
+            for N in (8, 32):
+                for nframe in (2, 4, 8):
+                    cases = [(0, 0, 0, 0), (0, V - 1, 0, V - 1), (V - 1, 0, 3 % V, 2 % V), (1, 1, 1, 1),
+                             (V, 1, 0, 2 % V), (1 % V, V + 3, 1 % V, 2 % V), (0, 1 % V, 0, 0)]
+                    cases += [tuple(int(x) for x in rng.integers(0, V, 4)) for _ in range(40)]
+                    for s0, e0, s1, e1 in cases:
+                        env = dict(video_lengths=[V], num_frames=N, nframe=nframe, np=np, torch=torch,
+                                   cand_start_index=[torch.tensor([s0]), torch.tensor([s1])],
+                                   cand_end_index=[torch.tensor([e0]), torch.tensor([e1])])
+                        exec(code, env)
+                        rows.append([vflag, V, N, nframe, s0, e0, s1, e1] + env["cand_index"].tolist() + [-1] * (8 - nframe))
+        # the except-fallback: python-int operands from the start (eval/utils/model.py:115-116)
+        for V in (4, 32, 96, 100, 256):
+            env = dict(video_lengths=[V], num_frames=32, nframe=8, np=np, torch=torch,
+                       cand_start_index=[[0]], cand_end_index=[[V - 1]])
+            exec(code, env)
+            fb.append([vflag, V, 32, 8] + env["cand_index"].tolist())
+    sf = []
+    for vlen in (1, 5, 31, 32, 33, 64, 96, 100, 250, 256):
+        for n in (4, 8, 32):
+            for fix in (-1, 1.0):
+                ids = list(sample_frames(n, vlen, "uniform", fix))
+                sf.append([vlen, n, int(fix)] + [int(x) for x in ids] + [-1] * (32 - len(ids)))
+    save("integer_tables", span_map=np.array(rows, dtype=np.int64), span_map_fallback=np.array(fb, dtype=np.int64),
+         sample_frames=np.array(sf, dtype=np.int64))
+
+
+def fullsize_probes():
+    """Full-size (ViT-g / Q-Former / BERT-base TGB) reference outputs reduced to probe elements."""
+    from transformers import BertConfig, InstructBlipQFormerConfig, InstructBlipVisionConfig
+    from src.models.components.xinstructblip import InstructBlipQFormerModel, InstructBlipVisionModel
+    from src.models.components.xropebert import RopeBertModel
+    from videotgb_amd.synth import QFormerCfg, TgbCfg, VitCfg, qformer_shapes, synth_state_dict, tgb_shapes, vit_shapes
+    g = torch.Generator().manual_seed(21)
+    probes = {}
+    # ViT-g, 2 frames
+    vm = InstructBlipVisionModel(InstructBlipVisionConfig()).eval()
+    vsd = synth_state_dict(vit_shapes(VitCfg(), ""), 0)
+    vm.load_state_dict(vsd, strict=True)
+    pq, pix = q8((2, 3, 224, 224), g, 1 / 48)
+    with torch.no_grad():
+        img = vm(pixel_values=pix, return_dict=True).last_hidden_state
+    pidx = torch.randint(0, img.numel(), (4096,), generator=g)
+    probes.update(vit_pixel_q8=pq, vit_probe_idx=pidx, vit_probe_val=img.flatten()[pidx],
+                  vit_absmean=img.abs().mean(), vit_shape=np.array(img.shape))
+    del vm, vsd
+    # Q-Former (InstructBLIP), those 2 frames, 9 text tokens
+    qm = InstructBlipQFormerModel(InstructBlipQFormerConfig()).eval()
+    qc = QFormerCfg()
+    qsd = synth_state_dict(qformer_shapes(qc, ""), 0)
+    qm.load_state_dict(qsd, strict=True)
+    from videotgb_amd.synth import synth_tensor
+    qtok = synth_tensor("model.query_tokens", (1, 32, 768))
+    qids = torch.randint(1000, 30000, (2, 9), generator=g)
+    am = torch.ones(2, 32 + 9, dtype=torch.long)
+    with torch.no_grad():
+        qo = qm(input_ids=qids, attention_mask=am, query_embeds=qtok.expand(2, -1, -1), encoder_hidden_states=img,
+                encoder_attention_mask=torch.ones(2, 257, dtype=torch.long), return_dict=True).last_hidden_state[:, :32]
+    qidx = torch.randint(0, qo.numel(), (2048,), generator=g)
+    probes.update(qf_ids=qids, qf_probe_idx=qidx, qf_probe_val=qo.flatten()[qidx], qf_absmean=qo.abs().mean())
+    del qm, qsd
+    # TGB BERT-base, T=24
+    tm = RopeBertModel(BertConfig(fusion_layer=6, encoder_width=768)).eval()
+    tsd = synth_state_dict(tgb_shapes(TgbCfg(), ""), 0)
+    tm.load_state_dict(tsd, strict=True)
+    oq, of = q8((1, 24, 2, 224, 224), g, 1 / 127)
+    tids = torch.randint(1000, 30000, (1, 14), generator=g)
+    with torch.no_grad():
+        for mode in ("multi_modal", "fusion"):
+            seq, logits = tm(encoder_embeds=of.clone(), attention_mask=torch.ones(1, 26, dtype=torch.long),
+                             encoder_hidden_states=tids, encoder_attention_mask=torch.ones_like(tids), mode=mode)
+            probes[f"tgb_logits_{mode}"] = logits
+            probes[f"tgb_seq_absmean_{mode}"] = seq.abs().mean()
+    probes.update(tgb_of_q8=oq, tgb_text_ids=tids)
+    save("full_probes", **probes)
+
+
+def main():
+    install_shim()
+    torch.manual_seed(0)
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["e2e", "int", "full"]
+    if "e2e" in which:
+        ref_ib, cfg_ib, sd_ib = e2e_fixture("instructblip")
+        ref_b2, cfg_b2, sd_b2 = e2e_fixture("blip2")
+        component_fixtures(ref_ib, cfg_ib, sd_ib, ref_b2, cfg_b2, sd_b2)
+    if "int" in which:
+        integer_tables()
+    if "full" in which:
+        fullsize_probes()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+"""The CPU oracle against the golden vectors recorded from the reference itself
+(tests/golden/make_golden.py).  This is what pins the oracle; the HIP path is then
+compared with the oracle in the -m gpu tests."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import deq, load_golden
+from oracle import vtgb_oracle as O
+
+TOL = dict(rtol=2e-5, atol=2e-5)     # fp32 reassociation only
+
+
+def close(a, b, **kw):
+    torch.testing.assert_close(a.float(), b.float(), **(kw or TOL))
+
+
+def test_span_map_tables_bit_exact():
+    g = load_golden("integer_tables")
+    rows = g["span_map"].numpy()
+    for r in rows:
+        variant = "AB"[r[0]]
+        V, N, nframe, s0, e0, s1, e1 = (int(x) for x in r[1:8])
+        got = O.span_to_frames([s0, s1], [e0, e1], V, N, nframe, variant)
+        assert got == [int(x) for x in r[8:8 + nframe]], (variant, V, N, nframe, s0, e0, s1, e1)
+    assert len(rows) > 5000
+
+
+def test_span_map_fallback_rows():
+    g = load_golden("integer_tables")
+    for r in g["span_map_fallback"].numpy():
+        variant, V, N, nframe = "AB"[r[0]], int(r[1]), int(r[2]), int(r[3])
+        # python-int operands: the (0, V-1) span through the float64 branch == out-of-range start
+        got = O.span_to_frames([V], [0], V, N, nframe, variant)
+        assert got == [int(x) for x in r[4:4 + nframe]]
+
+
+def test_sample_frames_table():
+    g = load_golden("integer_tables")
+    for r in g["sample_frames"].numpy():
+        vlen, n, fix = int(r[0]), int(r[1]), int(r[2])
+        exp = [int(x) for x in r[3:] if x >= 0]
+        assert O.sample_frames(n, vlen, "uniform", fix) == exp
+    assert O.sample_frames(32, 96, "uniform") == list(range(1, 96, 3))      # SURVEY 8a-1 known answer
+
+
+def test_rope_table_formula(tiny_sd):
+    cfg, sd = tiny_sd["instructblip"]
+    t = O.rope_table(64, 32)
+    assert torch.equal(t, sd["temporal_encoder.encoder.embed_positions.weight"])
+    assert t[0, :16].abs().max() == 0 and torch.all(t[0, 16:] == 1)
+    np.testing.assert_allclose(t[3, 1].item(), np.sin(3 / 10000 ** (2 / 32)), rtol=1e-6)
+
+
+def test_vit_vs_reference(tiny_sd):
+    cfg, sd = tiny_sd["instructblip"]
+    g = load_golden("tiny_vit")
+    out, hs = O.vit_forward(sd, "model.vision_model.", deq(g, "pixel_q8"), cfg.vit.heads, return_all=True)
+    for i in range(3):
+        close(hs[i], g[f"hidden_{i}"])
+    close(out, g["last_hidden_state"])
+    with pytest.raises(ValueError, match="pixel_values"):
+        O.vit_forward(sd, "model.vision_model.", None, cfg.vit.heads)
+
+
+def test_qformer_vs_reference(tiny_sd):
+    g = load_golden("tiny_qformer")
+    cfg, sd = tiny_sd["instructblip"]
+    seq = O.qformer_forward(sd, "model.qformer.", sd["model.query_tokens"], g["image_embeds"], cfg.qformer.heads,
+                            g["qformer_ids"], g["qformer_mask"], torch.ones(3, g["image_embeds"].shape[1]))
+    close(seq, g["seq_instructblip"])
+    q32 = seq[:, :32]
+    close(O.pool_project(sd, "model.language_projection", q32, [3], "mean"), g["prefix_mean"])
+    close(O.pool_project(sd, "model.language_projection", q32, [3], "concat"), g["prefix_concat"])
+    cfg2, sd2 = tiny_sd["blip2"]
+    seq2 = O.qformer_forward(sd2, "model.qformer.", sd2["model.query_tokens"], g["image_embeds_blip2"],
+                             cfg2.qformer.heads, image_mask=torch.ones(3, g["image_embeds_blip2"].shape[1]))
+    close(seq2, g["seq_blip2"])
+
+
+def test_pool_ragged_and_empty(tiny_sd):
+    cfg, sd = tiny_sd["instructblip"]
+    q = torch.randn(5, 32, cfg.qformer.hidden)
+    out = O.pool_project(sd, "model.language_projection", q, [2, 0, 3], "mean")
+    b = sd["model.language_projection.bias"]
+    close(out[1], b.expand(32, -1))                       # width 0 -> zeros -> bias only
+    close(out[2], torch.nn.functional.linear(q[2:].mean(0), sd["model.language_projection.weight"], b))
+
+
+@pytest.mark.parametrize("mode", ["multi_modal", "fusion", "vision"])
+def test_tgb_vs_reference(tiny_sd, mode):
+    cfg, sd = tiny_sd["instructblip"]
+    g = load_golden("tiny_tgb")
+    of = deq(g, "of_q8")
+    close(O.tgb_flow_embed(sd, "temporal_encoder.", of, g["of_mask"]), g["flow_embed"])
+    close(O.tgb_text_embed(sd, "temporal_encoder.", g["text_ids"]), g["text_embed"])
+    seq, logits = O.tgb_forward(sd, "temporal_encoder.", of, g["of_mask"], g["text_ids"], g["text_mask"], mode,
+                                cfg.tgb.heads, cfg.tgb.fusion_layer)
+    close(seq, g[f"seq_{mode}"])
+    close(logits, g[f"logits_{mode}"])
+
+
+def test_tgb_invalid_mode(tiny_sd):
+    with pytest.raises(ValueError, match="INVALID MODE"):
+        O.tgb_mode_layers("bogus", 6, 12)
+
+
+def test_raft_vs_reference(tiny_sd):
+    cfg, sd = tiny_sd["instructblip"]
+    g = load_golden("tiny_raft")
+    fr = deq(g, "frames_q8")
+    close(O.raft_forward(sd, "of_extractor.", fr[:-1], fr[1:], iters=5), g["flow_iters5"], rtol=1e-4, atol=1e-4)
+    close(O.raft_forward(sd, "of_extractor.", fr[:-1], fr[1:], iters=20), g["flow_iters20"], rtol=1e-3, atol=1e-3)
+
+
+def test_span_select_ties_and_noise():
+    logits = torch.zeros(1, 6, 2)
+    noise = torch.zeros(2, 2, 6)
+    assert O.span_select(logits, noise).tolist() == [[0, 0], [0, 0]]          # ties -> lowest index
+    noise[1, 1, 4] = 1.0
+    assert O.span_select(logits, noise).tolist() == [[0, 0], [0, 4]]
+
+
+@pytest.mark.parametrize("arch", ["instructblip", "blip2"])
+def test_e2e_prefix_vs_reference(tiny_sd, arch):
+    cfg, sd = tiny_sd[arch]
+    g = load_golden(f"tiny_{arch}_e2e")
+    r = O.lstp_prefix(sd, arch=arch, frames=deq(g, "frames_q8"), nframe=int(g["nframe"]),
+                      sampler_ids=g["sampler_ids"], sampler_mask=g["sampler_mask"], noise=g["noise"],
+                      vit_heads=cfg.vit.heads, qf_heads=cfg.qformer.heads, tgb_heads=cfg.tgb.heads,
+                      fusion_layer=cfg.tgb.fusion_layer, flow_frames=deq(g, "flow_frames_q8"),
+                      qformer_ids=g["qformer_ids"], qformer_mask=g["qformer_mask"])
+    close(r["of"][0, :-1], g["raft_flow"], rtol=1e-3, atol=1e-3)
+    close(r["tgb_logits"], g["tgb_logits"], rtol=1e-4, atol=1e-4)
+    assert r["cand_index"][0].tolist() == g["cand_index"].tolist()
+    assert torch.equal(r["sampled"], g["sampled"])
+    close(r["image_embeds"], g["image_embeds"], rtol=1e-4, atol=1e-4)
+    close(r["query_out"], g["query_out"], rtol=1e-4, atol=1e-4)
+    close(r["prefix"], g["prefix"], rtol=1e-4, atol=1e-4)
+    close(r["prefix"], g["inputs_embeds"][:, :32], rtol=1e-4, atol=1e-4)

@@ -1,0 +1,335 @@
+"""Seeded synthetic weights and clips for the VideoTGB hot path.
+
+There is no network for checkpoints, and HF's default init for the vision tower is
+degenerate (initializer_range 1e-10), so benchmarks, fixtures and parity
+tests all use this generator.  Every tensor is a pure function of (seed, key name,
+shape): the reference (in the fixture generator), the CPU oracle and the HIP build load
+bit-identical weights without sharing any code path but this file.
+
+Key names and shapes follow the reference checkpoint layout:
+  model.vision_model.*      src/models/components/xinstructblip.py:94-558
+  model.qformer.*           xinstructblip.py:565-1242 / xblip2.py:793-1174
+  temporal_encoder.*        src/models/components/xropebert.py:66-1178
+  of_extractor.*            src/models/components/xraft.py + raft_utils/*
+"""
+from __future__ import annotations
+
+import re
+import zlib
+from dataclasses import dataclass, field
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+Shapes = Dict[str, Tuple[int, ...]]
+
+_LN_W = re.compile(r"(LayerNorm|layernorm|layer_norm\d|post_layernorm|\.ln|norm\d)\.weight$")
+
+
+def rope_table(n_pos: int, dim: int) -> torch.Tensor:
+    """Sinusoid table of xropebert.py:149-164 (float64 numpy -> fp32; sin half then cos half)."""
+    pos = np.arange(n_pos, dtype=np.float64)[:, None]
+    j = np.arange(dim)
+    enc = pos / np.power(10000, 2 * (j // 2) / dim)[None, :]
+    out = np.zeros((n_pos, dim), dtype=np.float32)
+    out[:, : dim // 2] = np.sin(enc[:, 0::2]).astype(np.float32)
+    out[:, dim // 2:] = np.cos(enc[:, 1::2]).astype(np.float32)
+    return torch.from_numpy(out)
+
+
+def synth_tensor(key: str, shape: Tuple[int, ...], seed: int = 0, std: float = 0.02) -> torch.Tensor:
+    """Deterministic fp32 tensor for one state_dict entry (generated on CPU)."""
+    if key.endswith("position_ids"):
+        return torch.arange(shape[-1]).expand(shape).clone()
+    if key.endswith("num_batches_tracked"):
+        return torch.zeros((), dtype=torch.long)
+    if key.endswith("embed_positions.weight"):
+        return rope_table(*shape)
+    g = torch.Generator().manual_seed((zlib.crc32(key.encode()) + 1000003 * seed) & 0x7FFFFFFF)
+    x = torch.randn(shape, generator=g, dtype=torch.float32)
+    if key.endswith("running_var"):
+        return 1.0 + 0.1 * x.abs()
+    if key.endswith("running_mean"):
+        return 0.1 * x
+    if _LN_W.search(key):
+        return 1.0 + 0.1 * x
+    return std * x
+
+
+def synth_state_dict(shapes: Shapes, seed: int = 0) -> Dict[str, torch.Tensor]:
+    return {k: synth_tensor(k, s, seed) for k, s in shapes.items()}
+
+
+# ----------------------------------------------------------------------------
+# architecture descriptions
+# ----------------------------------------------------------------------------
+@dataclass
+class VitCfg:
+    hidden: int = 1408
+    layers: int = 39
+    heads: int = 16
+    mlp: int = 6144
+    image: int = 224
+    patch: int = 14
+    eps: float = 1e-6
+
+    @property
+    def tokens(self) -> int:
+        return (self.image // self.patch) ** 2 + 1
+
+
+@dataclass
+class QFormerCfg:
+    hidden: int = 768
+    layers: int = 12
+    heads: int = 12
+    ffn: int = 3072
+    enc_hidden: int = 1408
+    n_query: int = 32
+    vocab: int = 30523
+    max_pos: int = 512
+    cross_freq: int = 2
+    has_text: bool = True       # InstructBLIP: True; BLIP-2: False
+    eps: float = 1e-12
+
+
+@dataclass
+class TgbCfg:
+    hidden: int = 768
+    layers: int = 12
+    heads: int = 12
+    ffn: int = 3072
+    fusion_layer: int = 6
+    enc_width: int = 768
+    vocab: int = 30522
+    max_pos: int = 512
+    image: int = 224
+    patch: int = 16
+    eps: float = 1e-12
+
+
+@dataclass
+class PathCfg:
+    arch: str = "instructblip"            # or "blip2"
+    vit: VitCfg = field(default_factory=VitCfg)
+    qformer: QFormerCfg = field(default_factory=QFormerCfg)
+    tgb: TgbCfg = field(default_factory=TgbCfg)
+    llm_hidden: int = 4096
+
+
+def full_cfg(arch: str = "instructblip") -> PathCfg:
+    """InstructBLIP-Vicuna-7B (C3/C4/C5) or BLIP2-Flan-T5-xl (C1/C2) dims, SURVEY.md 8."""
+    if arch == "instructblip":
+        return PathCfg("instructblip", VitCfg(), QFormerCfg(has_text=True, vocab=30523), TgbCfg(), 4096)
+    return PathCfg("blip2", VitCfg(), QFormerCfg(has_text=False, vocab=30522), TgbCfg(), 2048)
+
+
+def tiny_cfg(arch: str = "instructblip") -> PathCfg:
+    """The small configuration the committed golden fixtures are generated at."""
+    return PathCfg(arch,
+                   VitCfg(hidden=64, layers=2, heads=2, mlp=128),
+                   QFormerCfg(hidden=48, layers=2, heads=2, ffn=96, enc_hidden=64, vocab=200, max_pos=64,
+                              has_text=(arch == "instructblip")),
+                   TgbCfg(hidden=64, layers=2, heads=2, ffn=128, fusion_layer=1, enc_width=64, vocab=200,
+                          max_pos=64),
+                   32)
+
+
+# ----------------------------------------------------------------------------
+# state_dict shape tables
+# ----------------------------------------------------------------------------
+def _lin(s: Shapes, name: str, out: int, inp: int, bias: bool = True):
+    s[name + ".weight"] = (out, inp)
+    if bias:
+        s[name + ".bias"] = (out,)
+
+
+def _lnp(s: Shapes, name: str, d: int):
+    s[name + ".weight"] = (d,)
+    s[name + ".bias"] = (d,)
+
+
+def vit_shapes(c: VitCfg, p: str = "model.vision_model.") -> Shapes:
+    s: Shapes = {}
+    s[p + "embeddings.class_embedding"] = (1, 1, c.hidden)
+    s[p + "embeddings.position_embedding"] = (1, c.tokens, c.hidden)
+    s[p + "embeddings.patch_embedding.weight"] = (c.hidden, 3, c.patch, c.patch)
+    s[p + "embeddings.patch_embedding.bias"] = (c.hidden,)
+    for i in range(c.layers):
+        lp = f"{p}encoder.layers.{i}."
+        _lin(s, lp + "self_attn.qkv", 3 * c.hidden, c.hidden)
+        _lin(s, lp + "self_attn.projection", c.hidden, c.hidden)
+        _lnp(s, lp + "layer_norm1", c.hidden)
+        _lin(s, lp + "mlp.fc1", c.mlp, c.hidden)
+        _lin(s, lp + "mlp.fc2", c.hidden, c.mlp)
+        _lnp(s, lp + "layer_norm2", c.hidden)
+    _lnp(s, p + "post_layernorm", c.hidden)
+    return s
+
+
+def qformer_shapes(c: QFormerCfg, p: str = "model.qformer.") -> Shapes:
+    s: Shapes = {}
+    if c.has_text:
+        s[p + "embeddings.word_embeddings.weight"] = (c.vocab, c.hidden)
+        s[p + "embeddings.position_embeddings.weight"] = (c.max_pos, c.hidden)
+        _lnp(s, p + "embeddings.layernorm", c.hidden)
+    else:
+        _lnp(s, p + "layernorm", c.hidden)
+    for i in range(c.layers):
+        lp = f"{p}encoder.layer.{i}."
+        for nm in ("query", "key", "value"):
+            _lin(s, f"{lp}attention.attention.{nm}", c.hidden, c.hidden)
+        _lin(s, lp + "attention.output.dense", c.hidden, c.hidden)
+        _lnp(s, lp + "attention.output.LayerNorm", c.hidden)
+        if i % c.cross_freq == 0:
+            _lin(s, lp + "crossattention.attention.query", c.hidden, c.hidden)
+            _lin(s, lp + "crossattention.attention.key", c.hidden, c.enc_hidden)
+            _lin(s, lp + "crossattention.attention.value", c.hidden, c.enc_hidden)
+            _lin(s, lp + "crossattention.output.dense", c.hidden, c.hidden)
+            _lnp(s, lp + "crossattention.output.LayerNorm", c.hidden)
+        if c.has_text:
+            _lin(s, lp + "intermediate.dense", c.ffn, c.hidden)
+            _lin(s, lp + "output.dense", c.hidden, c.ffn)
+            _lnp(s, lp + "output.LayerNorm", c.hidden)
+        _lin(s, lp + "intermediate_query.dense", c.ffn, c.hidden)
+        _lin(s, lp + "output_query.dense", c.hidden, c.ffn)
+        _lnp(s, lp + "output_query.LayerNorm", c.hidden)
+    return s
+
+
+def tgb_shapes(c: TgbCfg, p: str = "temporal_encoder.") -> Shapes:
+    s: Shapes = {}
+    hd = c.hidden // c.heads
+    s[p + "embeddings.word_embeddings.weight"] = (c.vocab, c.hidden)
+    s[p + "embeddings.token_type_embeddings.weight"] = (2, c.hidden)
+    s[p + "embeddings.position_embeddings.weight"] = (c.max_pos, c.hidden)     # present, unused
+    _lnp(s, p + "embeddings.LayerNorm", c.hidden)
+    t = p + "temporal_embeddings."
+    s[t + "bos"] = (c.hidden,)
+    s[t + "eos"] = (c.hidden,)
+    s[t + "position_ids"] = (1, c.max_pos)
+    s[t + "projection.weight"] = (c.hidden, 2, c.patch, c.patch)
+    s[t + "projection.bias"] = (c.hidden,)
+    _lin(s, t + "fc", 1, (c.image // c.patch) ** 2)
+    s[t + "frame_pos_embed.weight"] = (c.max_pos, c.hidden)
+    _lnp(s, t + "ln", c.hidden)
+    s[p + "encoder.embed_positions.weight"] = (c.max_pos, hd)
+    s[p + "encoder.c_embed_positions.weight"] = (c.max_pos, hd)
+    for i in range(c.layers):
+        lp = f"{p}encoder.layer.{i}."
+        for att, kv_in in (("attention", c.hidden),) + ((("crossattention", c.enc_width),) if i >= c.fusion_layer else ()):
+            _lin(s, f"{lp}{att}.self.query", c.hidden, c.hidden)
+            _lin(s, f"{lp}{att}.self.key", c.hidden, kv_in)
+            _lin(s, f"{lp}{att}.self.value", c.hidden, kv_in)
+            _lin(s, f"{lp}{att}.output.dense", c.hidden, c.hidden)
+            _lnp(s, f"{lp}{att}.output.LayerNorm", c.hidden)
+        _lin(s, lp + "intermediate.dense", c.ffn, c.hidden)
+        _lin(s, lp + "output.dense", c.hidden, c.ffn)
+        _lnp(s, lp + "output.LayerNorm", c.hidden)
+    _lin(s, p + "mrc_head", 2, c.hidden)
+    return s
+
+
+def raft_shapes(p: str = "of_extractor.") -> Shapes:
+    """RAFT-large (xraft.py:51-72): fnet instance-norm (no params), cnet batch-norm."""
+    s: Shapes = {}
+
+    def conv(name, out, inp, kh, kw=None):
+        s[name + ".weight"] = (out, inp, kh, kw or kh)
+        s[name + ".bias"] = (out,)
+
+    def bn(name, ch):
+        s[name + ".weight"] = (ch,)
+        s[name + ".bias"] = (ch,)
+        s[name + ".running_mean"] = (ch,)
+        s[name + ".running_var"] = (ch,)
+        s[name + ".num_batches_tracked"] = ()
+
+    for enc, out_dim, batch in (("fnet.", 256, False), ("cnet.", 256, True)):
+        e = p + enc
+        if batch:
+            bn(e + "norm1", 64)
+        conv(e + "conv1", 64, 3, 7)
+        inp = 64
+        for li, dim, stride in (("layer1", 64, 1), ("layer2", 96, 2), ("layer3", 128, 2)):
+            for bi, (cin, st) in enumerate(((inp, stride), (dim, 1))):
+                b = f"{e}{li}.{bi}."
+                conv(b + "conv1", dim, cin, 3)
+                conv(b + "conv2", dim, dim, 3)
+                if batch:
+                    bn(b + "norm1", dim)
+                    bn(b + "norm2", dim)
+                if st != 1:
+                    if batch:
+                        bn(b + "norm3", dim)
+                    conv(b + "downsample.0", dim, cin, 1)
+                    if batch:
+                        bn(b + "downsample.1", dim)     # same module object as norm3 in the reference
+            inp = dim
+        conv(e + "conv2", out_dim, 128, 1)
+    u = p + "update_block."
+    conv(u + "encoder.convc1", 256, 4 * 81, 1)
+    conv(u + "encoder.convc2", 192, 256, 3)
+    conv(u + "encoder.convf1", 128, 2, 7)
+    conv(u + "encoder.convf2", 64, 128, 3)
+    conv(u + "encoder.conv", 126, 256, 3)
+    for nm in ("convz", "convr", "convq"):
+        conv(u + f"gru.{nm}1", 128, 384, 1, 5)
+        conv(u + f"gru.{nm}2", 128, 384, 5, 1)
+    conv(u + "flow_head.conv1", 256, 128, 3)
+    conv(u + "flow_head.conv2", 2, 256, 3)
+    conv(u + "mask.0", 256, 128, 3)
+    conv(u + "mask.2", 576, 256, 1)
+    return s
+
+
+def path_shapes(c: PathCfg, with_raft: bool = True) -> Shapes:
+    s: Shapes = {}
+    s.update(vit_shapes(c.vit))
+    s.update(qformer_shapes(c.qformer))
+    s["model.query_tokens"] = (1, c.qformer.n_query, c.qformer.hidden)
+    _lin(s, "model.language_projection", c.llm_hidden, c.qformer.hidden)
+    _lin(s, "model.temporal_projection", c.llm_hidden, c.qformer.hidden)     # dead weight, must exist
+    s.update(tgb_shapes(c.tgb))
+    if with_raft:
+        s.update(raft_shapes())
+    return s
+
+
+def path_state_dict(c: PathCfg, seed: int = 0, with_raft: bool = True) -> Dict[str, torch.Tensor]:
+    sd = synth_state_dict(path_shapes(c, with_raft), seed)
+    # the reference ties downsample.1 to norm3 (one module registered twice)
+    for k in list(sd):
+        if ".downsample.1." in k:
+            sd[k] = sd[k.replace(".downsample.1.", ".norm3.")]
+    return sd
+
+
+# ----------------------------------------------------------------------------
+# synthetic clips
+# ----------------------------------------------------------------------------
+def synth_clip(clip_id: int, T: int, n_cand: int = 32, lq: int = 12, lt: int = 12, lp: int = 20,
+               vocab: int = 30522, llm_vocab: int = 32000, image: int = 224, draws: int = 2,
+               precomputed_flow: bool = True) -> Dict[str, torch.Tensor]:
+    """One synthetic VideoQA clip: candidate frames, flow (or flow frames), question ids, noise."""
+    g = torch.Generator().manual_seed(1234 + clip_id)
+    out: Dict[str, torch.Tensor] = {}
+    out["frames"] = torch.randn(n_cand, 3, image, image, generator=g)
+    if precomputed_flow:
+        out["of"] = torch.rand(1, T, 2, image, image, generator=g) * 2 - 1
+    else:
+        out["flow_frames"] = torch.randn(1, T, 3, image, image, generator=g)
+    lo, hi = min(1000, vocab // 2), vocab
+    def ids(n, v_lo, v_hi):
+        return torch.randint(v_lo, v_hi, (1, n), generator=g)
+    sq = ids(lq, lo, hi)
+    out["sampler_ids"] = torch.cat([torch.tensor([[101 % vocab]]), sq, torch.tensor([[102 % vocab]])], dim=1)
+    out["sampler_mask"] = torch.ones_like(out["sampler_ids"])
+    qt = ids(lt, lo, hi)
+    out["qformer_ids"] = torch.cat([torch.tensor([[101 % vocab]]), qt, torch.tensor([[102 % vocab]])], dim=1)
+    out["qformer_mask"] = torch.ones_like(out["qformer_ids"])
+    out["prompt_ids"] = ids(lp, 3, llm_vocab)
+    out["prompt_mask"] = torch.ones_like(out["prompt_ids"])
+    out["noise"] = -torch.empty(draws, 2, T).exponential_(generator=g).log()
+    return out
