@@ -1,0 +1,268 @@
+/* vtgb.h -- C ABI of libvtgb.so: the MI355X (gfx950) kernels behind the VideoTGB
+ * video -> LLM-prefix hot path.
+ *
+ * The reference (bigai-nlco/VideoTGB) is pure Python with no FFI of its own; each entry
+ * point below replaces the torch op sequence of one reference function (cited as
+ * file:line under /root/reference) and is what a ctypes stub on the reference side binds
+ * (INTEGRATION.md).  Conventions, common to every call:
+ *   - int return: 0 (VTGB_OK) or a negative VTGB_E* code; vtgb_last_error() returns a
+ *     thread-local message for the last failing call on the calling thread;
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless the field
+ *     comment says "host";  the library never allocates, frees or synchronises: the
+ *     caller passes a workspace whose size comes from vtgb_<op>_workspace_bytes();
+ *   - asynchronous on the given hipStream_t, re-entrant across streams, capturable
+ *     into a hipGraph;
+ *   - `dtype` selects the arithmetic of the GEMM/attention operands: VTGB_BF16 (bf16
+ *     MFMA, fp32 accumulate, fp32 residual stream / LayerNorm / softmax) or VTGB_F32
+ *     (fp32 everywhere: the exactness mode).  GEMM weights are passed in that dtype in
+ *     the reference's nn.Linear layout [out_features, in_features] row-major; for
+ *     VTGB_F32 these are the state_dict tensors themselves, for VTGB_BF16 a one-time
+ *     vtgb_pack_bf16() of them.  Biases, LayerNorm parameters, embeddings: always fp32.
+ */
+#ifndef VTGB_H
+#define VTGB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* vtgb_stream_t; /* == hipStream_t */
+
+#define VTGB_VERSION 100
+
+#define VTGB_OK 0
+#define VTGB_EINVAL (-1)       /* bad argument (NULL pointer, unsupported size, bad mode) */
+#define VTGB_EWORKSPACE (-2)   /* workspace missing or too small                         */
+#define VTGB_EHIP (-3)         /* a HIP launch failed                                    */
+#define VTGB_EUNSUPPORTED (-4) /* shape outside what the kernels are built for           */
+
+#define VTGB_F32 0
+#define VTGB_BF16 1
+
+int vtgb_version(void);
+const char* vtgb_last_error(void);
+
+/* One-time weight packing: dst[rows, cols_pad] bf16 <- src[rows, cols] fp32 (zero pad). */
+int vtgb_pack_bf16(const float* src, void* dst, int64_t rows, int64_t cols, int64_t cols_pad,
+                   vtgb_stream_t stream);
+
+/* ---- K16: Gumbel top-k span selection -----------------------------------------------
+ * Replaces eval/utils/model.py:101-113 (LSTP.generate), :315-327 (LSTP_blip2.generate),
+ * src/models/LSTP_module.py:403-418.  idx[d][r] = first argmax over L of
+ * (logit[r] + noise[d][r]) / tau, rows r < B from logits[..., 0] (start), rows >= B from
+ * logits[..., 1] (end).  The caller supplies the Gumbel noise. */
+typedef struct {
+    const float* logits; /* [B, L, 2]      */
+    const float* noise;  /* [draws, 2B, L] */
+    int64_t* idx;        /* [draws, 2B]    */
+    int32_t B, L, draws;
+    float tau;
+} vtgb_span_select_args;
+int vtgb_span_select(const vtgb_span_select_args* a, vtgb_stream_t stream);
+
+/* ---- K17: span -> candidate-frame index map + subsample -----------------------------
+ * Replaces eval/utils/model.py:124-150 (variant A, :135) and :337-366 (variant B, :350);
+ * src/models/LSTP_module.py:423-447, src/models/LSTP_SF_module.py:508-533.
+ * Rounding rules: SURVEY.md Appendix B.  On an empty union -> range(N); duplicate-double
+ * while shorter than nframe; float64 linspace midpoint subsample. */
+#define VTGB_MAP_A 0 /* int(s / V * N)             (float32 divide, float32 multiply) */
+#define VTGB_MAP_B 1 /* int(s * (N-1) / (V-1))     (int64 multiply, float32 divide)   */
+typedef struct {
+    const int64_t* sel;   /* [draws, 2B] from vtgb_span_select                        */
+    const int32_t* V;     /* [B] per-clip video length, or NULL -> V_all              */
+    int64_t* frame_idx;   /* [B, nframe]                                              */
+    int32_t B, draws, V_all, N, nframe, variant;
+} vtgb_span_to_frames_args;
+int vtgb_span_to_frames(const vtgb_span_to_frames_args* a, vtgb_stream_t stream);
+
+/* ---- K18: frame gather ---------------------------------------------------------------
+ * Replaces eval/utils/model.py:122,151: out[b, i] = pixel_values[b, frame_idx[b, i]],
+ * fp32, every output element written (the reference's zero-init buffer is fully
+ * overwritten). frame_elems = C*H*W, must be a multiple of 4. */
+typedef struct {
+    const float* pixel_values; /* [B, N, frame_elems]      */
+    const int64_t* frame_idx;  /* [B, nframe]              */
+    float* out;                /* [B, nframe, frame_elems] */
+    int32_t B, N, nframe;
+    int64_t frame_elems;
+} vtgb_gather_frames_args;
+int vtgb_gather_frames(const vtgb_gather_frames_args* a, vtgb_stream_t stream);
+
+/* ---- K1-K6: EVA-ViT-g vision tower ----------------------------------------------------
+ * Replaces InstructBlipVisionModel.forward, src/models/components/xinstructblip.py:515-558
+ * (embeddings :113-122, 39 x encoder layer :233-269 with attention :162-204 and MLP
+ * :216-220, post_layernorm :545) and the identical Blip2VisionModel (xblip2.py:500).
+ * weights (host array of device pointers), in this order:
+ *   [0] patch_embedding.weight  `dtype` [hidden, kpad]   (kpad: see vtgb_vit_patch_kpad)
+ *   [1] patch_embedding.bias  [2] class_embedding  [3] position_embedding [tokens, hidden]
+ *   [4] post_layernorm.weight [5] post_layernorm.bias
+ *   then per layer l, at 6 + 12*l:
+ *   +0 layer_norm1.weight +1 layer_norm1.bias +2 self_attn.qkv.weight `dtype` [3h, h]
+ *   +3 self_attn.qkv.bias +4 self_attn.projection.weight `dtype` +5 .bias
+ *   +6 layer_norm2.weight +7 layer_norm2.bias +8 mlp.fc1.weight `dtype` +9 .bias
+ *   +10 mlp.fc2.weight `dtype` +11 .bias                                              */
+#define VTGB_VIT_NW_GLOBAL 6
+#define VTGB_VIT_NW_LAYER 12
+typedef struct {
+    int32_t dtype, n_frames, image, patch, hidden, heads, mlp, layers;
+    float eps;
+    const float* pixel_values;  /* [n_frames, 3, image, image] fp32                    */
+    const void* const* weights; /* host array                                          */
+    float* out_f32;             /* [n_frames, tokens, hidden] fp32 or NULL             */
+    void* out_act;              /* same, in `dtype`, or NULL (feeds vtgb_qformer)      */
+    void* workspace;
+    size_t workspace_bytes;
+} vtgb_vit_args;
+int32_t vtgb_vit_patch_kpad(int32_t dtype, int32_t patch);
+size_t vtgb_vit_workspace_bytes(const vtgb_vit_args* a);
+int vtgb_vit_forward(const vtgb_vit_args* a, vtgb_stream_t stream);
+
+/* ---- K7-K10: Q-Former -----------------------------------------------------------------
+ * Replaces InstructBlipQFormerModel.forward xinstructblip.py:1122-1242 (has_text = 1:
+ * embeddings :1018-1046, layers :814-883, attention :611-694) and Blip2QFormerModel.forward
+ * xblip2.py:1063-1174 (has_text = 0: layernorm(query_embeds) :1108).  Output: the query
+ * rows [:, :n_query] of the last layer.
+ * weights: has_text: [0] embeddings.word_embeddings.weight [1] embeddings.position_embeddings.weight
+ *                    [2] embeddings.layernorm.weight [3] .bias
+ *          else:     [0] NULL [1] NULL [2] layernorm.weight [3] layernorm.bias
+ *   then per layer l at 4 + 32*l (entries of absent sub-blocks are NULL):
+ *   +0..+5  attention.attention.{query,key,value}.{weight `dtype`, bias}
+ *   +6 attention.output.dense.weight `dtype` +7 .bias +8 attention.output.LayerNorm.weight +9 .bias
+ *   +10..+15 crossattention.attention.{query,key,value}.{weight,bias}  (key/value: [h, enc_hidden])
+ *   +16 crossattention.output.dense.weight +17 .bias +18 crossattention.output.LayerNorm.weight +19 .bias
+ *   +20 intermediate_query.dense.weight +21 .bias +22 output_query.dense.weight +23 .bias
+ *   +24 output_query.LayerNorm.weight +25 .bias
+ *   +26 intermediate.dense.weight +27 .bias +28 output.dense.weight +29 .bias
+ *   +30 output.LayerNorm.weight +31 .bias                                              */
+#define VTGB_QF_NW_GLOBAL 4
+#define VTGB_QF_NW_LAYER 32
+typedef struct {
+    int32_t dtype, n_frames, n_query, n_text, hidden, heads, ffn, layers, cross_freq;
+    int32_t enc_tokens, enc_hidden, has_text;
+    float eps;
+    const void* image_embeds;   /* [n_frames, enc_tokens, enc_hidden] in `dtype`        */
+    const float* query_tokens;  /* [n_query, hidden] fp32                               */
+    const int64_t* text_ids;    /* [n_frames, n_text] or NULL                           */
+    const int64_t* text_mask;   /* [n_frames, n_text] (1 = attend) or NULL = all ones   */
+    const int64_t* image_mask;  /* [n_frames, enc_tokens] or NULL = all ones            */
+    const void* const* weights; /* host array                                           */
+    float* out_f32;             /* [n_frames, n_query, hidden]                          */
+    void* workspace;
+    size_t workspace_bytes;
+} vtgb_qformer_args;
+size_t vtgb_qformer_workspace_bytes(const vtgb_qformer_args* a);
+int vtgb_qformer_forward(const vtgb_qformer_args* a, vtgb_stream_t stream);
+
+/* ---- K11: frame pooling + language_projection -----------------------------------------
+ * mean: eval/utils/model.py:186-195 and the ragged `widths` form of
+ * src/models/LSTP_Vicuna_IVT_module.py:244-249 (width 0 -> zero row, i.e. bias only);
+ * concat: src/models/LSTP_module.py:477-481.
+ * out: mean [n_clips, n_query, out_dim]; concat [sum(widths) * n_query, out_dim].      */
+#define VTGB_POOL_MEAN 0
+#define VTGB_POOL_CONCAT 1
+typedef struct {
+    int32_t dtype, n_clips, n_query, hidden, out_dim, mode;
+    const float* query_out;  /* [sum(widths), n_query, hidden] fp32 */
+    const int32_t* widths;   /* host array [n_clips]                */
+    const void* proj_w;      /* `dtype` [out_dim, hidden]           */
+    const float* proj_b;     /* [out_dim]                           */
+    float* out;
+    void* workspace;
+    size_t workspace_bytes;
+} vtgb_pool_project_args;
+size_t vtgb_pool_project_workspace_bytes(const vtgb_pool_project_args* a);
+int vtgb_pool_project(const vtgb_pool_project_args* a, vtgb_stream_t stream);
+
+/* ---- K12-K15: Temporal Grounding Bridge encoder ---------------------------------------
+ * Replaces RopeBertModel.forward src/models/components/xropebert.py:1048-1169 called with
+ * encoder_embeds=of (TemporalOFEmbedding :103-129, RopeBertEmbeddings :190-208, rotary
+ * attention :243-377, layers :450-533, mode switch :621-634, mrc_head :1164).
+ * weights: [0] embeddings.word_embeddings.weight [1] embeddings.token_type_embeddings.weight
+ *   [2] embeddings.LayerNorm.weight [3] .bias [4] temporal_embeddings.bos [5] .eos
+ *   [6] temporal_embeddings.projection.weight fp32 [hidden, 2*patch*patch] [7] .bias
+ *   [8] temporal_embeddings.fc.weight [9] .fc.bias [10] temporal_embeddings.frame_pos_embed.weight
+ *   [11] temporal_embeddings.ln.weight [12] .ln.bias [13] encoder.embed_positions.weight
+ *   [14] encoder.c_embed_positions.weight [15] mrc_head.weight fp32 [2, hidden] [16] mrc_head.bias
+ *   then per layer l at 17 + 26*l (crossattention entries NULL below fusion_layer):
+ *   +0..+5 attention.self.{query,key,value}.{weight `dtype`, bias}
+ *   +6 attention.output.dense.weight `dtype` +7 .bias +8 attention.output.LayerNorm.weight +9 .bias
+ *   +10..+15 crossattention.self.{query,key,value}.{weight,bias}
+ *   +16 crossattention.output.dense.weight +17 .bias +18 crossattention.output.LayerNorm.weight +19 .bias
+ *   +20 intermediate.dense.weight +21 .bias +22 output.dense.weight +23 .bias
+ *   +24 output.LayerNorm.weight +25 .bias                                              */
+#define VTGB_TGB_NW_GLOBAL 17
+#define VTGB_TGB_NW_LAYER 26
+#define VTGB_TGB_MODE_TEXT 0       /* layers [0, fusion_layer)  ("text" / "vision") */
+#define VTGB_TGB_MODE_FUSION 1     /* layers [fusion_layer, layers)                 */
+#define VTGB_TGB_MODE_MULTIMODAL 2 /* all layers                                    */
+typedef struct {
+    int32_t dtype, B, L, n_text, hidden, heads, ffn, layers, fusion_layer, mode, image, patch;
+    float eps;
+    const float* of;            /* [B, L, 2, image, image] fp32 */
+    const int64_t* of_mask;     /* [B, L+2]                     */
+    const int64_t* text_ids;    /* [B, n_text]                  */
+    const int64_t* text_mask;   /* [B, n_text]                  */
+    const void* const* weights; /* host array                   */
+    float* seq_out;             /* [B, L+2, hidden] or NULL     */
+    float* logits;              /* [B, L, 2]                    */
+    void* workspace;
+    size_t workspace_bytes;
+} vtgb_tgb_args;
+size_t vtgb_tgb_workspace_bytes(const vtgb_tgb_args* a);
+int vtgb_tgb_forward(const vtgb_tgb_args* a, vtgb_stream_t stream);
+
+/* ---- building blocks, exported for the per-kernel parity tests and the roofline bench ----
+ * out[M, N] = epilogue(A[M, K] . W[N, K]^T + bias).  A, W in `dtype`; K % 8 == 0.       */
+#define VTGB_EPI_STORE 0      /* out `dtype`  = acc + bias                      */
+#define VTGB_EPI_GELU 1       /* out `dtype`  = gelu_erf(acc + bias)            */
+#define VTGB_EPI_RESID_F32 2  /* out fp32     = acc + bias + resid (may alias)  */
+#define VTGB_EPI_STORE_F32 3  /* out fp32     = acc + bias                      */
+typedef struct {
+    int32_t dtype, M, N, K, epilogue;
+    const void* A;
+    int64_t lda;
+    const void* W;
+    int64_t ldw;
+    const float* bias;  /* [N] or NULL */
+    const float* resid; /* [M, ldo] fp32 (VTGB_EPI_RESID_F32) */
+    void* out;
+    int64_t ldo;
+} vtgb_gemm_args;
+int vtgb_gemm(const vtgb_gemm_args* a, vtgb_stream_t stream);
+
+/* softmax(scale * Q K^T + key_mask) V over [batch, heads]; Q/K/V/out token-major in `dtype`. */
+typedef struct {
+    int32_t dtype, batch, heads, head_dim, s_q, s_kv;
+    const void* q;
+    const void* k;
+    const void* v;
+    int64_t q_tok_stride, kv_tok_stride; /* elements between consecutive tokens        */
+    int64_t q_batch_stride, kv_batch_stride;
+    const float* key_mask;               /* additive [batch, s_kv] fp32 or NULL        */
+    const float* rope_q;                 /* [>= s_q, head_dim] sin|cos table or NULL   */
+    const float* rope_k;                 /* [>= s_kv, head_dim] or NULL                */
+    float scale;
+    void* out;                           /* [batch, s_q, heads*head_dim] in `dtype`    */
+    int64_t out_tok_stride, out_batch_stride;
+} vtgb_attention_args;
+int vtgb_attention(const vtgb_attention_args* a, vtgb_stream_t stream);
+
+/* LayerNorm over the last dim of fp32 rows; writes fp32 and/or `dtype` copies. */
+typedef struct {
+    int32_t dtype, M, D;
+    float eps;
+    const float* x;
+    const float* gamma;
+    const float* beta;
+    float* out_f32; /* or NULL */
+    void* out_act;  /* or NULL */
+} vtgb_layernorm_args;
+int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTGB_H */

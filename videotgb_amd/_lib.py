@@ -1,0 +1,131 @@
+"""ctypes binding of libvtgb.so (include/vtgb.h).  There is no fallback: if the HIP library is
+missing or a call fails, the product path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvtgb.so")
+
+F32, BF16 = 0, 1
+MAP_A, MAP_B = 0, 1
+POOL_MEAN, POOL_CONCAT = 0, 1
+TGB_MODE = {"text": 0, "vision": 0, "fusion": 1, "multi_modal": 2}
+EPI_STORE, EPI_GELU, EPI_RESID_F32, EPI_STORE_F32 = 0, 1, 2, 3
+VIT_NW_GLOBAL, VIT_NW_LAYER = 6, 12
+QF_NW_GLOBAL, QF_NW_LAYER = 4, 32
+TGB_NW_GLOBAL, TGB_NW_LAYER = 17, 26
+
+EXPORTS = [
+    "vtgb_version", "vtgb_last_error", "vtgb_pack_bf16", "vtgb_span_select", "vtgb_span_to_frames",
+    "vtgb_gather_frames", "vtgb_vit_patch_kpad", "vtgb_vit_workspace_bytes", "vtgb_vit_forward",
+    "vtgb_qformer_workspace_bytes", "vtgb_qformer_forward", "vtgb_pool_project_workspace_bytes",
+    "vtgb_pool_project", "vtgb_tgb_workspace_bytes", "vtgb_tgb_forward", "vtgb_gemm", "vtgb_attention",
+    "vtgb_layernorm",
+]
+
+i32, i64, f32, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+
+class VtgbError(RuntimeError):
+    pass
+
+
+class SpanSelectArgs(C.Structure):
+    _fields_ = [("logits", vp), ("noise", vp), ("idx", vp), ("B", i32), ("L", i32), ("draws", i32), ("tau", f32)]
+
+
+class SpanToFramesArgs(C.Structure):
+    _fields_ = [("sel", vp), ("V", vp), ("frame_idx", vp), ("B", i32), ("draws", i32), ("V_all", i32), ("N", i32),
+                ("nframe", i32), ("variant", i32)]
+
+
+class GatherFramesArgs(C.Structure):
+    _fields_ = [("pixel_values", vp), ("frame_idx", vp), ("out", vp), ("B", i32), ("N", i32), ("nframe", i32),
+                ("frame_elems", i64)]
+
+
+class VitArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("n_frames", i32), ("image", i32), ("patch", i32), ("hidden", i32), ("heads", i32),
+                ("mlp", i32), ("layers", i32), ("eps", f32), ("pixel_values", vp), ("weights", C.POINTER(vp)),
+                ("out_f32", vp), ("out_act", vp), ("workspace", vp), ("workspace_bytes", sz)]
+
+
+class QFormerArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("n_frames", i32), ("n_query", i32), ("n_text", i32), ("hidden", i32), ("heads", i32),
+                ("ffn", i32), ("layers", i32), ("cross_freq", i32), ("enc_tokens", i32), ("enc_hidden", i32),
+                ("has_text", i32), ("eps", f32), ("image_embeds", vp), ("query_tokens", vp), ("text_ids", vp),
+                ("text_mask", vp), ("image_mask", vp), ("weights", C.POINTER(vp)), ("out_f32", vp), ("workspace", vp),
+                ("workspace_bytes", sz)]
+
+
+class PoolProjectArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("n_clips", i32), ("n_query", i32), ("hidden", i32), ("out_dim", i32), ("mode", i32),
+                ("query_out", vp), ("widths", C.POINTER(i32)), ("proj_w", vp), ("proj_b", vp), ("out", vp),
+                ("workspace", vp), ("workspace_bytes", sz)]
+
+
+class TgbArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("L", i32), ("n_text", i32), ("hidden", i32), ("heads", i32), ("ffn", i32),
+                ("layers", i32), ("fusion_layer", i32), ("mode", i32), ("image", i32), ("patch", i32), ("eps", f32),
+                ("of", vp), ("of_mask", vp), ("text_ids", vp), ("text_mask", vp), ("weights", C.POINTER(vp)),
+                ("seq_out", vp), ("logits", vp), ("workspace", vp), ("workspace_bytes", sz)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("M", i32), ("N", i32), ("K", i32), ("epilogue", i32), ("A", vp), ("lda", i64),
+                ("W", vp), ("ldw", i64), ("bias", vp), ("resid", vp), ("out", vp), ("ldo", i64)]
+
+
+class AttentionArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("batch", i32), ("heads", i32), ("head_dim", i32), ("s_q", i32), ("s_kv", i32),
+                ("q", vp), ("k", vp), ("v", vp), ("q_tok_stride", i64), ("kv_tok_stride", i64), ("q_batch_stride", i64),
+                ("kv_batch_stride", i64), ("key_mask", vp), ("rope_q", vp), ("rope_k", vp), ("scale", f32), ("out", vp),
+                ("out_tok_stride", i64), ("out_batch_stride", i64)]
+
+
+class LayerNormArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("M", i32), ("D", i32), ("eps", f32), ("x", vp), ("gamma", vp), ("beta", vp),
+                ("out_f32", vp), ("out_act", vp)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libvtgb.so; fail loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VtgbError(f"{LIB_PATH} is missing: build it with `python -m videotgb_amd.build` "
+                        "(there is no CPU fallback for the hot path)")
+    L = C.CDLL(LIB_PATH)
+    L.vtgb_version.restype = C.c_int
+    L.vtgb_last_error.restype = C.c_char_p
+    L.vtgb_pack_bf16.argtypes = [vp, vp, i64, i64, i64, vp]
+    L.vtgb_vit_patch_kpad.argtypes = [i32, i32]
+    L.vtgb_vit_patch_kpad.restype = i32
+    for name, st in (("span_select", SpanSelectArgs), ("span_to_frames", SpanToFramesArgs),
+                     ("gather_frames", GatherFramesArgs), ("vit_forward", VitArgs), ("qformer_forward", QFormerArgs),
+                     ("pool_project", PoolProjectArgs), ("tgb_forward", TgbArgs), ("gemm", GemmArgs),
+                     ("attention", AttentionArgs), ("layernorm", LayerNormArgs)):
+        fn = getattr(L, "vtgb_" + name)
+        fn.argtypes = [C.POINTER(st), vp]
+        fn.restype = C.c_int
+    for name, st in (("vit", VitArgs), ("qformer", QFormerArgs), ("pool_project", PoolProjectArgs), ("tgb", TgbArgs)):
+        fn = getattr(L, f"vtgb_{name}_workspace_bytes")
+        fn.argtypes = [C.POINTER(st)]
+        fn.restype = sz
+    _lib = L
+    return L
+
+
+_ERR = {-1: ValueError, -2: VtgbError, -3: VtgbError, -4: NotImplementedError}
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().vtgb_last_error().decode("utf-8", "replace")
+        raise _ERR.get(rc, VtgbError)(f"libvtgb: {msg} (code {rc})")

@@ -1,0 +1,334 @@
+// attn.hip -- softmax(scale * Q K^T + key_mask) V for gfx950, token-major operands.
+//
+// One kernel serves the ViT (16 heads x 88, S = 257, no mask), the Q-Former (12 x 64; self
+// S = 32+Lt with the -10000 pad mask, cross 32 x 257) and the TGB (12 x 64, S = L+2, rotary
+// Q/K, self / cross masks).  Sequences are short (<= 512 keys), so the whole K and V of one
+// (batch, head) live in LDS and the softmax is single pass (no online rescaling).
+//
+// bf16 path.  A workgroup (8 waves, two per SIMD so one wave's softmax VALU work overlaps the
+// other's MFMAs; 4 waves for the 512-key instantiation whose score tile needs > 256 registers)
+// owns one (batch, head [, q-split]); its waves walk 16-query tiles.
+// The products are computed transposed with v_mfma_f32_16x16x32_bf16 so that no LDS round
+// trip is needed between them:
+//   S^T[key][q]  = K (A operand: rows = keys, LDS [key][d])  x  Q^T (B operand from global)
+//   O^T[d][q]    = V^T (A operand: rows = d,  LDS [d][key])  x  P^T (B operand = S^T accum.)
+// The S^T accumulator of two 16-key tiles (lane: column q, rows 4*(lane>>4)+r) is packed to
+// bf16 and used directly as the B fragment of a 32-key step; the matching A fragment takes
+// its keys in the same permuted order (two 8-byte LDS reads instead of one 16-byte read).
+// K rows are padded to HD*2+16 bytes and V^T rows to NK*2+16 bytes, which makes the 16 rows
+// of every fragment read land on 16 distinct 16-byte / 8-byte bank groups.
+// Rotary embedding (interleaved pairs, sin|cos table rows) is applied while staging K and
+// loading Q.  fp32 path: one wave per query row, plain FMAs (exactness mode).
+#include "common.h"
+
+#include <math.h>
+
+template <int HD, int NKP>
+struct AttnCfg {
+    static constexpr int NK = NKP * 32;       // padded key count
+    static constexpr int KS = HD * 2 + 16;    // K row stride (bytes)
+    static constexpr int VS = NK * 2 + 16;    // V^T row stride (bytes)
+    static constexpr int K_BYTES = NK * KS;
+    static constexpr int V_BYTES = HD * VS;
+    static constexpr int LDS = K_BYTES + V_BYTES + NK * 4;
+};
+
+// rotate 8 consecutive elements (4 interleaved pairs) starting at even d0: x*cos + rot(x)*sin
+__device__ __forceinline__ bf16x8 rope8(bf16x8 v, const float* tab_row, int d0, int head_dim) {
+    const int half = head_dim >> 1;
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float sn = tab_row[(d0 >> 1) + i], cs = tab_row[half + (d0 >> 1) + i];
+        const float x0 = (float)v[2 * i], x1 = (float)v[2 * i + 1];
+        o[2 * i] = (bf16_t)(x0 * cs - x1 * sn);
+        o[2 * i + 1] = (bf16_t)(x1 * cs + x0 * sn);
+    }
+    return o;
+}
+
+template <int HD, int NKP>
+__global__ __launch_bounds__(NKP <= 9 ? 512 : 256, NKP <= 9 ? 2 : 1) void attn_bf16_kernel(const AttnDesc p, const int tiles_per_split) {
+    using C = AttnCfg<HD, NKP>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vt = smem + C::K_BYTES;
+    float* maskv = reinterpret_cast<float*>(smem + C::K_BYTES + C::V_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int hd = p.head_dim;
+    const bf16_t* __restrict__ Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.q_batch + head * hd;
+    const bf16_t* __restrict__ K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.kv_batch + head * hd;
+    const bf16_t* __restrict__ V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.kv_batch + head * hd;
+    bf16_t* __restrict__ O = reinterpret_cast<bf16_t*>(p.out) + (int64_t)b * p.o_batch + head * hd;
+    constexpr int CH = HD / 8;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- stage K [key][d] (rope applied), zero padded
+    for (int idx = tid; idx < C::NK * CH; idx += nthreads) {
+        const int key = idx / CH, c = idx - key * CH;
+        bf16x8 val = zero8;
+        if (key < p.s_kv && c * 8 < hd) {
+            val = *reinterpret_cast<const bf16x8*>(K + (int64_t)key * p.kv_tok + c * 8);
+            if (p.rope_k) val = rope8(val, p.rope_k + (int64_t)key * hd, c * 8, hd);
+        }
+        *reinterpret_cast<bf16x8*>(Ks + key * C::KS + c * 16) = val;
+    }
+    // ---- stage V^T [d][key]: each thread transposes 2 keys x 8 d into 8 packed dwords
+    for (int idx = tid; idx < (C::NK / 2) * CH; idx += nthreads) {
+        const int c = idx / (C::NK / 2), kp = idx - c * (C::NK / 2);
+        const int key = kp * 2;
+        bf16x8 v0 = zero8, v1 = zero8;
+        if (c * 8 < hd) {
+            if (key < p.s_kv) v0 = *reinterpret_cast<const bf16x8*>(V + (int64_t)key * p.kv_tok + c * 8);
+            if (key + 1 < p.s_kv) v1 = *reinterpret_cast<const bf16x8*>(V + (int64_t)(key + 1) * p.kv_tok + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            bf16x2 pr = {v0[i], v1[i]};
+            *reinterpret_cast<bf16x2*>(Vt + (c * 8 + i) * C::VS + key * 2) = pr;
+        }
+    }
+    for (int key = tid; key < C::NK; key += nthreads) {
+        float m = -INFINITY;
+        if (key < p.s_kv) m = p.key_mask ? p.key_mask[(int64_t)b * p.s_kv + key] : 0.f;
+        maskv[key] = m;
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n_qt = (p.s_q + 15) >> 4;
+    const int qt_begin = blockIdx.x * tiles_per_split;
+    int qt_end = qt_begin + tiles_per_split;
+    qt_end = qt_end < n_qt ? qt_end : n_qt;
+
+    for (int qt = qt_begin + wave; qt < qt_end; qt += nwaves) {
+        const int q = qt * 16 + fr;
+        const bool qvalid = q < p.s_q;
+        bf16x8 qf[HD / 32];
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ks++) {
+            const int d0 = (ks * 4 + fg) * 8;
+            bf16x8 val = zero8;
+            if (qvalid && d0 < hd) {
+                val = *reinterpret_cast<const bf16x8*>(Q + (int64_t)q * p.q_tok + d0);
+                if (p.rope_q) val = rope8(val, p.rope_q + (int64_t)q * hd, d0, hd);
+            }
+            qf[ks] = val;
+        }
+        // ---- S^T tiles, two 16-key tiles (one 32-key pair) per step; the next pair's K fragments
+        // are issued before the current pair's MFMAs, and sched_barrier keeps the compiler from
+        // hoisting every LDS read of the unrolled loop to the top (which spills).
+        f32x4 s[2 * NKP];
+        bf16x8 kcur[2][HD / 32], knxt[2][HD / 32];
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ks++)
+                kcur[tt][ks] = *reinterpret_cast<const bf16x8*>(Ks + (tt * 16 + fr) * C::KS + (ks * 4 + fg) * 16);
+#pragma unroll
+        for (int u = 0; u < NKP; u++) {
+            if (u + 1 < NKP) {
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                    for (int ks = 0; ks < HD / 32; ks++)
+                        knxt[tt][ks] = *reinterpret_cast<const bf16x8*>(Ks + ((2 * u + 2 + tt) * 16 + fr) * C::KS + (ks * 4 + fg) * 16);
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < HD / 32; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kcur[tt][ks], qf[ks], acc, 0, 0, 0);
+                s[2 * u + tt] = acc;
+            }
+            if (u + 1 < NKP) {
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                    for (int ks = 0; ks < HD / 32; ks++) kcur[tt][ks] = knxt[tt][ks];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- softmax over keys: registers (t, r) x lane groups fg
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2 * NKP; t++) {
+            const float4 mk = *reinterpret_cast<const float4*>(maskv + t * 16 + fg * 4);
+            s[t][0] = s[t][0] * p.scale + mk.x;
+            s[t][1] = s[t][1] * p.scale + mk.y;
+            s[t][2] = s[t][2] * p.scale + mk.z;
+            s[t][3] = s[t][3] * p.scale + mk.w;
+            mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2 * NKP; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float e = __expf(s[t][r] - mx);
+                s[t][r] = e;
+                sum += e;
+            }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        // ---- O^T = V^T P^T, one 32-key pair per step, V^T fragments prefetched one step ahead
+        f32x4 o[HD / 16];
+        bf16x8 vcur[HD / 16], vnxt[HD / 16];
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; dt++) {
+            o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const char* row = Vt + (dt * 16 + fr) * C::VS + (fg * 4) * 2;
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row);
+            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + 32);
+            vcur[dt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int u = 0; u < NKP; u++) {
+            if (u + 1 < NKP) {
+#pragma unroll
+                for (int dt = 0; dt < HD / 16; dt++) {
+                    const char* row = Vt + (dt * 16 + fr) * C::VS + ((u + 1) * 32 + fg * 4) * 2;
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row);
+                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + 32);
+                    vnxt[dt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            }
+            const bf16x8 pf = {(bf16_t)s[2 * u][0],     (bf16_t)s[2 * u][1],     (bf16_t)s[2 * u][2],     (bf16_t)s[2 * u][3],
+                               (bf16_t)s[2 * u + 1][0], (bf16_t)s[2 * u + 1][1], (bf16_t)s[2 * u + 1][2], (bf16_t)s[2 * u + 1][3]};
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; dt++) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcur[dt], pf, o[dt], 0, 0, 0);
+            if (u + 1 < NKP) {
+#pragma unroll
+                for (int dt = 0; dt < HD / 16; dt++) vcur[dt] = vnxt[dt];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float inv = 1.0f / sum;
+        if (qvalid) {
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; dt++) {
+                const int d = dt * 16 + fg * 4;
+                if (d < hd) {
+                    const bf16x4 pk = {(bf16_t)(o[dt][0] * inv), (bf16_t)(o[dt][1] * inv), (bf16_t)(o[dt][2] * inv),
+                                       (bf16_t)(o[dt][3] * inv)};
+                    *reinterpret_cast<bf16x4*>(O + (int64_t)q * p.o_tok + d) = pk;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// fp32: one wave per (batch, head, query)
+// ---------------------------------------------------------------------------------------
+constexpr int F32_MAX_KV = 1024, F32_MAX_HD = 128;
+
+__device__ __forceinline__ float rope_elem(const float* x, int d, const float* tab_row, int head_dim) {
+    const int half = head_dim >> 1, i = d >> 1;
+    const float sn = tab_row[i], cs = tab_row[half + i];
+    return (d & 1) ? (x[d] * cs + x[d - 1] * sn) : (x[d] * cs - x[d + 1] * sn);
+}
+
+__global__ __launch_bounds__(256) void attn_f32_kernel(const AttnDesc p) {
+    __shared__ float qs[4][F32_MAX_HD];
+    __shared__ float sc[4][F32_MAX_KV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t total = (int64_t)p.batch * p.heads * p.s_q;
+    int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    const bool active = row < total;
+    if (!active) row = total - 1;   // keep every wave at the barriers; stores are predicated
+    const int q = row % p.s_q, head = (row / p.s_q) % p.heads, b = row / ((int64_t)p.s_q * p.heads);
+    const int hd = p.head_dim;
+    const float* Q = reinterpret_cast<const float*>(p.q) + (int64_t)b * p.q_batch + (int64_t)q * p.q_tok + head * hd;
+    const float* K = reinterpret_cast<const float*>(p.k) + (int64_t)b * p.kv_batch + head * hd;
+    const float* V = reinterpret_cast<const float*>(p.v) + (int64_t)b * p.kv_batch + head * hd;
+    for (int d = lane; d < hd; d += 64) qs[wave][d] = p.rope_q ? rope_elem(Q, d, p.rope_q + (int64_t)q * hd, hd) : Q[d];
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int key = lane; key < p.s_kv; key += 64) {
+        const float* kr = K + (int64_t)key * p.kv_tok;
+        float dot = 0.f;
+        if (p.rope_k) {
+            const float* tr = p.rope_k + (int64_t)key * hd;
+            for (int d = 0; d < hd; d++) dot = fmaf(qs[wave][d], rope_elem(kr, d, tr, hd), dot);
+        } else {
+            for (int d = 0; d < hd; d++) dot = fmaf(qs[wave][d], kr[d], dot);
+        }
+        float v = dot * p.scale;
+        if (p.key_mask) v += p.key_mask[(int64_t)b * p.s_kv + key];
+        sc[wave][key] = v;
+        mx = fmaxf(mx, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.f;
+    for (int key = lane; key < p.s_kv; key += 64) {
+        const float e = expf(sc[wave][key] - mx);
+        sc[wave][key] = e;
+        sum += e;
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    float* O = reinterpret_cast<float*>(p.out) + (int64_t)b * p.o_batch + (int64_t)q * p.o_tok + head * hd;
+    for (int d = lane; d < hd; d += 64) {
+        float acc = 0.f;
+        for (int key = 0; key < p.s_kv; key++) acc = fmaf(sc[wave][key] * inv, V[(int64_t)key * p.kv_tok + d], acc);
+        if (active) O[d] = acc;
+    }
+}
+
+template <int HD, int NKP>
+static int launch_bf16(const AttnDesc& d, hipStream_t s) {
+    using C = AttnCfg<HD, NKP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel<HD, NKP>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+        attr_set = true;
+    }
+    const int n_qt = (d.s_q + 15) / 16;
+    int splits = 1;
+    while ((int64_t)d.batch * d.heads * splits < 256 && splits * 2 <= n_qt && splits < 4) splits *= 2;
+    const int tps = (n_qt + splits - 1) / splits;
+    const int max_waves = NKP <= 9 ? 8 : 4;
+    const int waves = tps < max_waves ? tps : max_waves;
+    hipLaunchKernelGGL((attn_bf16_kernel<HD, NKP>), dim3(splits, d.heads, d.batch), dim3(64 * waves), C::LDS, s, d, tps);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+int launch_attention(const AttnDesc& d, hipStream_t s) {
+    VTGB_REQUIRE(d.q && d.k && d.v && d.out, VTGB_EINVAL, "attention: NULL operand");
+    VTGB_REQUIRE(d.batch > 0 && d.heads > 0 && d.s_q > 0 && d.s_kv > 0, VTGB_EINVAL, "attention: empty problem");
+    if (d.dtype == VTGB_F32) {
+        VTGB_REQUIRE(d.s_kv <= F32_MAX_KV && d.head_dim <= F32_MAX_HD && (d.head_dim % 2) == 0, VTGB_EUNSUPPORTED,
+                     "attention fp32: s_kv=%d head_dim=%d outside [<=%d, <=%d even]", d.s_kv, d.head_dim, F32_MAX_KV, F32_MAX_HD);
+        const int64_t rows = (int64_t)d.batch * d.heads * d.s_q;
+        hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, d);
+        VTGB_HIP(hipGetLastError());
+        return VTGB_OK;
+    }
+    VTGB_REQUIRE(d.dtype == VTGB_BF16, VTGB_EINVAL, "attention: bad dtype %d", d.dtype);
+    VTGB_REQUIRE((d.head_dim % 8) == 0 && d.head_dim <= 96, VTGB_EUNSUPPORTED, "attention bf16: head_dim=%d must be a multiple of 8, <= 96", d.head_dim);
+    VTGB_REQUIRE((d.q_tok % 8) == 0 && (d.kv_tok % 8) == 0 && (d.o_tok % 4) == 0 && (d.q_batch % 8) == 0 &&
+                     (d.kv_batch % 8) == 0 && (d.o_batch % 4) == 0,
+                 VTGB_EUNSUPPORTED, "attention bf16: strides must keep 16-byte alignment");
+    const int kv = d.s_kv;
+    if (d.head_dim <= 64) {
+        if (kv <= 64) return launch_bf16<64, 2>(d, s);
+        if (kv <= 128) return launch_bf16<64, 4>(d, s);
+        if (kv <= 288) return launch_bf16<64, 9>(d, s);
+        if (kv <= 512) return launch_bf16<64, 16>(d, s);
+    } else {
+        if (kv <= 64) return launch_bf16<96, 2>(d, s);
+        if (kv <= 128) return launch_bf16<96, 4>(d, s);
+        if (kv <= 288) return launch_bf16<96, 9>(d, s);
+    }
+    vtgb_set_error("attention bf16: s_kv=%d with head_dim=%d exceeds the single-pass LDS budget", kv, d.head_dim);
+    return VTGB_EUNSUPPORTED;
+}

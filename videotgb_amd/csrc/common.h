@@ -1,0 +1,143 @@
+// common.h -- internal declarations shared by the libvtgb.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "vtgb.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---------------------------------------------------------------------------------------
+// error plumbing (thread-local message, negative return codes; include/vtgb.h)
+// ---------------------------------------------------------------------------------------
+void vtgb_set_error(const char* fmt, ...);
+
+#define VTGB_REQUIRE(cond, code, ...)  \
+    do {                               \
+        if (!(cond)) {                 \
+            vtgb_set_error(__VA_ARGS__); \
+            return (code);             \
+        }                              \
+    } while (0)
+
+#define VTGB_HIP(expr)                                                              \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            vtgb_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return VTGB_EHIP;                                                       \
+        }                                                                           \
+    } while (0)
+
+#define VTGB_TRY(expr)        \
+    do {                      \
+        int _r = (expr);      \
+        if (_r != VTGB_OK) return _r; \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// logical row -> physical row.  seg_rows == 0: identity.  Otherwise the logical rows are the
+// concatenation of segments of seg_rows rows; segment s starts at physical row
+// s * seg_stride + seg_off.  (Q-Former query rows / text rows of each frame; ViT patch rows
+// interleaved with the cls row; position-embedding rows broadcast over frames.)
+// ---------------------------------------------------------------------------------------
+struct RowMap {
+    int32_t seg_rows;
+    int64_t seg_stride;
+    int64_t seg_off;
+};
+static inline RowMap rowmap_identity() { return RowMap{0, 0, 0}; }
+static inline RowMap rowmap(int seg_rows, int64_t seg_stride, int64_t seg_off) {
+    return RowMap{seg_rows, seg_stride, seg_off};
+}
+__host__ __device__ static inline int64_t map_row(const RowMap& m, int64_t r) {
+    if (m.seg_rows == 0) return r;
+    return (r / m.seg_rows) * m.seg_stride + m.seg_off + (r % m.seg_rows);
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline size_t dtype_size(int dtype) { return dtype == VTGB_BF16 ? 2 : 4; }
+
+// bump allocator over the caller's workspace
+struct Workspace {
+    char* base;
+    size_t size, used;
+    bool dry;  // size query: only count
+    Workspace(void* p, size_t n) : base((char*)p), size(n), used(0), dry(p == nullptr) {}
+    void* take(size_t bytes) {
+        size_t off = align_up(used, 256);
+        used = off + bytes;
+        return dry ? nullptr : (void*)(base + off);
+    }
+    bool ok() const { return dry || used <= size; }
+};
+
+// ---------------------------------------------------------------------------------------
+// kernel launchers (each returns VTGB_OK or a negative code with the message set)
+// ---------------------------------------------------------------------------------------
+struct GemmDesc {
+    int dtype, M, N, K, epi;
+    const void* A;
+    int64_t lda;
+    RowMap a_map;
+    const void* W;
+    int64_t ldw;
+    const float* bias;
+    const float* resid;
+    int64_t ldr;
+    RowMap r_map;
+    void* out;
+    int64_t ldo;
+    RowMap o_map;
+};
+int launch_gemm(const GemmDesc& d, hipStream_t s);
+
+struct AttnDesc {
+    int dtype, batch, heads, head_dim, s_q, s_kv;
+    const void *q, *k, *v;
+    int64_t q_tok, kv_tok, q_batch, kv_batch;  // element strides
+    const float* key_mask;                     // additive fp32 [batch, s_kv] or null
+    const float* rope_q;
+    const float* rope_k;
+    float scale;
+    void* out;
+    int64_t o_tok, o_batch;
+};
+int launch_attention(const AttnDesc& d, hipStream_t s);
+
+struct LnDesc {
+    int dtype, M, D;
+    float eps;
+    const float* x;
+    int64_t ldx;
+    RowMap x_map;
+    const float* gamma;
+    const float* beta;
+    float* out_f32;  // nullable
+    void* out_act;   // nullable, `dtype`
+    int64_t ldo;
+    RowMap o_map;
+};
+int launch_layernorm(const LnDesc& d, hipStream_t s);
+
+// elementwise helpers (elementwise.hip)
+int launch_im2col(int dtype, const float* pix, void* out, int n_img, int ch, int image, int patch, int kpad, hipStream_t s);
+int launch_vit_cls_rows(const float* cls, const float* pos, float* x, int n_frames, int tokens, int hidden, hipStream_t s);
+int launch_cast_act(int dtype, const float* src, void* dst, int64_t n, hipStream_t s);
+int launch_mask_to_additive(const int64_t* mask, float* out, int64_t n, float neg, hipStream_t s);
+int launch_fill_f32(float* dst, float v, int64_t n, hipStream_t s);
+int launch_qformer_embed(const float* query, const int64_t* ids, const float* wemb, const float* pemb, float* x,
+                         int n_frames, int n_query, int n_text, int hidden, hipStream_t s);
+int launch_tgb_text_embed(const int64_t* ids, const float* wemb, const float* temb, float* x, int64_t rows, int hidden,
+                          hipStream_t s);
+int launch_flow_reduce(const float* of, const float* fcw, float* red, int n_img, int image, int patch, hipStream_t s);
+int launch_flow_assemble(const float* conv, const float* proj_b, const float* fcw, const float* fcb, const float* bos,
+                         const float* eos, const float* pos, const int64_t* of_mask, float* x, int B, int L,
+                         int hidden, int n_patches, hipStream_t s);
+int launch_mean_pool_uniform(const float* q, float* out, int n_clips, int width, int64_t row_elems, hipStream_t s);
+int launch_pack_bf16(const float* src, void* dst, int64_t rows, int64_t cols, int64_t cols_pad, hipStream_t s);
+int launch_mrc_head(const float* x, const float* w, const float* b, float* logits, int B, int L, int hidden, hipStream_t s);

@@ -1,0 +1,411 @@
+"""Tensor-level wrappers over the C ABI (include/vtgb.h).  PyTorch is plumbing here: it owns
+device memory and the stream; all arithmetic of the hot path happens inside libvtgb.so.
+
+Every function takes CUDA(=HIP) tensors, launches asynchronously on the current stream and
+returns fresh tensors on the same device.  Nothing here falls back to torch ops."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from ._lib import BF16, F32
+
+Tensor = torch.Tensor
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts: Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.VtgbError("videotgb_amd ops need device tensors: the hot path has no CPU implementation")
+
+
+def dtype_code(dtype) -> int:
+    if dtype in (BF16, "bf16", torch.bfloat16):
+        return BF16
+    if dtype in (F32, "f32", "fp32", torch.float32):
+        return F32
+    raise ValueError(f"unsupported compute dtype {dtype!r}")
+
+
+def act_dtype(code: int) -> torch.dtype:
+    return torch.bfloat16 if code == BF16 else torch.float32
+
+
+class _Workspace:
+    """Per-device scratch buffer handed to the library (grown on demand, never shrunk)."""
+
+    def __init__(self):
+        self.bufs: Dict[int, Tensor] = {}
+
+    def get(self, nbytes: int, device) -> Tensor:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        b = self.bufs.get(idx)
+        if b is None or b.numel() < nbytes:
+            self.bufs[idx] = b = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        return b
+
+
+_ws = _Workspace()
+
+
+def pack_weight(w: Tensor, code: int, cols_pad: Optional[int] = None) -> Tensor:
+    """GEMM weight in the dtype the kernels consume: fp32 -> as is; bf16 -> one-time vtgb_pack_bf16."""
+    _need_cuda(w)
+    w2 = w.reshape(w.shape[0], -1).contiguous().float()
+    if code == F32:
+        return w2
+    rows, cols = w2.shape
+    if cols_pad is None and cols % 8:
+        raise NotImplementedError(f"bf16 GEMM weights need in_features % 8 == 0 (got {cols})")
+    cp = cols_pad or cols
+    out = torch.empty(rows, cp, dtype=torch.bfloat16, device=w.device)
+    L.check(L.lib().vtgb_pack_bf16(w2.data_ptr(), out.data_ptr(), rows, cols, cp, _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------- K16-K18
+def span_select(logits: Tensor, noise: Tensor, tau: float = 0.5) -> Tensor:
+    """logits [B, L, 2] fp32, noise [draws, 2B, L] fp32 -> idx [draws, 2B] int64."""
+    _need_cuda(logits, noise)
+    logits, noise = logits.contiguous().float(), noise.contiguous().float()
+    B, Lf, two = logits.shape
+    draws = noise.shape[0]
+    if two != 2 or tuple(noise.shape) != (draws, 2 * B, Lf):
+        raise ValueError(f"span_select: logits {tuple(logits.shape)} / noise {tuple(noise.shape)} mismatch")
+    idx = torch.empty(draws, 2 * B, dtype=torch.int64, device=logits.device)
+    a = L.SpanSelectArgs(logits.data_ptr(), noise.data_ptr(), idx.data_ptr(), B, Lf, draws, float(tau))
+    L.check(L.lib().vtgb_span_select(C.byref(a), _stream()))
+    return idx
+
+
+def span_to_frames(sel: Tensor, V, N: int, nframe: int, variant: str) -> Tensor:
+    """sel [draws, 2B] int64; V int or int32 tensor [B] -> frame_idx [B, nframe] int64."""
+    _need_cuda(sel)
+    sel = sel.contiguous()
+    draws, twoB = sel.shape
+    B = twoB // 2
+    out = torch.empty(B, nframe, dtype=torch.int64, device=sel.device)
+    vt = None
+    if isinstance(V, Tensor):
+        vt = V.to(device=sel.device, dtype=torch.int32).contiguous()
+    a = L.SpanToFramesArgs(sel.data_ptr(), _ptr(vt), out.data_ptr(), B, draws, 0 if vt is not None else int(V), N, nframe,
+                           {"A": L.MAP_A, "B": L.MAP_B}[variant])
+    L.check(L.lib().vtgb_span_to_frames(C.byref(a), _stream()))
+    return out
+
+
+def gather_frames(pixel_values: Tensor, frame_idx: Tensor) -> Tensor:
+    """pixel_values [B, N, ...] fp32, frame_idx [B, nframe] int64 -> [B, nframe, ...] fp32."""
+    _need_cuda(pixel_values, frame_idx)
+    pv = pixel_values.contiguous().float()
+    fi = frame_idx.contiguous()
+    B, N = pv.shape[:2]
+    nframe = fi.shape[1]
+    out = torch.empty((B, nframe) + tuple(pv.shape[2:]), dtype=torch.float32, device=pv.device)
+    a = L.GatherFramesArgs(pv.data_ptr(), fi.data_ptr(), out.data_ptr(), B, N, nframe, pv[0, 0].numel())
+    L.check(L.lib().vtgb_gather_frames(C.byref(a), _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------- building blocks
+def gemm(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, epilogue: int = L.EPI_STORE, resid: Optional[Tensor] = None,
+         K: Optional[int] = None) -> Tensor:
+    """A [M, K] and W [N, K] in bf16 or fp32 -> out [M, N]."""
+    _need_cuda(A, W)
+    code = dtype_code(A.dtype)
+    M, Ka = A.shape
+    N = W.shape[0]
+    K = K or Ka
+    out_dtype = torch.float32 if epilogue in (L.EPI_RESID_F32, L.EPI_STORE_F32) else A.dtype
+    out = torch.empty(M, N, dtype=out_dtype, device=A.device)
+    a = L.GemmArgs(code, M, N, K, epilogue, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), _ptr(bias), _ptr(resid),
+                   out.data_ptr(), N)
+    L.check(L.lib().vtgb_gemm(C.byref(a), _stream()))
+    return out
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, key_mask: Optional[Tensor] = None,
+              rope_q: Optional[Tensor] = None, rope_k: Optional[Tensor] = None) -> Tensor:
+    """q [B, Sq, H*hd], k/v [B, Skv, H*hd] (any token/batch strides, unit channel stride) -> [B, Sq, H*hd]."""
+    _need_cuda(q, k, v)
+    code = dtype_code(q.dtype)
+    B, Sq, D = q.shape
+    Skv = k.shape[1]
+    assert k.stride() == v.stride() and q.stride(2) == 1 and k.stride(2) == 1
+    out = torch.empty(B, Sq, D, dtype=q.dtype, device=q.device)
+    a = L.AttentionArgs(code, B, heads, D // heads, Sq, Skv, q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1), k.stride(1),
+                        q.stride(0), k.stride(0), _ptr(key_mask), _ptr(rope_q), _ptr(rope_k), float(scale), out.data_ptr(),
+                        out.stride(1), out.stride(0))
+    L.check(L.lib().vtgb_attention(C.byref(a), _stream()))
+    return out
+
+
+def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_dtype=torch.float32) -> Tensor:
+    _need_cuda(x, gamma, beta)
+    x = x.contiguous().float()
+    M, D = x.numel() // x.shape[-1], x.shape[-1]
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    f32_out = out_dtype == torch.float32
+    a = L.LayerNormArgs(BF16 if out_dtype == torch.bfloat16 else F32, M, D, float(eps), x.data_ptr(), gamma.data_ptr(),
+                        beta.data_ptr(), out.data_ptr() if f32_out else None, None if f32_out else out.data_ptr())
+    L.check(L.lib().vtgb_layernorm(C.byref(a), _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------- weight tables
+class _WeightTable:
+    """Keeps the (packed) device tensors of one stage alive next to the pointer array the ABI takes."""
+
+    def __init__(self, code: int):
+        self.code = code
+        self.tensors: List[Optional[Tensor]] = []
+
+    def add(self, t: Optional[Tensor], gemm_weight: bool = False, cols_pad: Optional[int] = None, force_f32: bool = False):
+        if t is None:
+            self.tensors.append(None)
+        elif gemm_weight and not force_f32:
+            self.tensors.append(pack_weight(t, self.code, cols_pad))
+        else:
+            self.tensors.append(t.detach().contiguous().float())
+
+    def finish(self):
+        self.array = (C.c_void_p * len(self.tensors))(*[_ptr(t) for t in self.tensors])
+        return self
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.tensors if t is not None)
+
+
+class VitWeights(_WeightTable):
+    """model.vision_model.* -> the pointer table of vtgb_vit_forward (include/vtgb.h)."""
+
+    def __init__(self, sd: Dict[str, Tensor], prefix: str, code: int, heads: int, eps: float = 1e-6):
+        super().__init__(code)
+        p = prefix
+        pw = sd[p + "embeddings.patch_embedding.weight"]
+        self.hidden, _, self.patch, _ = pw.shape
+        pos = sd[p + "embeddings.position_embedding"]
+        self.tokens = pos.shape[1]
+        self.image = int(round(math.sqrt(self.tokens - 1))) * self.patch
+        self.heads, self.eps = heads, eps
+        kpad = L.lib().vtgb_vit_patch_kpad(code, self.patch)
+        self.add(pw, True, kpad)
+        self.add(sd[p + "embeddings.patch_embedding.bias"])
+        self.add(sd[p + "embeddings.class_embedding"].reshape(-1))
+        self.add(pos.reshape(self.tokens, self.hidden))
+        self.add(sd[p + "post_layernorm.weight"])
+        self.add(sd[p + "post_layernorm.bias"])
+        self.layers = 0
+        while f"{p}encoder.layers.{self.layers}.self_attn.qkv.weight" in sd:
+            lp = f"{p}encoder.layers.{self.layers}."
+            self.add(sd[lp + "layer_norm1.weight"]); self.add(sd[lp + "layer_norm1.bias"])
+            self.add(sd[lp + "self_attn.qkv.weight"], True); self.add(sd[lp + "self_attn.qkv.bias"])
+            self.add(sd[lp + "self_attn.projection.weight"], True); self.add(sd[lp + "self_attn.projection.bias"])
+            self.add(sd[lp + "layer_norm2.weight"]); self.add(sd[lp + "layer_norm2.bias"])
+            self.add(sd[lp + "mlp.fc1.weight"], True); self.add(sd[lp + "mlp.fc1.bias"])
+            self.add(sd[lp + "mlp.fc2.weight"], True); self.add(sd[lp + "mlp.fc2.bias"])
+            self.mlp = sd[lp + "mlp.fc1.weight"].shape[0]
+            self.layers += 1
+        self.finish()
+
+
+class QFormerWeights(_WeightTable):
+    """model.qformer.* (InstructBLIP with text branch, or BLIP-2) -> table of vtgb_qformer_forward."""
+
+    def __init__(self, sd: Dict[str, Tensor], prefix: str, code: int, heads: int, cross_freq: int = 2, eps: float = 1e-12):
+        super().__init__(code)
+        p = prefix
+        self.has_text = (p + "embeddings.word_embeddings.weight") in sd
+        self.heads, self.cross_freq, self.eps = heads, cross_freq, eps
+        if self.has_text:
+            self.add(sd[p + "embeddings.word_embeddings.weight"]); self.add(sd[p + "embeddings.position_embeddings.weight"])
+            self.add(sd[p + "embeddings.layernorm.weight"]); self.add(sd[p + "embeddings.layernorm.bias"])
+        else:
+            self.add(None); self.add(None)
+            self.add(sd[p + "layernorm.weight"]); self.add(sd[p + "layernorm.bias"])
+
+        def lin(name):
+            w = sd.get(name + ".weight")
+            self.add(w, True); self.add(sd.get(name + ".bias"))
+
+        def lnp(name):
+            self.add(sd.get(name + ".weight")); self.add(sd.get(name + ".bias"))
+
+        self.layers = 0
+        while f"{p}encoder.layer.{self.layers}.attention.attention.query.weight" in sd:
+            lp = f"{p}encoder.layer.{self.layers}."
+            for nm in ("query", "key", "value"):
+                lin(f"{lp}attention.attention.{nm}")
+            lin(lp + "attention.output.dense"); lnp(lp + "attention.output.LayerNorm")
+            for nm in ("query", "key", "value"):
+                lin(f"{lp}crossattention.attention.{nm}")
+            lin(lp + "crossattention.output.dense"); lnp(lp + "crossattention.output.LayerNorm")
+            lin(lp + "intermediate_query.dense"); lin(lp + "output_query.dense"); lnp(lp + "output_query.LayerNorm")
+            lin(lp + "intermediate.dense"); lin(lp + "output.dense"); lnp(lp + "output.LayerNorm")
+            self.hidden = sd[lp + "attention.attention.query.weight"].shape[0]
+            self.ffn = sd[lp + "intermediate_query.dense.weight"].shape[0]
+            if (lp + "crossattention.attention.key.weight") in sd:
+                self.enc_hidden = sd[lp + "crossattention.attention.key.weight"].shape[1]
+            self.layers += 1
+        self.finish()
+
+
+class TgbWeights(_WeightTable):
+    """temporal_encoder.* -> table of vtgb_tgb_forward."""
+
+    def __init__(self, sd: Dict[str, Tensor], prefix: str, code: int, heads: int, fusion_layer: int, eps: float = 1e-12):
+        super().__init__(code)
+        p = prefix
+        self.heads, self.fusion_layer, self.eps = heads, fusion_layer, eps
+        t = p + "temporal_embeddings."
+        pw = sd[t + "projection.weight"]
+        self.hidden, _, self.patch, _ = pw.shape
+        self.image = int(round(math.sqrt(sd[t + "fc.weight"].shape[1]))) * self.patch
+        self.add(sd[p + "embeddings.word_embeddings.weight"]); self.add(sd[p + "embeddings.token_type_embeddings.weight"])
+        self.add(sd[p + "embeddings.LayerNorm.weight"]); self.add(sd[p + "embeddings.LayerNorm.bias"])
+        self.add(sd[t + "bos"]); self.add(sd[t + "eos"])
+        self.add(pw.reshape(self.hidden, -1)); self.add(sd[t + "projection.bias"])
+        self.add(sd[t + "fc.weight"].reshape(-1)); self.add(sd[t + "fc.bias"])
+        self.add(sd[t + "frame_pos_embed.weight"])
+        self.add(sd[t + "ln.weight"]); self.add(sd[t + "ln.bias"])
+        self.add(sd[p + "encoder.embed_positions.weight"]); self.add(sd[p + "encoder.c_embed_positions.weight"])
+        self.add(sd[p + "mrc_head.weight"]); self.add(sd[p + "mrc_head.bias"])
+        self.max_pos = sd[p + "encoder.embed_positions.weight"].shape[0]
+
+        def lin(name):
+            self.add(sd.get(name + ".weight"), True); self.add(sd.get(name + ".bias"))
+
+        def lnp(name):
+            self.add(sd.get(name + ".weight")); self.add(sd.get(name + ".bias"))
+
+        self.layers = 0
+        while f"{p}encoder.layer.{self.layers}.attention.self.query.weight" in sd:
+            lp = f"{p}encoder.layer.{self.layers}."
+            for att in ("attention", "crossattention"):
+                for nm in ("query", "key", "value"):
+                    lin(f"{lp}{att}.self.{nm}")
+                lin(f"{lp}{att}.output.dense"); lnp(f"{lp}{att}.output.LayerNorm")
+            lin(lp + "intermediate.dense"); lin(lp + "output.dense"); lnp(lp + "output.LayerNorm")
+            self.ffn = sd[lp + "intermediate.dense.weight"].shape[0]
+            self.layers += 1
+        self.finish()
+
+
+# ----------------------------------------------------------------------------- stages
+def vit_forward(w: VitWeights, pixel_values: Tensor, want_f32: bool = True, want_act: bool = False):
+    """pixel_values [n, 3, image, image] fp32 -> last_hidden_state [n, tokens, hidden] (fp32 and/or compute dtype)."""
+    if pixel_values is None:
+        raise ValueError("You have to specify pixel_values")
+    _need_cuda(pixel_values)
+    pv = pixel_values.contiguous().float()
+    n = pv.shape[0]
+    if tuple(pv.shape[1:]) != (3, w.image, w.image):
+        raise ValueError(f"vit: pixel_values {tuple(pv.shape)} does not match image size {w.image}")
+    dev = pv.device
+    out32 = torch.empty(n, w.tokens, w.hidden, dtype=torch.float32, device=dev) if want_f32 else None
+    outa = torch.empty(n, w.tokens, w.hidden, dtype=act_dtype(w.code), device=dev) if want_act else None
+    a = L.VitArgs(w.code, n, w.image, w.patch, w.hidden, w.heads, w.mlp, w.layers, float(w.eps), pv.data_ptr(),
+                  C.cast(w.array, C.POINTER(C.c_void_p)), _ptr(out32), _ptr(outa), None, 0)
+    need = L.lib().vtgb_vit_workspace_bytes(C.byref(a))
+    ws = _ws.get(need, dev)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.check(L.lib().vtgb_vit_forward(C.byref(a), _stream()))
+    return out32, outa
+
+
+def qformer_forward(w: QFormerWeights, query_tokens: Tensor, image_embeds: Tensor, text_ids: Optional[Tensor] = None,
+                    text_mask: Optional[Tensor] = None, image_mask: Optional[Tensor] = None) -> Tensor:
+    """image_embeds [n, tokens, enc_hidden] in the compute dtype -> query rows [n, n_query, hidden] fp32."""
+    _need_cuda(image_embeds, query_tokens)
+    ie = image_embeds.contiguous()
+    if ie.dtype != act_dtype(w.code):
+        ie = ie.to(act_dtype(w.code))
+    n, enc_tokens, enc_hidden = ie.shape
+    qt = query_tokens.reshape(-1, query_tokens.shape[-1]).contiguous().float()
+    nq = qt.shape[0]
+    nt = 0
+    if w.has_text and text_ids is not None:
+        text_ids = text_ids.contiguous().to(torch.int64)
+        nt = text_ids.shape[1]
+        if text_mask is not None:
+            text_mask = text_mask.contiguous().to(torch.int64)
+    else:
+        text_ids = text_mask = None
+    if image_mask is not None:
+        image_mask = image_mask.contiguous().to(torch.int64)
+    out = torch.empty(n, nq, w.hidden, dtype=torch.float32, device=ie.device)
+    a = L.QFormerArgs(w.code, n, nq, nt, w.hidden, w.heads, w.ffn, w.layers, w.cross_freq, enc_tokens, enc_hidden,
+                      1 if (w.has_text and nt > 0) else 0, float(w.eps), ie.data_ptr(), qt.data_ptr(), _ptr(text_ids),
+                      _ptr(text_mask), _ptr(image_mask), C.cast(w.array, C.POINTER(C.c_void_p)), out.data_ptr(), None, 0)
+    need = L.lib().vtgb_qformer_workspace_bytes(C.byref(a))
+    ws = _ws.get(need, ie.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.check(L.lib().vtgb_qformer_forward(C.byref(a), _stream()))
+    return out
+
+
+def pool_project(query_out: Tensor, widths: Sequence[int], proj_w: Tensor, proj_b: Tensor, mode: str, code: int) -> Tensor:
+    """query_out [sum(widths), n_query, hidden] fp32; proj_w packed for `code` -> LLM prefix tokens (fp32)."""
+    _need_cuda(query_out, proj_w)
+    if mode not in ("mean", "concat"):
+        raise ValueError(f"INVALID POOL MODE: {mode}")
+    qo = query_out.contiguous().float()
+    total, nq, hidden = qo.shape
+    if sum(widths) != total:
+        raise ValueError(f"pool_project: widths sum {sum(widths)} != {total} frames")
+    n_clips = len(widths)
+    out_dim = proj_w.shape[0]
+    if mode == "mean":
+        out = torch.empty(n_clips, nq, out_dim, dtype=torch.float32, device=qo.device)
+    else:
+        out = torch.empty(total * nq, out_dim, dtype=torch.float32, device=qo.device)
+    wd = (C.c_int32 * n_clips)(*[int(x) for x in widths])
+    a = L.PoolProjectArgs(code, n_clips, nq, hidden, out_dim, L.POOL_MEAN if mode == "mean" else L.POOL_CONCAT, qo.data_ptr(),
+                          C.cast(wd, C.POINTER(C.c_int32)), proj_w.data_ptr(), proj_b.data_ptr(), out.data_ptr(), None, 0)
+    need = L.lib().vtgb_pool_project_workspace_bytes(C.byref(a))
+    ws = _ws.get(need, qo.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.check(L.lib().vtgb_pool_project(C.byref(a), _stream()))
+    if mode == "concat":
+        if len(set(widths)) != 1:
+            raise ValueError("concat pooling needs equal widths")
+        out = out.reshape(n_clips, -1, out_dim)
+    return out
+
+
+def tgb_forward(w: TgbWeights, of: Tensor, of_mask: Tensor, text_ids: Tensor, text_mask: Tensor, mode: str):
+    """of [B, L, 2, image, image] fp32 -> (sequence_output [B, L+2, hidden], logits [B, L, 2]) fp32."""
+    if mode not in L.TGB_MODE:
+        raise ValueError(f"INVALID MODE: {mode}")
+    _need_cuda(of, of_mask, text_ids, text_mask)
+    of = of.contiguous().float()
+    B, Lf = of.shape[:2]
+    if tuple(of.shape[2:]) != (2, w.image, w.image):
+        raise ValueError(f"tgb: flow {tuple(of.shape)} does not match image size {w.image}")
+    if Lf + 2 > w.max_pos:
+        raise ValueError(f"tgb: {Lf} flow frames exceed the {w.max_pos} position table")
+    of_mask = of_mask.contiguous().to(torch.int64)
+    text_ids = text_ids.contiguous().to(torch.int64)
+    text_mask = text_mask.contiguous().to(torch.int64)
+    seq = torch.empty(B, Lf + 2, w.hidden, dtype=torch.float32, device=of.device)
+    logits = torch.empty(B, Lf, 2, dtype=torch.float32, device=of.device)
+    a = L.TgbArgs(w.code, B, Lf, text_ids.shape[1], w.hidden, w.heads, w.ffn, w.layers, w.fusion_layer, L.TGB_MODE[mode],
+                  w.image, w.patch, float(w.eps), of.data_ptr(), of_mask.data_ptr(), text_ids.data_ptr(), text_mask.data_ptr(),
+                  C.cast(w.array, C.POINTER(C.c_void_p)), seq.data_ptr(), logits.data_ptr(), None, 0)
+    need = L.lib().vtgb_tgb_workspace_bytes(C.byref(a))
+    ws = _ws.get(need, of.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.check(L.lib().vtgb_tgb_forward(C.byref(a), _stream()))
+    return seq, logits

@@ -87,7 +87,7 @@ class QFormerCfg:
     ffn: int = 3072
     enc_hidden: int = 1408
     n_query: int = 32
-    vocab: int = 30523
+    vocab: int = 30522
     max_pos: int = 512
     cross_freq: int = 2
     has_text: bool = True       # InstructBLIP: True; BLIP-2: False
@@ -121,7 +121,7 @@ class PathCfg:
 def full_cfg(arch: str = "instructblip") -> PathCfg:
     """InstructBLIP-Vicuna-7B (C3/C4/C5) or BLIP2-Flan-T5-xl (C1/C2) dims, SURVEY.md 8."""
     if arch == "instructblip":
-        return PathCfg("instructblip", VitCfg(), QFormerCfg(has_text=True, vocab=30523), TgbCfg(), 4096)
+        return PathCfg("instructblip", VitCfg(), QFormerCfg(has_text=True, vocab=30522), TgbCfg(), 4096)
     return PathCfg("blip2", VitCfg(), QFormerCfg(has_text=False, vocab=30522), TgbCfg(), 2048)
 
 
