@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""clips/s of the VideoTGB video -> LLM hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--clips B] [--flow precomputed|raft]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): InstructBLIP-Vicuna-7B + TGB, T = 96 flow frames -> 8 of 32 candidate
+frames, bf16, greedy decode of 16 new tokens (BASELINE.json configs[2], the configuration the
+metric is quoted on).  One step = one pass of the whole path over a batch of B synthetic clips
+per GPU, inputs already resident in HBM:
+    [RAFT flow, --flow raft only] -> TGB span scorer -> Gumbel top-k select -> index map ->
+    frame gather -> EVA-ViT-g (8 frames/clip) -> Q-Former -> mean-pool + language_projection ->
+    HF LlamaForCausalLM.generate (Vicuna-7B geometry, random init, third-party on both sides).
+Clips shard across ranks with no data-path collective (weak scaling: B clips per GPU per step).
+Weights are random-init (seeded N(0, 0.02)), data synthetic: there is no network here.
+
+The JSON line also carries
+  roofline     for the dominant kernel family (gemm_bf16_kernel, the ViT/Q-Former/TGB GEMMs):
+               algorithmic FLOPs / summed launch time, both recorded per launch with HIP events on
+               the launch stream inside the timed region (include/vtgb.h, vtgb_prof_*);
+  cpu_baseline the CPU oracle (a port: the reference's Python cannot travel) timed on this box's
+               host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+VIT_GFLOP_PER_FRAME = 520.72   # SURVEY.md 8d / BASELINE.md 2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--clips", type=int, default=16, help="clips per GPU per step")
+    ap.add_argument("--T", type=int, default=96, help="flow frames per clip")
+    ap.add_argument("--nframe", type=int, default=8)
+    ap.add_argument("--flow", choices=["precomputed", "raft"], default="precomputed")
+    ap.add_argument("--max-new-tokens", type=int, default=16)
+    ap.add_argument("--llm", default="vicuna-7b")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not record per-launch HIP events")
+    ap.add_argument("--stage-times", action="store_true", help="print a per-stage breakdown to stderr")
+    return ap.parse_args()
+
+
+def synth_batch(rank, step_id, B, T, flow, dev, cfg):
+    """B synthetic clips generated directly in HBM with a device generator."""
+    g = torch.Generator(device=dev).manual_seed(1234 + 7919 * rank + step_id)
+    d = {}
+    d["frames"] = torch.randn(B * 32, 3, 224, 224, generator=g, device=dev)
+    if flow == "precomputed":
+        d["of"] = torch.rand(B, T, 2, 224, 224, generator=g, device=dev) * 2 - 1
+        d["flow_frames"] = None
+    else:
+        d["of"] = None
+        d["flow_frames"] = torch.randn(B, T, 3, 224, 224, generator=g, device=dev)
+
+    def ids(n, lo, hi):
+        return torch.randint(lo, hi, (B, n), generator=g, device=dev)
+    cls = torch.full((B, 1), 101, device=dev)
+    sep = torch.full((B, 1), 102, device=dev)
+    d["sampler_ids"] = torch.cat([cls, ids(12, 1000, 30000), sep], 1)
+    d["qformer_ids"] = torch.cat([cls, ids(12, 1000, 30000), sep], 1)
+    d["prompt_ids"] = ids(20, 3, 32000)
+    d["noise"] = -torch.empty(2, 2 * B, T, device=dev).exponential_(generator=g).log()
+    return d
+
+
+def run_step(m, d, B, nframe, max_new_tokens, ev=None):
+    """One pass of the path over a resident batch.  Returns the generated ids."""
+    te = {"input_ids": d["prompt_ids"], "attention_mask": torch.ones_like(d["prompt_ids"]),
+          "qformer_input_ids": d["qformer_ids"], "qformer_attention_mask": torch.ones_like(d["qformer_ids"])}
+    se = {"input_ids": d["sampler_ids"], "attention_mask": torch.ones_like(d["sampler_ids"])}
+
+    def mark(name):
+        if ev is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev.append((name, e))
+    mark("start")
+    of = d["of"] if d["of"] is not None else m.flow(d["flow_frames"])
+    mark("flow")
+    pix = d["frames"].view(B, 32, 3, 224, 224)
+    sampled, idx, _ = m.select_frames(pix, of, se["input_ids"], se["attention_mask"], nframe, d["noise"])
+    mark("tgb+select+gather")
+    img = m.model.vision_model(pixel_values=sampled, act_output=True).last_hidden_state
+    mark("vit")
+    qt = m.model.query_tokens.expand(img.shape[0], -1, -1)
+    qi = torch.repeat_interleave(te["qformer_input_ids"], nframe, 0)
+    am = torch.ones(img.shape[0], qt.shape[1] + qi.shape[1], dtype=torch.long, device=img.device)
+    qo = m.model.qformer(input_ids=qi, attention_mask=am, query_embeds=qt, encoder_hidden_states=img).last_hidden_state
+    prefix = m.model.language_projection.pool(qo, [nframe] * B, "mean")
+    mark("qformer+pool")
+    lm = m.model.language_model
+    prefix = prefix.to(torch.bfloat16)
+    emb = torch.cat([prefix, m.model.get_input_embeddings()(te["input_ids"])], dim=1)
+    mask = torch.ones(emb.shape[:2], dtype=torch.long, device=emb.device)
+    out = lm.generate(inputs_embeds=emb, attention_mask=mask, do_sample=False, max_new_tokens=max_new_tokens,
+                      min_new_tokens=max_new_tokens, use_cache=True)
+    mark("llm")
+    return out, idx
+
+
+def cpu_baseline(cfg, T, nframe, seed_sd):
+    """Oracle (port of the reference's CPU path) on one clip: TGB -> select -> gather -> ViT-g ->
+    Q-Former -> mean-pool + projection, fp32, flow precomputed.  The 7B LLM decode is left out of
+    the sample (27 GB of fp32 weights; third-party arithmetic on both sides)."""
+    from oracle import vtgb_oracle as O
+    from videotgb_amd import synth
+    cores = torch.get_num_threads()
+    clip = synth.synth_clip(0, T)
+    t0 = time.time()
+    with torch.no_grad():
+        O.lstp_prefix(seed_sd, arch="instructblip", frames=clip["frames"], nframe=nframe, sampler_ids=clip["sampler_ids"],
+                      sampler_mask=clip["sampler_mask"], noise=clip["noise"], vit_heads=cfg.vit.heads,
+                      qf_heads=cfg.qformer.heads, tgb_heads=cfg.tgb.heads, fusion_layer=cfg.tgb.fusion_layer, of=clip["of"],
+                      qformer_ids=clip["qformer_ids"], qformer_mask=clip["qformer_mask"])
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"1 clip (T={T}->{nframe} of 32 frames, precomputed flow), TGB+select+gather+ViT-g+Q-Former+projection "
+                      f"in fp32 on {cores} host threads, {dt:.1f} s; LLM decode excluded"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (the hot path has no CPU implementation)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from videotgb_amd import _lib, llm, models, synth
+    _lib.lib()
+    cfg = synth.full_cfg("instructblip")
+    t_setup = time.time()
+    lm = llm.build_llama(args.llm, torch.bfloat16, dev, seed=0)
+    m = models.LSTP(cfg, dev, language_model=lm, compute_dtype="bf16")
+    sd = synth.path_state_dict(cfg, seed=0, with_raft=True)
+    m.load_state_dict(sd, strict=False)
+    m.to(dev)
+    lm.to(torch.bfloat16)
+    B, T, nframe = args.clips, args.T, args.nframe
+    batches = [synth_batch(rank, i, B, T, args.flow, dev, cfg) for i in range(2)]
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f"[bench] setup {time.time() - t_setup:.1f}s, world={world}, clips/step/gpu={B}, flow={args.flow}", file=sys.stderr)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        run_step(m, batches[i % 2], B, nframe, args.max_new_tokens)
+    prof = not args.no_prof
+    L = _lib.lib()
+    L.vtgb_prof_reset()
+    L.vtgb_prof_enable(1 if prof else 0)
+    stage_ev = []
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev = [] if args.stage_times else None
+        run_step(m, batches[i % 2], B, nframe, args.max_new_tokens, ev)
+        if ev:
+            stage_ev.append(ev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L.vtgb_prof_enable(0)
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    total_clips = B * args.steps * world
+    value = total_clips / elapsed
+
+    roofline = None
+    if prof:
+        n, ms, fl = _lib.prof_summary(0)
+        na, msa, fla = _lib.prof_summary(1)
+        if n and ms > 0:
+            ach = fl / (ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel (128x128x64 MFMA tiles, all epilogues)",
+                        "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                        "traffic": None, "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
+                        "gemm_ms_per_step": round(ms / args.steps, 3), "gemm_gflop_per_step": round(fl / args.steps / 1e9, 1),
+                        "attention": {"launches": na, "avg_launch_us": round(msa * 1e3 / max(na, 1), 2),
+                                      "achieved_tflops": round(fla / max(msa, 1e-9) / 1e9, 2)}}
+    if stage_ev and rank == 0:
+        acc = {}
+        for ev in stage_ev:
+            for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+                acc[n1] = acc.get(n1, 0.0) + e0.elapsed_time(e1)
+        print("[bench] ms/step by stage: " + ", ".join(f"{k}={v / len(stage_ev):.1f}" for k, v in acc.items()), file=sys.stderr)
+
+    if rank == 0:
+        out = {"metric": "clips/sec end-to-end VideoQA (96->8 frames)", "value": round(value, 3), "unit": "clips/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"InstructBLIP-Vicuna-7B + TGB, T={T}->{nframe} of 32 frames, 224x224, greedy {args.max_new_tokens} new tokens "
+                                      f"(BASELINE.json configs[2])", "flow": args.flow, "clips_per_gpu_per_step": B,
+                          "global_batch": B * world, "parallelism": f"clip-parallel x{world} (no data-path collective)",
+                          "llm": f"HF LlamaForCausalLM {args.llm} geometry, random init, KV cache", "weights": "seeded N(0,0.02) random init"},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(cfg, T, nframe, sd)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

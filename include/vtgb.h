@@ -262,6 +262,18 @@ typedef struct {
 } vtgb_layernorm_args;
 int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream);
 
+/* ---- in-library launch timing (used by bench.py for the roofline figure) -------------------
+ * While enabled, every GEMM / attention launch of the bf16 path is bracketed by a pair of HIP
+ * events recorded on the launch stream (no synchronisation at record time).  vtgb_prof_summary
+ * synchronises on the recorded events and returns launch count, summed kernel time and summed
+ * algorithmic FLOPs (2*M*N*K per GEMM, 4*B*H*Sq*Skv*hd per attention) of one kind since the
+ * last vtgb_prof_reset. */
+#define VTGB_PROF_GEMM 0
+#define VTGB_PROF_ATTN 1
+void vtgb_prof_enable(int on);
+void vtgb_prof_reset(void);
+int vtgb_prof_summary(int kind, int64_t* launches, double* ms, double* flops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,95 @@
+"""-m gpu: the whole path (LSTP.generate / LSTP_blip2.generate twins) against the vectors
+recorded from the reference's own generate() on a tiny configuration, RAFT inline, noise
+injected.  fp32 mode: frame indices and greedy token ids bit-exact, tensors to 1e-3 of their
+scale (RAFT runs 20 recurrent iterations through MIOpen on the GPU vs. the CPU reference);
+bf16 mode: indices equal, tensors to the bf16 tolerance of test_gpu_stages.py."""
+import pytest
+import torch
+
+from conftest import deq, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from videotgb_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def build(arch, tiny_sd, dev, dtype):
+    from videotgb_amd import llm, models
+    from videotgb_amd.synth import synth_tensor
+    cfg, sd = tiny_sd[arch]
+    lm = llm.build_llama("tiny", torch.float32, dev)
+    lsd = {k: synth_tensor("model.language_model." + k, tuple(v.shape)).to(dev) for k, v in lm.state_dict().items()}
+    lm.load_state_dict(lsd, strict=True)
+    cls = models.LSTP if arch == "instructblip" else models.LSTP_blip2
+    m = cls(cfg, dev, language_model=lm, compute_dtype=dtype)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("model.language_model.") for k in missing), (missing[:4], unexpected[:4])
+    m.to(dev)
+    return m, cfg
+
+
+class BE(dict):
+    __getattr__ = dict.__getitem__
+
+
+@pytest.mark.parametrize("arch", ["instructblip", "blip2"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_generate_vs_reference(dev, tiny_sd, arch, dtype):
+    m, cfg = build(arch, tiny_sd, dev, dtype)
+    g = load_golden(f"tiny_{arch}_e2e")
+    te = BE(input_ids=g["prompt_ids"].to(dev), attention_mask=g["prompt_mask"].to(dev))
+    if arch == "instructblip":
+        te["qformer_input_ids"] = g["qformer_ids"].to(dev)
+        te["qformer_attention_mask"] = g["qformer_mask"].to(dev)
+    se = BE(input_ids=g["sampler_ids"].to(dev), attention_mask=g["sampler_mask"].to(dev))
+    ids, cand, st = m.generate(deq(g, "frames_q8").to(dev), deq(g, "flow_frames_q8").to(dev), int(g["nframe"]), te, se,
+                               do_sample=False, temperature=None, max_new_tokens=6, use_cache=False, noise=g["noise"].to(dev),
+                               return_stages=True)
+
+    def chk(name, got, ref, tol):
+        got, ref = got.float().cpu(), ref.float()
+        err, scale = (got - ref).abs().max().item(), ref.abs().max().item()
+        print(f"[e2e {arch} {dtype}] {name}: max|diff|={err:.3e} max|ref|={scale:.3e}")
+        assert err <= tol * scale, name
+    tol = 1e-3 if dtype == "f32" else 6e-2
+    chk("raft flow", st["of"][0, :-1], g["raft_flow"], 1e-3)
+    assert torch.equal(st["of"][0, -1], st["of"][0, -2])            # last flow repeated (eval/utils/model.py:82)
+    chk("tgb logits", st["tgb_logits"], g["tgb_logits"], tol)
+    assert cand.cpu().tolist() == g["cand_index"].tolist()
+    assert torch.equal(st["sampled"].cpu(), g["sampled"])
+    chk("prefix", st["prefix"], g["prefix"], tol)
+    chk("inputs_embeds", st["inputs_embeds"], g["inputs_embeds"], tol)
+    if dtype == "f32":
+        assert ids.cpu().tolist() == g["greedy_ids"].tolist()      # greedy token ids bit-exact at fp32
+
+
+def test_precomputed_flow_and_concat_pool(dev, tiny_sd):
+    """batch['of'] contract (src/models/LSTP_SF_module.py:476) + concat pooling (LSTP_module.py:477-481)
+    against the oracle composed in the same order."""
+    from oracle import vtgb_oracle as O
+    m, cfg = build("instructblip", tiny_sd, dev, "f32")
+    sd = tiny_sd["instructblip"][1]
+    g = torch.Generator().manual_seed(8)
+    B, T, N, nframe = 2, 10, 8, 4
+    frames = torch.randn(B * N, 3, 56, 56, generator=g)
+    of = torch.rand(B, T, 2, 224, 224, generator=g) * 2 - 1
+    sids = torch.randint(3, cfg.tgb.vocab, (B, 7), generator=g)
+    qids = torch.randint(3, cfg.qformer.vocab, (B, 5), generator=g)
+    noise = O.gumbel_noise((2, 2 * B, T), g)
+    ref = O.lstp_prefix(sd, arch="instructblip", frames=frames, nframe=nframe, sampler_ids=sids, sampler_mask=torch.ones_like(sids),
+                        noise=noise, vit_heads=cfg.vit.heads, qf_heads=cfg.qformer.heads, tgb_heads=cfg.tgb.heads,
+                        fusion_layer=cfg.tgb.fusion_layer, of=of, qformer_ids=qids, qformer_mask=torch.ones_like(qids), pool="concat")
+    sampled, idx, _ = m.select_frames(frames.to(dev).view(B, N, 3, 56, 56), of.to(dev), sids.to(dev), torch.ones_like(sids).to(dev),
+                                      nframe, noise.to(dev))
+    assert idx.cpu().tolist() == ref["cand_index"].tolist()
+    te = {"qformer_input_ids": qids.to(dev), "qformer_attention_mask": torch.ones_like(qids).to(dev)}
+    prefix = m.prefix(sampled, B, nframe, te, "concat")
+    assert prefix.shape == ref["prefix"].shape == (B, nframe * 32, cfg.llm_hidden)
+    assert (prefix.cpu() - ref["prefix"]).abs().max().item() <= 2e-4 * ref["prefix"].abs().max().item()

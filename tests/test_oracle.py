@@ -138,3 +138,45 @@ def test_e2e_prefix_vs_reference(tiny_sd, arch):
     close(r["query_out"], g["query_out"], rtol=1e-4, atol=1e-4)
     close(r["prefix"], g["prefix"], rtol=1e-4, atol=1e-4)
     close(r["prefix"], g["inputs_embeds"][:, :32], rtol=1e-4, atol=1e-4)
+
+
+def _c_oracle():
+    import ctypes as C
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-s", "-C", here])
+    return C.CDLL(os.path.join(here, "libvtgb_oracle.so"))
+
+
+def test_c_restatement_matches_reference_tables():
+    """oracle/span_map.c (the plain-C restatement) against the table recorded from the reference."""
+    import ctypes as C
+    lib = _c_oracle()
+    rows = load_golden("integer_tables")["span_map"].numpy()
+    for r in rows[::7]:
+        variant, V, N, nframe = (int(x) for x in r[:4])
+        sel = np.array([[r[4], r[5]], [r[6], r[7]]], dtype=np.int64)
+        out = np.zeros(nframe, dtype=np.int64)
+        rc = lib.vo_span_to_frames(sel.ctypes.data_as(C.c_void_p), None, out.ctypes.data_as(C.c_void_p), 1, 2, V, N, nframe, variant)
+        assert rc == 0 and out.tolist() == [int(x) for x in r[8:8 + nframe]]
+    g = torch.Generator().manual_seed(2)
+    logits = torch.randn(3, 50, 2, generator=g)
+    noise = O.gumbel_noise((2, 6, 50), g)
+    idx = np.zeros((2, 6), dtype=np.int64)
+    lib.vo_span_select(C.c_void_p(logits.data_ptr()), C.c_void_p(noise.data_ptr()), idx.ctypes.data_as(C.c_void_p), 3, 50, 2, C.c_float(0.5))
+    assert idx.tolist() == O.span_select(logits, noise).tolist()
+
+
+def test_full_size_oracle_vs_reference_probes():
+    """Full-size Q-Former and BERT-base TGB: oracle vs probe elements recorded from the reference.
+    (ViT-g full size is checked on the GPU box against the same probes: tests/test_gpu_stages.py.)"""
+    from videotgb_amd.synth import QFormerCfg, TgbCfg, qformer_shapes, synth_state_dict, synth_tensor, tgb_shapes
+    p = load_golden("full_probes")
+    tsd = synth_state_dict(tgb_shapes(TgbCfg(), ""), 0)
+    of = p["tgb_of_q8"].float() / 127
+    for mode in ("multi_modal", "fusion"):
+        seq, logits = O.tgb_forward(tsd, "", of, torch.ones(1, 26, dtype=torch.long), p["tgb_text_ids"],
+                                    torch.ones_like(p["tgb_text_ids"]), mode, 12, 6)
+        close(logits, p[f"tgb_logits_{mode}"], rtol=1e-4, atol=1e-4)
+        assert abs(seq.abs().mean().item() - float(p[f"tgb_seq_absmean_{mode}"])) < 1e-4

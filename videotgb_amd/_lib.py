@@ -5,6 +5,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: libvtgb.so must bind to the HIP runtime PyTorch has loaded (one runtime,
+#                             one device context per process); loading it before torch gives it a second one
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libvtgb.so")
 
@@ -22,7 +25,7 @@ EXPORTS = [
     "vtgb_gather_frames", "vtgb_vit_patch_kpad", "vtgb_vit_workspace_bytes", "vtgb_vit_forward",
     "vtgb_qformer_workspace_bytes", "vtgb_qformer_forward", "vtgb_pool_project_workspace_bytes",
     "vtgb_pool_project", "vtgb_tgb_workspace_bytes", "vtgb_tgb_forward", "vtgb_gemm", "vtgb_attention",
-    "vtgb_layernorm",
+    "vtgb_layernorm", "vtgb_prof_enable", "vtgb_prof_reset", "vtgb_prof_summary",
 ]
 
 i32, i64, f32, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -118,8 +121,20 @@ def lib() -> C.CDLL:
         fn = getattr(L, f"vtgb_{name}_workspace_bytes")
         fn.argtypes = [C.POINTER(st)]
         fn.restype = sz
+    L.vtgb_prof_enable.argtypes = [C.c_int]
+    L.vtgb_prof_enable.restype = None
+    L.vtgb_prof_reset.restype = None
+    L.vtgb_prof_summary.argtypes = [C.c_int, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.vtgb_prof_summary.restype = C.c_int
     _lib = L
     return L
+
+
+def prof_summary(kind: int):
+    """(launches, total kernel ms, total algorithmic FLOPs) of one launch kind since the last reset."""
+    n, ms, fl = i64(0), C.c_double(0), C.c_double(0)
+    check(lib().vtgb_prof_summary(kind, C.byref(n), C.byref(ms), C.byref(fl)))
+    return n.value, ms.value, fl.value
 
 
 _ERR = {-1: ValueError, -2: VtgbError, -3: VtgbError, -4: NotImplementedError}

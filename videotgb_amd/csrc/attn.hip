@@ -297,6 +297,7 @@ static int launch_bf16(const AttnDesc& d, hipStream_t s) {
     const int tps = (n_qt + splits - 1) / splits;
     const int max_waves = NKP <= 9 ? 8 : 4;
     const int waves = tps < max_waves ? tps : max_waves;
+    ProfScope prof(VTGB_PROF_ATTN, 4.0 * d.batch * d.heads * (double)d.s_q * d.s_kv * d.head_dim, s);
     hipLaunchKernelGGL((attn_bf16_kernel<HD, NKP>), dim3(splits, d.heads, d.batch), dim3(64 * waves), C::LDS, s, d, tps);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;

@@ -141,3 +141,11 @@ int launch_flow_assemble(const float* conv, const float* proj_b, const float* fc
 int launch_mean_pool_uniform(const float* q, float* out, int n_clips, int width, int64_t row_elems, hipStream_t s);
 int launch_pack_bf16(const float* src, void* dst, int64_t rows, int64_t cols, int64_t cols_pad, hipStream_t s);
 int launch_mrc_head(const float* x, const float* w, const float* b, float* logits, int B, int L, int hidden, hipStream_t s);
+
+// launch timing (forward.hip): bracket a launch with events when profiling is enabled
+struct ProfScope {
+    int slot;
+    hipStream_t s;
+    ProfScope(int kind, double flops, hipStream_t stream);
+    ~ProfScope();
+};

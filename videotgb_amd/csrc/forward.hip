@@ -26,6 +26,52 @@ extern "C" int vtgb_pack_bf16(const float* src, void* dst, int64_t rows, int64_t
     return launch_pack_bf16(src, dst, rows, cols, cols_pad, stream);
 }
 
+// ---------------------------------------------------------------------------------------
+// launch timing
+// ---------------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+struct Prof {
+    bool on = false;
+    std::vector<ProfRec> recs;   // pool: events are created once and reused after reset
+    size_t used = 0;
+} g_prof;
+}  // namespace
+ProfScope::ProfScope(int kind, double flops, hipStream_t stream) : slot(-1), s(stream) {
+    if (!g_prof.on) return;
+    if (g_prof.used == g_prof.recs.size()) {
+        ProfRec r;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        g_prof.recs.push_back(r);
+    }
+    slot = (int)g_prof.used++;
+    g_prof.recs[slot].kind = kind;
+    g_prof.recs[slot].flops = flops;
+    (void)hipEventRecord(g_prof.recs[slot].a, s);
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof.recs[slot].b, s);
+}
+extern "C" void vtgb_prof_enable(int on) { g_prof.on = on != 0; }
+extern "C" void vtgb_prof_reset(void) { g_prof.used = 0; }
+extern "C" int vtgb_prof_summary(int kind, int64_t* launches, double* ms, double* flops) {
+    int64_t n = 0;
+    double t = 0, f = 0;
+    for (size_t i = 0; i < g_prof.used; i++) {
+        const ProfRec& r = g_prof.recs[i];
+        if (r.kind != kind) continue;
+        VTGB_HIP(hipEventSynchronize(r.b));
+        float e = 0.f;
+        VTGB_HIP(hipEventElapsedTime(&e, r.a, r.b));
+        n++; t += e; f += r.flops;
+    }
+    if (launches) *launches = n;
+    if (ms) *ms = t;
+    if (flops) *flops = f;
+    return VTGB_OK;
+}
+
 static inline const void* off(const void* p, int64_t elems, int dtype) { return (const char*)p + elems * (int64_t)dtype_size(dtype); }
 static inline void* off(void* p, int64_t elems, int dtype) { return (char*)p + elems * (int64_t)dtype_size(dtype); }
 

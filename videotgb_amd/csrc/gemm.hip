@@ -230,6 +230,7 @@ static int launch_epi(const GemmDesc& d, hipStream_t s) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
+        ProfScope prof(VTGB_PROF_GEMM, 2.0 * d.M * d.N * d.K, s);
         hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(256), lds, s, d);
     } else {
         dim3 grid((d.N + 63) / 64, (d.M + 63) / 64);

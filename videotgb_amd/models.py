@@ -55,7 +55,6 @@ class ParamTree(nn.Module):
                 if p not in mod._modules:
                     mod.add_module(p, nn.Module())
                 mod = mod._modules[p]
-            init = synth.synth_tensor(key, shape, seed=0) if False else None
             if parts[-1] in self._BUFFERS:
                 dt = torch.long if parts[-1] in ("position_ids", "num_batches_tracked") else torch.float32
                 buf = torch.zeros(shape, dtype=dt)
