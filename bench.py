@@ -43,12 +43,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clips", type=int, default=16, help="clips per GPU per step")
+    ap.add_argument("--clips", type=int, default=32, help="clips per GPU per step")
     ap.add_argument("--T", type=int, default=96, help="flow frames per clip")
     ap.add_argument("--nframe", type=int, default=8)
     ap.add_argument("--flow", choices=["precomputed", "raft"], default="precomputed")
     ap.add_argument("--max-new-tokens", type=int, default=16)
     ap.add_argument("--llm", default="vicuna-7b")
+    ap.add_argument("--decode", choices=["graph", "hf"], default="graph",
+                    help="graph: videotgb_amd.decode.GreedyDecoder (one hipGraph replay per token); hf: HF generate, eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-launch HIP events")
     ap.add_argument("--stage-times", action="store_true", help="print a per-stage breakdown to stderr")
@@ -78,7 +80,7 @@ def synth_batch(rank, step_id, B, T, flow, dev, cfg):
     return d
 
 
-def run_step(m, d, B, nframe, max_new_tokens, ev=None):
+def run_step(m, d, B, nframe, max_new_tokens, ev=None, decoder=None):
     """One pass of the path over a resident batch.  Returns the generated ids."""
     te = {"input_ids": d["prompt_ids"], "attention_mask": torch.ones_like(d["prompt_ids"]),
           "qformer_input_ids": d["qformer_ids"], "qformer_attention_mask": torch.ones_like(d["qformer_ids"])}
@@ -107,8 +109,11 @@ def run_step(m, d, B, nframe, max_new_tokens, ev=None):
     prefix = prefix.to(torch.bfloat16)
     emb = torch.cat([prefix, m.model.get_input_embeddings()(te["input_ids"])], dim=1)
     mask = torch.ones(emb.shape[:2], dtype=torch.long, device=emb.device)
-    out = lm.generate(inputs_embeds=emb, attention_mask=mask, do_sample=False, max_new_tokens=max_new_tokens,
-                      min_new_tokens=max_new_tokens, use_cache=True)
+    if decoder is not None:
+        out = decoder.generate(emb, max_new_tokens)
+    else:
+        out = lm.generate(inputs_embeds=emb, attention_mask=mask, do_sample=False, max_new_tokens=max_new_tokens,
+                          min_new_tokens=max_new_tokens, use_cache=True)
     mark("llm")
     return out, idx
 
@@ -166,8 +171,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        run_step(m, batches[i % 2], B, nframe, args.max_new_tokens)
+    decoder = None
+    if args.decode == "graph":
+        from videotgb_amd.decode import GreedyDecoder
+        decoder = GreedyDecoder(lm)
+    for i in range(max(args.warmup, 1 if decoder else 0)):   # the first graph-decode call captures the graph
+        run_step(m, batches[i % 2], B, nframe, args.max_new_tokens, None, decoder)
     prof = not args.no_prof
     L = _lib.lib()
     L.vtgb_prof_reset()
@@ -177,7 +186,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev = [] if args.stage_times else None
-        run_step(m, batches[i % 2], B, nframe, args.max_new_tokens, ev)
+        run_step(m, batches[i % 2], B, nframe, args.max_new_tokens, ev, decoder)
         if ev:
             stage_ev.append(ev)
     barrier()
@@ -216,7 +225,7 @@ def main():
                "config": {"workload": f"InstructBLIP-Vicuna-7B + TGB, T={T}->{nframe} of 32 frames, 224x224, greedy {args.max_new_tokens} new tokens "
                                       f"(BASELINE.json configs[2])", "flow": args.flow, "clips_per_gpu_per_step": B,
                           "global_batch": B * world, "parallelism": f"clip-parallel x{world} (no data-path collective)",
-                          "llm": f"HF LlamaForCausalLM {args.llm} geometry, random init, KV cache", "weights": "seeded N(0,0.02) random init"},
+                          "llm": f"HF LlamaForCausalLM {args.llm} geometry, random init, KV cache, decode={args.decode}", "weights": "seeded N(0,0.02) random init"},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()

@@ -1,0 +1,155 @@
+"""Greedy decode for the LLM at the end of the path, replayed from a hipGraph.
+
+The LLM is third-party on both sides: the reference calls HF
+``language_model.generate(inputs_embeds=...)`` one eager forward per token, which on MI355X is
+launch-bound (~500 small launches per token).  This module runs the SAME arithmetic (the HF
+Llama weights, RMSNorm / rotary / SwiGLU definitions of transformers' modeling_llama) as plain
+PyTorch-ROCm ops over a static KV cache and captures ONE decode step -- embedding lookup, all
+layers, lm_head, argmax, token/position feedback -- into a hipGraph (torch.cuda.CUDAGraph),
+so the N-token loop is N graph replays with no host round trip.  At the batch sizes of the
+throughput harness the step is then HBM-bound (13.5 GB of bf16 weights per token for Vicuna-7B).
+
+Scope: Llama-architecture models, greedy, all-ones attention mask (no padding) -- the case of
+every benchmark configuration.  Anything else goes through HF generate (models.LSTP.generate).
+Greedy ids are checked token-for-token against HF generate at fp32 in tests/test_gpu_e2e.py.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+def _rms(x: Tensor, w: Tensor, eps: float) -> Tensor:
+    # LlamaRMSNorm.forward: fp32 variance, weight * x.to(input_dtype)
+    dt = x.dtype
+    xf = x.float()
+    xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    return w * xf.to(dt)
+
+
+def _rot_half(x: Tensor) -> Tensor:
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+class GreedyDecoder:
+    def __init__(self, lm):
+        cfg = lm.config
+        if "llama" not in cfg.model_type:
+            raise NotImplementedError("GreedyDecoder handles Llama-architecture models; use HF generate otherwise")
+        self.lm, self.cfg = lm, cfg
+        self.nh, self.nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+        self.hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+        self.eps = cfg.rms_norm_eps
+        rp = getattr(cfg, "rope_parameters", None) or {}
+        self.theta = float(rp.get("rope_theta", getattr(cfg, "rope_theta", 10000.0)))
+        self.layers = [(l.input_layernorm.weight, l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight,
+                        l.self_attn.o_proj.weight, l.post_attention_layernorm.weight, l.mlp.gate_proj.weight, l.mlp.up_proj.weight,
+                        l.mlp.down_proj.weight) for l in lm.model.layers]
+        self.graphs: Dict[Tuple[int, int, int], dict] = {}
+
+    def _rope(self, tmax: int, device, dtype):
+        inv = 1.0 / (self.theta ** (torch.arange(0, self.hd, 2, device=device, dtype=torch.float32) / self.hd))
+        fr = torch.arange(tmax, device=device, dtype=torch.float32)[:, None] * inv[None]
+        emb = torch.cat((fr, fr), dim=-1)
+        return emb.cos().to(dtype), emb.sin().to(dtype)
+
+    def _layer(self, x, w, cos, sin, kc, vc, pos_idx, mask):
+        """x [B, S, H]; cos/sin [S, hd]; kc/vc [B, nkv, Tmax, hd]; pos_idx [S] cache rows to write."""
+        ln1, wq, wk, wv, wo, ln2, wg, wu, wd = w
+        B, S, _ = x.shape
+        h = _rms(x, ln1, self.eps)
+        q = F.linear(h, wq).view(B, S, self.nh, self.hd).transpose(1, 2)
+        k = F.linear(h, wk).view(B, S, self.nkv, self.hd).transpose(1, 2)
+        v = F.linear(h, wv).view(B, S, self.nkv, self.hd).transpose(1, 2)
+        q = q * cos + _rot_half(q) * sin
+        k = k * cos + _rot_half(k) * sin
+        kc.index_copy_(2, pos_idx, k)
+        vc.index_copy_(2, pos_idx, v)
+        kk, vv = kc, vc
+        if self.nkv != self.nh:
+            rep = self.nh // self.nkv
+            kk, vv = kc.repeat_interleave(rep, 1), vc.repeat_interleave(rep, 1)
+        a = F.scaled_dot_product_attention(q, kk, vv, attn_mask=mask)
+        x = x + F.linear(a.transpose(1, 2).reshape(B, S, self.nh * self.hd), wo)
+        h = _rms(x, ln2, self.eps)
+        return x + F.linear(F.silu(F.linear(h, wg)) * F.linear(h, wu), wd)
+
+    def _head(self, x):
+        return F.linear(_rms(x, self.lm.model.norm.weight, self.eps), self.lm.lm_head.weight)
+
+    def _state(self, B: int, P: int, N: int, device, dtype):
+        key = (B, P, N)
+        st = self.graphs.get(key)
+        if st is None:
+            tmax = P + N
+            cos, sin = self._rope(tmax, device, dtype)
+            st = dict(cos=cos, sin=sin, tmax=tmax,
+                      kc=[torch.zeros(B, self.nkv, tmax, self.hd, device=device, dtype=dtype) for _ in self.layers],
+                      vc=[torch.zeros(B, self.nkv, tmax, self.hd, device=device, dtype=dtype) for _ in self.layers],
+                      tok=torch.zeros(B, dtype=torch.long, device=device), pos=torch.zeros(1, dtype=torch.long, device=device),
+                      step=torch.zeros(1, dtype=torch.long, device=device), out=torch.zeros(B, N, dtype=torch.long, device=device),
+                      ar=torch.arange(tmax, device=device), graph=None)
+            self.graphs[key] = st
+        return st
+
+    def _decode_step(self, st):
+        """One token for every sequence, entirely on the device (captured)."""
+        emb = self.lm.get_input_embeddings()
+        x = emb(st["tok"])[:, None, :]
+        pos = st["pos"]
+        cos, sin = st["cos"].index_select(0, pos), st["sin"].index_select(0, pos)
+        neg = torch.finfo(x.dtype).min
+        mask = torch.where(st["ar"][None, None, None, :] <= pos, 0.0, neg).to(x.dtype)
+        for li, w in enumerate(self.layers):
+            x = self._layer(x, w, cos, sin, st["kc"][li], st["vc"][li], pos, mask)
+        nxt = self._head(x[:, -1]).argmax(-1)
+        st["tok"].copy_(nxt)
+        st["out"].index_copy_(1, st["step"], nxt[:, None])
+        st["pos"].add_(1)
+        st["step"].add_(1)
+
+    @torch.no_grad()
+    def generate(self, inputs_embeds: Tensor, max_new_tokens: int, use_graph: bool = True) -> Tensor:
+        """inputs_embeds [B, P, H] (no padding) -> greedy ids [B, max_new_tokens]."""
+        B, P, _ = inputs_embeds.shape
+        N = max_new_tokens
+        dev, dt = inputs_embeds.device, inputs_embeds.dtype
+        st = self._state(B, P, N, dev, dt)
+        # ---- prefill (eager: a handful of large GEMMs)
+        x = inputs_embeds
+        pidx = st["ar"][:P]
+        causal = torch.where(st["ar"][None, :] <= pidx[:, None], 0.0, torch.finfo(dt).min).to(dt)[None, None]   # [1,1,P,Tmax]
+        cos, sin = st["cos"][:P], st["sin"][:P]
+        for li, w in enumerate(self.layers):
+            x = self._layer(x, w, cos, sin, st["kc"][li], st["vc"][li], pidx, causal)
+        first = self._head(x[:, -1]).argmax(-1)
+        st["tok"].copy_(first)
+        st["out"][:, 0] = first
+        st["pos"].fill_(P)
+        st["step"].fill_(1)
+        if N > 1:
+            if use_graph and st["graph"] is None:
+                # warm up on a side stream (handles, workspaces), then capture one step
+                keep = (st["tok"].clone(), st["pos"].clone(), st["step"].clone(), st["out"].clone())
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._decode_step(st)
+                torch.cuda.current_stream().wait_stream(s)
+                st["tok"].copy_(keep[0]); st["pos"].copy_(keep[1]); st["step"].copy_(keep[2]); st["out"].copy_(keep[3])
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._decode_step(st)
+                st["graph"] = g
+                st["tok"].copy_(keep[0]); st["pos"].copy_(keep[1]); st["step"].copy_(keep[2]); st["out"].copy_(keep[3])
+            for _ in range(N - 1):
+                if use_graph:
+                    st["graph"].replay()
+                else:
+                    self._decode_step(st)
+        return st["out"].clone()

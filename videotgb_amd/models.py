@@ -422,7 +422,8 @@ class _LSTPBase(nn.Module):
     @torch.no_grad()
     def generate(self, frames, flow_frames, nframe, text_encoding, sampler_text_encoding, do_sample=True, temperature=0.2,
                  max_new_tokens=1024, use_cache=True, stopping_criteria=None, of: Optional[Tensor] = None,
-                 noise: Optional[Tensor] = None, pool: str = "mean", return_stages: bool = False, **gen_kwargs):
+                 noise: Optional[Tensor] = None, pool: str = "mean", return_stages: bool = False, fast_decode: bool = False,
+                 **gen_kwargs):
         """eval/utils/model.py:48-235 (LSTP) / :267-445 (LSTP_blip2).  Extensions: ``of`` supplies a
         precomputed flow (the batch["of"] contract of the LightningModules), ``noise`` injects the
         Gumbel noise, ``pool`` selects mean (eval) or concat (LightningModules) pooling."""
@@ -445,9 +446,16 @@ class _LSTPBase(nn.Module):
         attention_mask = torch.cat([lm_mask, text_encoding["attention_mask"]], dim=1)
         inputs_embeds = self.model.get_input_embeddings()(text_encoding["input_ids"])
         inputs_embeds = torch.cat([lm_inputs, inputs_embeds.to(lm_dtype)], dim=1)
-        outputs = lm.generate(inputs_embeds=inputs_embeds, attention_mask=attention_mask, do_sample=do_sample,
-                              temperature=temperature, max_new_tokens=max_new_tokens, use_cache=use_cache,
-                              stopping_criteria=stopping_criteria, **gen_kwargs)
+        if fast_decode and not do_sample and stopping_criteria is None and bool((attention_mask != 0).all()):
+            # greedy, unpadded: hipGraph-replayed decode of the same HF weights (videotgb_amd/decode.py)
+            from .decode import GreedyDecoder
+            if getattr(self, "_decoder", None) is None or self._decoder.lm is not lm:
+                self._decoder = GreedyDecoder(lm)
+            outputs = self._decoder.generate(inputs_embeds, max_new_tokens)
+        else:
+            outputs = lm.generate(inputs_embeds=inputs_embeds, attention_mask=attention_mask, do_sample=do_sample,
+                                  temperature=temperature, max_new_tokens=max_new_tokens, use_cache=use_cache,
+                                  stopping_criteria=stopping_criteria, **gen_kwargs)
         if self.model.config.text_config.architectures[0] == "LLaMAForCausalLM":
             outputs[outputs == 0] = 2
         cand_index = idx[-1]
