@@ -19,9 +19,23 @@ enum { EPI_STORE = VTGB_EPI_STORE, EPI_GELU = VTGB_EPI_GELU, EPI_RESID_F32 = VTG
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// GELU for bf16 outputs: erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below the bf16
+// rounding of the result) -- 1 rcp + 1 exp + 8 FMA instead of libm erff's ~40 instructions, which
+// otherwise makes the fc1 epilogue as long as its whole k-loop.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = 1.0f - poly * t * __expf(-z * z);      // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
 // Store 4 consecutive n (n0..n0+3) of logical row m.  TAct is the activation type of
 // EPI_STORE / EPI_GELU outputs.
-template <int EPI, typename TAct>
+template <int EPI, typename TAct, bool FAST_GELU = false>
 __device__ __forceinline__ void epilogue4(const GemmDesc& p, int m, int n0, float v0, float v1, float v2, float v3) {
     if (m >= p.M || n0 >= p.N) return;
     float v[4] = {v0, v1, v2, v3};
@@ -57,7 +71,7 @@ __device__ __forceinline__ void epilogue4(const GemmDesc& p, int m, int n0, floa
     } else {
         if (EPI == EPI_GELU) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) v[i] = gelu_erf(v[i]);
+            for (int i = 0; i < 4; i++) v[i] = FAST_GELU ? gelu_erf_fast(v[i]) : gelu_erf(v[i]);
         }
         TAct* o = reinterpret_cast<TAct*>(p.out) + orow * p.ldo + n0;
         if (full && ((p.ldo & 3) == 0)) {
@@ -167,7 +181,232 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmDesc p) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int n = n0 + wn * 64 + i * 16 + fg * 4;
-            epilogue4<EPI, bf16_t>(p, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            epilogue4<EPI, bf16_t, true>(p, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
+// Large-kernel epilogue split: bias (and the fp32 residual) are loaded INTO the accumulators before
+// the k-loop -- 32 independent 16-byte loads per lane in flight while the first LDS-DMA tiles
+// land, with the accumulator registers themselves as destination -- so that the tail of the tile
+// is store-only.  (Measured: with the residual read in the tail, load -> add -> store chains at
+// ~250 live VGPRs ran at ~6 B/clk/CU and the epilogue of the K=1408 projection took longer than its
+// whole k-loop.)
+template <int EPI>
+__device__ __forceinline__ f32x4 acc_init4(const GemmDesc& p, int m, int n0) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m >= p.M || n0 >= p.N) return v;
+    const bool full = (n0 + 3 < p.N);
+    if (p.bias) {
+        if (full) {
+            v = *reinterpret_cast<const f32x4*>(p.bias + n0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) if (n0 + i < p.N) v[i] = p.bias[n0 + i];
+        }
+    }
+    if constexpr (EPI == EPI_RESID_F32) {
+        const float* r = p.resid + map_row(p.r_map, m) * p.ldr + n0;
+        if (full && ((p.ldr & 3) == 0)) {
+            v += *reinterpret_cast<const f32x4*>(r);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) if (n0 + i < p.N) v[i] += r[i];
+        }
+    }
+    return v;
+}
+
+template <int EPI>
+__device__ __forceinline__ void store4(const GemmDesc& p, int m, int n0, f32x4 v) {
+    if (m >= p.M || n0 >= p.N) return;
+    const bool full = (n0 + 3 < p.N) && ((p.ldo & 3) == 0);
+    const int64_t orow = map_row(p.o_map, m);
+    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
+        float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + n0;
+        if (full) {
+            *reinterpret_cast<f32x4*>(o) = v;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) if (n0 + i < p.N) o[i] = v[i];
+        }
+    } else {
+        if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = gelu_erf_fast(v[i]);
+        }
+        bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + orow * p.ldo + n0;
+        if (full) {
+            const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4*>(o) = pk;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) if (n0 + i < p.N) o[i] = (bf16_t)v[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// bf16 MFMA kernel, large-problem variant: 256x256x64 tile, 512 threads = 8 waves in
+// 2(M) x 4(N), each wave 128(m) x 64(n) = 8 x 4 v_mfma_f32_16x16x32_bf16 tiles (128 accumulator
+// VGPRs).  Operands are staged by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no
+// ds_write).  The whole 160 KiB of LDS is the staging ring: THREE 32 KiB slots for the
+// activation tile (streamed from HBM: two k-tiles of lookahead) and TWO for the weight tile
+// (L2 / Infinity-Cache resident: one k-tile of lookahead).  The k-loop is rotated so that a
+// wave's LDS fragment reads (two 48-register sets) always run under its own MFMAs; once per
+// k-tile there is a COUNTED s_waitcnt vmcnt(4) -- everything but the four youngest DMAs has
+// landed -- and one barrier, after which the freed slots are re-armed.  (Ablations on MI355X,
+// tools/gemm_ablate.py: MFMAs alone ~1.37 PFLOP/s at the clock the chip holds under load; the
+// exposed DMA wait and the exposed LDS reads each cost ~20 % in the un-rotated loop.)
+// The LDS image is lane-linear per DMA instruction (8 rows x 128 B per wave-instruction), so
+// the bank swizzle is applied to the per-lane SOURCE chunk and to the fragment reads (same
+// involution: slot = chunk ^ ((row >> 1) & 7); SQ_LDS_BANK_CONFLICT = 0 measured).
+// Workgroup -> tile map is XCD-aware: the 8 XCDs (private 4 MiB L2 each) take interleaved
+// m-tiles, and the ~32 workgroups resident on one XCD form a 4 (m) x 8 (n) super-tile so
+// that every A k-slice fetched into that L2 is used by 8 workgroups and every W k-slice by 4.
+// Requires K % 64 == 0 (every GEMM of the full-size path); anything else uses the kernel above.
+// ABL != 0: timing-only ablation builds for tools/gemm_ablate.py (results are wrong).
+// ---------------------------------------------------------------------------------------
+constexpr int L_BM = 256, L_BN = 256, L_BK = 64;
+constexpr int L_OP_BYTES = 256 * L_BK * 2;   // 32 KiB per operand tile
+constexpr int L_A_SLOTS = 3, L_W_SLOTS = 2;
+constexpr int L_LDS = (L_A_SLOTS + L_W_SLOTS) * L_OP_BYTES;   // 160 KiB
+
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc p, const int m_tiles, const int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const smem_w = smem + L_A_SLOTS * L_OP_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- XCD-aware tile assignment
+    constexpr int G = 4;
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int group = idx / (G * n_tiles), r = idx - group * (G * n_tiles);
+    const int nt = r / G, ml = group * G + (r - nt * G);
+    const int mt = ml * 8 + xcd;
+    if (mt >= m_tiles) return;
+    const int m0 = mt * L_BM, n0 = nt * L_BN;
+    const int wm = wave & 1, wn = wave >> 1;
+    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
+
+    // ---- LDS-DMA assignment: wave w stages rows [32w, 32w+32) of both operands, 4 instructions of
+    // 8 rows each; lane l of an instruction fills slot (l & 7) of row r0 + (l >> 3)
+    const bf16_t* a_src[4];
+    const bf16_t* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = wave * 32 + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
+        const int am = (m0 + row) < p.M ? (m0 + row) : p.M - 1;
+        const int wr = (n0 + row) < p.N ? (n0 + row) : p.N - 1;
+        a_src[i] = A + map_row(p.a_map, am) * p.lda + c * 8;
+        w_src[i] = W + (int64_t)wr * p.ldw + c * 8;
+    }
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+#define L_ISSUE_A(slot, k0)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; i++)                                                       \
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + (k0)), (lptr_t)(smem + (slot) * L_OP_BYTES + (wave * 32 + i * 8) * 128), 16, 0, 0);
+#define L_ISSUE_W(slot, k0)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; i++)                                                       \
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (k0)), (lptr_t)(smem_w + (slot) * L_OP_BYTES + (wave * 32 + i * 8) * 128), 16, 0, 0);
+    const int nk = p.K / L_BK;
+    const int fr = lane & 15, fg = lane >> 4;
+    // accumulators start at bias (+ residual): these loads are OLDER than every DMA below, so the
+    // counted vmcnt waits of the k-loop also cover them
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            acc[i][j] = acc_init4<EPI>(p, m0 + wm * 128 + j * 16 + fr, n0 + wn * 64 + i * 16 + fg * 4);
+    L_ISSUE_A(0, 0)
+    L_ISSUE_W(0, 0)
+    if (nk > 1) {
+        L_ISSUE_A(1, L_BK)
+        L_ISSUE_W(1, L_BK)
+    }
+    if (nk > 2) L_ISSUE_A(2, 2 * L_BK)
+    if (nk > 2) __builtin_amdgcn_s_waitcnt(0x0F7C);        // vmcnt(12): A(0), W(0) landed
+    else if (nk == 2) __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
+    else __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+
+    // fragment byte offsets inside an operand tile for the two 32-deep halves of a k-tile
+    int w_off[2][4], x_off[2][8];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) w_off[ks][i] = swz(wn * 64 + i * 16 + fr, ks * 4 + fg);
+#pragma unroll
+        for (int j = 0; j < 8; j++) x_off[ks][j] = swz(wm * 128 + j * 16 + fr, ks * 4 + fg);
+    }
+    bf16x8 wf0[4], xf0[8], wf1[4], xf1[8];
+#define L_READ(WF, XF, as_, ws_, ks)                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; i++) WF[i] = *reinterpret_cast<const bf16x8*>((ws_) + w_off[ks][i]); \
+    _Pragma("unroll") for (int j = 0; j < 8; j++) XF[j] = *reinterpret_cast<const bf16x8*>((as_) + x_off[ks][j]);
+#define L_MFMA(WF, XF)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; i++)                                                        \
+        _Pragma("unroll") for (int j = 0; j < 8; j++)                                                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], XF[j], acc[i][j], 0, 0, 0);
+    // Rotated k-loop: a wave's LDS fragment reads always run under its own MFMAs.
+    //   read half 1 of tile t | MFMAs of half 0 | counted wait + barrier (tile t fully read by everyone;
+    //   A(t+1), W(t+1) visible) | re-arm the freed slots with W(t+2), A(t+3) | read half 0 of tile t+1 |
+    //   MFMAs of half 1
+    int a_slot = 0;   // A(t) lives in slot t % 3, W(t) in slot t % 2
+    L_READ(wf0, xf0, smem, smem_w, 0)
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): see the note at the bottom of the loop
+    for (int kt = 0; kt + 1 < nk; kt++) {     // every iteration has a successor tile (no join before the MFMAs)
+        const char* as = smem + a_slot * L_OP_BYTES;
+        const char* ws = smem_w + (kt & 1) * L_OP_BYTES;
+        const int a_nxt = a_slot == 2 ? 0 : a_slot + 1;
+        L_READ(wf1, xf1, as, ws, 1)
+        L_MFMA(wf0, xf0)
+        if constexpr (!(ABL & 8)) {
+            if (kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4) lgkmcnt(0): all but A(t+2) landed
+            else __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (!(ABL & 1)) {
+            if (kt + 2 < nk) { L_ISSUE_W(kt & 1, (kt + 2) * L_BK) }
+            if (kt + 3 < nk) { L_ISSUE_A(a_slot, (kt + 3) * L_BK) }
+        }
+        L_READ(wf0, xf0, smem + a_nxt * L_OP_BYTES, smem_w + ((kt + 1) & 1) * L_OP_BYTES, 0)
+        L_MFMA(wf1, xf1)
+        // The half-0 fragments of the next tile were requested 32 MFMAs ago: this wait is free, and it
+        // lets hipcc's waitcnt pass see (at the loop-header join) that set 0 is complete, so it does not
+        // put an lgkmcnt(0) between the next iteration's set-1 reads and its set-0 MFMAs.
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        a_slot = a_nxt;
+    }
+    {   // last k-tile
+        const char* as = smem + a_slot * L_OP_BYTES;
+        const char* ws = smem_w + ((nk - 1) & 1) * L_OP_BYTES;
+        L_READ(wf1, xf1, as, ws, 1)
+        L_MFMA(wf0, xf0)
+        L_MFMA(wf1, xf1)
+    }
+#undef L_READ
+#undef L_MFMA
+#undef L_ISSUE_A
+#undef L_ISSUE_W
+    // D layout: column (lane & 15) <- X row (m), rows (lane >> 4) * 4 + reg <- W row (n)
+    if constexpr ((ABL & 16) != 0) {   // timing-only: no epilogue (keep the accumulators live)
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) reinterpret_cast<float*>(p.out)[0] = t;
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int m = m0 + wm * 128 + j * 16 + fr;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int n = n0 + wn * 64 + i * 16 + fg * 4;
+            store4<EPI>(p, m, n, acc[i][j]);
         }
     }
 }
@@ -219,9 +458,43 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc p) {
         epilogue4<EPI, float>(p, m0 + ty * 4 + i, n0 + tx * 4, acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
 }
 
+// tile-count threshold above which the 256x256 LDS-DMA kernel is used (tunable for experiments)
+static int g_large_min_tiles = 200;
+static int g_large_variant = 1;   // 1: 32x32x16 MFMA, 0: 16x16x32 MFMA
+extern "C" void vtgb_debug_set_gemm_large_min_tiles(int v) { g_large_min_tiles = v; }
+extern "C" void vtgb_debug_set_gemm_large_variant(int v) { g_large_variant = v; }
+static int g_ablate = 0;   // timing-only experiments (compile-time variants) (results are wrong when non-zero): 1 no DMA, 2 one LDS stage, 4 no LDS reads, 8 no barrier
+extern "C" void vtgb_debug_set_gemm_ablate(int v) { g_ablate = v; }
+
 template <int EPI>
 static int launch_epi(const GemmDesc& d, hipStream_t s) {
     if (d.dtype == VTGB_BF16) {
+        const int m_tiles = (d.M + L_BM - 1) / L_BM, n_tiles = (d.N + L_BN - 1) / L_BN;
+        if ((d.K % L_BK) == 0 && (int64_t)m_tiles * n_tiles >= g_large_min_tiles) {
+            const int mx = (m_tiles + 7) / 8, groups = (mx + 3) / 4;
+            const dim3 grid(8 * groups * 4 * n_tiles);
+            ProfScope prof(VTGB_PROF_GEMM, 2.0 * d.M * d.N * d.K, s);
+            if (g_ablate && (EPI == EPI_STORE || EPI == EPI_RESID_F32)) {
+#define ABL_CASE(v)                                                                                              \
+    case v:                                                                                                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_large_kernel<EPI, v>),                 \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS);                            \
+        hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, v>), grid, dim3(512), L_LDS, s, d, m_tiles, n_tiles);    \
+        break;
+                switch (g_ablate) { ABL_CASE(1) ABL_CASE(8) ABL_CASE(16) ABL_CASE(17) ABL_CASE(25) default: break; }
+#undef ABL_CASE
+            } else {
+                static bool attr0 = false;
+                if (!attr0) {
+                    VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_large_kernel<EPI, 0>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS));
+                    attr0 = true;
+                }
+                hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, 0>), grid, dim3(512), L_LDS, s, d, m_tiles, n_tiles);
+            }
+            VTGB_HIP(hipGetLastError());
+            return VTGB_OK;
+        }
         dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM);
         const size_t lds = 4 * TILE_BYTES;
         static bool attr_set = false;
