@@ -24,7 +24,9 @@ Tensor = torch.Tensor
 
 
 def _rms(x: Tensor, w: Tensor, eps: float) -> Tensor:
-    # LlamaRMSNorm.forward: fp32 variance, weight * x.to(input_dtype)
+    # LlamaRMSNorm.forward: fp32 variance, weight * x.to(input_dtype); one fused kernel on the device
+    if x.is_cuda:
+        return F.rms_norm(x, (x.shape[-1],), w, eps)
     dt = x.dtype
     xf = x.float()
     xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
@@ -47,9 +49,15 @@ class GreedyDecoder:
         self.eps = cfg.rms_norm_eps
         rp = getattr(cfg, "rope_parameters", None) or {}
         self.theta = float(rp.get("rope_theta", getattr(cfg, "rope_theta", 10000.0)))
-        self.layers = [(l.input_layernorm.weight, l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight,
-                        l.self_attn.o_proj.weight, l.post_attention_layernorm.weight, l.mlp.gate_proj.weight, l.mlp.up_proj.weight,
-                        l.mlp.down_proj.weight) for l in lm.model.layers]
+        # fused projection weights (one GEMM for q|k|v, one for gate|up): fewer, larger launches per token
+        self.layers = []
+        for l in lm.model.layers:
+            a, m = l.self_attn, l.mlp
+            wqkv = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0).contiguous()
+            wgu = torch.cat([m.gate_proj.weight, m.up_proj.weight], dim=0).contiguous()
+            self.layers.append((l.input_layernorm.weight, wqkv, a.o_proj.weight, l.post_attention_layernorm.weight, wgu,
+                                m.down_proj.weight))
+        self.inter = cfg.intermediate_size
         self.graphs: Dict[Tuple[int, int, int], dict] = {}
 
     def _rope(self, tmax: int, device, dtype):
@@ -60,24 +68,25 @@ class GreedyDecoder:
 
     def _layer(self, x, w, cos, sin, kc, vc, pos_idx, mask):
         """x [B, S, H]; cos/sin [S, hd]; kc/vc [B, nkv, Tmax, hd]; pos_idx [S] cache rows to write."""
-        ln1, wq, wk, wv, wo, ln2, wg, wu, wd = w
+        ln1, wqkv, wo, ln2, wgu, wd = w
         B, S, _ = x.shape
+        nq, nkv, hd = self.nh, self.nkv, self.hd
         h = _rms(x, ln1, self.eps)
-        q = F.linear(h, wq).view(B, S, self.nh, self.hd).transpose(1, 2)
-        k = F.linear(h, wk).view(B, S, self.nkv, self.hd).transpose(1, 2)
-        v = F.linear(h, wv).view(B, S, self.nkv, self.hd).transpose(1, 2)
-        q = q * cos + _rot_half(q) * sin
-        k = k * cos + _rot_half(k) * sin
+        qkv = F.linear(h, wqkv).view(B, S, nq + 2 * nkv, hd).transpose(1, 2)      # [B, heads, S, hd]
+        qk = qkv[:, : nq + nkv]
+        qk = qk * cos + _rot_half(qk) * sin                                        # rotary on q and k together
+        q, k, v = qk[:, :nq], qk[:, nq:], qkv[:, nq + nkv:]
         kc.index_copy_(2, pos_idx, k)
         vc.index_copy_(2, pos_idx, v)
         kk, vv = kc, vc
-        if self.nkv != self.nh:
-            rep = self.nh // self.nkv
+        if nkv != nq:
+            rep = nq // nkv
             kk, vv = kc.repeat_interleave(rep, 1), vc.repeat_interleave(rep, 1)
         a = F.scaled_dot_product_attention(q, kk, vv, attn_mask=mask)
-        x = x + F.linear(a.transpose(1, 2).reshape(B, S, self.nh * self.hd), wo)
+        x = x + F.linear(a.transpose(1, 2).reshape(B, S, nq * hd), wo)
         h = _rms(x, ln2, self.eps)
-        return x + F.linear(F.silu(F.linear(h, wg)) * F.linear(h, wu), wd)
+        gu = F.linear(h, wgu)
+        return x + F.linear(F.silu(gu[..., : self.inter]) * gu[..., self.inter:], wd)
 
     def _head(self, x):
         return F.linear(_rms(x, self.lm.model.norm.weight, self.eps), self.lm.lm_head.weight)
