@@ -1,0 +1,60 @@
+"""N > 1 path on CPU: two gloo ranks shard a clip list exactly like eval/inference.py, never
+exchange clip data, merge in rank order; and the flat-bucket gradient all-reduce (config 5)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from videotgb_amd import dist as vd
+    clips = list(range(11))
+    mine = vd.get_chunk(clips, world, rank)
+    results = [(c, c * c) for c in mine]                 # stands for one generate() per clip
+    merged = vd.gather_results(results)
+    t = vd.max_over_ranks(1.0 + rank)
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(4, 3)
+    lin.weight.grad = torch.full_like(lin.weight, float(rank + 1))
+    lin.bias.grad = torch.full_like(lin.bias, 10.0 * (rank + 1))
+    vd.FlatGradBucket(lin.parameters()).all_reduce(average=False)
+    q.put((rank, list(mine), merged, t, lin.weight.grad[0, 0].item(), lin.bias.grad[0].item()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_clip_sharding_and_grad_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (r0, c0, m0, t0, w0, b0), (r1, c1, m1, t1, w1, b1) = out
+    assert c0 == [0, 1, 2, 3, 4, 5] and c1 == [6, 7, 8, 9, 10]          # ceil(11/2) = 6 per chunk, contiguous
+    assert m0 == m1 == [(c, c * c) for c in range(11)]                  # rank-order merge == `cat` of the shell driver
+    assert t0 == t1 == 2.0                                              # slowest rank
+    assert w0 == w1 == 3.0 and b0 == b1 == 30.0                         # sum over ranks, one flat collective
+
+
+def test_split_list_matches_reference_semantics():
+    from videotgb_amd.dist import get_chunk, split_list
+    assert split_list(list(range(10)), 4) == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9]]
+    assert split_list(list(range(8)), 8) == [[i] for i in range(8)]
+    assert get_chunk(list(range(3)), 8, 5) == []                         # more ranks than clips
