@@ -38,12 +38,25 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MI
 VIT_GFLOP_PER_FRAME = 520.72   # SURVEY.md 8d / BASELINE.md 2
 
 
+def pmc_traffic():
+    """Mean HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 per the
+    gfx950 correction + WRITE_SIZE; profiles/r01_pmc_traffic_gemm.json, collected with tools/gemm_pmc.py on the
+    four ViT-g layer shapes at 31 clips).  None if the file is absent."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_traffic_gemm.json")
+    try:
+        ks = json.load(open(path))["kernels"]
+        tot = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ks.values())
+        return int(tot / sum(v["launches"] for v in ks.values()))
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clips", type=int, default=32, help="clips per GPU per step")
+    ap.add_argument("--clips", type=int, default=31, help="clips per GPU per step")
     ap.add_argument("--T", type=int, default=96, help="flow frames per clip")
     ap.add_argument("--nframe", type=int, default=8)
     ap.add_argument("--flow", choices=["precomputed", "raft"], default="precomputed")
@@ -205,9 +218,9 @@ def main():
         na, msa, fla = _lib.prof_summary(1)
         if n and ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel (128x128x64 MFMA tiles, all epilogues)",
+            roofline = {"bound": "mfma", "kernel": "gemm_bf16_large_kernel / gemm_bf16_kernel (bf16 MFMA GEMM family, all epilogues)",
                         "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                        "traffic": None, "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
+                        "traffic": pmc_traffic(), "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                         "gemm_ms_per_step": round(ms / args.steps, 3), "gemm_gflop_per_step": round(fl / args.steps / 1e9, 1),
                         "attention": {"launches": na, "avg_launch_us": round(msa * 1e3 / max(na, 1), 2),
                                       "achieved_tflops": round(fla / max(msa, 1e-9) / 1e9, 2)}}
