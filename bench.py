@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clips", type=int, default=31, help="clips per GPU per step")
+    ap.add_argument("--clips", type=int, default=62, help="clips per GPU per step")
     ap.add_argument("--T", type=int, default=96, help="flow frames per clip")
     ap.add_argument("--nframe", type=int, default=8)
     ap.add_argument("--flow", choices=["precomputed", "raft"], default="precomputed")

@@ -273,13 +273,12 @@ constexpr int L_A_SLOTS = 3, L_W_SLOTS = 2;
 constexpr int L_LDS = (L_A_SLOTS + L_W_SLOTS) * L_OP_BYTES;   // 160 KiB
 
 template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc p, const int m_tiles, const int n_tiles) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const smem_w = smem + L_A_SLOTS * L_OP_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- XCD-aware tile assignment
-    constexpr int G = 4;
     const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
     const int group = idx / (G * n_tiles), r = idx - group * (G * n_tiles);
     const int nt = r / G, ml = group * G + (r - nt * G);
@@ -287,6 +286,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     if (mt >= m_tiles) return;
     const int m0 = mt * L_BM, n0 = nt * L_BN;
     const int wm = wave & 1, wn = wave >> 1;
+    // a wave whose 128 x 64 sub-tile lies wholly outside the matrix (N = 1408 is 5.5 tiles wide) still
+    // stages its share of the operands and joins every barrier, but issues no LDS reads and no MFMAs:
+    // its SIMD partner then has the matrix pipe to itself and the edge tile finishes in half the time
+    const bool wave_active = (n0 + wn * 64 < p.N) && (m0 + wm * 128 < p.M);
+    const bool staged_store = ((p.N & 7) == 0) && ((p.ldo & 7) == 0);   // bf16 outputs leave through LDS as whole rows
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
 
@@ -354,6 +358,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     //   A(t+1), W(t+1) visible) | re-arm the freed slots with W(t+2), A(t+3) | read half 0 of tile t+1 |
     //   MFMAs of half 1
     int a_slot = 0;   // A(t) lives in slot t % 3, W(t) in slot t % 2
+    if (!wave_active) {
+        // same DMA issues, waits and barriers as the active waves, nothing else
+        for (int kt = 0; kt + 1 < nk; kt++) {
+            if (kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4)
+            else __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) { L_ISSUE_W(kt & 1, (kt + 2) * L_BK) }
+            if (kt + 3 < nk) { L_ISSUE_A(a_slot, (kt + 3) * L_BK) }
+            a_slot = a_slot == 2 ? 0 : a_slot + 1;
+        }
+        if constexpr (EPI == EPI_STORE || EPI == EPI_GELU) {
+            if (staged_store) __builtin_amdgcn_s_barrier();   // the barrier in front of the LDS-staged stores
+        }
+        return;
+    }
     L_READ(wf0, xf0, smem, smem_w, 0)
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): see the note at the bottom of the loop
     for (int kt = 0; kt + 1 < nk; kt++) {     // every iteration has a successor tile (no join before the MFMAs)
@@ -399,6 +418,39 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
             for (int i = 0; i < 4; i++) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
         if (t == 123.456f) reinterpret_cast<float*>(p.out)[0] = t;
         return;
+    }
+    if constexpr (EPI == EPI_STORE || EPI == EPI_GELU) {
+        if (staged_store) {
+            // bf16 outputs: each wave transposes its 128 x 64 tile through a private 16 KiB LDS region
+            // (16-byte chunks XOR-swizzled by row & 7) and stores 16 bytes per lane, 8 whole 128-byte
+            // rows per instruction: half the store instructions of the 8-byte fragment-shaped stores
+            // (the tail is store-issue bound), and full lines.
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // my fragment reads are done
+            __builtin_amdgcn_s_barrier();         // ... and everyone else's: the ring can be overwritten
+            char* const cst = smem + wave * 16384;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    f32x4 v = acc[i][j];
+                    if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = gelu_erf_fast(v[e]);
+                    }
+                    const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    const int row = j * 16 + fr, c16 = (i * 2 + (fg >> 1)) ^ (row & 7);
+                    *reinterpret_cast<bf16x4*>(cst + row * 128 + c16 * 16 + (fg & 1) * 8) = pk;
+                }
+            bf16_t* const outp = reinterpret_cast<bf16_t*>(p.out);
+#pragma unroll
+            for (int rr = 0; rr < 16; rr++) {
+                const int row = rr * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(cst + row * 128 + ((ch ^ (row & 7)) << 4));
+                const int m = m0 + wm * 128 + row, n = n0 + wn * 64 + ch * 8;
+                if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(outp + map_row(p.o_map, m) * p.ldo + n) = v;
+            }
+            return;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -460,7 +512,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc p) {
 
 // tile-count threshold above which the 256x256 LDS-DMA kernel is used (tunable for experiments)
 static int g_large_min_tiles = 200;
-static int g_large_variant = 1;   // 1: 32x32x16 MFMA, 0: 16x16x32 MFMA
+static int g_large_variant = 0;   // > 0 forces the m-tiles per XCD super-tile (G); 0 = heuristic
 extern "C" void vtgb_debug_set_gemm_large_min_tiles(int v) { g_large_min_tiles = v; }
 extern "C" void vtgb_debug_set_gemm_large_variant(int v) { g_large_variant = v; }
 static int g_ablate = 0;   // timing-only experiments (compile-time variants) (results are wrong when non-zero): 1 no DMA, 2 one LDS stage, 4 no LDS reads, 8 no barrier
@@ -471,15 +523,17 @@ static int launch_epi(const GemmDesc& d, hipStream_t s) {
     if (d.dtype == VTGB_BF16) {
         const int m_tiles = (d.M + L_BM - 1) / L_BM, n_tiles = (d.N + L_BN - 1) / L_BN;
         if ((d.K % L_BK) == 0 && (int64_t)m_tiles * n_tiles >= g_large_min_tiles) {
-            const int mx = (m_tiles + 7) / 8, groups = (mx + 3) / 4;
-            const dim3 grid(8 * groups * 4 * n_tiles);
+            // m-tiles per XCD super-tile: measured best 2 for narrow outputs (<= 8 n-tiles), 8 for wide ones
+            const int G = g_large_variant > 0 ? g_large_variant : (n_tiles <= 8 ? 2 : 8);
+            const int mx = (m_tiles + 7) / 8, groups = (mx + G - 1) / G;
+            const dim3 grid(8 * groups * G * n_tiles);
             ProfScope prof(VTGB_PROF_GEMM, 2.0 * d.M * d.N * d.K, s);
             if (g_ablate && (EPI == EPI_STORE || EPI == EPI_RESID_F32)) {
 #define ABL_CASE(v)                                                                                              \
     case v:                                                                                                       \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_large_kernel<EPI, v>),                 \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS);                            \
-        hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, v>), grid, dim3(512), L_LDS, s, d, m_tiles, n_tiles);    \
+        hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, v>), grid, dim3(512), L_LDS, s, d, m_tiles, n_tiles, G);    \
         break;
                 switch (g_ablate) { ABL_CASE(1) ABL_CASE(8) ABL_CASE(16) ABL_CASE(17) ABL_CASE(25) default: break; }
 #undef ABL_CASE
@@ -490,7 +544,7 @@ static int launch_epi(const GemmDesc& d, hipStream_t s) {
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS));
                     attr0 = true;
                 }
-                hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, 0>), grid, dim3(512), L_LDS, s, d, m_tiles, n_tiles);
+                hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, 0>), grid, dim3(512), L_LDS, s, d, m_tiles, n_tiles, G);
             }
             VTGB_HIP(hipGetLastError());
             return VTGB_OK;
