@@ -262,6 +262,24 @@ typedef struct {
 } vtgb_layernorm_args;
 int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream);
 
+/* ---- LLM decode-step building blocks ("next" row) ----------------------------
+ * The LLM itself is third-party on both sides (HF weights and GEMMs); these fuse the small
+ * per-layer ops of a KV-cached greedy decode step with the exact rounding points of
+ * transformers' modeling_llama (LlamaRMSNorm, apply_rotary_pos_emb, LlamaMLP).  `dtype` is the
+ * activation dtype (VTGB_BF16 / VTGB_F32); `pos` is a DEVICE int64 (current position), so one
+ * captured hipGraph serves every step.
+ *   vtgb_llm_rmsnorm:          x[rows,H] (+= delta, written back if delta != NULL); h = w * norm(x)
+ *   vtgb_llm_rope_cache:       qkv[B, nq+2nkv, hd] -> q_out[B,nq,hd] rotated; K/V cache [B,nkv,tmax,hd] row *pos
+ *   vtgb_llm_decode_attention: out[B, nq*hd] = softmax(scale q K[0..*pos]^T) V[0..*pos]
+ *   vtgb_llm_silu_mul:         act[rows, I] = silu(gu[:, :I]) * gu[:, I:]                       */
+int vtgb_llm_rmsnorm(int dtype, void* x, const void* delta, const void* w, void* h, int64_t rows, int32_t H, float eps,
+                     vtgb_stream_t stream);
+int vtgb_llm_rope_cache(int dtype, const void* qkv, void* q_out, void* kc, void* vc, const void* cos_t, const void* sin_t,
+                        const int64_t* pos, int32_t B, int32_t nq, int32_t nkv, int32_t hd, int32_t tmax, vtgb_stream_t stream);
+int vtgb_llm_decode_attention(int dtype, const void* q, const void* kc, const void* vc, void* out, const int64_t* pos, int32_t B,
+                              int32_t nq, int32_t nkv, int32_t hd, int32_t tmax, float scale, vtgb_stream_t stream);
+int vtgb_llm_silu_mul(int dtype, const void* gu, void* act, int64_t rows, int32_t I, vtgb_stream_t stream);
+
 /* ---- in-library launch timing (used by bench.py for the roofline figure) -------------------
  * While enabled, every GEMM / attention launch of the bf16 path is bracketed by a pair of HIP
  * events recorded on the launch stream (no synchronisation at record time).  vtgb_prof_summary

@@ -26,6 +26,7 @@ EXPORTS = [
     "vtgb_qformer_workspace_bytes", "vtgb_qformer_forward", "vtgb_pool_project_workspace_bytes",
     "vtgb_pool_project", "vtgb_tgb_workspace_bytes", "vtgb_tgb_forward", "vtgb_gemm", "vtgb_attention",
     "vtgb_layernorm", "vtgb_prof_enable", "vtgb_prof_reset", "vtgb_prof_summary",
+    "vtgb_llm_rmsnorm", "vtgb_llm_rope_cache", "vtgb_llm_decode_attention", "vtgb_llm_silu_mul",
 ]
 
 i32, i64, f32, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -121,6 +122,10 @@ def lib() -> C.CDLL:
         fn = getattr(L, f"vtgb_{name}_workspace_bytes")
         fn.argtypes = [C.POINTER(st)]
         fn.restype = sz
+    L.vtgb_llm_rmsnorm.argtypes = [C.c_int, vp, vp, vp, vp, i64, i32, f32, vp]
+    L.vtgb_llm_rope_cache.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.vtgb_llm_decode_attention.argtypes = [C.c_int, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]
+    L.vtgb_llm_silu_mul.argtypes = [C.c_int, vp, vp, i64, i32, vp]
     L.vtgb_prof_enable.argtypes = [C.c_int]
     L.vtgb_prof_enable.restype = None
     L.vtgb_prof_reset.restype = None

@@ -39,7 +39,7 @@ def _rot_half(x: Tensor) -> Tensor:
 
 
 class GreedyDecoder:
-    def __init__(self, lm):
+    def __init__(self, lm, fused: bool = True):
         cfg = lm.config
         if "llama" not in cfg.model_type:
             raise NotImplementedError("GreedyDecoder handles Llama-architecture models; use HF generate otherwise")
@@ -58,6 +58,7 @@ class GreedyDecoder:
             self.layers.append((l.input_layernorm.weight, wqkv, a.o_proj.weight, l.post_attention_layernorm.weight, wgu,
                                 m.down_proj.weight))
         self.inter = cfg.intermediate_size
+        self.fused = fused
         self.graphs: Dict[Tuple[int, int, int], dict] = {}
 
     def _rope(self, tmax: int, device, dtype):
@@ -102,12 +103,56 @@ class GreedyDecoder:
                       vc=[torch.zeros(B, self.nkv, tmax, self.hd, device=device, dtype=dtype) for _ in self.layers],
                       tok=torch.zeros(B, dtype=torch.long, device=device), pos=torch.zeros(1, dtype=torch.long, device=device),
                       step=torch.zeros(1, dtype=torch.long, device=device), out=torch.zeros(B, N, dtype=torch.long, device=device),
-                      ar=torch.arange(tmax, device=device), graph=None)
+                      ar=torch.arange(tmax, device=device), graph=None,
+                      x=torch.zeros(B, self.cfg.hidden_size, device=device, dtype=dtype),
+                      h=torch.zeros(B, self.cfg.hidden_size, device=device, dtype=dtype),
+                      q=torch.zeros(B, self.nh * self.hd, device=device, dtype=dtype),
+                      a=torch.zeros(B, self.nh * self.hd, device=device, dtype=dtype),
+                      act=torch.zeros(B, self.inter, device=device, dtype=dtype))
             self.graphs[key] = st
         return st
 
+    def _decode_step_fused(self, st):
+        """One token for every sequence with the per-layer small ops fused in libvtgb.so
+        (include/vtgb.h vtgb_llm_*): per layer 4 GEMMs + 5 fused launches instead of ~25."""
+        import ctypes as C
+        from . import _lib as L
+        lib = L.lib()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        emb = self.lm.get_input_embeddings()
+        x = st["x"]
+        x.copy_(emb(st["tok"]))
+        B, H = x.shape
+        code = L.BF16 if x.dtype == torch.bfloat16 else L.F32
+        nq, nkv, hd, tmax = self.nh, self.nkv, self.hd, st["tmax"]
+        pos = st["pos"]
+        h, q, a, act = st["h"], st["q"], st["a"], st["act"]
+        delta = None
+        for li, (ln1, wqkv, wo, ln2, wgu, wd) in enumerate(self.layers):
+            L.check(lib.vtgb_llm_rmsnorm(code, x.data_ptr(), None if delta is None else delta.data_ptr(), ln1.data_ptr(), h.data_ptr(),
+                                         B, H, self.eps, stream))
+            qkv = F.linear(h, wqkv)
+            L.check(lib.vtgb_llm_rope_cache(code, qkv.data_ptr(), q.data_ptr(), st["kc"][li].data_ptr(), st["vc"][li].data_ptr(),
+                                            st["cos"].data_ptr(), st["sin"].data_ptr(), pos.data_ptr(), B, nq, nkv, hd, tmax, stream))
+            L.check(lib.vtgb_llm_decode_attention(code, q.data_ptr(), st["kc"][li].data_ptr(), st["vc"][li].data_ptr(), a.data_ptr(),
+                                                  pos.data_ptr(), B, nq, nkv, hd, tmax, float(hd) ** -0.5, stream))
+            o = F.linear(a, wo)
+            L.check(lib.vtgb_llm_rmsnorm(code, x.data_ptr(), o.data_ptr(), ln2.data_ptr(), h.data_ptr(), B, H, self.eps, stream))
+            gu = F.linear(h, wgu)
+            L.check(lib.vtgb_llm_silu_mul(code, gu.data_ptr(), act.data_ptr(), B, self.inter, stream))
+            delta = F.linear(act, wd)
+        L.check(lib.vtgb_llm_rmsnorm(code, x.data_ptr(), delta.data_ptr(), self.lm.model.norm.weight.data_ptr(), h.data_ptr(), B, H,
+                                     self.eps, stream))
+        nxt = F.linear(h, self.lm.lm_head.weight).argmax(-1)
+        st["tok"].copy_(nxt)
+        st["out"].index_copy_(1, st["step"], nxt[:, None])
+        st["pos"].add_(1)
+        st["step"].add_(1)
+
     def _decode_step(self, st):
         """One token for every sequence, entirely on the device (captured)."""
+        if self.fused and st["tok"].is_cuda:
+            return self._decode_step_fused(st)
         emb = self.lm.get_input_embeddings()
         x = emb(st["tok"])[:, None, :]
         pos = st["pos"]
