@@ -6,7 +6,7 @@ import torch
 from videotgb_amd import _lib as L, ops
 dev = torch.device("cuda:0"); lib = L.lib()
 lib.vtgb_debug_set_gemm_large_min_tiles(0); lib.vtgb_debug_set_gemm_large_variant(0)
-M = 257 * 256
+M = 257 * 248
 g = torch.Generator(device=dev).manual_seed(0)
 for name, n, k, epi in (("fc2", 1408, 6144, L.EPI_RESID_F32), ("proj", 1408, 1408, L.EPI_RESID_F32), ("qkv", 4224, 1408, L.EPI_STORE)):
     A = torch.randn(M, k, generator=g, device=dev).bfloat16(); W = (torch.randn(n, k, generator=g, device=dev) * 0.05).bfloat16()
