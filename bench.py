@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--llm", default="vicuna-7b")
     ap.add_argument("--decode", choices=["graph", "hf"], default="graph",
                     help="graph: videotgb_amd.decode.GreedyDecoder (one hipGraph replay per token); hf: HF generate, eager")
+    ap.add_argument("--overlap", action="store_true",
+                    help="two HIP streams: the prefix stage of batch i+1 over the LLM decode of batch i (measured +7 % clips/s; off by "
+                         "default because concurrent kernels inflate the per-launch durations the roofline object is computed from)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-launch HIP events")
     ap.add_argument("--stage-times", action="store_true", help="print a per-stage breakdown to stderr")
@@ -93,17 +96,11 @@ def synth_batch(rank, step_id, B, T, flow, dev, cfg):
     return d
 
 
-def run_step(m, d, B, nframe, max_new_tokens, ev=None, decoder=None):
-    """One pass of the path over a resident batch.  Returns the generated ids."""
+def run_prefix(m, d, B, nframe, mark=lambda name: None):
+    """Everything up to the LLM input: (flow) -> TGB -> select -> gather -> ViT -> Q-Former -> pool+projection -> inputs_embeds."""
     te = {"input_ids": d["prompt_ids"], "attention_mask": torch.ones_like(d["prompt_ids"]),
           "qformer_input_ids": d["qformer_ids"], "qformer_attention_mask": torch.ones_like(d["qformer_ids"])}
     se = {"input_ids": d["sampler_ids"], "attention_mask": torch.ones_like(d["sampler_ids"])}
-
-    def mark(name):
-        if ev is not None:
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            ev.append((name, e))
     mark("start")
     of = d["of"] if d["of"] is not None else m.flow(d["flow_frames"])
     mark("flow")
@@ -118,17 +115,47 @@ def run_step(m, d, B, nframe, max_new_tokens, ev=None, decoder=None):
     qo = m.model.qformer(input_ids=qi, attention_mask=am, query_embeds=qt, encoder_hidden_states=img).last_hidden_state
     prefix = m.model.language_projection.pool(qo, [nframe] * B, "mean")
     mark("qformer+pool")
-    lm = m.model.language_model
     prefix = prefix.to(torch.bfloat16)
-    emb = torch.cat([prefix, m.model.get_input_embeddings()(te["input_ids"])], dim=1)
-    mask = torch.ones(emb.shape[:2], dtype=torch.long, device=emb.device)
+    return torch.cat([prefix, m.model.get_input_embeddings()(te["input_ids"])], dim=1), idx
+
+
+def run_llm(m, emb, max_new_tokens, decoder=None):
     if decoder is not None:
-        out = decoder.generate(emb, max_new_tokens)
-    else:
-        out = lm.generate(inputs_embeds=emb, attention_mask=mask, do_sample=False, max_new_tokens=max_new_tokens,
-                          min_new_tokens=max_new_tokens, use_cache=True)
+        return decoder.generate(emb, max_new_tokens)
+    mask = torch.ones(emb.shape[:2], dtype=torch.long, device=emb.device)
+    return m.model.language_model.generate(inputs_embeds=emb, attention_mask=mask, do_sample=False, max_new_tokens=max_new_tokens,
+                                           min_new_tokens=max_new_tokens, use_cache=True)
+
+
+def run_step(m, d, B, nframe, max_new_tokens, ev=None, decoder=None):
+    """One pass of the path over a resident batch on the current stream.  Returns the generated ids."""
+    def mark(name):
+        if ev is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev.append((name, e))
+    emb, idx = run_prefix(m, d, B, nframe, mark)
+    out = run_llm(m, emb, max_new_tokens, decoder)
     mark("llm")
     return out, idx
+
+
+def run_steps_overlapped(m, batches, steps, B, nframe, max_new_tokens, decoder, side):
+    """K passes with the two halves of a pass on two HIP streams: the prefix stage of batch i+1 (MFMA-bound:
+    ViT-g GEMMs) runs while the LLM decode of batch i (HBM-bound weight streaming) runs on `side`.  Every one of
+    the K batches is processed start to finish inside the caller's timed region (pipeline fill and drain included)."""
+    main = torch.cuda.current_stream()
+    outs = []
+    for i in range(steps):
+        emb, idx = run_prefix(m, batches[i % 2], B, nframe)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            outs.append(run_llm(m, emb, max_new_tokens, decoder))
+        emb.record_stream(side)
+    main.wait_stream(side)
+    return outs
 
 
 def cpu_baseline(cfg, T, nframe, seed_sd):
@@ -195,13 +222,21 @@ def main():
     L.vtgb_prof_reset()
     L.vtgb_prof_enable(1 if prof else 0)
     stage_ev = []
+    overlap = args.overlap and not args.stage_times
+    side = torch.cuda.Stream(priority=-1) if overlap else None   # decode stream: high priority, short memory-bound kernels
+    if overlap:   # one untimed overlapped pass so that both streams have their handles / graph ready
+        run_steps_overlapped(m, batches, 2, B, nframe, args.max_new_tokens, decoder, side)
+        L.vtgb_prof_reset()
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev = [] if args.stage_times else None
-        run_step(m, batches[i % 2], B, nframe, args.max_new_tokens, ev, decoder)
-        if ev:
-            stage_ev.append(ev)
+    if overlap:
+        run_steps_overlapped(m, batches, args.steps, B, nframe, args.max_new_tokens, decoder, side)
+    else:
+        for i in range(args.steps):
+            ev = [] if args.stage_times else None
+            run_step(m, batches[i % 2], B, nframe, args.max_new_tokens, ev, decoder)
+            if ev:
+                stage_ev.append(ev)
     barrier()
     elapsed = time.perf_counter() - t0
     L.vtgb_prof_enable(0)
@@ -238,7 +273,8 @@ def main():
                "config": {"workload": f"InstructBLIP-Vicuna-7B + TGB, T={T}->{nframe} of 32 frames, 224x224, greedy {args.max_new_tokens} new tokens "
                                       f"(BASELINE.json configs[2])", "flow": args.flow, "clips_per_gpu_per_step": B,
                           "global_batch": B * world, "parallelism": f"clip-parallel x{world} (no data-path collective)",
-                          "llm": f"HF LlamaForCausalLM {args.llm} geometry, random init, KV cache, decode={args.decode}", "weights": "seeded N(0,0.02) random init"},
+                          "llm": f"HF LlamaForCausalLM {args.llm} geometry, random init, KV cache, decode={args.decode}",
+                          "streams": "2 (prefix of batch i+1 over LLM decode of batch i)" if overlap else "1", "weights": "seeded N(0,0.02) random init"},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
