@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--llm", default="vicuna-7b")
     ap.add_argument("--decode", choices=["graph", "hf"], default="graph",
                     help="graph: videotgb_amd.decode.GreedyDecoder (one hipGraph replay per token); hf: HF generate, eager")
+    ap.add_argument("--raft-dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="precision of the RAFT convolutions in --flow raft mode (reference: fp32; bf16 keeps coords/correlation in fp32)")
     ap.add_argument("--overlap", action="store_true",
                     help="two HIP streams: the prefix stage of batch i+1 over the LLM decode of batch i (measured +7 % clips/s; off by "
                          "default because concurrent kernels inflate the per-launch durations the roofline object is computed from)")
@@ -191,10 +193,15 @@ def main():
     dev = torch.device("cuda", local)
     from videotgb_amd import _lib, llm, models, synth
     _lib.lib()
+    if args.flow == "raft":
+        # RAFT runs on MIOpen for now: let it search its solvers once, in the warm-up
+        # (without this several RAFT convolutions fall back to MIOpen's naive kernel, 45 % of the stage)
+        torch.backends.cudnn.benchmark = True
     cfg = synth.full_cfg("instructblip")
     t_setup = time.time()
     lm = llm.build_llama(args.llm, torch.bfloat16, dev, seed=0)
-    m = models.LSTP(cfg, dev, language_model=lm, compute_dtype="bf16")
+    m = models.LSTP(cfg, dev, language_model=lm, compute_dtype="bf16",
+                    raft_dtype=torch.bfloat16 if args.raft_dtype == "bf16" else torch.float32)
     sd = synth.path_state_dict(cfg, seed=0, with_raft=True)
     m.load_state_dict(sd, strict=False)
     m.to(dev)
