@@ -66,6 +66,9 @@ def parse():
                     help="graph: videotgb_amd.decode.GreedyDecoder (one hipGraph replay per token); hf: HF generate, eager")
     ap.add_argument("--raft-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="precision of the RAFT convolutions in --flow raft mode (reference: fp32; bf16 keeps coords/correlation in fp32)")
+    ap.add_argument("--raft-channels-last", action="store_true", help="NHWC activations for the MIOpen encoder convolutions of RAFT")
+    ap.add_argument("--raft-update", choices=["hip", "torch"], default="hip",
+                    help="RAFT refinement loop: libvtgb.so (bf16 MFMA implicit-GEMM convolutions) or PyTorch-ROCm/MIOpen ops")
     ap.add_argument("--overlap", action="store_true",
                     help="two HIP streams: the prefix stage of batch i+1 over the LLM decode of batch i (measured +7 % clips/s; off by "
                          "default because concurrent kernels inflate the per-launch durations the roofline object is computed from)")
@@ -201,7 +204,9 @@ def main():
     t_setup = time.time()
     lm = llm.build_llama(args.llm, torch.bfloat16, dev, seed=0)
     m = models.LSTP(cfg, dev, language_model=lm, compute_dtype="bf16",
-                    raft_dtype=torch.bfloat16 if args.raft_dtype == "bf16" else torch.float32)
+                    raft_dtype=torch.bfloat16 if args.raft_dtype == "bf16" else torch.float32,
+                    raft_hip_update=(args.raft_update == "hip"))
+    m.of_extractor.channels_last = args.raft_channels_last
     sd = synth.path_state_dict(cfg, seed=0, with_raft=True)
     m.load_state_dict(sd, strict=False)
     m.to(dev)
@@ -278,7 +283,8 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"InstructBLIP-Vicuna-7B + TGB, T={T}->{nframe} of 32 frames, 224x224, greedy {args.max_new_tokens} new tokens "
-                                      f"(BASELINE.json configs[2])", "flow": args.flow, "clips_per_gpu_per_step": B,
+                                      f"(BASELINE.json configs[2])", "flow": args.flow if args.flow == "precomputed" else f"raft inline (update={args.raft_update}, encoders={args.raft_dtype})",
+                          "clips_per_gpu_per_step": B,
                           "global_batch": B * world, "parallelism": f"clip-parallel x{world} (no data-path collective)",
                           "llm": f"HF LlamaForCausalLM {args.llm} geometry, random init, KV cache, decode={args.decode}",
                           "streams": "2 (prefix of batch i+1 over LLM decode of batch i)" if overlap else "1", "weights": "seeded N(0,0.02) random init"},

@@ -262,6 +262,37 @@ typedef struct {
 } vtgb_layernorm_args;
 int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream);
 
+/* ---- a2 / f1: RAFT recurrent update ---------------------------------------------------------
+ * Replaces the refinement loop of RAFT.forward, src/models/components/xraft.py:135-156: per iteration
+ * CorrBlock.__call__ (raft_utils/corr.py:29-50; the reference's optional `alt_cuda_corr`, corr.py:63-91,
+ * is the CUDA counterpart of the lookup kernel), BasicUpdateBlock (raft_utils/update.py:123-144:
+ * BasicMotionEncoder :75-97, SepConvGRU :39-65, FlowHead :6-18), then the mask head and upsample_flow
+ * (xraft.py:88-99) of the last iteration.  The two encoders and the all-pairs correlation stay with the
+ * caller.  Convolutions are bf16 MFMA implicit GEMMs with fp32 accumulation; hidden state, flow and the
+ * correlation pyramid stay fp32 (a reduced-precision mode: the reference runs RAFT in fp32).
+ * weights (host array of device pointers; conv weights bf16 packed [C_out, KH, KW, C_in]):
+ *   [0] encoder.convc1.weight [256, 384] (324 input channels zero-padded to 384) [1] .bias
+ *   [2] encoder.convc2.weight [192, 3,3,256] [3] .bias   [4] encoder.convf1.weight fp32 [128,2,7,7] [5] .bias
+ *   [6] encoder.convf2.weight [64, 3,3,128]  [7] .bias   [8] encoder.conv.weight [126, 3,3,256]     [9] .bias
+ *   [10] gru.convz1|convr1.weight [256, 1,5,384] [11] bias [256]  [12] gru.convq1.weight [128, 1,5,384] [13] .bias
+ *   [14] gru.convz2|convr2.weight [256, 5,1,384] [15] bias [256]  [16] gru.convq2.weight [128, 5,1,384] [17] .bias
+ *   [18] flow_head.conv1.weight [256, 3,3,128] [19] .bias  [20] flow_head.conv2.weight fp32 [2, 3,3,256] [21] .bias
+ *   [22] mask.0.weight [256, 3,3,128] [23] .bias           [24] mask.2.weight [576, 256] [25] .bias
+ * Biases fp32.  GRU input channels are [h(128) | inp(128) | motion(126) | flow(2)] as in the reference. */
+#define VTGB_RAFT_NW 26
+typedef struct {
+    int32_t n_pairs, H8, W8, iters;
+    const float* net;           /* [n_pairs, 128, H8, W8] tanh(cnet[:, :128])   (xraft.py:126-127) */
+    const float* inp;           /* [n_pairs, 128, H8, W8] relu(cnet[:, 128:])                      */
+    const float* corr[4];       /* pyramid level l: [n_pairs*H8*W8, H8>>l, W8>>l] fp32 (corr.py:19-27) */
+    const void* const* weights; /* host array                                                      */
+    float* flow_up;             /* [n_pairs, 2, 8*H8, 8*W8]                                        */
+    void* workspace;
+    size_t workspace_bytes;
+} vtgb_raft_update_args;
+size_t vtgb_raft_update_workspace_bytes(const vtgb_raft_update_args* a);
+int vtgb_raft_update(const vtgb_raft_update_args* a, vtgb_stream_t stream);
+
 /* ---- LLM decode-step building blocks ("next" row) ----------------------------
  * The LLM itself is third-party on both sides (HF weights and GEMMs); these fuse the small
  * per-layer ops of a KV-cached greedy decode step with the exact rounding points of

@@ -93,8 +93,27 @@ struct GemmDesc {
     void* out;
     int64_t ldo;
     RowMap o_map;
+    // ---- extensions used by the RAFT update block (zero-initialised = plain GEMM)
+    int act;            // applied to acc + bias before the store: 0 none, 1 relu, 2 sigmoid
+    float out_scale;    // 0 -> 1
+    // implicit-GEMM convolution (stride 1, "same" zero padding) over NHWC activations: A rows are
+    // pixels of conv_H x conv_W images, K = KH*KW*Cin ordered (tap, channel), Cin % 64 == 0.
+    // Channels [0, split_c) come from A (row stride lda), channels [split_c, Cin) from A2 (lda2):
+    // a virtual concat.  conv_KH == 0 -> not a convolution.
+    int conv_H, conv_W, conv_KH, conv_KW, conv_Cin, conv_split;
+    const void* A2;
+    int64_t lda2;
+    const void* zero_page;   // >= 256 B of zeros (out-of-image taps read it)
+    // EPI_GRU: h' = (1 - z) * h + z * tanh(acc + bias): h fp32 in `resid` (ldr), z bf16 in `aux` (ldaux);
+    // h' written fp32 to `out` (ldo) and bf16 to `out2` (ldo2)
+    const void* aux;
+    int64_t ldaux;
+    void* out2;
+    int64_t ldo2;
 };
+#define VTGB_EPI_GRU 4
 int launch_gemm(const GemmDesc& d, hipStream_t s);
+int launch_conv_gemm(const GemmDesc& d, hipStream_t s);   // large kernel forced: implicit conv / activations / GRU
 
 struct AttnDesc {
     int dtype, batch, heads, head_dim, s_q, s_kv;

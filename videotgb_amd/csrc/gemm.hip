@@ -15,7 +15,7 @@
 #include "common.h"
 
 enum { EPI_STORE = VTGB_EPI_STORE, EPI_GELU = VTGB_EPI_GELU, EPI_RESID_F32 = VTGB_EPI_RESID_F32,
-       EPI_STORE_F32 = VTGB_EPI_STORE_F32 };
+       EPI_STORE_F32 = VTGB_EPI_STORE_F32, EPI_GRU = VTGB_EPI_GRU };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -186,6 +186,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmDesc p) {
     }
 }
 
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return 1.0f / (1.0f + __expf(-v));
+    return v;
+}
+
 // Large-kernel epilogue split: bias (and the fp32 residual) are loaded INTO the accumulators before
 // the k-loop -- 32 independent 16-byte loads per lane in flight while the first LDS-DMA tiles
 // land, with the accumulator registers themselves as destination -- so that the tail of the tile
@@ -222,6 +228,29 @@ __device__ __forceinline__ void store4(const GemmDesc& p, int m, int n0, f32x4 v
     if (m >= p.M || n0 >= p.N) return;
     const bool full = (n0 + 3 < p.N) && ((p.ldo & 3) == 0);
     const int64_t orow = map_row(p.o_map, m);
+    if constexpr (EPI == EPI_STORE || EPI == EPI_STORE_F32) {
+        if (p.act | (p.out_scale != 0.f)) {
+            const float sc = p.out_scale != 0.f ? p.out_scale : 1.0f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = apply_act(v[i], p.act) * sc;
+        }
+    }
+    if constexpr (EPI == EPI_GRU) {
+        // h' = (1 - z) h + z tanh(acc + bias)
+        const float* hp = p.resid + map_row(p.r_map, m) * p.ldr + n0;
+        const bf16_t* zp = reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)m * p.ldaux + n0;
+        float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + n0;
+        bf16_t* o2 = reinterpret_cast<bf16_t*>(p.out2) + (int64_t)m * p.ldo2 + n0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (n0 + i < p.N) {
+                const float z = (float)zp[i], h = hp[i], q = tanhf(v[i]);
+                const float hn = (1.0f - z) * h + z * q;
+                o[i] = hn;
+                o2[i] = (bf16_t)hn;
+            }
+        return;
+    }
     if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
         float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + n0;
         if (full) {
@@ -272,7 +301,7 @@ constexpr int L_OP_BYTES = 256 * L_BK * 2;   // 32 KiB per operand tile
 constexpr int L_A_SLOTS = 3, L_W_SLOTS = 2;
 constexpr int L_LDS = (L_A_SLOTS + L_W_SLOTS) * L_OP_BYTES;   // 160 KiB
 
-template <int EPI, int ABL = 0>
+template <int EPI, int ABL = 0, bool CONV = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const smem_w = smem + L_A_SLOTS * L_OP_BYTES;
@@ -298,19 +327,47 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     // 8 rows each; lane l of an instruction fills slot (l & 7) of row r0 + (l >> 3)
     const bf16_t* a_src[4];
     const bf16_t* w_src[4];
+    int a_row[4], a_yx[4];   // CONV: pixel index of the staged row and its (y << 16 | x)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int row = wave * 32 + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
         const int am = (m0 + row) < p.M ? (m0 + row) : p.M - 1;
         const int wr = (n0 + row) < p.N ? (n0 + row) : p.N - 1;
-        a_src[i] = A + map_row(p.a_map, am) * p.lda + c * 8;
+        if constexpr (CONV) {
+            const int rem = am % (p.conv_H * p.conv_W);
+            a_row[i] = am;
+            a_yx[i] = ((rem / p.conv_W) << 16) | (rem % p.conv_W);
+            a_src[i] = nullptr;
+        } else {
+            a_src[i] = A + map_row(p.a_map, am) * p.lda + c * 8;
+        }
         w_src[i] = W + (int64_t)wr * p.ldw + c * 8;
     }
+    // CONV: running (tap, channel) of the next A k-tile to stage; A tiles are issued in k order
+    int cv_tap = 0, cv_c0 = 0;
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 #define L_ISSUE_A(slot, k0)                                                                             \
-    _Pragma("unroll") for (int i = 0; i < 4; i++)                                                       \
-        __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + (k0)), (lptr_t)(smem + (slot) * L_OP_BYTES + (wave * 32 + i * 8) * 128), 16, 0, 0);
+    if constexpr (CONV) {                                                                               \
+        const int dy = cv_tap / p.conv_KW - (p.conv_KH >> 1), dx = cv_tap % p.conv_KW - (p.conv_KW >> 1); \
+        const bool first = cv_c0 < p.conv_split;                                                        \
+        const bf16_t* base = first ? A : reinterpret_cast<const bf16_t*>(p.A2);                         \
+        const int64_t ld = first ? p.lda : p.lda2;                                                      \
+        const int cc = first ? cv_c0 : cv_c0 - p.conv_split;                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                 \
+            const int c8 = ((lane & 7) ^ ((i * 4 + (lane >> 4)) & 7)) * 8;                              \
+            const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;                            \
+            const bool ok = (unsigned)y < (unsigned)p.conv_H && (unsigned)x < (unsigned)p.conv_W;       \
+            const bf16_t* src = ok ? base + (int64_t)(a_row[i] + dy * p.conv_W + dx) * ld + cc + c8     \
+                                   : reinterpret_cast<const bf16_t*>(p.zero_page) + c8;                 \
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (slot) * L_OP_BYTES + (wave * 32 + i * 8) * 128), 16, 0, 0); \
+        }                                                                                               \
+        cv_c0 += L_BK;                                                                                  \
+        if (cv_c0 == p.conv_Cin) { cv_c0 = 0; cv_tap++; }                                               \
+    } else {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; i++)                                                   \
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + (k0)), (lptr_t)(smem + (slot) * L_OP_BYTES + (wave * 32 + i * 8) * 128), 16, 0, 0); \
+    }
 #define L_ISSUE_W(slot, k0)                                                                             \
     _Pragma("unroll") for (int i = 0; i < 4; i++)                                                       \
         __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (k0)), (lptr_t)(smem_w + (slot) * L_OP_BYTES + (wave * 32 + i * 8) * 128), 16, 0, 0);
@@ -370,8 +427,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         }
         if constexpr (EPI == EPI_STORE || EPI == EPI_GELU) {
             if (staged_store) __builtin_amdgcn_s_barrier();   // the barrier in front of the LDS-staged stores
-        } else {
-            if (((p.N & 3) == 0) && ((p.ldo & 3) == 0)) __builtin_amdgcn_s_barrier();
+        } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
+            if (((p.N & 3) == 0) && ((p.ldo & 3) == 0) && p.act == 0 && p.out_scale == 0.f) __builtin_amdgcn_s_barrier();
         }
         return;
     }
@@ -438,6 +495,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                     if constexpr (EPI == EPI_GELU) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] = gelu_erf_fast(v[e]);
+                    } else if (p.act) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act);
                     }
                     const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                     const int row = j * 16 + fr, c16 = (i * 2 + (fg >> 1)) ^ (row & 7);
@@ -455,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         }
     }
     if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
-        if (((p.N & 3) == 0) && ((p.ldo & 3) == 0)) {
+        if (((p.N & 3) == 0) && ((p.ldo & 3) == 0) && p.act == 0 && p.out_scale == 0.f) {
             // fp32 outputs: same idea, 64 rows per pass (the wave's region is 16 KiB): 16-byte chunks of a
             // 256-byte row XOR-swizzled by row & 15; each store instruction then covers 4 whole 256-byte row
             // segments.  (Fragment-shaped fp32 stores -- 16 rows x 64 B per instruction, half lines --
@@ -598,6 +658,45 @@ static int launch_epi(const GemmDesc& d, hipStream_t s) {
     }
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
+}
+
+// Implicit-GEMM convolution (and plain GEMMs that need the activation / GRU epilogues) on the large
+// kernel.  d.conv_KH == 0: plain GEMM through the same kernel (RAFT's 1x1 convolutions).
+template <int EPI, bool CONV>
+static int launch_large_forced(const GemmDesc& d, hipStream_t s) {
+    const int m_tiles = (d.M + L_BM - 1) / L_BM, n_tiles = (d.N + L_BN - 1) / L_BN;
+    const int G = n_tiles <= 8 ? 2 : 8;
+    const int mx = (m_tiles + 7) / 8, groups = (mx + G - 1) / G;
+    static bool attr = false;
+    if (!attr) {
+        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_large_kernel<EPI, 0, CONV>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS));
+        attr = true;
+    }
+    ProfScope prof(VTGB_PROF_GEMM, 2.0 * d.M * d.N * d.K, s);
+    hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, 0, CONV>), dim3(8 * groups * G * n_tiles), dim3(512), L_LDS, s, d, m_tiles, n_tiles, G);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+int launch_conv_gemm(const GemmDesc& d, hipStream_t s) {
+    VTGB_REQUIRE(d.dtype == VTGB_BF16 && d.A && d.W && d.out && d.M > 0 && d.N > 0, VTGB_EINVAL, "conv gemm: bad argument");
+    VTGB_REQUIRE((d.K % L_BK) == 0 && (d.lda % 8) == 0 && (d.ldw % 8) == 0, VTGB_EUNSUPPORTED, "conv gemm: K=%d must be a multiple of 64", d.K);
+    const bool conv = d.conv_KH > 0;
+    if (conv) {
+        VTGB_REQUIRE(d.zero_page && (d.conv_Cin % L_BK) == 0 && (d.conv_split % L_BK) == 0 && d.K == d.conv_KH * d.conv_KW * d.conv_Cin &&
+                         (d.M % (d.conv_H * d.conv_W)) == 0 && (d.conv_split == d.conv_Cin || d.A2),
+                     VTGB_EINVAL, "conv gemm: inconsistent convolution geometry");
+    }
+    switch (d.epi) {
+        case EPI_STORE: return conv ? launch_large_forced<EPI_STORE, true>(d, s) : launch_large_forced<EPI_STORE, false>(d, s);
+        case EPI_STORE_F32: return conv ? launch_large_forced<EPI_STORE_F32, true>(d, s) : launch_large_forced<EPI_STORE_F32, false>(d, s);
+        case EPI_GRU:
+            VTGB_REQUIRE(conv && d.resid && d.aux && d.out2, VTGB_EINVAL, "conv gemm: GRU epilogue needs h, z and both outputs");
+            return launch_large_forced<EPI_GRU, true>(d, s);
+    }
+    vtgb_set_error("conv gemm: unsupported epilogue %d", d.epi);
+    return VTGB_EINVAL;
 }
 
 int launch_gemm(const GemmDesc& d, hipStream_t s) {

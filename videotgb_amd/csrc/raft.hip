@@ -1,0 +1,292 @@
+// raft.hip -- the recurrent part of RAFT on gfx950: per refinement iteration the
+// correlation-pyramid lookup (the reference's missing `alt_cuda_corr`, raft_utils/corr.py:29-50,63-91),
+// BasicMotionEncoder, SepConvGRU and FlowHead (raft_utils/update.py:39-144), then the mask head and the
+// convex 8x upsample of the last iteration (xraft.py:88-99).  The two CNN encoders and the all-pairs
+// correlation matmul stay with the caller (MIOpen / rocBLAS through PyTorch).
+//
+// Layout: every activation is NHWC ("pixel-major") bf16, so each convolution is an implicit GEMM on the
+// MFMA kernel of gemm.hip (LDS-DMA gathers the k-tile of the shifted pixel directly; out-of-image taps read
+// a zero page; channel concatenations [h | inp | motion | flow] are virtual: two base pointers, no copies).
+// The hidden state h, the flow / coordinates and the correlation pyramid stay fp32; GEMM operands are bf16
+// with fp32 accumulation, gates (sigmoid / tanh) are evaluated in fp32 in the GEMM epilogue.
+#include <math.h>
+#include <string.h>
+
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------
+// state init: NCHW fp32 -> pixel-major buffers
+// ---------------------------------------------------------------------------------------
+__global__ void raft_init_kernel(const float* __restrict__ net, const float* __restrict__ inp, float* __restrict__ h32,
+                                 bf16_t* __restrict__ hb, bf16_t* __restrict__ X, float* __restrict__ flow, int64_t M, int HW) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * 128) return;
+    const int64_t m = i >> 7;
+    const int c = (int)(i & 127);
+    const int64_t n = m / HW, p = m % HW;
+    const float hv = net[(n * 128 + c) * HW + p];
+    h32[i] = hv;
+    hb[i] = (bf16_t)hv;
+    X[m * 256 + c] = (bf16_t)inp[(n * 128 + c) * HW + p];
+    if (c < 2) {
+        flow[m * 2 + c] = 0.f;
+        X[m * 256 + 254 + c] = (bf16_t)0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// correlation lookup: one wave per pixel, 4 levels x 9 x 9 bilinear taps (zero outside), bf16 out,
+// columns 324..383 zero (K padded to a multiple of 64 for the 1x1 convolution that follows).
+// NB the reference adds stack(meshgrid(dy, dx)) to (x, y): the x coordinate receives the ROW offset of
+// the 9x9 window (corr.py:36-43) -- replicated as is.
+// ---------------------------------------------------------------------------------------
+struct CorrPyr { const float* lvl[4]; int h[4], w[4]; };
+
+__global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr, const float* __restrict__ flow, bf16_t* __restrict__ out,
+                                                               int64_t M, int H8, int W8) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int p = (int)(m % (H8 * W8));
+    const float cx = (float)(p % W8) + flow[m * 2], cy = (float)(p / W8) + flow[m * 2 + 1];
+    for (int k = lane; k < 384; k += 64) {
+        float v = 0.f;
+        if (k < 324) {
+            const int l = k / 81, t = k - l * 81, i = t / 9, j = t - i * 9;
+            const int hl = pyr.h[l], wl = pyr.w[l];
+            const float* img = pyr.lvl[l] + m * (int64_t)(hl * wl);
+            const float sc = 1.0f / (float)(1 << l);
+            const float xs = cx * sc + (float)(i - 4), ys = cy * sc + (float)(j - 4);
+            const float x0f = floorf(xs), y0f = floorf(ys);
+            const int x0 = (int)x0f, y0 = (int)y0f;
+            const float wx = xs - x0f, wy = ys - y0f;
+            float a = 0.f;
+            if ((unsigned)y0 < (unsigned)hl) {
+                if ((unsigned)x0 < (unsigned)wl) a += (1.f - wx) * (1.f - wy) * img[y0 * wl + x0];
+                if ((unsigned)(x0 + 1) < (unsigned)wl) a += wx * (1.f - wy) * img[y0 * wl + x0 + 1];
+            }
+            if ((unsigned)(y0 + 1) < (unsigned)hl) {
+                if ((unsigned)x0 < (unsigned)wl) a += (1.f - wx) * wy * img[(y0 + 1) * wl + x0];
+                if ((unsigned)(x0 + 1) < (unsigned)wl) a += wx * wy * img[(y0 + 1) * wl + x0 + 1];
+            }
+            v = a;
+        }
+        out[m * 384 + k] = (bf16_t)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// convf1: 7x7 convolution of the 2-channel flow -> 128 channels + ReLU (update.py:82,92).  Too thin for the
+// MFMA path (K = 98): direct fp32, 32 pixels per workgroup, weights and the 32 input windows in LDS.
+// Also deposits the flow (bf16) in columns 254..255 of X (the motion features end with the flow, :97).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void raft_convf1_kernel(const float* __restrict__ flow, const float* __restrict__ w, const float* __restrict__ b,
+                                                          bf16_t* __restrict__ f1, bf16_t* __restrict__ X, int64_t M, int H8, int W8) {
+    __shared__ float ws[98 * 128];
+    __shared__ float xs[32 * 98];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 98 * 128; i += 256) {   // w is [128][2][7][7]; ws[k][co], k = c*49 + ky*7 + kx
+        const int co = i & 127, k = i >> 7;
+        ws[i] = w[co * 98 + k];
+    }
+    const int64_t m0 = (int64_t)blockIdx.x * 32;
+    for (int i = tid; i < 32 * 98; i += 256) {
+        const int p = i / 98, k = i - p * 98;
+        const int64_t m = m0 + p;
+        float v = 0.f;
+        if (m < M) {
+            const int c = k / 49, t = k - c * 49, ky = t / 7, kx = t - ky * 7;
+            const int pix = (int)(m % (H8 * W8)), y = pix / W8 + ky - 3, x = pix % W8 + kx - 3;
+            if ((unsigned)y < (unsigned)H8 && (unsigned)x < (unsigned)W8) v = flow[(m + (ky - 3) * W8 + (kx - 3)) * 2 + c];
+        }
+        xs[i] = v;
+    }
+    __syncthreads();
+    const int p = tid >> 3, cg = (tid & 7) * 16;
+    const int64_t m = m0 + p;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) acc[c] = b[cg + c];
+    for (int k = 0; k < 98; k++) {
+        const float x = xs[p * 98 + k];
+#pragma unroll
+        for (int c = 0; c < 16; c++) acc[c] = fmaf(x, ws[k * 128 + cg + c], acc[c]);
+    }
+    if (m < M) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) f1[m * 128 + cg + c] = (bf16_t)fmaxf(acc[c], 0.f);
+        if ((tid & 7) == 0) {
+            X[m * 256 + 254] = (bf16_t)flow[m * 2];
+            X[m * 256 + 255] = (bf16_t)flow[m * 2 + 1];
+        }
+    }
+}
+
+// RH = r * h   (update.py:55,62): r = ZR[:, 128:256] (bf16, sigmoid applied), h fp32
+__global__ void raft_rh_kernel(const bf16_t* __restrict__ ZR, const float* __restrict__ h32, bf16_t* __restrict__ RH, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t m = i >> 7;
+    const int c = (int)(i & 127);
+    RH[i] = (bf16_t)((float)ZR[m * 256 + 128 + c] * h32[i]);
+}
+
+// FlowHead.conv2 (3x3, 256 -> 2; update.py:14,18) + coords1 += delta (xraft.py:145): one wave per pixel
+__global__ __launch_bounds__(256) void raft_flow_head2_kernel(const bf16_t* __restrict__ FH, const float* __restrict__ w, const float* __restrict__ b,
+                                                              float* __restrict__ flow, int64_t M, int H8, int W8) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int pix = (int)(m % (H8 * W8)), y = pix / W8, x = pix % W8;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        if ((unsigned)(y + dy) < (unsigned)H8 && (unsigned)(x + dx) < (unsigned)W8) {
+            const bf16x4 v = *reinterpret_cast<const bf16x4*>(FH + (m + dy * W8 + dx) * 256 + lane * 4);
+            const float4 w0 = *reinterpret_cast<const float4*>(w + (0 * 9 + tap) * 256 + lane * 4);   // w packed [2][9][256]
+            const float4 w1 = *reinterpret_cast<const float4*>(w + (1 * 9 + tap) * 256 + lane * 4);
+            a0 += (float)v[0] * w0.x + (float)v[1] * w0.y + (float)v[2] * w0.z + (float)v[3] * w0.w;
+            a1 += (float)v[0] * w1.x + (float)v[1] * w1.y + (float)v[2] * w1.z + (float)v[3] * w1.w;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a0 += __shfl_xor(a0, off);
+        a1 += __shfl_xor(a1, off);
+    }
+    if (lane == 0) {
+        flow[m * 2] += a0 + b[0];
+        flow[m * 2 + 1] += a1 + b[1];
+    }
+}
+
+// upsample_flow (xraft.py:88-99): softmax over the 9 mask logits of each fine pixel, convex combination of
+// the 3x3 neighbourhood of 8 * flow (zero padded unfold).  mask [M, 576] fp32 with channel = k*64 + sy*8 + sx.
+__global__ void raft_upsample_kernel(const float* __restrict__ flow, const float* __restrict__ mask, float* __restrict__ up, int64_t n_img,
+                                     int H8, int W8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int HF = 8 * H8, WF = 8 * W8;
+    if (i >= n_img * HF * WF) return;
+    const int X = (int)(i % WF), Y = (int)((i / WF) % HF);
+    const int64_t n = i / ((int64_t)WF * HF);
+    const int x = X >> 3, sx = X & 7, y = Y >> 3, sy = Y & 7;
+    const int64_t m = (n * H8 + y) * W8 + x;
+    float lg[9], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        lg[k] = mask[m * 576 + k * 64 + sy * 8 + sx];
+        mx = fmaxf(mx, lg[k]);
+    }
+    float sum = 0.f, f0 = 0.f, f1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const float e = expf(lg[k] - mx);
+        sum += e;
+        const int dy = k / 3 - 1, dx = k % 3 - 1;
+        if ((unsigned)(y + dy) < (unsigned)H8 && (unsigned)(x + dx) < (unsigned)W8) {
+            const int64_t mm = m + dy * W8 + dx;
+            f0 += e * 8.f * flow[mm * 2];
+            f1 += e * 8.f * flow[mm * 2 + 1];
+        }
+    }
+    up[((n * 2 + 0) * HF + Y) * WF + X] = f0 / sum;
+    up[((n * 2 + 1) * HF + Y) * WF + X] = f1 / sum;
+}
+
+// ---------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------
+static GemmDesc conv_desc(int M, int N, int H, int W, int KH, int KW, int Cin, int split, const void* A, int64_t lda, const void* A2,
+                          int64_t lda2, const void* Wt, const float* bias, int epi, int act, void* out, int64_t ldo, const void* zero) {
+    GemmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = VTGB_BF16; d.M = M; d.N = N; d.K = KH * KW * Cin; d.epi = epi; d.act = act;
+    d.A = A; d.lda = lda; d.A2 = A2; d.lda2 = lda2; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = out; d.ldo = ldo;
+    d.conv_H = H; d.conv_W = W; d.conv_KH = KH; d.conv_KW = KW; d.conv_Cin = Cin; d.conv_split = split; d.zero_page = zero;
+    return d;
+}
+
+static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
+    VTGB_REQUIRE(a, VTGB_EINVAL, "raft_update: NULL args");
+    VTGB_REQUIRE(a->n_pairs > 0 && a->H8 >= 8 && a->W8 >= 8 && a->iters > 0, VTGB_EINVAL, "raft_update: bad dims n=%d H8=%d W8=%d iters=%d",
+                 a->n_pairs, a->H8, a->W8, a->iters);
+    const int H8 = a->H8, W8 = a->W8, HW = H8 * W8;
+    const int64_t M = (int64_t)a->n_pairs * HW;
+    VTGB_REQUIRE(M < (1ll << 31), VTGB_EUNSUPPORTED, "raft_update: too many pixels");
+    float* h32 = (float*)ws.take(M * 128 * 4);
+    bf16_t* hb = (bf16_t*)ws.take(M * 128 * 2);
+    bf16_t* X = (bf16_t*)ws.take(M * 256 * 2);
+    bf16_t* corrf = (bf16_t*)ws.take(M * 384 * 2);
+    bf16_t* c1 = (bf16_t*)ws.take(M * 256 * 2);
+    bf16_t* CF = (bf16_t*)ws.take(M * 256 * 2);
+    bf16_t* f1 = (bf16_t*)ws.take(M * 128 * 2);
+    bf16_t* ZR = (bf16_t*)ws.take(M * 256 * 2);
+    bf16_t* RH = (bf16_t*)ws.take(M * 128 * 2);
+    bf16_t* FH = (bf16_t*)ws.take(M * 256 * 2);
+    float* flow = (float*)ws.take(M * 2 * 4);
+    float* mask = (float*)ws.take(M * 576 * 4);
+    void* zero = ws.take(256);
+    if (ws.dry) return VTGB_OK;
+    VTGB_REQUIRE(ws.ok(), VTGB_EWORKSPACE, "raft_update: workspace %zu < %zu bytes", ws.size, ws.used);
+    VTGB_REQUIRE(a->net && a->inp && a->weights && a->flow_up, VTGB_EINVAL, "raft_update: NULL operand");
+    const void* const* w = a->weights;
+    for (int i = 0; i < VTGB_RAFT_NW; i++) VTGB_REQUIRE(w[i], VTGB_EINVAL, "raft_update: weights[%d] is NULL", i);
+    CorrPyr pyr;
+    int hl = H8, wl = W8;
+    for (int l = 0; l < 4; l++) {
+        VTGB_REQUIRE(a->corr[l] && hl >= 1 && wl >= 1, VTGB_EINVAL, "raft_update: correlation level %d missing", l);
+        pyr.lvl[l] = a->corr[l]; pyr.h[l] = hl; pyr.w[l] = wl;
+        hl /= 2; wl /= 2;
+    }
+    VTGB_HIP(hipMemsetAsync(zero, 0, 256, s));
+    hipLaunchKernelGGL(raft_init_kernel, dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, s, a->net, a->inp, h32, hb, X, flow, M, HW);
+    const int Mi = (int)M;
+    auto F = [](const void* p) { return (const float*)p; };
+    for (int it = 0; it < a->iters; it++) {
+        // ---- BasicMotionEncoder (update.py:88-97)
+        hipLaunchKernelGGL(raft_corr_lookup_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, pyr, flow, corrf, M, H8, W8);
+        {
+            GemmDesc d = conv_desc(Mi, 256, H8, W8, 0, 0, 0, 0, corrf, 384, nullptr, 0, w[0], F(w[1]), VTGB_EPI_STORE, 1, c1, 256, zero);
+            d.K = 384; d.ldw = 384;
+            VTGB_TRY(launch_conv_gemm(d, s));
+        }
+        VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 192, H8, W8, 3, 3, 256, 256, c1, 256, nullptr, 0, w[2], F(w[3]), VTGB_EPI_STORE, 1, CF, 256, zero), s));
+        hipLaunchKernelGGL(raft_convf1_kernel, dim3((unsigned)((M + 31) / 32)), dim3(256), 0, s, flow, F(w[4]), F(w[5]), f1, X, M, H8, W8);
+        VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 64, H8, W8, 3, 3, 128, 128, f1, 128, nullptr, 0, w[6], F(w[7]), VTGB_EPI_STORE, 1, CF + 192, 256, zero), s));
+        VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 126, H8, W8, 3, 3, 256, 256, CF, 256, nullptr, 0, w[8], F(w[9]), VTGB_EPI_STORE, 1, X + 128, 256, zero), s));
+        // ---- SepConvGRU (update.py:50-65): horizontal (1x5) then vertical (5x1)
+        for (int half = 0; half < 2; half++) {
+            const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1, wi = 10 + 4 * half;
+            VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 256, H8, W8, kh, kw, 384, 128, hb, 128, X, 256, w[wi], F(w[wi + 1]), VTGB_EPI_STORE, 2, ZR, 256, zero), s));
+            hipLaunchKernelGGL(raft_rh_kernel, dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, s, ZR, h32, RH, M * 128);
+            GemmDesc q = conv_desc(Mi, 128, H8, W8, kh, kw, 384, 128, RH, 128, X, 256, w[wi + 2], F(w[wi + 3]), VTGB_EPI_GRU, 0, h32, 128, zero);
+            q.resid = h32; q.ldr = 128; q.aux = ZR; q.ldaux = 256; q.out2 = hb; q.ldo2 = 128;
+            VTGB_TRY(launch_conv_gemm(q, s));
+        }
+        // ---- FlowHead (update.py:10-18) and coords1 += delta_flow (xraft.py:145)
+        VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 256, H8, W8, 3, 3, 128, 128, hb, 128, nullptr, 0, w[18], F(w[19]), VTGB_EPI_STORE, 1, FH, 256, zero), s));
+        hipLaunchKernelGGL(raft_flow_head2_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, FH, F(w[20]), F(w[21]), flow, M, H8, W8);
+    }
+    // ---- mask head of the last iteration (update.py:129-132,143) and convex upsample (xraft.py:88-99)
+    VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 256, H8, W8, 3, 3, 128, 128, hb, 128, nullptr, 0, w[22], F(w[23]), VTGB_EPI_STORE, 1, FH, 256, zero), s));
+    {
+        GemmDesc d = conv_desc(Mi, 576, H8, W8, 0, 0, 0, 0, FH, 256, nullptr, 0, w[24], F(w[25]), VTGB_EPI_STORE_F32, 0, mask, 576, zero);
+        d.K = 256; d.ldw = 256; d.out_scale = 0.25f;
+        VTGB_TRY(launch_conv_gemm(d, s));
+    }
+    const int64_t npx = (int64_t)a->n_pairs * 64 * HW;
+    hipLaunchKernelGGL(raft_upsample_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, flow, mask, a->flow_up, (int64_t)a->n_pairs, H8, W8);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+extern "C" size_t vtgb_raft_update_workspace_bytes(const vtgb_raft_update_args* a) {
+    Workspace ws(nullptr, 0);
+    if (raft_impl(a, ws, nullptr) != VTGB_OK) return 0;
+    return align_up(ws.used, 256);
+}
+extern "C" int vtgb_raft_update(const vtgb_raft_update_args* a, vtgb_stream_t stream) {
+    VTGB_REQUIRE(a && a->workspace, VTGB_EWORKSPACE, "raft_update: workspace is NULL");
+    Workspace ws(a->workspace, a->workspace_bytes);
+    return raft_impl(a, ws, stream);
+}

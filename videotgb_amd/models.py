@@ -239,16 +239,26 @@ class Raft(nn.Module):
     ``raft_dtype`` (fp32 by default as in the reference, xraft.py:118-119).  Only the last
     iteration's upsampled flow is materialised."""
 
-    def __init__(self, raft_dtype=torch.float32):
+    def __init__(self, raft_dtype=torch.float32, hip_update: bool = False):
         super().__init__()
         tree = ParamTree(synth.raft_shapes(""), "")
         for name, child in list(tree._modules.items()):
             self.add_module(name, child)
         self.raft_dtype = raft_dtype
+        self.hip_update = hip_update     # run the 20 refinement iterations in libvtgb.so (bf16 MFMA implicit-GEMM convs)
+        self.channels_last = False       # NHWC activations for the MIOpen encoder convolutions
+        self._table = None
+
+    def _apply(self, fn, *a, **k):
+        self._table = None
+        return super()._apply(fn, *a, **k)
 
     def _c(self, name, x, stride=1, padding=0):
         m = self.get_submodule(name)
-        return F.conv2d(x, m.weight.to(x.dtype), m.bias.to(x.dtype), stride=stride, padding=padding)
+        w = m.weight.to(x.dtype)
+        if self.channels_last:
+            w = w.contiguous(memory_format=torch.channels_last)
+        return F.conv2d(x, w, m.bias.to(x.dtype), stride=stride, padding=padding)
 
     def _norm(self, name, x, kind):
         if kind == "instance":
@@ -277,6 +287,9 @@ class Raft(nn.Module):
         image1 = (2 * (image1.float() / 255.0) - 1.0).contiguous().to(dt)
         image2 = (2 * (image2.float() / 255.0) - 1.0).contiguous().to(dt)
         n, _, h, w = image1.shape
+        if self.channels_last:
+            image1 = image1.contiguous(memory_format=torch.channels_last)
+            image2 = image2.contiguous(memory_format=torch.channels_last)
         f = self._encoder("fnet.", torch.cat([image1, image2], 0), "instance").float()
         fmap1, fmap2 = f[:n], f[n:]
         d, hh, ww = fmap1.shape[1:]
@@ -288,6 +301,10 @@ class Raft(nn.Module):
             pyr.append(corr)
         c = self._encoder("cnet.", image1, "batch")
         net, inp = torch.tanh(c[:, :128]), torch.relu(c[:, 128:])
+        if self.hip_update and flow_init is None:
+            if self._table is None:
+                self._table = ops.RaftWeights({k: v for k, v in self.state_dict().items()})
+            return ops.raft_update(self._table, net.float(), inp.float(), pyr, iters)
         ys, xs = torch.meshgrid(torch.arange(hh, device=image1.device), torch.arange(ww, device=image1.device), indexing="ij")
         coords0 = torch.stack([xs, ys], 0).float()[None].repeat(n, 1, 1, 1)
         coords1 = coords0.clone() if flow_init is None else coords0 + flow_init
@@ -357,12 +374,12 @@ class _LSTPBase(nn.Module):
     MAP = "A"
 
     def __init__(self, cfg: synth.PathCfg, device="cuda", language_model: Optional[nn.Module] = None, compute_dtype="bf16",
-                 raft_dtype=torch.float32):
+                 raft_dtype=torch.float32, raft_hip_update: bool = False):
         super().__init__()
         self.cfg = cfg
         self.model = PathModel(cfg, language_model, compute_dtype)
         self.temporal_encoder = TemporalEncoder(cfg.tgb, compute_dtype)
-        self.of_extractor = Raft(raft_dtype)
+        self.of_extractor = Raft(raft_dtype, raft_hip_update)
         self.device = device
         self.fell_back = False
 
@@ -375,14 +392,21 @@ class _LSTPBase(nn.Module):
 
     # ---- stages -------------------------------------------------------------------------------
     @torch.no_grad()
-    def flow(self, flow_frames: Tensor) -> Tensor:
-        """eval/utils/model.py:76-84: RAFT between consecutive frames, last flow repeated."""
-        of = []
-        for ff in flow_frames:
-            ff = InputPadder(ff[0].shape).pad(ff)
-            fl = self.of_extractor(ff[:-1], ff[1:])
-            of.append(torch.cat([fl, fl[-1:]], dim=0))
-        return torch.stack(of)
+    def flow(self, flow_frames: Tensor, clips_per_call: int = 8) -> Tensor:
+        """eval/utils/model.py:76-84: RAFT between consecutive frames of each clip, last flow repeated.
+        The frame pairs of up to ``clips_per_call`` clips go through RAFT in one call (the reference loops
+        over clips; pairs are independent, so batching them changes nothing but the launch count)."""
+        b, t = flow_frames.shape[:2]
+        outs = []
+        for c0 in range(0, b, clips_per_call):
+            ff = flow_frames[c0:c0 + clips_per_call]
+            ff = InputPadder(ff.shape).pad(ff.reshape(-1, *ff.shape[2:])).reshape(ff.shape[0], t, ff.shape[2], -1, ff.shape[4]) \
+                if (ff.shape[-1] % 8 or ff.shape[-2] % 8) else ff
+            i1 = ff[:, :-1].reshape(-1, *ff.shape[2:])
+            i2 = ff[:, 1:].reshape(-1, *ff.shape[2:])
+            fl = self.of_extractor(i1, i2).view(ff.shape[0], t - 1, 2, ff.shape[3], ff.shape[4])
+            outs.append(torch.cat([fl, fl[:, -1:]], dim=1))
+        return torch.cat(outs, dim=0)
 
     @torch.no_grad()
     def select_frames(self, pixel_values: Tensor, of: Tensor, sampler_ids: Tensor, sampler_mask: Tensor, nframe: int,

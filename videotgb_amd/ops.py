@@ -409,3 +409,58 @@ def tgb_forward(w: TgbWeights, of: Tensor, of_mask: Tensor, text_ids: Tensor, te
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     L.check(L.lib().vtgb_tgb_forward(C.byref(a), _stream()))
     return seq, logits
+
+
+# ----------------------------------------------------------------------------- RAFT recurrent update (f1)
+class RaftWeights(_WeightTable):
+    """of_extractor.update_block.* -> the packed table of vtgb_raft_update (bf16, [C_out, KH, KW, C_in])."""
+
+    def __init__(self, sd: Dict[str, Tensor], prefix: str = "update_block."):
+        super().__init__(BF16)
+        p = prefix
+
+        def conv(name, cin_pad=None):
+            w = sd[p + name + ".weight"].float()
+            co, ci, kh, kw = w.shape
+            w = w.permute(0, 2, 3, 1)                       # [co, kh, kw, ci]
+            if cin_pad and cin_pad != ci:
+                w = torch.nn.functional.pad(w, (0, cin_pad - ci))
+            return w.reshape(co, -1).contiguous()
+
+        def add_conv(name, cin_pad=None):
+            self.add(conv(name, cin_pad), True)
+            self.add(sd[p + name + ".bias"])
+
+        add_conv("encoder.convc1", 384)
+        add_conv("encoder.convc2")
+        self.add(sd[p + "encoder.convf1.weight"]); self.add(sd[p + "encoder.convf1.bias"])        # fp32, direct kernel
+        add_conv("encoder.convf2")
+        add_conv("encoder.conv")
+        for sfx in ("1", "2"):
+            self.add(torch.cat([conv("gru.convz" + sfx), conv("gru.convr" + sfx)], 0), True)
+            self.add(torch.cat([sd[p + "gru.convz" + sfx + ".bias"], sd[p + "gru.convr" + sfx + ".bias"]], 0))
+            add_conv("gru.convq" + sfx)
+        add_conv("flow_head.conv1")
+        self.add(sd[p + "flow_head.conv2.weight"].float().permute(0, 2, 3, 1).reshape(2, -1).contiguous())   # fp32 [2, 9*256]
+        self.add(sd[p + "flow_head.conv2.bias"])
+        add_conv("mask.0")
+        add_conv("mask.2")
+        self.finish()
+
+
+def raft_update(w: RaftWeights, net: Tensor, inp: Tensor, pyramid: Sequence[Tensor], iters: int = 20) -> Tensor:
+    """net/inp [n, 128, H8, W8] fp32 (tanh / relu applied), pyramid: 4 fp32 levels [n*H8*W8, 1, h, w] -> flow_up [n, 2, 8H8, 8W8]."""
+    _need_cuda(net, inp, *pyramid)
+    net, inp = net.contiguous().float(), inp.contiguous().float()
+    n, _, H8, W8 = net.shape
+    lv = [t.contiguous().float() for t in pyramid]
+    if len(lv) != 4:
+        raise ValueError("raft_update: the correlation pyramid has 4 levels")
+    out = torch.empty(n, 2, 8 * H8, 8 * W8, dtype=torch.float32, device=net.device)
+    a = L.RaftUpdateArgs(n, H8, W8, iters, net.data_ptr(), inp.data_ptr(), (C.c_void_p * 4)(*[t.data_ptr() for t in lv]),
+                         C.cast(w.array, C.POINTER(C.c_void_p)), out.data_ptr(), None, 0)
+    need = L.lib().vtgb_raft_update_workspace_bytes(C.byref(a))
+    ws = _ws.get(need, net.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.check(L.lib().vtgb_raft_update(C.byref(a), _stream()))
+    return out
