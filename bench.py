@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--raft-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="precision of the RAFT convolutions in --flow raft mode (reference: fp32; bf16 keeps coords/correlation in fp32)")
     ap.add_argument("--raft-channels-last", action="store_true", help="NHWC activations for the MIOpen encoder convolutions of RAFT")
+    ap.add_argument("--raft-encoders", choices=["hip", "torch"], default="hip",
+                    help="RAFT fnet/cnet: libvtgb.so (bf16 MFMA implicit-GEMM convolutions, fnet once per distinct frame) or MIOpen")
     ap.add_argument("--raft-update", choices=["hip", "torch"], default="hip",
                     help="RAFT refinement loop: libvtgb.so (bf16 MFMA implicit-GEMM convolutions) or PyTorch-ROCm/MIOpen ops")
     ap.add_argument("--overlap", action="store_true",
@@ -196,8 +198,8 @@ def main():
     dev = torch.device("cuda", local)
     from videotgb_amd import _lib, llm, models, synth
     _lib.lib()
-    if args.flow == "raft":
-        # RAFT runs on MIOpen for now: let it search its solvers once, in the warm-up
+    if args.flow == "raft" and not (args.raft_encoders == "hip" and args.raft_update == "hip"):
+        # RAFT (partly) on MIOpen: let it search its solvers once, in the warm-up
         # (without this several RAFT convolutions fall back to MIOpen's naive kernel, 45 % of the stage)
         torch.backends.cudnn.benchmark = True
     cfg = synth.full_cfg("instructblip")
@@ -207,6 +209,7 @@ def main():
                     raft_dtype=torch.bfloat16 if args.raft_dtype == "bf16" else torch.float32,
                     raft_hip_update=(args.raft_update == "hip"))
     m.of_extractor.channels_last = args.raft_channels_last
+    m.of_extractor.hip_encoders = (args.raft_encoders == "hip" and args.raft_update == "hip")
     sd = synth.path_state_dict(cfg, seed=0, with_raft=True)
     m.load_state_dict(sd, strict=False)
     m.to(dev)
@@ -283,7 +286,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"InstructBLIP-Vicuna-7B + TGB, T={T}->{nframe} of 32 frames, 224x224, greedy {args.max_new_tokens} new tokens "
-                                      f"(BASELINE.json configs[2])", "flow": args.flow if args.flow == "precomputed" else f"raft inline (update={args.raft_update}, encoders={args.raft_dtype})",
+                                      f"(BASELINE.json configs[2])", "flow": args.flow if args.flow == "precomputed" else f"raft inline (update={args.raft_update}, encoders={args.raft_encoders if args.raft_update == 'hip' else 'torch'}/{args.raft_dtype})",
                           "clips_per_gpu_per_step": B,
                           "global_batch": B * world, "parallelism": f"clip-parallel x{world} (no data-path collective)",
                           "llm": f"HF LlamaForCausalLM {args.llm} geometry, random init, KV cache, decode={args.decode}",

@@ -293,6 +293,26 @@ typedef struct {
 size_t vtgb_raft_update_workspace_bytes(const vtgb_raft_update_args* a);
 int vtgb_raft_update(const vtgb_raft_update_args* a, vtgb_stream_t stream);
 
+/* RAFT BasicEncoder (raft_utils/extractor.py:116-189): stem 7x7/2, six ResidualBlocks, 1x1 head; the input
+ * scaling 2*(x/255)-1 of RAFT.forward (xraft.py:105-106) is applied inside.  norm = 0: InstanceNorm2d (fnet);
+ * norm = 1: the caller has folded the eval-mode BatchNorm2d that follows every convolution into the packed
+ * weights and biases (cnet).  Output: NHWC features [n_images * H/8 * W/8, 256] fp32.
+ * weights: [0] conv1.weight fp32 [64,3,7,7] [1] conv1.bias; per block b (layer1.0, 1.1, 2.0, 2.1, 3.0, 3.1) at
+ *   2 + 6 b: conv1.weight bf16 [C, 3,3,Cin_pad] , conv1.bias, conv2.weight [C, 3,3,C_pad], conv2.bias,
+ *   downsample.0.weight [C, Cin_pad] or NULL, downsample.0.bias or NULL  (96-channel stages: C_pad = 128, zero-filled);
+ *   [38] conv2.weight bf16 [256, 128] [39] conv2.bias */
+#define VTGB_RAFT_ENC_NW 40
+typedef struct {
+    int32_t n_images, H, W, norm;
+    const float* images;        /* [n_images, 3, H, W] fp32 */
+    const void* const* weights; /* host array              */
+    float* out;                 /* [n_images * H/8 * W/8, 256] fp32 */
+    void* workspace;
+    size_t workspace_bytes;
+} vtgb_raft_encoder_args;
+size_t vtgb_raft_encoder_workspace_bytes(const vtgb_raft_encoder_args* a);
+int vtgb_raft_encoder(const vtgb_raft_encoder_args* a, vtgb_stream_t stream);
+
 /* ---- LLM decode-step building blocks ("next" row) ----------------------------
  * The LLM itself is third-party on both sides (HF weights and GEMMs); these fuse the small
  * per-layer ops of a KV-cached greedy decode step with the exact rounding points of

@@ -55,3 +55,31 @@ def test_raft_update_single_iteration_pieces(dev, tiny_sd):
     e = rel_rms(hip, ref)
     print(f"[raft 1 iteration] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
     assert e <= 2e-2
+
+
+@pytest.mark.parametrize("net,kind", [("fnet.", "instance"), ("cnet.", "batch")])
+def test_raft_encoder_vs_oracle(dev, tiny_sd, net, kind):
+    """BasicEncoder in HIP (bf16 MFMA implicit-GEMM convs, fp32 norms) vs the fp32 oracle."""
+    from oracle import vtgb_oracle as O
+    from videotgb_amd import ops
+    sd = tiny_sd["instructblip"][1]
+    g = load_golden("tiny_raft")
+    fr = deq(g, "frames_q8")                                   # [3, 3, 128, 128]
+    ref = O.raft_encoder(sd, "of_extractor." + net, 2 * (fr / 255.0) - 1.0, kind)       # [3, 256, 16, 16]
+    rsd = {k[len("of_extractor."):]: v.to(dev) for k, v in sd.items() if k.startswith("of_extractor.")}
+    w = ops.RaftEncoderWeights(rsd, net, kind == "batch")
+    out = ops.raft_encoder(w, fr.to(dev)).cpu().view(3, 16, 16, 256).permute(0, 3, 1, 2)
+    e = rel_rms(out, ref)
+    print(f"[raft encoder {net}] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
+    assert e <= 2e-2
+
+
+def test_raft_all_hip_clip_path_vs_reference(dev, tiny_sd):
+    """forward_clips: encoders + update in HIP, fnet once per distinct frame; vs the reference flows."""
+    g = load_golden("tiny_raft")
+    fr = deq(g, "frames_q8").to(dev)
+    r = make(dev, tiny_sd, True)
+    flow = r.forward_clips(fr[None], iters=20)[0].cpu()          # [2, 2, 128, 128]
+    e = rel_rms(flow, g["flow_iters20"])
+    print(f"[raft all-HIP] rel_rms={e:.3e}")
+    assert e <= 5e-2

@@ -27,7 +27,7 @@ EXPORTS = [
     "vtgb_pool_project", "vtgb_tgb_workspace_bytes", "vtgb_tgb_forward", "vtgb_gemm", "vtgb_attention",
     "vtgb_layernorm", "vtgb_prof_enable", "vtgb_prof_reset", "vtgb_prof_summary",
     "vtgb_llm_rmsnorm", "vtgb_llm_rope_cache", "vtgb_llm_decode_attention", "vtgb_llm_silu_mul",
-    "vtgb_raft_update_workspace_bytes", "vtgb_raft_update",
+    "vtgb_raft_update_workspace_bytes", "vtgb_raft_update", "vtgb_raft_encoder_workspace_bytes", "vtgb_raft_encoder",
 ]
 
 i32, i64, f32, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -83,6 +83,11 @@ class RaftUpdateArgs(C.Structure):
                 ("weights", C.POINTER(vp)), ("flow_up", vp), ("workspace", vp), ("workspace_bytes", sz)]
 
 
+class RaftEncoderArgs(C.Structure):
+    _fields_ = [("n_images", i32), ("H", i32), ("W", i32), ("norm", i32), ("images", vp), ("weights", C.POINTER(vp)), ("out", vp),
+                ("workspace", vp), ("workspace_bytes", sz)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [("dtype", i32), ("M", i32), ("N", i32), ("K", i32), ("epilogue", i32), ("A", vp), ("lda", i64),
                 ("W", vp), ("ldw", i64), ("bias", vp), ("resid", vp), ("out", vp), ("ldo", i64)]
@@ -132,6 +137,10 @@ def lib() -> C.CDLL:
     L.vtgb_raft_update.restype = C.c_int
     L.vtgb_raft_update_workspace_bytes.argtypes = [C.POINTER(RaftUpdateArgs)]
     L.vtgb_raft_update_workspace_bytes.restype = sz
+    L.vtgb_raft_encoder.argtypes = [C.POINTER(RaftEncoderArgs), vp]
+    L.vtgb_raft_encoder.restype = C.c_int
+    L.vtgb_raft_encoder_workspace_bytes.argtypes = [C.POINTER(RaftEncoderArgs)]
+    L.vtgb_raft_encoder_workspace_bytes.restype = sz
     L.vtgb_llm_rmsnorm.argtypes = [C.c_int, vp, vp, vp, vp, i64, i32, f32, vp]
     L.vtgb_llm_rope_cache.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.vtgb_llm_decode_attention.argtypes = [C.c_int, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]

@@ -101,6 +101,7 @@ struct GemmDesc {
     // Channels [0, split_c) come from A (row stride lda), channels [split_c, Cin) from A2 (lda2):
     // a virtual concat.  conv_KH == 0 -> not a convolution.
     int conv_H, conv_W, conv_KH, conv_KW, conv_Cin, conv_split;
+    int conv_stride, conv_Hi, conv_Wi;   // 0 -> stride 1, input grid == output grid; padding is always KH/2, KW/2
     const void* A2;
     int64_t lda2;
     const void* zero_page;   // >= 256 B of zeros (out-of-image taps read it)

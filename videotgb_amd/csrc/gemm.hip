@@ -334,9 +334,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         const int am = (m0 + row) < p.M ? (m0 + row) : p.M - 1;
         const int wr = (n0 + row) < p.N ? (n0 + row) : p.N - 1;
         if constexpr (CONV) {
-            const int rem = am % (p.conv_H * p.conv_W);
-            a_row[i] = am;
-            a_yx[i] = ((rem / p.conv_W) << 16) | (rem % p.conv_W);
+            const int hw = p.conv_H * p.conv_W, img = am / hw, rem = am - img * hw;
+            a_row[i] = img * (p.conv_Hi ? p.conv_Hi * p.conv_Wi : hw);      // first input pixel of this row's image
+            a_yx[i] = ((rem / p.conv_W) << 16) | (rem % p.conv_W);          // output (y, x)
             a_src[i] = nullptr;
         } else {
             a_src[i] = A + map_row(p.a_map, am) * p.lda + c * 8;
@@ -350,15 +350,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
 #define L_ISSUE_A(slot, k0)                                                                             \
     if constexpr (CONV) {                                                                               \
         const int dy = cv_tap / p.conv_KW - (p.conv_KH >> 1), dx = cv_tap % p.conv_KW - (p.conv_KW >> 1); \
+        const int cst = p.conv_stride ? p.conv_stride : 1;                                              \
+        const int Hi = p.conv_Hi ? p.conv_Hi : p.conv_H, Wi = p.conv_Wi ? p.conv_Wi : p.conv_W;         \
         const bool first = cv_c0 < p.conv_split;                                                        \
         const bf16_t* base = first ? A : reinterpret_cast<const bf16_t*>(p.A2);                         \
         const int64_t ld = first ? p.lda : p.lda2;                                                      \
         const int cc = first ? cv_c0 : cv_c0 - p.conv_split;                                            \
         _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                 \
             const int c8 = ((lane & 7) ^ ((i * 4 + (lane >> 4)) & 7)) * 8;                              \
-            const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;                            \
-            const bool ok = (unsigned)y < (unsigned)p.conv_H && (unsigned)x < (unsigned)p.conv_W;       \
-            const bf16_t* src = ok ? base + (int64_t)(a_row[i] + dy * p.conv_W + dx) * ld + cc + c8     \
+            const int y = (a_yx[i] >> 16) * cst + dy, x = (a_yx[i] & 0xffff) * cst + dx;                \
+            const bool ok = (unsigned)y < (unsigned)Hi && (unsigned)x < (unsigned)Wi;                   \
+            const bf16_t* src = ok ? base + (int64_t)(a_row[i] + y * Wi + x) * ld + cc + c8             \
                                    : reinterpret_cast<const bf16_t*>(p.zero_page) + c8;                 \
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (slot) * L_OP_BYTES + (wave * 32 + i * 8) * 128), 16, 0, 0); \
         }                                                                                               \

@@ -1,0 +1,195 @@
+// raft_enc.hip -- RAFT's BasicEncoder (raft_utils/extractor.py:116-189: 7x7/2 stem, six ResidualBlocks
+// :6-56 at 1/2, 1/4, 1/8 resolution, 1x1 head) on gfx950, the remaining piece of SURVEY.md row f1.
+// NHWC bf16 activations (96-channel stages padded to 128), every 3x3 / 1x1 convolution an implicit GEMM on
+// the MFMA kernel of gemm.hip (stride 1 and 2) with fp32 outputs; the norm that follows each convolution
+// (InstanceNorm2d for fnet, eval-mode BatchNorm2d for cnet -- folded into the packed weights by the
+// caller) is applied by a separate HBM-bound pass that also does ReLU, the residual add and the bf16 cast.
+// The stem (3 input channels, K = 147) is a direct fp32 kernel.
+#include <math.h>
+#include <string.h>
+
+#include "common.h"
+
+// ---- stem: conv 7x7 stride 2 pad 3, 3 -> 64, on 2*(x/255)-1 (xraft.py:105-106); one workgroup per output row
+__global__ __launch_bounds__(256) void raft_stem_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ b,
+                                                        float* __restrict__ out, int H, int W) {
+    extern __shared__ float sm[];
+    const int Wo = W >> 1, Ho = H >> 1;
+    float* ws = sm;                    // [147][64]
+    float* xs = sm + 147 * 64;         // [3][7][W + 6]
+    const int n = blockIdx.y, yo = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < 147 * 64; i += 256) {   // w is [64][3][7][7] -> ws[k][co]
+        const int co = i & 63, k = i >> 6;
+        ws[i] = w[co * 147 + k];
+    }
+    const int WP = W + 6;
+    for (int i = tid; i < 3 * 7 * WP; i += 256) {
+        const int c = i / (7 * WP), r = (i / WP) % 7, xx = i % WP;
+        const int y = yo * 2 + r - 3, x = xx - 3;
+        float v = 0.f;
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = 2.0f * (img[(((int64_t)n * 3 + c) * H + y) * W + x] / 255.0f) - 1.0f;
+        xs[i] = v;
+    }
+    __syncthreads();
+    // thread -> (pixel, 32-channel half); pixels beyond Wo idle
+    for (int item = tid; item < Wo * 2; item += 256) {
+        const int px = item >> 1, c0 = (item & 1) * 32;
+        float acc[32];
+#pragma unroll
+        for (int c = 0; c < 32; c++) acc[c] = b[c0 + c];
+        for (int k = 0; k < 147; k++) {
+            const int c = k / 49, t = k - c * 49, ky = t / 7, kx = t - ky * 7;
+            const float x = xs[(c * 7 + ky) * WP + px * 2 + kx];
+#pragma unroll
+            for (int cc = 0; cc < 32; cc++) acc[cc] = fmaf(x, ws[k * 64 + c0 + cc], acc[cc]);
+        }
+        float* o = out + (((int64_t)n * Ho + yo) * Wo + px) * 64 + c0;
+#pragma unroll
+        for (int cc = 0; cc < 32; cc += 4) *reinterpret_cast<float4*>(o + cc) = make_float4(acc[cc], acc[cc + 1], acc[cc + 2], acc[cc + 3]);
+    }
+}
+
+// ---- InstanceNorm2d statistics: per (image, channel) mean and 1/sqrt(biased var + 1e-5) over the HW pixels
+__global__ __launch_bounds__(256) void inorm_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int HW, int C, int ldx) {
+    __shared__ float s1[256], s2[256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int c = tid % C, lane_p = tid / C, np = 256 / C;   // C in {64, 96, 128}: 4, 2, 2 pixel lanes (tid >= np*C idle)
+    float a = 0.f, q = 0.f;
+    if (lane_p < np) {
+        const float* base = x + (int64_t)n * HW * ldx + c;
+        for (int p = lane_p; p < HW; p += np) {
+            const float v = base[(int64_t)p * ldx];
+            a += v;
+            q = fmaf(v, v, q);
+        }
+    }
+    s1[tid] = a; s2[tid] = q;
+    __syncthreads();
+    if (tid < C) {
+        float sa = 0.f, sq = 0.f;
+        for (int l = 0; l < np; l++) { sa += s1[l * C + tid]; sq += s2[l * C + tid]; }
+        const float mean = sa / (float)HW, var = fmaxf(sq / (float)HW - mean * mean, 0.f);
+        stats[((int64_t)n * C + tid) * 2] = mean;
+        stats[((int64_t)n * C + tid) * 2 + 1] = rsqrtf(var + 1e-5f);
+    }
+}
+
+// ---- y = [relu]((x - mean) * rstd); out = [relu](resid + y); bf16 NHWC with Cpad channels (pad = 0)
+__global__ void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const bf16_t* __restrict__ resid,
+                                  bf16_t* __restrict__ out, int64_t M, int HW, int C, int Cpad, int ldx, int relu_inner, int relu_outer) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * Cpad) return;
+    const int64_t m = i / Cpad;
+    const int c = (int)(i - m * Cpad);
+    float v = 0.f;
+    if (c < C) {
+        v = x[m * ldx + c];
+        if (stats) {
+            const int64_t n = m / HW;
+            v = (v - stats[(n * C + c) * 2]) * stats[(n * C + c) * 2 + 1];
+        }
+        if (relu_inner) v = fmaxf(v, 0.f);
+        if (resid) v += (float)resid[i];
+        if (relu_outer) v = fmaxf(v, 0.f);
+    }
+    out[i] = (bf16_t)v;
+}
+
+static GemmDesc enc_conv(int Mo, int N, int Ho, int Wo, int K, int Cin, int stride, int Hi, int Wi, const void* A, const void* Wt, const float* bias,
+                         float* out, int ldo, const void* zero) {
+    GemmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = VTGB_BF16; d.M = Mo; d.N = N; d.K = K * K * Cin; d.epi = VTGB_EPI_STORE_F32;
+    d.A = A; d.lda = Cin; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = out; d.ldo = ldo;
+    d.conv_H = Ho; d.conv_W = Wo; d.conv_KH = K; d.conv_KW = K; d.conv_Cin = Cin; d.conv_split = Cin;
+    d.conv_stride = stride; d.conv_Hi = Hi; d.conv_Wi = Wi; d.zero_page = zero;
+    return d;
+}
+
+static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t s) {
+    VTGB_REQUIRE(a, VTGB_EINVAL, "raft_encoder: NULL args");
+    VTGB_REQUIRE(a->n_images > 0 && a->H >= 64 && a->W >= 64 && (a->H % 8) == 0 && (a->W % 8) == 0 && (a->norm == 0 || a->norm == 1), VTGB_EINVAL,
+                 "raft_encoder: bad dims n=%d H=%d W=%d", a->n_images, a->H, a->W);
+    VTGB_REQUIRE(a->W + 6 <= 1024, VTGB_EUNSUPPORTED, "raft_encoder: width %d too large for the stem kernel", a->W);
+    const int n = a->n_images;
+    const int H2 = a->H / 2, W2 = a->W / 2, H4 = a->H / 4, W4 = a->W / 4, H8 = a->H / 8, W8 = a->W / 8;
+    const int64_t M2 = (int64_t)n * H2 * W2, M4 = (int64_t)n * H4 * W4, M8 = (int64_t)n * H8 * W8;
+    VTGB_REQUIRE(M2 < (1ll << 31), VTGB_EUNSUPPORTED, "raft_encoder: too many pixels per call (chunk the images)");
+    float* cf = (float*)ws.take(M2 * 64 * 4);          // fp32 conv output (largest stage; later stages reuse it)
+    float* cf2 = (float*)ws.take(M4 * 128 * 4);        // fp32 output of the downsample branch
+    bf16_t* act0 = (bf16_t*)ws.take(M2 * 64 * 2);
+    bf16_t* act1 = (bf16_t*)ws.take(M2 * 64 * 2);
+    bf16_t* act2 = (bf16_t*)ws.take(M2 * 64 * 2);
+    float* stats = (float*)ws.take((int64_t)n * 128 * 2 * 4);
+    void* zero = ws.take(256);
+    if (ws.dry) return VTGB_OK;
+    VTGB_REQUIRE(ws.ok(), VTGB_EWORKSPACE, "raft_encoder: workspace %zu < %zu bytes", ws.size, ws.used);
+    VTGB_REQUIRE(a->images && a->weights && a->out, VTGB_EINVAL, "raft_encoder: NULL operand");
+    const void* const* w = a->weights;
+    auto F = [](const void* p) { return (const float*)p; };
+    const bool inorm = a->norm == 0;
+    VTGB_HIP(hipMemsetAsync(zero, 0, 256, s));
+
+    auto norm = [&](const float* x, int64_t M, int HW, int C, int Cpad, int ldx, const bf16_t* resid, bf16_t* out, int relu_in, int relu_out) -> int {
+        if (inorm) hipLaunchKernelGGL(inorm_stats_kernel, dim3(n), dim3(256), 0, s, x, stats, HW, C, ldx);
+        hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)((M * Cpad + 255) / 256)), dim3(256), 0, s, x, inorm ? stats : nullptr, resid, out, M, HW, C,
+                           Cpad, ldx, relu_in, relu_out);
+        VTGB_HIP(hipGetLastError());
+        return VTGB_OK;
+    };
+    // ---- stem
+    const size_t stem_lds = (147 * 64 + 3 * 7 * (a->W + 6)) * sizeof(float);
+    hipLaunchKernelGGL(raft_stem_kernel, dim3(H2, n), dim3(256), stem_lds, s, a->images, F(w[0]), F(w[1]), cf, a->H, a->W);
+    VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0));
+    // ---- six residual blocks
+    struct Stage { int C, Cpad, stride, Ho, Wo; };
+    const Stage st[6] = {{64, 64, 1, H2, W2}, {64, 64, 1, H2, W2}, {96, 128, 2, H4, W4}, {96, 128, 1, H4, W4}, {128, 128, 2, H8, W8}, {128, 128, 1, H8, W8}};
+    bf16_t* x = act0;
+    bf16_t* t1 = act1;
+    bf16_t* t2 = act2;
+    int Cin_pad = 64, Hi = H2, Wi = W2;
+    for (int b = 0; b < 6; b++) {
+        const Stage& g = st[b];
+        const void* const* bw = w + 2 + 6 * b;
+        const int64_t Mo = (int64_t)n * g.Ho * g.Wo;
+        const int HWo = g.Ho * g.Wo;
+        VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), cf, g.Cpad, zero), s));
+        VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t1, 1, 0));                       // y = relu(norm1(conv1(x)))
+        VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), cf, g.Cpad, zero), s));
+        const bf16_t* res = x;
+        if (g.stride != 1) {                                                                      // x = norm3(downsample(x))
+            VTGB_REQUIRE(bw[4] && bw[5], VTGB_EINVAL, "raft_encoder: block %d lacks its downsample weights", b);
+            VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 1, Cin_pad, g.stride, Hi, Wi, x, bw[4], F(bw[5]), cf2, g.Cpad, zero), s));
+            VTGB_TRY(norm(cf2, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t2, 0, 0));
+            res = t2;
+        }
+        bf16_t* outb = t1;
+        // out = relu(x + relu(norm2(conv2(y))))   -- t1 is free once conv2 has consumed it (stream order)
+        VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, res, outb, 1, 1));
+        // rotate buffers: the block output becomes the next input
+        bf16_t* old = x;
+        x = outb;
+        t1 = old;
+        Cin_pad = g.Cpad; Hi = g.Ho; Wi = g.Wo;
+    }
+    // ---- head: 1x1, 128 -> 256 (no norm)
+    {
+        GemmDesc d;
+        memset(&d, 0, sizeof(d));
+        d.dtype = VTGB_BF16; d.M = (int)M8; d.N = 256; d.K = 128; d.epi = VTGB_EPI_STORE_F32;
+        d.A = x; d.lda = 128; d.W = w[38]; d.ldw = 128; d.bias = F(w[39]); d.out = a->out; d.ldo = 256;
+        VTGB_TRY(launch_conv_gemm(d, s));
+    }
+    return VTGB_OK;
+}
+
+extern "C" size_t vtgb_raft_encoder_workspace_bytes(const vtgb_raft_encoder_args* a) {
+    Workspace ws(nullptr, 0);
+    if (enc_impl(a, ws, nullptr) != VTGB_OK) return 0;
+    return align_up(ws.used, 256);
+}
+extern "C" int vtgb_raft_encoder(const vtgb_raft_encoder_args* a, vtgb_stream_t stream) {
+    VTGB_REQUIRE(a && a->workspace, VTGB_EWORKSPACE, "raft_encoder: workspace is NULL");
+    Workspace ws(a->workspace, a->workspace_bytes);
+    return enc_impl(a, ws, stream);
+}

@@ -247,11 +247,39 @@ class Raft(nn.Module):
         self.raft_dtype = raft_dtype
         self.hip_update = hip_update     # run the 20 refinement iterations in libvtgb.so (bf16 MFMA implicit-GEMM convs)
         self.channels_last = False       # NHWC activations for the MIOpen encoder convolutions
+        self.hip_encoders = False        # fnet / cnet in libvtgb.so as well (forward_clips)
         self._table = None
 
     def _apply(self, fn, *a, **k):
         self._table = None
         return super()._apply(fn, *a, **k)
+
+    def _hip_tables(self):
+        if self._table is None:
+            sd = {k: v for k, v in self.state_dict().items()}
+            self._table = (ops.RaftWeights(sd), ops.RaftEncoderWeights(sd, "fnet.", False), ops.RaftEncoderWeights(sd, "cnet.", True))
+        return self._table
+
+    @torch.no_grad()
+    def forward_clips(self, frames: Tensor, iters: int = 20) -> Tensor:
+        """All-HIP path for whole clips: frames [B, T, 3, H, W] -> flow [B, T-1, 2, H, W] between consecutive frames.
+        fnet runs once per distinct frame (the reference encodes cat(image1, image2), i.e. every inner frame
+        twice, with identical results since InstanceNorm is per image); cnet on frames[:, :-1]."""
+        upd, fw, cw = self._hip_tables()
+        b, t, _, h, w = frames.shape
+        h8, w8 = h // 8, w // 8
+        fmap = ops.raft_encoder(fw, frames.reshape(b * t, 3, h, w)).view(b, t, h8 * w8, 256)
+        cmap = ops.raft_encoder(cw, frames[:, :-1].reshape(b * (t - 1), 3, h, w))             # [n, HW, 256]
+        n = b * (t - 1)
+        corr = torch.matmul(fmap[:, :-1].reshape(n, h8 * w8, 256), fmap[:, 1:].reshape(n, h8 * w8, 256).transpose(1, 2))
+        corr = (corr / 16.0).reshape(n * h8 * w8, 1, h8, w8)                                   # / sqrt(256)  (corr.py:60)
+        pyr = [corr]
+        for _ in range(3):
+            corr = F.avg_pool2d(corr, 2, stride=2)
+            pyr.append(corr)
+        cm = cmap.view(n, h8, w8, 256).permute(0, 3, 1, 2)
+        net, inp = torch.tanh(cm[:, :128]).contiguous(), torch.relu(cm[:, 128:]).contiguous()
+        return ops.raft_update(upd, net, inp, pyr, iters).view(b, t - 1, 2, h, w)
 
     def _c(self, name, x, stride=1, padding=0):
         m = self.get_submodule(name)
@@ -302,9 +330,7 @@ class Raft(nn.Module):
         c = self._encoder("cnet.", image1, "batch")
         net, inp = torch.tanh(c[:, :128]), torch.relu(c[:, 128:])
         if self.hip_update and flow_init is None:
-            if self._table is None:
-                self._table = ops.RaftWeights({k: v for k, v in self.state_dict().items()})
-            return ops.raft_update(self._table, net.float(), inp.float(), pyr, iters)
+            return ops.raft_update(self._hip_tables()[0], net.float(), inp.float(), pyr, iters)
         ys, xs = torch.meshgrid(torch.arange(hh, device=image1.device), torch.arange(ww, device=image1.device), indexing="ij")
         coords0 = torch.stack([xs, ys], 0).float()[None].repeat(n, 1, 1, 1)
         coords1 = coords0.clone() if flow_init is None else coords0 + flow_init
@@ -402,9 +428,12 @@ class _LSTPBase(nn.Module):
             ff = flow_frames[c0:c0 + clips_per_call]
             ff = InputPadder(ff.shape).pad(ff.reshape(-1, *ff.shape[2:])).reshape(ff.shape[0], t, ff.shape[2], -1, ff.shape[4]) \
                 if (ff.shape[-1] % 8 or ff.shape[-2] % 8) else ff
-            i1 = ff[:, :-1].reshape(-1, *ff.shape[2:])
-            i2 = ff[:, 1:].reshape(-1, *ff.shape[2:])
-            fl = self.of_extractor(i1, i2).view(ff.shape[0], t - 1, 2, ff.shape[3], ff.shape[4])
+            if getattr(self.of_extractor, "hip_encoders", False):
+                fl = self.of_extractor.forward_clips(ff)
+            else:
+                i1 = ff[:, :-1].reshape(-1, *ff.shape[2:])
+                i2 = ff[:, 1:].reshape(-1, *ff.shape[2:])
+                fl = self.of_extractor(i1, i2).view(ff.shape[0], t - 1, 2, ff.shape[3], ff.shape[4])
             outs.append(torch.cat([fl, fl[:, -1:]], dim=1))
         return torch.cat(outs, dim=0)
 

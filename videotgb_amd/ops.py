@@ -464,3 +464,65 @@ def raft_update(w: RaftWeights, net: Tensor, inp: Tensor, pyramid: Sequence[Tens
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     L.check(L.lib().vtgb_raft_update(C.byref(a), _stream()))
     return out
+
+
+class RaftEncoderWeights(_WeightTable):
+    """of_extractor.{fnet,cnet}.* -> the packed table of vtgb_raft_encoder.  batch_norm=True folds the eval-mode
+    BatchNorm2d that follows each convolution (extractor.py:20-24,124) into the convolution's weight and bias."""
+
+    def __init__(self, sd: Dict[str, Tensor], prefix: str, batch_norm: bool):
+        super().__init__(BF16)
+        self.batch_norm = batch_norm
+        p = prefix
+
+        def folded(conv, bn):
+            w, b = sd[p + conv + ".weight"].float(), sd[p + conv + ".bias"].float()
+            if batch_norm:
+                g = sd[p + bn + ".weight"].float() / torch.sqrt(sd[p + bn + ".running_var"].float() + 1e-5)
+                w = w * g.view(-1, 1, 1, 1)
+                b = (b - sd[p + bn + ".running_mean"].float()) * g + sd[p + bn + ".bias"].float()
+            return w, b
+
+        def packed(w, cin_pad):
+            co, ci, kh, kw = w.shape
+            w = w.permute(0, 2, 3, 1)
+            if cin_pad != ci:
+                w = torch.nn.functional.pad(w, (0, cin_pad - ci))
+            return w.reshape(co, -1).contiguous()
+
+        w, b = folded("conv1", "norm1")
+        self.add(w.contiguous()); self.add(b)
+        cin_pad = 64
+        for li, c, cpad in (("layer1", 64, 64), ("layer2", 96, 128), ("layer3", 128, 128)):
+            for bi in range(2):
+                bp = f"{li}.{bi}."
+                w1, b1 = folded(bp + "conv1", bp + "norm1")
+                self.add(packed(w1, cin_pad), True); self.add(b1)
+                w2, b2 = folded(bp + "conv2", bp + "norm2")
+                self.add(packed(w2, cpad), True); self.add(b2)
+                if (p + bp + "downsample.0.weight") in sd:
+                    wd, bd = folded(bp + "downsample.0", bp + "norm3")
+                    self.add(packed(wd, cin_pad), True); self.add(bd)
+                else:
+                    self.add(None); self.add(None)
+                cin_pad = cpad
+        self.add(sd[p + "conv2.weight"].float().reshape(256, 128).contiguous(), True)
+        self.add(sd[p + "conv2.bias"])
+        self.finish()
+
+
+def raft_encoder(w: RaftEncoderWeights, images: Tensor, max_images: int = 384) -> Tensor:
+    """images [n, 3, H, W] fp32 (RAFT's 0..255 convention) -> NHWC features [n, H/8 * W/8, 256] fp32."""
+    _need_cuda(images)
+    images = images.contiguous().float()
+    n, _, H, W = images.shape
+    out = torch.empty(n, (H // 8) * (W // 8), 256, dtype=torch.float32, device=images.device)
+    for i0 in range(0, n, max_images):
+        chunk = images[i0:i0 + max_images]
+        a = L.RaftEncoderArgs(chunk.shape[0], H, W, 1 if w.batch_norm else 0, chunk.data_ptr(), C.cast(w.array, C.POINTER(C.c_void_p)),
+                              out[i0:i0 + max_images].data_ptr(), None, 0)
+        need = L.lib().vtgb_raft_encoder_workspace_bytes(C.byref(a))
+        ws = _ws.get(need, images.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        L.check(L.lib().vtgb_raft_encoder(C.byref(a), _stream()))
+    return out
