@@ -297,7 +297,7 @@ int vtgb_raft_update(const vtgb_raft_update_args* a, vtgb_stream_t stream);
  * scaling 2*(x/255)-1 of RAFT.forward (xraft.py:105-106) is applied inside.  norm = 0: InstanceNorm2d (fnet);
  * norm = 1: the caller has folded the eval-mode BatchNorm2d that follows every convolution into the packed
  * weights and biases (cnet).  Output: NHWC features [n_images * H/8 * W/8, 256] fp32.
- * weights: [0] conv1.weight fp32 [64,3,7,7] [1] conv1.bias; per block b (layer1.0, 1.1, 2.0, 2.1, 3.0, 3.1) at
+ * weights: [0] conv1.weight fp32 TRANSPOSED to [3*7*7, 64] [1] conv1.bias; per block b (layer1.0, 1.1, 2.0, 2.1, 3.0, 3.1) at
  *   2 + 6 b: conv1.weight bf16 [C, 3,3,Cin_pad] , conv1.bias, conv2.weight [C, 3,3,C_pad], conv2.bias,
  *   downsample.0.weight [C, Cin_pad] or NULL, downsample.0.bias or NULL  (96-channel stages: C_pad = 128, zero-filled);
  *   [38] conv2.weight bf16 [256, 128] [39] conv2.bias */
@@ -337,8 +337,9 @@ int vtgb_llm_silu_mul(int dtype, const void* gu, void* act, int64_t rows, int32_
  * synchronises on the recorded events and returns launch count, summed kernel time and summed
  * algorithmic FLOPs (2*M*N*K per GEMM, 4*B*H*Sq*Skv*hd per attention) of one kind since the
  * last vtgb_prof_reset. */
-#define VTGB_PROF_GEMM 0
+#define VTGB_PROF_GEMM 0   /* plain GEMM launches (ViT / Q-Former / TGB / projections)             */
 #define VTGB_PROF_ATTN 1
+#define VTGB_PROF_CONV 2   /* implicit-GEMM convolution launches of the same kernel (RAFT)          */
 void vtgb_prof_enable(int on);
 void vtgb_prof_reset(void);
 int vtgb_prof_summary(int kind, int64_t* launches, double* ms, double* flops);

@@ -301,8 +301,17 @@ constexpr int L_OP_BYTES = 256 * L_BK * 2;   // 32 KiB per operand tile
 constexpr int L_A_SLOTS = 3, L_W_SLOTS = 2;
 constexpr int L_LDS = (L_A_SLOTS + L_W_SLOTS) * L_OP_BYTES;   // 160 KiB
 
-template <int EPI, int ABL = 0, bool CONV = false>
+// NWN (waves along N): 4 = the 256 x 256 tile above; 2 / 1 = 256 x 128 / 256 x 64 tiles for narrow outputs
+// (RAFT's 64..128-channel convolutions): waves 4(M) x 2(N) of 64 x 64 or 8(M) x 1(N) of 32 x 64, so that all
+// eight waves have work and only the output channels that exist are staged (weight slots of 16 / 8 KiB).
+template <int EPI, int ABL = 0, bool CONV = false, int NWN = 4>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G) {
+    constexpr int NX = 2 * NWN;          // activation fragments per wave: wave tile = (16 NX) x 64
+    constexpr int WROWS = 16 * NX;       // rows of the wave tile
+    constexpr int MW = 8 / NWN;          // waves along M
+    constexpr int T_BN = 64 * NWN;       // tile width
+    constexpr int W_OP = T_BN * 128;     // bytes per weight slot
+    constexpr int WI = NWN;              // weight DMA instructions per wave and k-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const smem_w = smem + L_A_SLOTS * L_OP_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -313,12 +322,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     const int nt = r / G, ml = group * G + (r - nt * G);
     const int mt = ml * 8 + xcd;
     if (mt >= m_tiles) return;
-    const int m0 = mt * L_BM, n0 = nt * L_BN;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int m0 = mt * L_BM, n0 = nt * T_BN;
+    const int wm = wave % MW, wn = wave / MW;
     // a wave whose 128 x 64 sub-tile lies wholly outside the matrix (N = 1408 is 5.5 tiles wide) still
     // stages its share of the operands and joins every barrier, but issues no LDS reads and no MFMAs:
     // its SIMD partner then has the matrix pipe to itself and the edge tile finishes in half the time
-    const bool wave_active = (n0 + wn * 64 < p.N) && (m0 + wm * 128 < p.M);
+    const bool wave_active = (n0 + wn * 64 < p.N) && (m0 + wm * WROWS < p.M);
     const bool staged_store = ((p.N & 7) == 0) && ((p.ldo & 7) == 0);   // bf16 outputs leave through LDS as whole rows
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
@@ -326,13 +335,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     // ---- LDS-DMA assignment: wave w stages rows [32w, 32w+32) of both operands, 4 instructions of
     // 8 rows each; lane l of an instruction fills slot (l & 7) of row r0 + (l >> 3)
     const bf16_t* a_src[4];
-    const bf16_t* w_src[4];
+    const bf16_t* w_src[WI];
     int a_row[4], a_yx[4];   // CONV: pixel index of the staged row and its (y << 16 | x)
+#pragma unroll
+    for (int i = 0; i < WI; i++) {
+        const int row = wave * (8 * WI) + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
+        const int wr = (n0 + row) < p.N ? (n0 + row) : p.N - 1;
+        w_src[i] = W + (int64_t)wr * p.ldw + c * 8;
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int row = wave * 32 + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
         const int am = (m0 + row) < p.M ? (m0 + row) : p.M - 1;
-        const int wr = (n0 + row) < p.N ? (n0 + row) : p.N - 1;
         if constexpr (CONV) {
             const int hw = p.conv_H * p.conv_W, img = am / hw, rem = am - img * hw;
             a_row[i] = img * (p.conv_Hi ? p.conv_Hi * p.conv_Wi : hw);      // first input pixel of this row's image
@@ -341,7 +355,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         } else {
             a_src[i] = A + map_row(p.a_map, am) * p.lda + c * 8;
         }
-        w_src[i] = W + (int64_t)wr * p.ldw + c * 8;
     }
     // CONV: running (tap, channel) of the next A k-tile to stage; A tiles are issued in k order
     int cv_tap = 0, cv_c0 = 0;
@@ -371,18 +384,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
             __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + (k0)), (lptr_t)(smem + (slot) * L_OP_BYTES + (wave * 32 + i * 8) * 128), 16, 0, 0); \
     }
 #define L_ISSUE_W(slot, k0)                                                                             \
-    _Pragma("unroll") for (int i = 0; i < 4; i++)                                                       \
-        __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (k0)), (lptr_t)(smem_w + (slot) * L_OP_BYTES + (wave * 32 + i * 8) * 128), 16, 0, 0);
+    _Pragma("unroll") for (int i = 0; i < WI; i++)                                                      \
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (k0)), (lptr_t)(smem_w + (slot) * W_OP + (wave * (8 * WI) + i * 8) * 128), 16, 0, 0);
     const int nk = p.K / L_BK;
     const int fr = lane & 15, fg = lane >> 4;
     // accumulators start at bias (+ residual): these loads are OLDER than every DMA below, so the
     // counted vmcnt waits of the k-loop also cover them
-    f32x4 acc[4][8];
+    f32x4 acc[4][NX];
 #pragma unroll
-    for (int j = 0; j < 8; j++)
+    for (int j = 0; j < NX; j++)
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            acc[i][j] = acc_init4<EPI>(p, m0 + wm * 128 + j * 16 + fr, n0 + wn * 64 + i * 16 + fg * 4);
+            acc[i][j] = acc_init4<EPI>(p, m0 + wm * WROWS + j * 16 + fr, n0 + wn * 64 + i * 16 + fg * 4);
     L_ISSUE_A(0, 0)
     L_ISSUE_W(0, 0)
     if (nk > 1) {
@@ -390,27 +403,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         L_ISSUE_W(1, L_BK)
     }
     if (nk > 2) L_ISSUE_A(2, 2 * L_BK)
-    if (nk > 2) __builtin_amdgcn_s_waitcnt(0x0F7C);        // vmcnt(12): A(0), W(0) landed
-    else if (nk == 2) __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
+    if (nk > 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (8 + WI));        // vmcnt(8 + WI): A(0), W(0) landed
+    else if (nk == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (4 + WI));  // vmcnt(4 + WI)
     else __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
     __builtin_amdgcn_s_barrier();
 
     // fragment byte offsets inside an operand tile for the two 32-deep halves of a k-tile
-    int w_off[2][4], x_off[2][8];
+    int w_off[2][4], x_off[2][NX];
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
 #pragma unroll
         for (int i = 0; i < 4; i++) w_off[ks][i] = swz(wn * 64 + i * 16 + fr, ks * 4 + fg);
 #pragma unroll
-        for (int j = 0; j < 8; j++) x_off[ks][j] = swz(wm * 128 + j * 16 + fr, ks * 4 + fg);
+        for (int j = 0; j < NX; j++) x_off[ks][j] = swz(wm * WROWS + j * 16 + fr, ks * 4 + fg);
     }
-    bf16x8 wf0[4], xf0[8], wf1[4], xf1[8];
+    bf16x8 wf0[4], xf0[NX], wf1[4], xf1[NX];
 #define L_READ(WF, XF, as_, ws_, ks)                                                                     \
     _Pragma("unroll") for (int i = 0; i < 4; i++) WF[i] = *reinterpret_cast<const bf16x8*>((ws_) + w_off[ks][i]); \
-    _Pragma("unroll") for (int j = 0; j < 8; j++) XF[j] = *reinterpret_cast<const bf16x8*>((as_) + x_off[ks][j]);
+    _Pragma("unroll") for (int j = 0; j < NX; j++) XF[j] = *reinterpret_cast<const bf16x8*>((as_) + x_off[ks][j]);
 #define L_MFMA(WF, XF)                                                                                   \
     _Pragma("unroll") for (int i = 0; i < 4; i++)                                                        \
-        _Pragma("unroll") for (int j = 0; j < 8; j++)                                                    \
+        _Pragma("unroll") for (int j = 0; j < NX; j++)                                                   \
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i], XF[j], acc[i][j], 0, 0, 0);
     // Rotated k-loop: a wave's LDS fragment reads always run under its own MFMAs.
     //   read half 1 of tile t | MFMAs of half 0 | counted wait + barrier (tile t fully read by everyone;
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): see the note at the bottom of the loop
     for (int kt = 0; kt + 1 < nk; kt++) {     // every iteration has a successor tile (no join before the MFMAs)
         const char* as = smem + a_slot * L_OP_BYTES;
-        const char* ws = smem_w + (kt & 1) * L_OP_BYTES;
+        const char* ws = smem_w + (kt & 1) * W_OP;
         const int a_nxt = a_slot == 2 ? 0 : a_slot + 1;
         L_READ(wf1, xf1, as, ws, 1)
         L_MFMA(wf0, xf0)
@@ -451,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
             if (kt + 2 < nk) { L_ISSUE_W(kt & 1, (kt + 2) * L_BK) }
             if (kt + 3 < nk) { L_ISSUE_A(a_slot, (kt + 3) * L_BK) }
         }
-        L_READ(wf0, xf0, smem + a_nxt * L_OP_BYTES, smem_w + ((kt + 1) & 1) * L_OP_BYTES, 0)
+        L_READ(wf0, xf0, smem + a_nxt * L_OP_BYTES, smem_w + ((kt + 1) & 1) * W_OP, 0)
         L_MFMA(wf1, xf1)
         // The half-0 fragments of the next tile were requested 32 MFMAs ago: this wait is free, and it
         // lets hipcc's waitcnt pass see (at the loop-header join) that set 0 is complete, so it does not
@@ -461,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     }
     {   // last k-tile
         const char* as = smem + a_slot * L_OP_BYTES;
-        const char* ws = smem_w + ((nk - 1) & 1) * L_OP_BYTES;
+        const char* ws = smem_w + ((nk - 1) & 1) * W_OP;
         L_READ(wf1, xf1, as, ws, 1)
         L_MFMA(wf0, xf0)
         L_MFMA(wf1, xf1)
@@ -474,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     if constexpr ((ABL & 16) != 0) {   // timing-only: no epilogue (keep the accumulators live)
         float t = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; j++)
+        for (int j = 0; j < NX; j++)
 #pragma unroll
             for (int i = 0; i < 4; i++) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
         if (t == 123.456f) reinterpret_cast<float*>(p.out)[0] = t;
@@ -488,9 +501,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
             // (the tail is store-issue bound), and full lines.
             __builtin_amdgcn_s_waitcnt(0xC07F);   // my fragment reads are done
             __builtin_amdgcn_s_barrier();         // ... and everyone else's: the ring can be overwritten
-            char* const cst = smem + wave * 16384;
+            char* const cst = smem + wave * (WROWS * 128);
 #pragma unroll
-            for (int j = 0; j < 8; j++)
+            for (int j = 0; j < NX; j++)
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     f32x4 v = acc[i][j];
@@ -507,10 +520,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                 }
             bf16_t* const outp = reinterpret_cast<bf16_t*>(p.out);
 #pragma unroll
-            for (int rr = 0; rr < 16; rr++) {
+            for (int rr = 0; rr < WROWS / 8; rr++) {
                 const int row = rr * 8 + (lane >> 3), ch = lane & 7;
                 const uint4 v = *reinterpret_cast<const uint4*>(cst + row * 128 + ((ch ^ (row & 7)) << 4));
-                const int m = m0 + wm * 128 + row, n = n0 + wn * 64 + ch * 8;
+                const int m = m0 + wm * WROWS + row, n = n0 + wn * 64 + ch * 8;
                 if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(outp + map_row(p.o_map, m) * p.ldo + n) = v;
             }
             return;
@@ -524,23 +537,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
             // measured 1.6 TB/s against 6.5 TB/s for whole-line stores.)
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();
-            char* const cst = smem + wave * 16384;
+            constexpr int PR = WROWS < 64 ? WROWS : 64;   // rows per pass
+            char* const cst = smem + wave * (PR * 256);
             float* const outp = reinterpret_cast<float*>(p.out);
             const int rl = lane >> 4, cl = lane & 15;
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
+            for (int half = 0; half < WROWS / PR; half++) {
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++)
+                for (int jj = 0; jj < PR / 16; jj++)
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const int row = jj * 16 + fr, chunk = i * 4 + fg;
-                        *reinterpret_cast<f32x4*>(cst + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][half * 4 + jj];
+                        *reinterpret_cast<f32x4*>(cst + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][half * (PR / 16) + jj];
                     }
 #pragma unroll
-                for (int rr = 0; rr < 16; rr++) {
+                for (int rr = 0; rr < PR / 4; rr++) {
                     const int row = rr * 4 + rl;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(cst + row * 256 + ((cl ^ (row & 15)) << 4));
-                    const int m = m0 + wm * 128 + half * 64 + row, n = n0 + wn * 64 + cl * 4;
+                    const int m = m0 + wm * WROWS + half * PR + row, n = n0 + wn * 64 + cl * 4;
                     if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(outp + map_row(p.o_map, m) * p.ldo + n) = v;
                 }
             }
@@ -548,8 +562,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int m = m0 + wm * 128 + j * 16 + fr;
+    for (int j = 0; j < NX; j++) {
+        const int m = m0 + wm * WROWS + j * 16 + fr;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int n = n0 + wn * 64 + i * 16 + fg * 4;
@@ -664,21 +678,33 @@ static int launch_epi(const GemmDesc& d, hipStream_t s) {
 
 // Implicit-GEMM convolution (and plain GEMMs that need the activation / GRU epilogues) on the large
 // kernel.  d.conv_KH == 0: plain GEMM through the same kernel (RAFT's 1x1 convolutions).
-template <int EPI, bool CONV>
-static int launch_large_forced(const GemmDesc& d, hipStream_t s) {
-    const int m_tiles = (d.M + L_BM - 1) / L_BM, n_tiles = (d.N + L_BN - 1) / L_BN;
+template <int EPI, bool CONV, int NWN>
+static int launch_large_nwn(const GemmDesc& d, hipStream_t s) {
+    constexpr int T_BN = 64 * NWN, LDS = L_A_SLOTS * L_OP_BYTES + L_W_SLOTS * T_BN * 128;
+    const int m_tiles = (d.M + L_BM - 1) / L_BM, n_tiles = (d.N + T_BN - 1) / T_BN;
     const int G = n_tiles <= 8 ? 2 : 8;
     const int mx = (m_tiles + 7) / 8, groups = (mx + G - 1) / G;
     static bool attr = false;
     if (!attr) {
-        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_large_kernel<EPI, 0, CONV>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS));
+        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_large_kernel<EPI, 0, CONV, NWN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
-    ProfScope prof(VTGB_PROF_GEMM, 2.0 * d.M * d.N * d.K, s);
-    hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, 0, CONV>), dim3(8 * groups * G * n_tiles), dim3(512), L_LDS, s, d, m_tiles, n_tiles, G);
+    ProfScope prof(CONV ? VTGB_PROF_CONV : VTGB_PROF_GEMM, 2.0 * d.M * d.N * d.K, s);
+    hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, 0, CONV, NWN>), dim3(8 * groups * G * n_tiles), dim3(512), LDS, s, d, m_tiles, n_tiles, G);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
+}
+
+static int g_conv_nwn = 0;   // > 0 forces the tile width (experiments); 0 = by output width
+extern "C" void vtgb_debug_set_conv_nwn(int v) { g_conv_nwn = v; }
+
+template <int EPI, bool CONV>
+static int launch_large_forced(const GemmDesc& d, hipStream_t s) {
+    const int nwn = g_conv_nwn > 0 ? g_conv_nwn : (d.N <= 64 ? 1 : d.N <= 128 ? 2 : 4);
+    if (nwn == 1) return launch_large_nwn<EPI, CONV, 1>(d, s);
+    if (nwn == 2) return launch_large_nwn<EPI, CONV, 2>(d, s);
+    return launch_large_nwn<EPI, CONV, 4>(d, s);
 }
 
 int launch_conv_gemm(const GemmDesc& d, hipStream_t s) {

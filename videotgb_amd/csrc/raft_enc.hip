@@ -10,38 +10,44 @@
 
 #include "common.h"
 
-// ---- stem: conv 7x7 stride 2 pad 3, 3 -> 64, on 2*(x/255)-1 (xraft.py:105-106); one workgroup per output row
-__global__ __launch_bounds__(256) void raft_stem_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ b,
+// ---- stem: conv 7x7 stride 2 pad 3, 3 -> 64, on 2*(x/255)-1 (xraft.py:105-106).  One workgroup per STEM_ROWS
+// output rows (weights are staged in LDS once per workgroup; they arrive pre-transposed [147][64]).
+constexpr int STEM_ROWS = 4;
+__global__ __launch_bounds__(256) void raft_stem_kernel(const float* __restrict__ img, const float* __restrict__ wt, const float* __restrict__ b,
                                                         float* __restrict__ out, int H, int W) {
     extern __shared__ float sm[];
     const int Wo = W >> 1, Ho = H >> 1;
     float* ws = sm;                    // [147][64]
-    float* xs = sm + 147 * 64;         // [3][7][W + 6]
-    const int n = blockIdx.y, yo = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < 147 * 64; i += 256) {   // w is [64][3][7][7] -> ws[k][co]
-        const int co = i & 63, k = i >> 6;
-        ws[i] = w[co * 147 + k];
-    }
-    const int WP = W + 6;
-    for (int i = tid; i < 3 * 7 * WP; i += 256) {
-        const int c = i / (7 * WP), r = (i / WP) % 7, xx = i % WP;
-        const int y = yo * 2 + r - 3, x = xx - 3;
+    float* xs = sm + 147 * 64;         // [3][2*STEM_ROWS + 5][W + 6]
+    const int n = blockIdx.y, yo0 = blockIdx.x * STEM_ROWS, tid = threadIdx.x;
+    for (int i = tid; i < 147 * 64; i += 256) ws[i] = wt[i];
+    const int WP = W + 6, RI = 2 * STEM_ROWS + 5;
+    for (int i = tid; i < 3 * RI * WP; i += 256) {
+        const int c = i / (RI * WP), r = (i / WP) % RI, xx = i % WP;
+        const int y = yo0 * 2 + r - 3, x = xx - 3;
         float v = 0.f;
         if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = 2.0f * (img[(((int64_t)n * 3 + c) * H + y) * W + x] / 255.0f) - 1.0f;
         xs[i] = v;
     }
     __syncthreads();
-    // thread -> (pixel, 32-channel half); pixels beyond Wo idle
-    for (int item = tid; item < Wo * 2; item += 256) {
-        const int px = item >> 1, c0 = (item & 1) * 32;
+    // item -> (row, pixel, 32-channel half)
+    for (int item = tid; item < STEM_ROWS * Wo * 2; item += 256) {
+        const int ry = item / (Wo * 2), rem = item - ry * (Wo * 2), px = rem >> 1, c0 = (rem & 1) * 32;
+        const int yo = yo0 + ry;
+        if (yo >= Ho) continue;
         float acc[32];
 #pragma unroll
         for (int c = 0; c < 32; c++) acc[c] = b[c0 + c];
         for (int k = 0; k < 147; k++) {
             const int c = k / 49, t = k - c * 49, ky = t / 7, kx = t - ky * 7;
-            const float x = xs[(c * 7 + ky) * WP + px * 2 + kx];
+            const float x = xs[(c * RI + ry * 2 + ky) * WP + px * 2 + kx];
+            const float4* wr = reinterpret_cast<const float4*>(ws + k * 64 + c0);
 #pragma unroll
-            for (int cc = 0; cc < 32; cc++) acc[cc] = fmaf(x, ws[k * 64 + c0 + cc], acc[cc]);
+            for (int q = 0; q < 8; q++) {
+                const float4 w4 = wr[q];
+                acc[4 * q] = fmaf(x, w4.x, acc[4 * q]); acc[4 * q + 1] = fmaf(x, w4.y, acc[4 * q + 1]);
+                acc[4 * q + 2] = fmaf(x, w4.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(x, w4.w, acc[4 * q + 3]);
+            }
         }
         float* o = out + (((int64_t)n * Ho + yo) * Wo + px) * 64 + c0;
 #pragma unroll
@@ -110,7 +116,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     VTGB_REQUIRE(a, VTGB_EINVAL, "raft_encoder: NULL args");
     VTGB_REQUIRE(a->n_images > 0 && a->H >= 64 && a->W >= 64 && (a->H % 8) == 0 && (a->W % 8) == 0 && (a->norm == 0 || a->norm == 1), VTGB_EINVAL,
                  "raft_encoder: bad dims n=%d H=%d W=%d", a->n_images, a->H, a->W);
-    VTGB_REQUIRE(a->W + 6 <= 1024, VTGB_EUNSUPPORTED, "raft_encoder: width %d too large for the stem kernel", a->W);
+    VTGB_REQUIRE(a->W + 6 <= 2048, VTGB_EUNSUPPORTED, "raft_encoder: width %d too large for the stem kernel", a->W);
     const int n = a->n_images;
     const int H2 = a->H / 2, W2 = a->W / 2, H4 = a->H / 4, W4 = a->W / 4, H8 = a->H / 8, W8 = a->W / 8;
     const int64_t M2 = (int64_t)n * H2 * W2, M4 = (int64_t)n * H4 * W4, M8 = (int64_t)n * H8 * W8;
@@ -138,8 +144,13 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
         return VTGB_OK;
     };
     // ---- stem
-    const size_t stem_lds = (147 * 64 + 3 * 7 * (a->W + 6)) * sizeof(float);
-    hipLaunchKernelGGL(raft_stem_kernel, dim3(H2, n), dim3(256), stem_lds, s, a->images, F(w[0]), F(w[1]), cf, a->H, a->W);
+    const size_t stem_lds = (147 * 64 + 3 * (2 * STEM_ROWS + 5) * (a->W + 6)) * sizeof(float);
+    static bool stem_attr = false;
+    if (!stem_attr) {
+        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        stem_attr = true;
+    }
+    hipLaunchKernelGGL(raft_stem_kernel, dim3((H2 + STEM_ROWS - 1) / STEM_ROWS, n), dim3(256), stem_lds, s, a->images, F(w[0]), F(w[1]), cf, a->H, a->W);
     VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0));
     // ---- six residual blocks
     struct Stage { int C, Cpad, stride, Ho, Wo; };

@@ -491,7 +491,7 @@ class RaftEncoderWeights(_WeightTable):
             return w.reshape(co, -1).contiguous()
 
         w, b = folded("conv1", "norm1")
-        self.add(w.contiguous()); self.add(b)
+        self.add(w.reshape(64, 147).t().contiguous()); self.add(b)       # [k = c*49 + ky*7 + kx][co]
         cin_pad = 64
         for li, c, cpad in (("layer1", 64, 64), ("layer2", 96, 128), ("layer3", 128, 128)):
             for bi in range(2):
