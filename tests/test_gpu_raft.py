@@ -74,6 +74,23 @@ def test_raft_encoder_vs_oracle(dev, tiny_sd, net, kind):
     assert e <= 2e-2
 
 
+@pytest.mark.parametrize("size,n", [(224, 5), (64, 3), (96, 2)])
+def test_raft_encoder_image_sizes(dev, tiny_sd, size, n):
+    """InstanceNorm moments come from the convolution epilogue: 224 -> 28x28 = 784-row images straddle the
+    256-row GEMM tiles, 64 -> 8x8 images are below the fused path's minimum (separate statistics pass)."""
+    from oracle import vtgb_oracle as O
+    from videotgb_amd import ops
+    sd = tiny_sd["instructblip"][1]
+    fr = torch.randint(0, 256, (n, 3, size, size), generator=torch.Generator().manual_seed(size)).float()
+    ref = O.raft_encoder(sd, "of_extractor.fnet.", 2 * (fr / 255.0) - 1.0, "instance")
+    rsd = {k[len("of_extractor."):]: v.to(dev) for k, v in sd.items() if k.startswith("of_extractor.")}
+    w = ops.RaftEncoderWeights(rsd, "fnet.", False)
+    out = ops.raft_encoder(w, fr.to(dev)).cpu().view(n, size // 8, size // 8, 256).permute(0, 3, 1, 2)
+    e = rel_rms(out, ref)
+    print(f"[raft encoder {size}x{size}] rel_rms={e:.3e}")
+    assert e <= 2e-2
+
+
 def test_raft_all_hip_clip_path_vs_reference(dev, tiny_sd):
     """forward_clips: encoders + update in HIP, fnet once per distinct frame; vs the reference flows."""
     g = load_golden("tiny_raft")

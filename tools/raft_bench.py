@@ -6,6 +6,9 @@ import torch
 from videotgb_amd import models, synth
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+NWN = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # > 0 forces the conv tile width (4 = 256 wide for every conv)
+from videotgb_amd import _lib
+_lib.lib().vtgb_debug_set_conv_nwn(NWN)
 r = models.Raft(torch.float32, hip_update=True)
 sd = {k[len("of_extractor."):]: v for k, v in synth.synth_state_dict(synth.raft_shapes("of_extractor."), 0).items()}
 for k in list(sd):
@@ -18,4 +21,4 @@ for _ in range(2): r.forward_clips(frames)
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(3): out = r.forward_clips(frames)
 torch.cuda.synchronize(); dt = (time.time() - t0) / 3
-print(f"RAFT all-HIP: {dt * 1e3 / B:.2f} ms per clip (B={B}, T=96), flow absmax {out.abs().max().item():.3f}")
+print(f"nwn={NWN} RAFT all-HIP: {dt * 1e3 / B:.2f} ms per clip (B={B}, T=96), flow absmax {out.abs().max().item():.3f}")

@@ -111,6 +111,11 @@ struct GemmDesc {
     int64_t ldaux;
     void* out2;
     int64_t ldo2;
+    // EPI_STORE_F32 (N % 4 == 0): per (image, column) sum and sum of squares of the stored values are
+    // accumulated (atomics) into col_stats[(row / stats_rows) * N + n][2] -- InstanceNorm statistics
+    // without a second pass over the output.  stats_rows >= 256; the caller zeroes the buffer.
+    float* col_stats;
+    int stats_rows;
 };
 #define VTGB_EPI_GRU 4
 int launch_gemm(const GemmDesc& d, hipStream_t s);

@@ -297,6 +297,9 @@ __device__ __forceinline__ void store4(const GemmDesc& p, int m, int n0, f32x4 v
 // ABL != 0: timing-only ablation builds for tools/gemm_ablate.py (results are wrong).
 // ---------------------------------------------------------------------------------------
 constexpr int L_BM = 256, L_BN = 256, L_BK = 64;
+__device__ __forceinline__ bool gru_staged(const GemmDesc& p) {
+    return ((p.N | p.ldo | p.ldr | p.ldaux | p.ldo2) & 3) == 0;
+}
 constexpr int L_OP_BYTES = 256 * L_BK * 2;   // 32 KiB per operand tile
 constexpr int L_A_SLOTS = 3, L_W_SLOTS = 2;
 constexpr int L_LDS = (L_A_SLOTS + L_W_SLOTS) * L_OP_BYTES;   // 160 KiB
@@ -443,7 +446,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         if constexpr (EPI == EPI_STORE || EPI == EPI_GELU) {
             if (staged_store) __builtin_amdgcn_s_barrier();   // the barrier in front of the LDS-staged stores
         } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
-            if (((p.N & 3) == 0) && ((p.ldo & 3) == 0) && p.act == 0 && p.out_scale == 0.f) __builtin_amdgcn_s_barrier();
+            if (((p.N & 3) == 0) && ((p.ldo & 3) == 0) && p.act == 0 && p.out_scale == 0.f) {
+                __builtin_amdgcn_s_barrier();
+                if (EPI == EPI_STORE_F32 && p.col_stats) __builtin_amdgcn_s_barrier();   // the partial-sum exchange
+            }
+        } else if constexpr (EPI == EPI_GRU) {
+            if (gru_staged(p)) __builtin_amdgcn_s_barrier();
         }
         return;
     }
@@ -541,6 +549,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
             char* const cst = smem + wave * (PR * 256);
             float* const outp = reinterpret_cast<float*>(p.out);
             const int rl = lane >> 4, cl = lane & 15;
+            // column statistics (EPI_STORE_F32 + col_stats): the 256 rows of a tile touch at most two images
+            // (stats_rows >= 256): set a = the image of row m0, set b = the next one
+            const bool do_stats = (EPI == EPI_STORE_F32) && p.col_stats != nullptr;
+            const int img_a = do_stats ? m0 / p.stats_rows : 0;
+            const int m_b = do_stats ? (img_a + 1) * p.stats_rows : 0x7fffffff;   // first row of image b
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, qa = sa, sb = sa, qb = sa;
 #pragma unroll
             for (int half = 0; half < WROWS / PR; half++) {
 #pragma unroll
@@ -555,7 +569,95 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                     const int row = rr * 4 + rl;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(cst + row * 256 + ((cl ^ (row & 15)) << 4));
                     const int m = m0 + wm * WROWS + half * PR + row, n = n0 + wn * 64 + cl * 4;
-                    if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(outp + map_row(p.o_map, m) * p.ldo + n) = v;
+                    if (m < p.M && n < p.N) {
+                        *reinterpret_cast<f32x4*>(outp + map_row(p.o_map, m) * p.ldo + n) = v;
+                        if constexpr (EPI == EPI_STORE_F32) {
+                            if (do_stats) {
+                                if (m < m_b) { sa += v; qa += v * v; }
+                                else { sb += v; qb += v * v; }
+                            }
+                        }
+                    }
+                }
+            }
+            if constexpr (EPI == EPI_STORE_F32) {
+                if (do_stats) {
+                    // lanes with equal cl hold the same four columns: fold the four row groups, park the
+                    // wave's partials in its own staging region, then 64 NWN threads fold the MW waves of a
+                    // column and issue one atomic per (image, column, moment)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        sa[e] += __shfl_xor(sa[e], 16); sa[e] += __shfl_xor(sa[e], 32);
+                        qa[e] += __shfl_xor(qa[e], 16); qa[e] += __shfl_xor(qa[e], 32);
+                        sb[e] += __shfl_xor(sb[e], 16); sb[e] += __shfl_xor(sb[e], 32);
+                        qb[e] += __shfl_xor(qb[e], 16); qb[e] += __shfl_xor(qb[e], 32);
+                    }
+                    if (rl == 0) {
+                        f32x4* const pr = reinterpret_cast<f32x4*>(cst);
+                        pr[cl] = sa; pr[16 + cl] = qa; pr[32 + cl] = sb; pr[48 + cl] = qb;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_s_barrier();
+                    if (tid < 64 * NWN) {
+                        const int wn_ = tid >> 6, c = tid & 63, n = n0 + wn_ * 64 + c;
+                        if (n < p.N) {
+                            float t[4] = {0.f, 0.f, 0.f, 0.f};
+                            for (int wm_ = 0; wm_ < MW; wm_++) {
+                                if (m0 + wm_ * WROWS >= p.M) break;
+                                const float* pr = reinterpret_cast<const float*>(smem + (wn_ * MW + wm_) * (PR * 256));
+#pragma unroll
+                                for (int e = 0; e < 4; e++) t[e] += pr[e * 64 + c];
+                            }
+                            float* st = p.col_stats + ((int64_t)img_a * p.N + n) * 2;
+                            unsafeAtomicAdd(st, t[0]);
+                            unsafeAtomicAdd(st + 1, t[1]);
+                            if (m0 + L_BM > m_b && m_b < p.M) {
+                                unsafeAtomicAdd(st + 2 * p.N, t[2]);
+                                unsafeAtomicAdd(st + 2 * p.N + 1, t[3]);
+                            }
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
+    if constexpr (EPI == EPI_GRU) {
+        if (gru_staged(p)) {
+            // h' = (1 - z) h + z tanh(acc): the accumulators go through LDS as in the fp32 path so that h, z
+            // and both outputs are touched as whole row segments (16 B of fp32 / 8 B of bf16 per lane)
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            constexpr int PR = WROWS < 64 ? WROWS : 64;
+            char* const cst = smem + wave * (PR * 256);
+            const int rl = lane >> 4, cl = lane & 15;
+#pragma unroll
+            for (int half = 0; half < WROWS / PR; half++) {
+#pragma unroll
+                for (int jj = 0; jj < PR / 16; jj++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int row = jj * 16 + fr, chunk = i * 4 + fg;
+                        *reinterpret_cast<f32x4*>(cst + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][half * (PR / 16) + jj];
+                    }
+#pragma unroll
+                for (int rr = 0; rr < PR / 4; rr++) {
+                    const int row = rr * 4 + rl;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(cst + row * 256 + ((cl ^ (row & 15)) << 4));
+                    const int m = m0 + wm * WROWS + half * PR + row, n = n0 + wn * 64 + cl * 4;
+                    if (m < p.M && n < p.N) {
+                        const f32x4 h = *reinterpret_cast<const f32x4*>(p.resid + map_row(p.r_map, m) * p.ldr + n);
+                        const bf16x4 zb = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)m * p.ldaux + n);
+                        f32x4 hn;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float z = (float)zb[e];
+                            hn[e] = (1.0f - z) * h[e] + z * tanhf(v[e]);
+                        }
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + map_row(p.o_map, m) * p.ldo + n) = hn;
+                        const bf16x4 pk = {(bf16_t)hn[0], (bf16_t)hn[1], (bf16_t)hn[2], (bf16_t)hn[3]};
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out2) + (int64_t)m * p.ldo2 + n) = pk;
+                    }
                 }
             }
             return;

@@ -55,60 +55,90 @@ __global__ __launch_bounds__(256) void raft_stem_kernel(const float* __restrict_
     }
 }
 
-// ---- InstanceNorm2d statistics: per (image, channel) mean and 1/sqrt(biased var + 1e-5) over the HW pixels
+// ---- InstanceNorm2d statistics: per (image, channel) sum and sum of squares over the HW pixels, accumulated
+// into stats[(n * C + c) * 2 + {0, 1}] (zeroed by the caller).  The implicit-GEMM convolutions produce them in
+// their epilogue (GemmDesc::col_stats); this pass serves the stem and images of fewer than 256 pixels.
+// grid (n, splits): each workgroup reduces a slice of the image, then one atomic per channel and moment.
 __global__ __launch_bounds__(256) void inorm_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int HW, int C, int ldx) {
     __shared__ float s1[256], s2[256];
     const int n = blockIdx.x, tid = threadIdx.x;
-    const int c = tid % C, lane_p = tid / C, np = 256 / C;   // C in {64, 96, 128}: 4, 2, 2 pixel lanes (tid >= np*C idle)
-    float a = 0.f, q = 0.f;
+    const int c4 = C >> 2, cq = tid % c4, lane_p = tid / c4, np = 256 / c4;   // a thread owns 4 channels of every np-th pixel
+    const int per = (HW + gridDim.y - 1) / gridDim.y, p0 = blockIdx.y * per, p1 = min(HW, p0 + per);
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
     if (lane_p < np) {
-        const float* base = x + (int64_t)n * HW * ldx + c;
-        for (int p = lane_p; p < HW; p += np) {
-            const float v = base[(int64_t)p * ldx];
-            a += v;
-            q = fmaf(v, v, q);
+        const float* base = x + (int64_t)n * HW * ldx + cq * 4;
+        for (int p = p0 + lane_p; p < p1; p += np) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)p * ldx);
+            a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+            q[0] = fmaf(v.x, v.x, q[0]); q[1] = fmaf(v.y, v.y, q[1]); q[2] = fmaf(v.z, v.z, q[2]); q[3] = fmaf(v.w, v.w, q[3]);
         }
     }
-    s1[tid] = a; s2[tid] = q;
-    __syncthreads();
-    if (tid < C) {
-        float sa = 0.f, sq = 0.f;
-        for (int l = 0; l < np; l++) { sa += s1[l * C + tid]; sq += s2[l * C + tid]; }
-        const float mean = sa / (float)HW, var = fmaxf(sq / (float)HW - mean * mean, 0.f);
-        stats[((int64_t)n * C + tid) * 2] = mean;
-        stats[((int64_t)n * C + tid) * 2 + 1] = rsqrtf(var + 1e-5f);
+    for (int e = 0; e < 4; e++) {
+        __syncthreads();
+        s1[tid] = a[e]; s2[tid] = q[e];
+        __syncthreads();
+        if (tid < c4) {
+            float sa = 0.f, sq = 0.f;
+            for (int l = 0; l < np; l++) { sa += s1[l * c4 + tid]; sq += s2[l * c4 + tid]; }
+            float* st = stats + ((int64_t)n * C + tid * 4 + e) * 2;
+            unsafeAtomicAdd(st, sa);
+            unsafeAtomicAdd(st + 1, sq);
+        }
     }
 }
 
-// ---- y = [relu]((x - mean) * rstd); out = [relu](resid + y); bf16 NHWC with Cpad channels (pad = 0)
+// ---- y = [relu]((x - mean) * rstd); out = [relu](resid + y); bf16 NHWC with Cpad channels (pad = 0).
+// mean = sum / HW, rstd = 1 / sqrt(biased var + 1e-5) from the accumulated moments; 4 channels per thread.
 __global__ void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const bf16_t* __restrict__ resid,
                                   bf16_t* __restrict__ out, int64_t M, int HW, int C, int Cpad, int ldx, int relu_inner, int relu_outer) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M * Cpad) return;
-    const int64_t m = i / Cpad;
-    const int c = (int)(i - m * Cpad);
-    float v = 0.f;
+    const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cp4 = Cpad >> 2;
+    if (i4 >= M * cp4) return;
+    const int64_t m = i4 / cp4;
+    const int c = (int)(i4 - m * cp4) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
-        v = x[m * ldx + c];
+        const float4 xv = *reinterpret_cast<const float4*>(x + m * ldx + c);
+        v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w;
         if (stats) {
             const int64_t n = m / HW;
-            v = (v - stats[(n * C + c) * 2]) * stats[(n * C + c) * 2 + 1];
+            const float inv = 1.0f / (float)HW;
+            const float4 s01 = *reinterpret_cast<const float4*>(stats + (n * C + c) * 2);
+            const float4 s23 = *reinterpret_cast<const float4*>(stats + (n * C + c) * 2 + 4);
+            const float sm[4] = {s01.x, s01.z, s23.x, s23.z}, sq[4] = {s01.y, s01.w, s23.y, s23.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float mean = sm[e] * inv, var = fmaxf(sq[e] * inv - mean * mean, 0.f);
+                v[e] = (v[e] - mean) * rsqrtf(var + 1e-5f);
+            }
         }
-        if (relu_inner) v = fmaxf(v, 0.f);
-        if (resid) v += (float)resid[i];
-        if (relu_outer) v = fmaxf(v, 0.f);
+        if (relu_inner) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (resid) {
+            const bf16x4 r = *reinterpret_cast<const bf16x4*>(resid + m * Cpad + c);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += (float)r[e];
+        }
+        if (relu_outer) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+        }
     }
-    out[i] = (bf16_t)v;
+    const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *reinterpret_cast<bf16x4*>(out + m * Cpad + c) = o;
 }
 
 static GemmDesc enc_conv(int Mo, int N, int Ho, int Wo, int K, int Cin, int stride, int Hi, int Wi, const void* A, const void* Wt, const float* bias,
-                         float* out, int ldo, const void* zero) {
+                         float* out, int ldo, const void* zero, float* col_stats) {
     GemmDesc d;
     memset(&d, 0, sizeof(d));
     d.dtype = VTGB_BF16; d.M = Mo; d.N = N; d.K = K * K * Cin; d.epi = VTGB_EPI_STORE_F32;
     d.A = A; d.lda = Cin; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = out; d.ldo = ldo;
     d.conv_H = Ho; d.conv_W = Wo; d.conv_KH = K; d.conv_KW = K; d.conv_Cin = Cin; d.conv_split = Cin;
     d.conv_stride = stride; d.conv_Hi = Hi; d.conv_Wi = Wi; d.zero_page = zero;
+    d.col_stats = col_stats; d.stats_rows = Ho * Wo;
     return d;
 }
 
@@ -127,6 +157,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     bf16_t* act1 = (bf16_t*)ws.take(M2 * 64 * 2);
     bf16_t* act2 = (bf16_t*)ws.take(M2 * 64 * 2);
     float* stats = (float*)ws.take((int64_t)n * 128 * 2 * 4);
+    float* stats2 = (float*)ws.take((int64_t)n * 128 * 2 * 4);   // the downsample branch's moments
     void* zero = ws.take(256);
     if (ws.dry) return VTGB_OK;
     VTGB_REQUIRE(ws.ok(), VTGB_EWORKSPACE, "raft_encoder: workspace %zu < %zu bytes", ws.size, ws.used);
@@ -136,12 +167,25 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     const bool inorm = a->norm == 0;
     VTGB_HIP(hipMemsetAsync(zero, 0, 256, s));
 
-    auto norm = [&](const float* x, int64_t M, int HW, int C, int Cpad, int ldx, const bf16_t* resid, bf16_t* out, int relu_in, int relu_out) -> int {
-        if (inorm) hipLaunchKernelGGL(inorm_stats_kernel, dim3(n), dim3(256), 0, s, x, stats, HW, C, ldx);
-        hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)((M * Cpad + 255) / 256)), dim3(256), 0, s, x, inorm ? stats : nullptr, resid, out, M, HW, C,
-                           Cpad, ldx, relu_in, relu_out);
+    // `fused`: the convolution that produced x has already accumulated the moments (stats zeroed before it)
+    auto norm = [&](const float* x, int64_t M, int HW, int C, int Cpad, int ldx, const bf16_t* resid, bf16_t* out, int relu_in, int relu_out,
+                    float* st, bool fused) -> int {
+        if (inorm && !fused) {
+            VTGB_HIP(hipMemsetAsync(st, 0, (size_t)n * C * 2 * sizeof(float), s));
+            const int splits = HW >= 4096 ? 16 : HW >= 1024 ? 4 : 1;
+            hipLaunchKernelGGL(inorm_stats_kernel, dim3(n, splits), dim3(256), 0, s, x, st, HW, C, ldx);
+        }
+        hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)((M * (Cpad / 4) + 255) / 256)), dim3(256), 0, s, x, inorm ? st : nullptr, resid, out, M, HW,
+                           C, Cpad, ldx, relu_in, relu_out);
         VTGB_HIP(hipGetLastError());
         return VTGB_OK;
+    };
+    // moments for a convolution output: zero the buffer and hand it to the GEMM epilogue when the image is
+    // large enough for the two-images-per-tile bookkeeping, else leave it to the separate pass
+    auto stats_for = [&](float* st, int HW, int C) -> float* {
+        if (!inorm || HW < 256) return nullptr;
+        (void)hipMemsetAsync(st, 0, (size_t)n * C * 2 * sizeof(float), s);
+        return st;
     };
     // ---- stem
     const size_t stem_lds = (147 * 64 + 3 * (2 * STEM_ROWS + 5) * (a->W + 6)) * sizeof(float);
@@ -151,7 +195,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
         stem_attr = true;
     }
     hipLaunchKernelGGL(raft_stem_kernel, dim3((H2 + STEM_ROWS - 1) / STEM_ROWS, n), dim3(256), stem_lds, s, a->images, F(w[0]), F(w[1]), cf, a->H, a->W);
-    VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0));
+    VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, false));
     // ---- six residual blocks
     struct Stage { int C, Cpad, stride, Ho, Wo; };
     const Stage st[6] = {{64, 64, 1, H2, W2}, {64, 64, 1, H2, W2}, {96, 128, 2, H4, W4}, {96, 128, 1, H4, W4}, {128, 128, 2, H8, W8}, {128, 128, 1, H8, W8}};
@@ -164,19 +208,22 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
         const void* const* bw = w + 2 + 6 * b;
         const int64_t Mo = (int64_t)n * g.Ho * g.Wo;
         const int HWo = g.Ho * g.Wo;
-        VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), cf, g.Cpad, zero), s));
-        VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t1, 1, 0));                       // y = relu(norm1(conv1(x)))
-        VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), cf, g.Cpad, zero), s));
+        float* sf = stats_for(stats, HWo, g.C);
+        VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), cf, g.Cpad, zero, sf), s));
+        VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t1, 1, 0, stats, sf != nullptr));  // y = relu(norm1(conv1(x)))
+        sf = stats_for(stats, HWo, g.C);
+        VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), cf, g.Cpad, zero, sf), s));
         const bf16_t* res = x;
         if (g.stride != 1) {                                                                      // x = norm3(downsample(x))
             VTGB_REQUIRE(bw[4] && bw[5], VTGB_EINVAL, "raft_encoder: block %d lacks its downsample weights", b);
-            VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 1, Cin_pad, g.stride, Hi, Wi, x, bw[4], F(bw[5]), cf2, g.Cpad, zero), s));
-            VTGB_TRY(norm(cf2, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t2, 0, 0));
+            float* sf2 = stats_for(stats2, HWo, g.C);
+            VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 1, Cin_pad, g.stride, Hi, Wi, x, bw[4], F(bw[5]), cf2, g.Cpad, zero, sf2), s));
+            VTGB_TRY(norm(cf2, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t2, 0, 0, stats2, sf2 != nullptr));
             res = t2;
         }
         bf16_t* outb = t1;
         // out = relu(x + relu(norm2(conv2(y))))   -- t1 is free once conv2 has consumed it (stream order)
-        VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, res, outb, 1, 1));
+        VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, res, outb, 1, 1, stats, sf != nullptr));
         // rotate buffers: the block output becomes the next input
         bf16_t* old = x;
         x = outb;
