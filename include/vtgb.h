@@ -272,11 +272,11 @@ int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream);
  * correlation pyramid stay fp32 (a reduced-precision mode: the reference runs RAFT in fp32).
  * weights (host array of device pointers; conv weights bf16 packed [C_out, KH, KW, C_in]):
  *   [0] encoder.convc1.weight [256, 384] (324 input channels zero-padded to 384) [1] .bias
- *   [2] encoder.convc2.weight [192, 3,3,256] [3] .bias   [4] encoder.convf1.weight fp32 [128,2,7,7] [5] .bias
+ *   [2] encoder.convc2.weight [192, 3,3,256] [3] .bias   [4] encoder.convf1.weight bf16 [128, 56 taps, {x,y,x,y}] (49 taps zero-padded) [5] .bias
  *   [6] encoder.convf2.weight [64, 3,3,128]  [7] .bias   [8] encoder.conv.weight [126, 3,3,256]     [9] .bias
  *   [10] gru.convz1|convr1.weight [256, 1,5,384] [11] bias [256]  [12] gru.convq1.weight [128, 1,5,384] [13] .bias
  *   [14] gru.convz2|convr2.weight [256, 5,1,384] [15] bias [256]  [16] gru.convq2.weight [128, 5,1,384] [17] .bias
- *   [18] flow_head.conv1.weight [256, 3,3,128] [19] .bias  [20] flow_head.conv2.weight fp32 [2, 3,3,256] [21] .bias
+ *   [18] flow_head.conv1.weight [256, 3,3,128] [19] .bias  [20] flow_head.conv2.weight bf16 [32, 256], row tap*2+o (18 rows zero-padded) [21] .bias
  *   [22] mask.0.weight [256, 3,3,128] [23] .bias           [24] mask.2.weight [576, 256] [25] .bias
  * Biases fp32.  GRU input channels are [h(128) | inp(128) | motion(126) | flow(2)] as in the reference. */
 #define VTGB_RAFT_NW 26

@@ -37,6 +37,9 @@ __global__ void raft_init_kernel(const float* __restrict__ net, const float* __r
 // ---------------------------------------------------------------------------------------
 // correlation lookup: one wave per pixel, 4 levels x 9 x 9 bilinear taps (zero outside), bf16 out,
 // columns 324..383 zero (K padded to a multiple of 64 for the 1x1 convolution that follows).
+// The 81 taps of a level share their fractional weights and read a 10 x 10 window of the pixel's own
+// correlation map: the wave gathers the four windows into LDS once (2 loads per lane and level instead of
+// 4 per tap) and forms the taps from there.
 // NB the reference adds stack(meshgrid(dy, dx)) to (x, y): the x coordinate receives the ROW offset of
 // the 9x9 window (corr.py:36-43) -- replicated as is.
 // ---------------------------------------------------------------------------------------
@@ -44,78 +47,117 @@ struct CorrPyr { const float* lvl[4]; int h[4], w[4]; };
 
 __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr, const float* __restrict__ flow, bf16_t* __restrict__ out,
                                                                int64_t M, int H8, int W8) {
-    const int lane = threadIdx.x & 63;
-    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
+    __shared__ float win[4][4][104];   // [wave][level][10 x 10 window | wx | wy | pad]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t m = (int64_t)blockIdx.x * 4 + wave;
+    const bool valid = m < M;
+    if (!valid) m = M - 1;
     const int p = (int)(m % (H8 * W8));
     const float cx = (float)(p % W8) + flow[m * 2], cy = (float)(p / W8) + flow[m * 2 + 1];
-    for (int k = lane; k < 384; k += 64) {
+    const int wy0 = lane / 10, wx0 = lane - wy0 * 10;                 // window element `lane`
+    const int wy1 = (lane + 64) / 10, wx1 = lane + 64 - wy1 * 10;     // window element `lane + 64` (< 100 for lane < 36)
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        const int hl = pyr.h[l], wl = pyr.w[l];
+        const float* img = pyr.lvl[l] + m * (int64_t)(hl * wl);
+        const float sc = 1.0f / (float)(1 << l);
+        const float xs = cx * sc, ys = cy * sc, x0f = floorf(xs), y0f = floorf(ys);
+        const int x0 = (int)x0f - 4, y0 = (int)y0f - 4;
+        {
+            const int y = y0 + wy0, x = x0 + wx0;
+            win[wave][l][lane] = ((unsigned)y < (unsigned)hl && (unsigned)x < (unsigned)wl) ? img[y * wl + x] : 0.f;
+        }
+        if (lane < 36) {
+            const int y = y0 + wy1, x = x0 + wx1;
+            win[wave][l][lane + 64] = ((unsigned)y < (unsigned)hl && (unsigned)x < (unsigned)wl) ? img[y * wl + x] : 0.f;
+        }
+        if (lane == 63) { win[wave][l][100] = xs - x0f; win[wave][l][101] = ys - y0f; }
+    }
+    __syncthreads();
+    if (!valid) return;
+#pragma unroll
+    for (int kk = 0; kk < 6; kk++) {
+        const int k = kk * 64 + lane;
         float v = 0.f;
         if (k < 324) {
-            const int l = k / 81, t = k - l * 81, i = t / 9, j = t - i * 9;
-            const int hl = pyr.h[l], wl = pyr.w[l];
-            const float* img = pyr.lvl[l] + m * (int64_t)(hl * wl);
-            const float sc = 1.0f / (float)(1 << l);
-            const float xs = cx * sc + (float)(i - 4), ys = cy * sc + (float)(j - 4);
-            const float x0f = floorf(xs), y0f = floorf(ys);
-            const int x0 = (int)x0f, y0 = (int)y0f;
-            const float wx = xs - x0f, wy = ys - y0f;
-            float a = 0.f;
-            if ((unsigned)y0 < (unsigned)hl) {
-                if ((unsigned)x0 < (unsigned)wl) a += (1.f - wx) * (1.f - wy) * img[y0 * wl + x0];
-                if ((unsigned)(x0 + 1) < (unsigned)wl) a += wx * (1.f - wy) * img[y0 * wl + x0 + 1];
-            }
-            if ((unsigned)(y0 + 1) < (unsigned)hl) {
-                if ((unsigned)x0 < (unsigned)wl) a += (1.f - wx) * wy * img[(y0 + 1) * wl + x0];
-                if ((unsigned)(x0 + 1) < (unsigned)wl) a += wx * wy * img[(y0 + 1) * wl + x0 + 1];
-            }
-            v = a;
+            const int l = k / 81, t = k - l * 81, i = t / 9, j = t - i * 9;   // i: x offset, j: y offset
+            const float* wn = win[wave][l];
+            const float wx = wn[100], wy = wn[101];
+            const float* q = wn + j * 10 + i;
+            v = (1.f - wy) * ((1.f - wx) * q[0] + wx * q[1]) + wy * ((1.f - wx) * q[10] + wx * q[11]);
         }
         out[m * 384 + k] = (bf16_t)v;
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// convf1: 7x7 convolution of the 2-channel flow -> 128 channels + ReLU (update.py:82,92).  Too thin for the
-// MFMA path (K = 98): direct fp32, 32 pixels per workgroup, weights and the 32 input windows in LDS.
+// convf1: 7x7 convolution of the 2-channel flow -> 128 channels + ReLU (update.py:82,92) on the matrix cores.
+// K = 49 taps x {x_hi, y_hi, x_lo, y_lo}: the fp32 flow enters as a bf16 head plus a bf16 remainder (exact to
+// ~2^-17) against bf16 weights (each weight appears for the head and the remainder), 196 padded to 224 = 7
+// MFMA k-steps.  Persistent workgroups: the packed weights [128][224] live in LDS, a wave takes 16 pixels at
+// a time, builds its activation fragments straight from the flow field (two taps per lane and k-step) and
+// sends the 16 x 128 outputs through a swizzled LDS tile so that whole 256-byte rows are stored.
 // Also deposits the flow (bf16) in columns 254..255 of X (the motion features end with the flow, :97).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void raft_convf1_kernel(const float* __restrict__ flow, const float* __restrict__ w, const float* __restrict__ b,
+constexpr int CF1_K = 224, CF1_LD = 232;   // packed K and its LDS row pitch (elements)
+__global__ __launch_bounds__(256) void raft_convf1_kernel(const float* __restrict__ flow, const bf16_t* __restrict__ wp, const float* __restrict__ b,
                                                           bf16_t* __restrict__ f1, bf16_t* __restrict__ X, int64_t M, int H8, int W8) {
-    __shared__ float ws[98 * 128];
-    __shared__ float xs[32 * 98];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 98 * 128; i += 256) {   // w is [128][2][7][7]; ws[k][co], k = c*49 + ky*7 + kx
-        const int co = i & 127, k = i >> 7;
-        ws[i] = w[co * 98 + k];
-    }
-    const int64_t m0 = (int64_t)blockIdx.x * 32;
-    for (int i = tid; i < 32 * 98; i += 256) {
-        const int p = i / 98, k = i - p * 98;
-        const int64_t m = m0 + p;
-        float v = 0.f;
-        if (m < M) {
-            const int c = k / 49, t = k - c * 49, ky = t / 7, kx = t - ky * 7;
-            const int pix = (int)(m % (H8 * W8)), y = pix / W8 + ky - 3, x = pix % W8 + kx - 3;
-            if ((unsigned)y < (unsigned)H8 && (unsigned)x < (unsigned)W8) v = flow[(m + (ky - 3) * W8 + (kx - 3)) * 2 + c];
-        }
-        xs[i] = v;
+    extern __shared__ __attribute__((aligned(16))) char cf1_smem[];
+    bf16_t* const ws = reinterpret_cast<bf16_t*>(cf1_smem);              // [128][CF1_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* const cst = cf1_smem + 128 * CF1_LD * 2 + wave * 4096;         // [16 px][128 ch] bf16, 16-byte chunks XOR px
+    for (int i = tid; i < 128 * (CF1_K / 8); i += 256) {
+        const int row = i / (CF1_K / 8), c = i - row * (CF1_K / 8);
+        *reinterpret_cast<uint4*>(ws + row * CF1_LD + c * 8) = *reinterpret_cast<const uint4*>(wp + row * CF1_K + c * 8);
     }
     __syncthreads();
-    const int p = tid >> 3, cg = (tid & 7) * 16;
-    const int64_t m = m0 + p;
-    float acc[16];
+    const int fr = lane & 15, fg = lane >> 4, HW = H8 * W8;
+    const int64_t n_groups = (M + 15) >> 4;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < n_groups; g += (int64_t)gridDim.x * 4) {
+        const int64_t m = g * 16 + fr;
+        const bool valid = m < M;
+        const int pix = (int)((valid ? m : 0) % HW), y = pix / W8, x = pix - y * W8;
+        f32x4 acc[8];
 #pragma unroll
-    for (int c = 0; c < 16; c++) acc[c] = b[cg + c];
-    for (int k = 0; k < 98; k++) {
-        const float x = xs[p * 98 + k];
+        for (int ct = 0; ct < 8; ct++) acc[ct] = *reinterpret_cast<const f32x4*>(b + ct * 16 + fg * 4);
 #pragma unroll
-        for (int c = 0; c < 16; c++) acc[c] = fmaf(x, ws[k * 128 + cg + c], acc[c]);
-    }
-    if (m < M) {
+        for (int ks = 0; ks < 7; ks++) {
+            bf16x8 xf;
 #pragma unroll
-        for (int c = 0; c < 16; c++) f1[m * 128 + cg + c] = (bf16_t)fmaxf(acc[c], 0.f);
-        if ((tid & 7) == 0) {
+            for (int tt = 0; tt < 2; tt++) {
+                const int tap = ks * 8 + fg * 2 + tt, ky = tap / 7, kx = tap - ky * 7;
+                const int yy = y + ky - 3, xx = x + kx - 3;
+                float2 f = make_float2(0.f, 0.f);
+                if (valid && tap < 49 && (unsigned)yy < (unsigned)H8 && (unsigned)xx < (unsigned)W8)
+                    f = *reinterpret_cast<const float2*>(flow + (m + (ky - 3) * W8 + (kx - 3)) * 2);
+                const bf16_t hx = (bf16_t)f.x, hy = (bf16_t)f.y;
+                xf[tt * 4 + 0] = hx; xf[tt * 4 + 1] = hy;
+                xf[tt * 4 + 2] = (bf16_t)(f.x - (float)hx); xf[tt * 4 + 3] = (bf16_t)(f.y - (float)hy);
+            }
+#pragma unroll
+            for (int ct = 0; ct < 8; ct++) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + (ct * 16 + fr) * CF1_LD + ks * 32 + fg * 8);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[ct], 0, 0, 0);
+            }
+        }
+        // D: column (lane & 15) = pixel, rows fg * 4 + reg = channel within the 16-channel tile
+#pragma unroll
+        for (int ct = 0; ct < 8; ct++) {
+            const f32x4 v = acc[ct];
+            const bf16x4 pk = {(bf16_t)fmaxf(v[0], 0.f), (bf16_t)fmaxf(v[1], 0.f), (bf16_t)fmaxf(v[2], 0.f), (bf16_t)fmaxf(v[3], 0.f)};
+            const int chunk = (ct * 2 + (fg >> 1)) ^ fr;
+            *reinterpret_cast<bf16x4*>(cst + fr * 256 + chunk * 16 + (fg & 1) * 8) = pk;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the tile is exchanged between lanes of this wave only
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int row = rr * 4 + fg, ch = fr;
+            const uint4 v = *reinterpret_cast<const uint4*>(cst + row * 256 + ((ch ^ row) << 4));
+            const int64_t mo = g * 16 + row;
+            if (mo < M) *reinterpret_cast<uint4*>(f1 + mo * 128 + ch * 8) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (valid && fg == 0) {
             X[m * 256 + 254] = (bf16_t)flow[m * 2];
             X[m * 256 + 255] = (bf16_t)flow[m * 2 + 1];
         }
@@ -131,33 +173,29 @@ __global__ void raft_rh_kernel(const bf16_t* __restrict__ ZR, const float* __res
     RH[i] = (bf16_t)((float)ZR[m * 256 + 128 + c] * h32[i]);
 }
 
-// FlowHead.conv2 (3x3, 256 -> 2; update.py:14,18) + coords1 += delta (xraft.py:145): one wave per pixel
-__global__ __launch_bounds__(256) void raft_flow_head2_kernel(const bf16_t* __restrict__ FH, const float* __restrict__ w, const float* __restrict__ b,
-                                                              float* __restrict__ flow, int64_t M, int H8, int W8) {
-    const int lane = threadIdx.x & 63;
-    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+// FlowHead.conv2 (3x3, 256 -> 2; update.py:14,18) + coords1 += delta (xraft.py:145).  The convolution is a
+// GEMM with the taps moved to the OUTPUT side: P[m][tap*2 + o] = <FH[m], w[o][tap]> for every pixel (one pass
+// over FH on the MFMA kernel, N = 18 padded to 32), then delta[m][o] = sum_tap P[m + offset(tap)][tap*2 + o]
+// over the in-image neighbours -- 72 bytes per pixel instead of nine 512-byte rows.
+__global__ __launch_bounds__(256) void raft_flow_head2_kernel(const float* __restrict__ P, const float* __restrict__ b, float* __restrict__ flow,
+                                                              int64_t M, int H8, int W8) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    const int pix = (int)(m % (H8 * W8)), y = pix / W8, x = pix % W8;
-    float a0 = 0.f, a1 = 0.f;
+    const int pix = (int)(m % (H8 * W8)), y = pix / W8, x = pix - y * W8;
+    float a0 = b[0], a1 = b[1];
 #pragma unroll
     for (int tap = 0; tap < 9; tap++) {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         if ((unsigned)(y + dy) < (unsigned)H8 && (unsigned)(x + dx) < (unsigned)W8) {
-            const bf16x4 v = *reinterpret_cast<const bf16x4*>(FH + (m + dy * W8 + dx) * 256 + lane * 4);
-            const float4 w0 = *reinterpret_cast<const float4*>(w + (0 * 9 + tap) * 256 + lane * 4);   // w packed [2][9][256]
-            const float4 w1 = *reinterpret_cast<const float4*>(w + (1 * 9 + tap) * 256 + lane * 4);
-            a0 += (float)v[0] * w0.x + (float)v[1] * w0.y + (float)v[2] * w0.z + (float)v[3] * w0.w;
-            a1 += (float)v[0] * w1.x + (float)v[1] * w1.y + (float)v[2] * w1.z + (float)v[3] * w1.w;
+            const float2 v = *reinterpret_cast<const float2*>(P + (m + dy * W8 + dx) * 32 + tap * 2);
+            a0 += v.x;
+            a1 += v.y;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        a0 += __shfl_xor(a0, off);
-        a1 += __shfl_xor(a1, off);
-    }
-    if (lane == 0) {
-        flow[m * 2] += a0 + b[0];
-        flow[m * 2 + 1] += a1 + b[1];
-    }
+    float2* f = reinterpret_cast<float2*>(flow + m * 2);
+    float2 o = *f;
+    o.x += a0; o.y += a1;
+    *f = o;
 }
 
 // upsample_flow (xraft.py:88-99): softmax over the 9 mask logits of each fine pixel, convex combination of
@@ -225,6 +263,7 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     bf16_t* FH = (bf16_t*)ws.take(M * 256 * 2);
     float* flow = (float*)ws.take(M * 2 * 4);
     float* mask = (float*)ws.take(M * 576 * 4);
+    float* P2 = mask;   // [M, 32] per-tap partial products of FlowHead.conv2 (the mask buffer is idle until the last iteration)
     void* zero = ws.take(256);
     if (ws.dry) return VTGB_OK;
     VTGB_REQUIRE(ws.ok(), VTGB_EWORKSPACE, "raft_update: workspace %zu < %zu bytes", ws.size, ws.used);
@@ -241,6 +280,13 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     VTGB_HIP(hipMemsetAsync(zero, 0, 256, s));
     hipLaunchKernelGGL(raft_init_kernel, dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, s, a->net, a->inp, h32, hb, X, flow, M, HW);
     const int Mi = (int)M;
+    const size_t cf1_lds = 128 * CF1_LD * 2 + 4 * 4096;
+    static bool cf1_attr = false;
+    if (!cf1_attr) {
+        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_convf1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cf1_lds));
+        cf1_attr = true;
+    }
+    const int64_t cf1_groups = (M + 15) / 16, cf1_grid = cf1_groups < 4 * 512 ? (cf1_groups + 3) / 4 : 512;
     auto F = [](const void* p) { return (const float*)p; };
     for (int it = 0; it < a->iters; it++) {
         // ---- BasicMotionEncoder (update.py:88-97)
@@ -251,7 +297,7 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
             VTGB_TRY(launch_conv_gemm(d, s));
         }
         VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 192, H8, W8, 3, 3, 256, 256, c1, 256, nullptr, 0, w[2], F(w[3]), VTGB_EPI_STORE, 1, CF, 256, zero), s));
-        hipLaunchKernelGGL(raft_convf1_kernel, dim3((unsigned)((M + 31) / 32)), dim3(256), 0, s, flow, F(w[4]), F(w[5]), f1, X, M, H8, W8);
+        hipLaunchKernelGGL(raft_convf1_kernel, dim3((unsigned)cf1_grid), dim3(256), cf1_lds, s, flow, (const bf16_t*)w[4], F(w[5]), f1, X, M, H8, W8);
         VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 64, H8, W8, 3, 3, 128, 128, f1, 128, nullptr, 0, w[6], F(w[7]), VTGB_EPI_STORE, 1, CF + 192, 256, zero), s));
         VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 126, H8, W8, 3, 3, 256, 256, CF, 256, nullptr, 0, w[8], F(w[9]), VTGB_EPI_STORE, 1, X + 128, 256, zero), s));
         // ---- SepConvGRU (update.py:50-65): horizontal (1x5) then vertical (5x1)
@@ -265,7 +311,12 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
         }
         // ---- FlowHead (update.py:10-18) and coords1 += delta_flow (xraft.py:145)
         VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 256, H8, W8, 3, 3, 128, 128, hb, 128, nullptr, 0, w[18], F(w[19]), VTGB_EPI_STORE, 1, FH, 256, zero), s));
-        hipLaunchKernelGGL(raft_flow_head2_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, FH, F(w[20]), F(w[21]), flow, M, H8, W8);
+        {
+            GemmDesc d = conv_desc(Mi, 32, H8, W8, 0, 0, 0, 0, FH, 256, nullptr, 0, w[20], nullptr, VTGB_EPI_STORE_F32, 0, P2, 32, zero);
+            d.K = 256; d.ldw = 256;
+            VTGB_TRY(launch_conv_gemm(d, s));
+        }
+        hipLaunchKernelGGL(raft_flow_head2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, P2, F(w[21]), flow, M, H8, W8);
     }
     // ---- mask head of the last iteration (update.py:129-132,143) and convex upsample (xraft.py:88-99)
     VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 256, H8, W8, 3, 3, 128, 128, hb, 128, nullptr, 0, w[22], F(w[23]), VTGB_EPI_STORE, 1, FH, 256, zero), s));

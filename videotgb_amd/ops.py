@@ -433,7 +433,10 @@ class RaftWeights(_WeightTable):
 
         add_conv("encoder.convc1", 384)
         add_conv("encoder.convc2")
-        self.add(sd[p + "encoder.convf1.weight"]); self.add(sd[p + "encoder.convf1.bias"])        # fp32, direct kernel
+        # convf1 on the matrix cores: k = tap * 4 + {x, y, x, y} (flow head | flow remainder), 49 taps padded to 56
+        wf = sd[p + "encoder.convf1.weight"].float().reshape(128, 2, 49).permute(0, 2, 1)             # [co, tap, c]
+        wf = torch.nn.functional.pad(torch.cat([wf, wf], 2), (0, 0, 0, 7))                            # [co, 56, 4]
+        self.add(wf.reshape(128, 224).contiguous(), True); self.add(sd[p + "encoder.convf1.bias"])
         add_conv("encoder.convf2")
         add_conv("encoder.conv")
         for sfx in ("1", "2"):
@@ -441,7 +444,9 @@ class RaftWeights(_WeightTable):
             self.add(torch.cat([sd[p + "gru.convz" + sfx + ".bias"], sd[p + "gru.convr" + sfx + ".bias"]], 0))
             add_conv("gru.convq" + sfx)
         add_conv("flow_head.conv1")
-        self.add(sd[p + "flow_head.conv2.weight"].float().permute(0, 2, 3, 1).reshape(2, -1).contiguous())   # fp32 [2, 9*256]
+        # flow_head.conv2 as a GEMM with the taps on the output side: row tap*2 + o = w[o, :, ky, kx]; 18 rows padded to 32
+        w2 = sd[p + "flow_head.conv2.weight"].float().permute(2, 3, 0, 1).reshape(18, 256)
+        self.add(torch.nn.functional.pad(w2, (0, 0, 0, 14)).contiguous(), True)
         self.add(sd[p + "flow_head.conv2.bias"])
         add_conv("mask.0")
         add_conv("mask.2")
