@@ -297,7 +297,9 @@ int vtgb_raft_update(const vtgb_raft_update_args* a, vtgb_stream_t stream);
  * scaling 2*(x/255)-1 of RAFT.forward (xraft.py:105-106) is applied inside.  norm = 0: InstanceNorm2d (fnet);
  * norm = 1: the caller has folded the eval-mode BatchNorm2d that follows every convolution into the packed
  * weights and biases (cnet).  Output: NHWC features [n_images * H/8 * W/8, 256] fp32.
- * weights: [0] conv1.weight fp32 TRANSPOSED to [3*7*7, 64] [1] conv1.bias; per block b (layer1.0, 1.1, 2.0, 2.1, 3.0, 3.1) at
+ * weights: [0] conv1.weight bf16 [64, 4 (tY), 64]: the stem as a 4x1 convolution over the 2x2 space-to-depth
+ *   image, channel = dX*12 + py*6 + px*3 + c (48, zero-padded to 64), ky = 2 tY + py - 1, kx = 2 dX + px - 1,
+ *   scaled by 2/255 (raw 0..255 pixels enter the GEMM) [1] conv1.bias - 127.5 * sum(packed weights); per block b (layer1.0, 1.1, 2.0, 2.1, 3.0, 3.1) at
  *   2 + 6 b: conv1.weight bf16 [C, 3,3,Cin_pad] , conv1.bias, conv2.weight [C, 3,3,C_pad], conv2.bias,
  *   downsample.0.weight [C, Cin_pad] or NULL, downsample.0.bias or NULL  (96-channel stages: C_pad = 128, zero-filled);
  *   [38] conv2.weight bf16 [256, 128] [39] conv2.bias */

@@ -116,6 +116,10 @@ struct GemmDesc {
     // without a second pass over the output.  stats_rows >= 256; the caller zeroes the buffer.
     float* col_stats;
     int stats_rows;
+    // EPI_STORE (bf16, whole-row stores): columns n >= gate_from are not stored to `out` but multiplied by
+    // aux[m][n - gate_from] (bf16, ldaux) and stored to out2[m][n - gate_from] (bf16, ldo2) -- SepConvGRU's
+    // r * h straight from the z|r convolution.  gate_from % 8 == 0; 0 = off.
+    int gate_from;
 };
 #define VTGB_EPI_GRU 4
 int launch_gemm(const GemmDesc& d, hipStream_t s);

@@ -532,7 +532,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                 const int row = rr * 8 + (lane >> 3), ch = lane & 7;
                 const uint4 v = *reinterpret_cast<const uint4*>(cst + row * 128 + ((ch ^ (row & 7)) << 4));
                 const int m = m0 + wm * WROWS + row, n = n0 + wn * 64 + ch * 8;
-                if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(outp + map_row(p.o_map, m) * p.ldo + n) = v;
+                if (m < p.M && n < p.N) {
+                    if (EPI == EPI_STORE && p.gate_from > 0 && n >= p.gate_from) {
+                        const int ng = n - p.gate_from;
+                        const bf16x8 g = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)m * p.ldaux + ng);
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, v);
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) o[e] = (bf16_t)((float)a[e] * (float)g[e]);
+                        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.out2) + (int64_t)m * p.ldo2 + ng) = o;
+                    } else {
+                        *reinterpret_cast<uint4*>(outp + map_row(p.o_map, m) * p.ldo + n) = v;
+                    }
+                }
             }
             return;
         }
@@ -818,6 +830,13 @@ int launch_conv_gemm(const GemmDesc& d, hipStream_t s) {
                          (d.M % (d.conv_H * d.conv_W)) == 0 && (d.conv_split == d.conv_Cin || d.A2),
                      VTGB_EINVAL, "conv gemm: inconsistent convolution geometry");
     }
+    if (d.gate_from > 0)
+        VTGB_REQUIRE(d.epi == EPI_STORE && (d.gate_from % 8) == 0 && (d.N % 8) == 0 && (d.ldo % 8) == 0 && d.aux && d.out2 && (d.ldaux % 8) == 0 &&
+                         (d.ldo2 % 8) == 0,
+                     VTGB_EINVAL, "conv gemm: gated store needs 8-aligned bf16 rows, aux and out2");
+    if (d.col_stats)
+        VTGB_REQUIRE(d.epi == EPI_STORE_F32 && d.stats_rows >= L_BM && (d.N % 4) == 0 && (d.ldo % 4) == 0 && d.act == 0 && d.out_scale == 0.f,
+                     VTGB_EINVAL, "conv gemm: column statistics need fp32 whole-row stores and images of >= 256 rows");
     switch (d.epi) {
         case EPI_STORE: return conv ? launch_large_forced<EPI_STORE, true>(d, s) : launch_large_forced<EPI_STORE, false>(d, s);
         case EPI_STORE_F32: return conv ? launch_large_forced<EPI_STORE_F32, true>(d, s) : launch_large_forced<EPI_STORE_F32, false>(d, s);

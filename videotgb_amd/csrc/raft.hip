@@ -164,15 +164,6 @@ __global__ __launch_bounds__(256) void raft_convf1_kernel(const float* __restric
     }
 }
 
-// RH = r * h   (update.py:55,62): r = ZR[:, 128:256] (bf16, sigmoid applied), h fp32
-__global__ void raft_rh_kernel(const bf16_t* __restrict__ ZR, const float* __restrict__ h32, bf16_t* __restrict__ RH, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t m = i >> 7;
-    const int c = (int)(i & 127);
-    RH[i] = (bf16_t)((float)ZR[m * 256 + 128 + c] * h32[i]);
-}
-
 // FlowHead.conv2 (3x3, 256 -> 2; update.py:14,18) + coords1 += delta (xraft.py:145).  The convolution is a
 // GEMM with the taps moved to the OUTPUT side: P[m][tap*2 + o] = <FH[m], w[o][tap]> for every pixel (one pass
 // over FH on the MFMA kernel, N = 18 padded to 32), then delta[m][o] = sum_tap P[m + offset(tap)][tap*2 + o]
@@ -303,8 +294,10 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
         // ---- SepConvGRU (update.py:50-65): horizontal (1x5) then vertical (5x1)
         for (int half = 0; half < 2; half++) {
             const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1, wi = 10 + 4 * half;
-            VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 256, H8, W8, kh, kw, 384, 128, hb, 128, X, 256, w[wi], F(w[wi + 1]), VTGB_EPI_STORE, 2, ZR, 256, zero), s));
-            hipLaunchKernelGGL(raft_rh_kernel, dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, s, ZR, h32, RH, M * 128);
+            // z -> ZR[:, :128]; r is multiplied by h (bf16) in the epilogue and lands in RH (update.py:55,62)
+            GemmDesc zr = conv_desc(Mi, 256, H8, W8, kh, kw, 384, 128, hb, 128, X, 256, w[wi], F(w[wi + 1]), VTGB_EPI_STORE, 2, ZR, 256, zero);
+            zr.gate_from = 128; zr.aux = hb; zr.ldaux = 128; zr.out2 = RH; zr.ldo2 = 128;
+            VTGB_TRY(launch_conv_gemm(zr, s));
             GemmDesc q = conv_desc(Mi, 128, H8, W8, kh, kw, 384, 128, RH, 128, X, 256, w[wi + 2], F(w[wi + 3]), VTGB_EPI_GRU, 0, h32, 128, zero);
             q.resid = h32; q.ldr = 128; q.aux = ZR; q.ldaux = 256; q.out2 = hb; q.ldo2 = 128;
             VTGB_TRY(launch_conv_gemm(q, s));

@@ -4,54 +4,45 @@
 // the MFMA kernel of gemm.hip (stride 1 and 2) with fp32 outputs; the norm that follows each convolution
 // (InstanceNorm2d for fnet, eval-mode BatchNorm2d for cnet -- folded into the packed weights by the
 // caller) is applied by a separate HBM-bound pass that also does ReLU, the residual add and the bf16 cast.
-// The stem (3 input channels, K = 147) is a direct fp32 kernel.
+// The stem (3 input channels) runs on the same kernel after a space-to-depth repack (see below).
 #include <math.h>
 #include <string.h>
 
 #include "common.h"
 
-// ---- stem: conv 7x7 stride 2 pad 3, 3 -> 64, on 2*(x/255)-1 (xraft.py:105-106).  One workgroup per STEM_ROWS
-// output rows (weights are staged in LDS once per workgroup; they arrive pre-transposed [147][64]).
-constexpr int STEM_ROWS = 4;
-__global__ __launch_bounds__(256) void raft_stem_kernel(const float* __restrict__ img, const float* __restrict__ wt, const float* __restrict__ b,
-                                                        float* __restrict__ out, int H, int W) {
-    extern __shared__ float sm[];
-    const int Wo = W >> 1, Ho = H >> 1;
-    float* ws = sm;                    // [147][64]
-    float* xs = sm + 147 * 64;         // [3][2*STEM_ROWS + 5][W + 6]
-    const int n = blockIdx.y, yo0 = blockIdx.x * STEM_ROWS, tid = threadIdx.x;
-    for (int i = tid; i < 147 * 64; i += 256) ws[i] = wt[i];
-    const int WP = W + 6, RI = 2 * STEM_ROWS + 5;
-    for (int i = tid; i < 3 * RI * WP; i += 256) {
-        const int c = i / (RI * WP), r = (i / WP) % RI, xx = i % WP;
-        const int y = yo0 * 2 + r - 3, x = xx - 3;
-        float v = 0.f;
-        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = 2.0f * (img[(((int64_t)n * 3 + c) * H + y) * W + x] / 255.0f) - 1.0f;
-        xs[i] = v;
-    }
-    __syncthreads();
-    // item -> (row, pixel, 32-channel half)
-    for (int item = tid; item < STEM_ROWS * Wo * 2; item += 256) {
-        const int ry = item / (Wo * 2), rem = item - ry * (Wo * 2), px = rem >> 1, c0 = (rem & 1) * 32;
-        const int yo = yo0 + ry;
-        if (yo >= Ho) continue;
-        float acc[32];
+// ---- stem: conv 7x7 stride 2 pad 3, 3 -> 64, on 2*(x/255)-1 (xraft.py:105-106), as an implicit GEMM.
+// Space-to-depth: the image is repacked (bf16 NHWC at half resolution) so that pixel (Y, X) carries the 4 x 2 x 2 x 3
+// raw values img[c][2Y + py][2(X + dX - 2) + px], dX = 0..3 -- 48 channels padded to 64 -- and the stride-2 7x7
+// stencil becomes a 4 x 1 stride-1 convolution (vertical taps dY = -2..1; K = 4 * 64 = 256, 147 of them non-zero).
+// Raw 0..255 integers are exact in bf16; the normalisation lives in the packed weights (w * 2/255) and bias
+// (b - 127.5 * sum w'), and out-of-image taps hold 127.5 (= normalised 0): horizontally in the packed tensor,
+// vertically through the convolution's padding page.
+__global__ __launch_bounds__(256) void raft_stem_pack_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, bf16_t* __restrict__ pad_page,
+                                                             int64_t n_px, int H, int W) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 128) pad_page[i] = (bf16_t)((i & 63) < 48 ? 127.5f : 0.f);
+    if (i >= n_px * 4) return;
+    const int64_t px_i = i >> 2;
+    const int dX = (int)(i & 3), W2 = W >> 1, H2 = H >> 1;
+    const int X = (int)(px_i % W2), Y = (int)((px_i / W2) % H2);
+    const int64_t n = px_i / ((int64_t)W2 * H2);
+    bf16_t v[12];
 #pragma unroll
-        for (int c = 0; c < 32; c++) acc[c] = b[c0 + c];
-        for (int k = 0; k < 147; k++) {
-            const int c = k / 49, t = k - c * 49, ky = t / 7, kx = t - ky * 7;
-            const float x = xs[(c * RI + ry * 2 + ky) * WP + px * 2 + kx];
-            const float4* wr = reinterpret_cast<const float4*>(ws + k * 64 + c0);
+    for (int py = 0; py < 2; py++)
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const float4 w4 = wr[q];
-                acc[4 * q] = fmaf(x, w4.x, acc[4 * q]); acc[4 * q + 1] = fmaf(x, w4.y, acc[4 * q + 1]);
-                acc[4 * q + 2] = fmaf(x, w4.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(x, w4.w, acc[4 * q + 3]);
-            }
+        for (int pxx = 0; pxx < 2; pxx++) {
+            const int col = 2 * (X + dX - 2) + pxx, row = 2 * Y + py;
+            const bool ok = (unsigned)col < (unsigned)W;
+#pragma unroll
+            for (int c = 0; c < 3; c++) v[py * 6 + pxx * 3 + c] = (bf16_t)(ok ? img[((n * 3 + c) * H + row) * W + col] : 127.5f);
         }
-        float* o = out + (((int64_t)n * Ho + yo) * Wo + px) * 64 + c0;
+    bf16_t* o = out + px_i * 64 + dX * 12;
 #pragma unroll
-        for (int cc = 0; cc < 32; cc += 4) *reinterpret_cast<float4*>(o + cc) = make_float4(acc[cc], acc[cc + 1], acc[cc + 2], acc[cc + 3]);
+    for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4*>(o + q * 4) = bf16x4{v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+    if (dX == 3) {
+        const bf16x4 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+#pragma unroll
+        for (int q = 0; q < 4; q++) *reinterpret_cast<bf16x4*>(out + px_i * 64 + 48 + q * 4) = z;
     }
 }
 
@@ -146,7 +137,6 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     VTGB_REQUIRE(a, VTGB_EINVAL, "raft_encoder: NULL args");
     VTGB_REQUIRE(a->n_images > 0 && a->H >= 64 && a->W >= 64 && (a->H % 8) == 0 && (a->W % 8) == 0 && (a->norm == 0 || a->norm == 1), VTGB_EINVAL,
                  "raft_encoder: bad dims n=%d H=%d W=%d", a->n_images, a->H, a->W);
-    VTGB_REQUIRE(a->W + 6 <= 2048, VTGB_EUNSUPPORTED, "raft_encoder: width %d too large for the stem kernel", a->W);
     const int n = a->n_images;
     const int H2 = a->H / 2, W2 = a->W / 2, H4 = a->H / 4, W4 = a->W / 4, H8 = a->H / 8, W8 = a->W / 8;
     const int64_t M2 = (int64_t)n * H2 * W2, M4 = (int64_t)n * H4 * W4, M8 = (int64_t)n * H8 * W8;
@@ -159,6 +149,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     float* stats = (float*)ws.take((int64_t)n * 128 * 2 * 4);
     float* stats2 = (float*)ws.take((int64_t)n * 128 * 2 * 4);   // the downsample branch's moments
     void* zero = ws.take(256);
+    void* pad_page = ws.take(256);   // the stem's out-of-image value (raw 127.5)
     if (ws.dry) return VTGB_OK;
     VTGB_REQUIRE(ws.ok(), VTGB_EWORKSPACE, "raft_encoder: workspace %zu < %zu bytes", ws.size, ws.used);
     VTGB_REQUIRE(a->images && a->weights && a->out, VTGB_EINVAL, "raft_encoder: NULL operand");
@@ -187,15 +178,15 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
         (void)hipMemsetAsync(st, 0, (size_t)n * C * 2 * sizeof(float), s);
         return st;
     };
-    // ---- stem
-    const size_t stem_lds = (147 * 64 + 3 * (2 * STEM_ROWS + 5) * (a->W + 6)) * sizeof(float);
-    static bool stem_attr = false;
-    if (!stem_attr) {
-        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        stem_attr = true;
+    // ---- stem: repack, then a 4x1 implicit-GEMM convolution whose epilogue also yields the InstanceNorm moments
+    hipLaunchKernelGGL(raft_stem_pack_kernel, dim3((unsigned)((M2 * 4 + 255) / 256)), dim3(256), 0, s, a->images, act1, (bf16_t*)pad_page, M2, a->H, a->W);
+    {
+        float* sf = stats_for(stats, H2 * W2, 64);
+        GemmDesc d = enc_conv((int)M2, 64, H2, W2, 1, 64, 1, H2, W2, act1, w[0], F(w[1]), cf, 64, pad_page, sf);
+        d.conv_KH = 4; d.K = 256; d.ldw = 256;
+        VTGB_TRY(launch_conv_gemm(d, s));
+        VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, sf != nullptr));
     }
-    hipLaunchKernelGGL(raft_stem_kernel, dim3((H2 + STEM_ROWS - 1) / STEM_ROWS, n), dim3(256), stem_lds, s, a->images, F(w[0]), F(w[1]), cf, a->H, a->W);
-    VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, false));
     // ---- six residual blocks
     struct Stage { int C, Cpad, stride, Ho, Wo; };
     const Stage st[6] = {{64, 64, 1, H2, W2}, {64, 64, 1, H2, W2}, {96, 128, 2, H4, W4}, {96, 128, 1, H4, W4}, {128, 128, 2, H8, W8}, {128, 128, 1, H8, W8}};

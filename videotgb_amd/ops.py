@@ -495,8 +495,24 @@ class RaftEncoderWeights(_WeightTable):
                 w = torch.nn.functional.pad(w, (0, cin_pad - ci))
             return w.reshape(co, -1).contiguous()
 
+        # stem as a 4x1 convolution over the space-to-depth image (raft_enc.hip): [co][tY][dX, py, px, c | pad to 64],
+        # ky = 2 tY + py - 1, kx = 2 dX + px - 1; raw 0..255 pixels: w' = w * 2/255, b' = b - 127.5 * sum(w')
         w, b = folded("conv1", "norm1")
-        self.add(w.reshape(64, 147).t().contiguous()); self.add(b)       # [k = c*49 + ky*7 + kx][co]
+        w = w * (2.0 / 255.0)
+        wp = torch.zeros(64, 4, 4, 2, 2, 3, dtype=torch.float32, device=w.device)
+        for tY in range(4):
+            for py in range(2):
+                ky = 2 * tY + py - 1
+                if ky < 0:
+                    continue
+                for dX in range(4):
+                    for px in range(2):
+                        kx = 2 * dX + px - 1
+                        if kx >= 0:
+                            wp[:, tY, dX, py, px, :] = w[:, :, ky, kx]
+        wp = torch.nn.functional.pad(wp.reshape(64, 4, 48), (0, 16)).reshape(64, 256)
+        wq = wp.to(torch.bfloat16).float()
+        self.add(wq.contiguous(), True); self.add(b - 127.5 * wq.sum(1))
         cin_pad = 64
         for li, c, cpad in (("layer1", 64, 64), ("layer2", 96, 128), ("layer3", 128, 128)):
             for bi in range(2):
