@@ -74,6 +74,7 @@ def parse():
                     help="RAFT fnet/cnet: libvtgb.so (bf16 MFMA implicit-GEMM convolutions, fnet once per distinct frame) or MIOpen")
     ap.add_argument("--raft-update", choices=["hip", "torch"], default="hip",
                     help="RAFT refinement loop: libvtgb.so (bf16 MFMA implicit-GEMM convolutions) or PyTorch-ROCm/MIOpen ops")
+    ap.add_argument("--raft-clips", type=int, default=32, help="clips per RAFT call (pairs of that many clips form one batch)")
     ap.add_argument("--overlap", action="store_true",
                     help="two HIP streams: the prefix stage of batch i+1 over the LLM decode of batch i (measured +7 % clips/s; off by "
                          "default because concurrent kernels inflate the per-launch durations the roofline object is computed from)")
@@ -213,6 +214,7 @@ def main():
                     raft_hip_update=(args.raft_update == "hip"))
     m.of_extractor.channels_last = args.raft_channels_last
     m.of_extractor.hip_encoders = (args.raft_encoders == "hip" and args.raft_update == "hip")
+    m.flow_clips_per_call = args.raft_clips
     sd = synth.path_state_dict(cfg, seed=0, with_raft=True)
     m.load_state_dict(sd, strict=False)
     m.to(dev)

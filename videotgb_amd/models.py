@@ -417,12 +417,15 @@ class _LSTPBase(nn.Module):
         return self
 
     # ---- stages -------------------------------------------------------------------------------
+    flow_clips_per_call = 16  # RAFT batch (clips); ~1.7 GB of workspace per clip at T = 96, 224 x 224
+
     @torch.no_grad()
-    def flow(self, flow_frames: Tensor, clips_per_call: int = 8) -> Tensor:
+    def flow(self, flow_frames: Tensor, clips_per_call: Optional[int] = None) -> Tensor:
         """eval/utils/model.py:76-84: RAFT between consecutive frames of each clip, last flow repeated.
         The frame pairs of up to ``clips_per_call`` clips go through RAFT in one call (the reference loops
         over clips; pairs are independent, so batching them changes nothing but the launch count)."""
         b, t = flow_frames.shape[:2]
+        clips_per_call = clips_per_call or self.flow_clips_per_call
         outs = []
         for c0 in range(0, b, clips_per_call):
             ff = flow_frames[c0:c0 + clips_per_call]
