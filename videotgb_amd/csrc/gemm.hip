@@ -307,8 +307,33 @@ constexpr int L_LDS = (L_A_SLOTS + L_W_SLOTS) * L_OP_BYTES;   // 160 KiB
 // NWN (waves along N): 4 = the 256 x 256 tile above; 2 / 1 = 256 x 128 / 256 x 64 tiles for narrow outputs
 // (RAFT's 64..128-channel convolutions): waves 4(M) x 2(N) of 64 x 64 or 8(M) x 1(N) of 32 x 64, so that all
 // eight waves have work and only the output channels that exist are staged (weight slots of 16 / 8 KiB).
+// debug: shader-clock cycles and 100 MHz reference ticks spent inside the large kernel (summed over
+// workgroups), so that tools/gemm_ablate.py can report the clock the chip actually holds under each variant
+__device__ unsigned long long g_clk[2];
+extern "C" void vtgb_debug_read_clk(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(g_clk));
+    if (reset) {
+        const unsigned long long z[2] = {0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, sizeof(z));
+    }
+}
+struct ClkScope {
+    unsigned long long c0, r0;
+    bool on;
+    __device__ ClkScope(bool enable) : on(enable) {
+        if (on) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    }
+    __device__ void stop() {
+        if (on && threadIdx.x == 0) {
+            atomicAdd(&g_clk[0], __builtin_amdgcn_s_memtime() - c0);
+            atomicAdd(&g_clk[1], __builtin_amdgcn_s_memrealtime() - r0);
+        }
+    }
+};
+
 template <int EPI, int ABL = 0, bool CONV = false, int NWN = 4>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G) {
+    ClkScope clk(ABL != 0);
     constexpr int NX = 2 * NWN;          // activation fragments per wave: wave tile = (16 NX) x 64
     constexpr int WROWS = 16 * NX;       // rows of the wave tile
     constexpr int MW = 8 / NWN;          // waves along M
@@ -487,6 +512,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         L_MFMA(wf0, xf0)
         L_MFMA(wf1, xf1)
     }
+    clk.stop();
 #undef L_READ
 #undef L_MFMA
 #undef L_ISSUE_A
@@ -758,7 +784,7 @@ static int launch_epi(const GemmDesc& d, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS);                            \
         hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, v>), grid, dim3(512), L_LDS, s, d, m_tiles, n_tiles, G);    \
         break;
-                switch (g_ablate) { ABL_CASE(1) ABL_CASE(8) ABL_CASE(16) ABL_CASE(17) ABL_CASE(25) default: break; }
+                switch (g_ablate) { ABL_CASE(1) ABL_CASE(8) ABL_CASE(16) ABL_CASE(17) ABL_CASE(25) ABL_CASE(32) default: break; }
 #undef ABL_CASE
             } else {
                 static bool attr0 = false;
