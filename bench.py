@@ -38,11 +38,12 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MI
 VIT_GFLOP_PER_FRAME = 520.72   # SURVEY.md 8d / BASELINE.md 2
 
 
-def pmc_traffic():
-    """Mean HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 per the
-    gfx950 correction + WRITE_SIZE; profiles/r01_pmc_traffic_gemm.json, collected with tools/gemm_pmc.py on the
-    four ViT-g layer shapes at 31 clips).  None if the file is absent."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_traffic_gemm.json")
+def pmc_traffic(family="gemm"):
+    """Mean HBM-side bytes per launch of the dominant kernel family from the committed PMC passes (FETCH_SIZE x2 per
+    the gfx950 correction + WRITE_SIZE).  gemm: profiles/r01_pmc_traffic_gemm.json (tools/gemm_pmc.py, the four ViT-g
+    layer shapes at 31 clips); conv: profiles/r01_pmc_traffic_conv.json (tools/conv_pmc.py, one RAFT pass over the
+    bench's 32-clip batch).  None if the file is absent."""
+    path = os.path.join(REPO, "profiles", f"r01_pmc_traffic_{family}.json")
     try:
         ks = json.load(open(path))["kernels"]
         tot = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ks.values())
@@ -283,7 +284,7 @@ def main():
         fams = [f for f in (gemm, conv) if f]
         if fams:
             dom = max(fams, key=lambda f: f["ms_per_step"])          # the family the step spends most time in
-            roofline = {"bound": "mfma", **dom, "traffic": pmc_traffic() if dom is gemm else None,
+            roofline = {"bound": "mfma", **dom, "traffic": pmc_traffic("gemm" if dom is gemm else "conv"),
                         "other": [f for f in (gemm, conv, attn) if f and f is not dom]}
     if stage_ev and rank == 0:
         acc = {}

@@ -270,7 +270,8 @@ int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream);
  * (xraft.py:88-99) of the last iteration.  The two encoders and the all-pairs correlation stay with the
  * caller.  Convolutions are bf16 MFMA implicit GEMMs with fp32 accumulation; hidden state, flow and the
  * correlation pyramid stay fp32 (a reduced-precision mode: the reference runs RAFT in fp32).
- * weights (host array of device pointers; conv weights bf16 packed [C_out, KH, KW, C_in]):
+ * weights (host array of device pointers; conv weights bf16 packed [C_out, C_in/64, KH, KW, 64]: K runs 64-channel
+ * chunk major, tap minor -- written [C_out, KH,KW,C_in] below for the shapes only):
  *   [0] encoder.convc1.weight [256, 384] (324 input channels zero-padded to 384) [1] .bias
  *   [2] encoder.convc2.weight [192, 3,3,256] [3] .bias   [4] encoder.convf1.weight bf16 [128, 56 taps, {x,y,x,y}] (49 taps zero-padded) [5] .bias
  *   [6] encoder.convf2.weight [64, 3,3,128]  [7] .bias   [8] encoder.conv.weight [126, 3,3,256]     [9] .bias

@@ -4,6 +4,7 @@ corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH
 coalesced stream; both counters are in KiB)."""
 import csv, glob, json, os, sys, collections
 fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
+want = sys.argv[4] if len(sys.argv) > 4 else ""      # "conv": the implicit-GEMM instantiations (<EPI, 0, true, NWN>) only
 def load(d, counter):
     acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -15,6 +16,8 @@ fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
 res = {}
 for k in fe:
     if "gemm_bf16" not in k and "attn_bf16" not in k:
+        continue
+    if want == "conv" and ", true, " not in k:
         continue
     f = sum(fe[k]) / len(fe[k]); w = sum(wr.get(k, [0])) / max(len(wr.get(k, [0])), 1)
     res[k] = {"launches": len(fe[k]), "FETCH_SIZE_KiB_avg": round(f, 1), "WRITE_SIZE_KiB_avg": round(w, 1),

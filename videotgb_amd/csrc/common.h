@@ -97,7 +97,7 @@ struct GemmDesc {
     int act;            // applied to acc + bias before the store: 0 none, 1 relu, 2 sigmoid
     float out_scale;    // 0 -> 1
     // implicit-GEMM convolution (stride 1, "same" zero padding) over NHWC activations: A rows are
-    // pixels of conv_H x conv_W images, K = KH*KW*Cin ordered (tap, channel), Cin % 64 == 0.
+    // pixels of conv_H x conv_W images, K = KH*KW*Cin ordered (64-channel chunk, tap, channel in chunk), Cin % 64 == 0.
     // Channels [0, split_c) come from A (row stride lda), channels [split_c, Cin) from A2 (lda2):
     // a virtual concat.  conv_KH == 0 -> not a convolution.
     int conv_H, conv_W, conv_KH, conv_KW, conv_Cin, conv_split;

@@ -412,6 +412,13 @@ def tgb_forward(w: TgbWeights, of: Tensor, of_mask: Tensor, text_ids: Tensor, te
 
 
 # ----------------------------------------------------------------------------- RAFT recurrent update (f1)
+def conv_k_order(w: Tensor) -> Tensor:
+    """[co, kh, kw, ci] (ci % 64 == 0) -> [co, K] in the implicit-GEMM kernel's K order: 64-channel chunk major,
+    tap minor (the taps of one channel slab are gathered back to back, see gemm.hip)."""
+    co, kh, kw, ci = w.shape
+    return w.reshape(co, kh * kw, ci // 64, 64).permute(0, 2, 1, 3).reshape(co, -1).contiguous()
+
+
 class RaftWeights(_WeightTable):
     """of_extractor.update_block.* -> the packed table of vtgb_raft_update (bf16, [C_out, KH, KW, C_in])."""
 
@@ -425,7 +432,7 @@ class RaftWeights(_WeightTable):
             w = w.permute(0, 2, 3, 1)                       # [co, kh, kw, ci]
             if cin_pad and cin_pad != ci:
                 w = torch.nn.functional.pad(w, (0, cin_pad - ci))
-            return w.reshape(co, -1).contiguous()
+            return conv_k_order(w)
 
         def add_conv(name, cin_pad=None):
             self.add(conv(name, cin_pad), True)
@@ -493,7 +500,7 @@ class RaftEncoderWeights(_WeightTable):
             w = w.permute(0, 2, 3, 1)
             if cin_pad != ci:
                 w = torch.nn.functional.pad(w, (0, cin_pad - ci))
-            return w.reshape(co, -1).contiguous()
+            return conv_k_order(w)
 
         # stem as a 4x1 convolution over the space-to-depth image (raft_enc.hip): [co][tY][dX, py, px, c | pad to 64],
         # ky = 2 tY + py - 1, kx = 2 dX + px - 1; raw 0..255 pixels: w' = w * 2/255, b' = b - 127.5 * sum(w')
