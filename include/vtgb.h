@@ -91,6 +91,22 @@ typedef struct {
 } vtgb_gather_frames_args;
 int vtgb_gather_frames(const vtgb_gather_frames_args* a, vtgb_stream_t stream);
 
+/* ---- f3: frame preprocessing on the device ----------------------------------------------
+ * Replaces the transform chain of get_frames (eval/utils/builder_utils.py:117-128: ResizeVideo ->
+ * ToUint8 -> ToTHWC -> ToTensorVideo -> NormalizeVideo, i.e. src/gadgets/functional_video.py:33-41
+ * resize (F.interpolate bilinear, align_corners=False, no antialias), truncation to uint8, /255
+ * (:76-90) and (x - mean) / std (:93-110)) for decoded frames that are already in HBM.
+ * frame_idx (optional): the 32-frame pick of builder_utils.py:133-141 applied on the fly -- output frame i is
+ * source frame frame_idx[i]; NULL = identity (the flow_frames tensor). */
+typedef struct {
+    const uint8_t* raw;        /* [T, H0, W0, 3] decoded RGB frames                          */
+    const int64_t* frame_idx;  /* [n_out] or NULL                                            */
+    float* out;                /* [n_out, 3, size, size] fp32                                */
+    int32_t T, H0, W0, n_out, size;
+    float mean[3], std[3];
+} vtgb_preprocess_args;
+int vtgb_preprocess_frames(const vtgb_preprocess_args* a, vtgb_stream_t stream);
+
 /* ---- K1-K6: EVA-ViT-g vision tower ----------------------------------------------------
  * Replaces InstructBlipVisionModel.forward, src/models/components/xinstructblip.py:515-558
  * (embeddings :113-122, 39 x encoder layer :233-269 with attention :162-204 and MLP

@@ -386,6 +386,32 @@ def candidate_frame_ids(vlen: int, n_cand: int = 32) -> List[int]:
     return [indices[i] for i in ids]
 
 
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def preprocess_frames(raw: Tensor, size: int = 224) -> Tensor:
+    """The transform chain of get_frames (eval/utils/builder_utils.py:118-128) on decoded frames raw [T, H0, W0, 3] uint8:
+    read_videos_av's layout change (:86: THWC -> CTHW float), ResizeVideo = F.interpolate(bilinear, align_corners=False)
+    (src/gadgets/functional_video.py:33-41), ToUint8 (transforms.py:217-218), ToTHWC + ToTensorVideo = float / 255
+    (functional_video.py:76-90), NormalizeVideo (:93-110), then CTHW -> TCHW (builder_utils.py:127)."""
+    clip = raw.permute(3, 0, 1, 2).float()                                            # C T H W
+    clip = F.interpolate(clip, size=(size, size), mode="bilinear", align_corners=False)
+    clip = clip.to(torch.uint8)
+    clip = clip.permute(1, 2, 3, 0)                                                    # T H W C
+    clip = clip.float().permute(3, 0, 1, 2) / 255.0                                    # C T H W
+    mean = torch.as_tensor(CLIP_MEAN, dtype=clip.dtype)
+    std = torch.as_tensor(CLIP_STD, dtype=clip.dtype)
+    clip = (clip - mean[:, None, None, None]) / std[:, None, None, None]
+    return clip.permute(1, 0, 2, 3).contiguous()                                       # T C H W
+
+
+def get_frames(raw: Tensor, size: int = 224) -> Tuple[Tensor, Tensor]:
+    """eval/utils/builder_utils.py:117-144 from decoded frames: (frames [32, 3, S, S], flow_frames [T, 3, S, S])."""
+    flow_frames = preprocess_frames(raw, size)
+    return flow_frames[candidate_frame_ids(flow_frames.shape[0])], flow_frames
+
+
 def gather_frames(pixel_values: Tensor, idx: Tensor) -> Tensor:
     """eval/utils/model.py:122,151: index_select into a zero-initialised fp32 buffer.
     pixel_values [B, N, 3, H, W]; idx [B, nframe] -> [B, nframe, 3, H, W] fp32."""

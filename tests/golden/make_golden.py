@@ -381,11 +381,45 @@ def fullsize_probes():
     save("full_probes", **probes)
 
 
+def preprocess_fixture():
+    """get_frames' transform chain (eval/utils/builder_utils.py:118-128) executed with the reference's own functions
+    (src/gadgets/functional_video.py; the Compose wrappers of transforms.py need torchvision, which is absent, and add
+    nothing but the calls below) on small synthetic decoded clips, plus its 32-frame pick for several lengths."""
+    import src.gadgets.functional_video as FV
+    from src.data.components.util import sample_frames
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    for name, (T, H0, W0) in (("a", (5, 37, 53)), ("b", (3, 240, 320)), ("c", (2, 224, 224))):
+        raw = torch.randint(0, 256, (T, H0, W0, 3), generator=g, dtype=torch.uint8)
+        clip = raw.permute(3, 0, 1, 2).float()                       # read_videos_av, builder_utils.py:86
+        clip = FV.resize(clip, (224, 224), "bilinear")               # ResizeVideo(224)
+        clip = clip.to(torch.uint8)                                  # ToUint8
+        clip = clip.permute(1, 2, 3, 0)                              # ToTHWC
+        clip = FV.to_tensor(clip)                                    # ToTensorVideo
+        clip = FV.normalize(clip, (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711))
+        flow_frames = clip.permute(1, 0, 2, 3)                       # builder_utils.py:127
+        # the full tensor is large; keep the raw input, a strided probe of the output and its checksums
+        out[f"raw_{name}"] = raw.numpy()
+        out[f"probe_{name}"] = flow_frames[:, :, ::7, ::5].contiguous().numpy()
+        out[f"sum_{name}"] = flow_frames.double().sum(dim=(2, 3)).numpy()
+    picks = []
+    for vlen in (1, 3, 5, 17, 31, 32, 33, 40, 96, 100, 256):
+        indices = list(range(vlen))                                  # builder_utils.py:131-139
+        n = vlen
+        while n < 32:
+            indices = [f for ind in indices for f in (ind, ind)]
+            n = len(indices)
+        ids = sample_frames(32, n, "uniform", 1.)
+        picks.append([vlen] + [indices[i] for i in ids])
+    out["picks"] = np.array(picks, dtype=np.int64)
+    save("preprocess", **out)
+
+
 def main():
     install_shim()
     torch.manual_seed(0)
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["e2e", "int", "full"]
+    which = sys.argv[1:] or ["e2e", "int", "full", "pre"]
     if "e2e" in which:
         ref_ib, cfg_ib, sd_ib = e2e_fixture("instructblip")
         ref_b2, cfg_b2, sd_b2 = e2e_fixture("blip2")
@@ -394,6 +428,8 @@ def main():
         integer_tables()
     if "full" in which:
         fullsize_probes()
+    if "pre" in which:
+        preprocess_fixture()
 
 
 if __name__ == "__main__":

@@ -139,3 +139,32 @@ def test_vit_g_full_size_vs_reference_probes(dev, full_probes, dtype):
     assert list(out32.shape) == p["vit_shape"].tolist()
     got = out32.flatten()[p["vit_probe_idx"].to(dev)]
     check("vit-g probes", got, p["vit_probe_val"], dtype)
+
+
+# ------------------------------------------------------------------------------------------ f3 preprocessing
+@pytest.mark.gpu
+def test_preprocess_frames_vs_reference_and_oracle(dev):
+    """get_frames on the device: HIP resize / truncate / normalise vs the vectors recorded from the reference's
+    functional_video calls (probe elements) and vs the oracle on a full-HD-like clip.  The chain ends in a
+    truncation to uint8, so a 1-ulp difference of the fp32 bilinear value can move a pixel by one level
+    (1/255/std = 0.0146..0.0150 after normalisation) when it sits on an integer: at most 1e-4 of the
+    elements may differ, each by exactly one level; everything else must be bit-identical."""
+    from oracle import vtgb_oracle as O
+    from videotgb_amd import ops, video
+    g = load_golden("preprocess")
+    level = 1.0 / 255.0 / min(O.CLIP_STD) * 1.001
+    for name in "abc":
+        raw = g[f"raw_{name}"]
+        got = ops.preprocess_frames(raw.to(dev)).cpu()
+        ref = g[f"probe_{name}"]
+        d = (got[:, :, ::7, ::5] - ref).abs()
+        assert d.max() <= level and (d > 0).float().mean() <= 1e-4, (name, d.max(), (d > 0).float().mean())
+        assert torch.allclose(got.double().sum(dim=(2, 3)), g[f"sum_{name}"], rtol=0, atol=1.0)
+    raw = torch.randint(0, 256, (40, 180, 320, 3), generator=torch.Generator().manual_seed(3), dtype=torch.uint8)
+    frames, flow_frames = video.get_frames(raw.to(dev))
+    rf, rff = O.get_frames(raw)
+    for a, b in ((frames.cpu(), rf), (flow_frames.cpu(), rff)):
+        d = (a - b).abs()
+        assert a.shape == b.shape and d.max() <= level and (d > 0).float().mean() <= 1e-4
+    with pytest.raises(TypeError):
+        ops.preprocess_frames(raw.float().to(dev))

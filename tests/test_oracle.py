@@ -180,3 +180,25 @@ def test_full_size_oracle_vs_reference_probes():
                                     torch.ones_like(p["tgb_text_ids"]), mode, 12, 6)
         close(logits, p[f"tgb_logits_{mode}"], rtol=1e-4, atol=1e-4)
         assert abs(seq.abs().mean().item() - float(p[f"tgb_seq_absmean_{mode}"])) < 1e-4
+
+
+def test_preprocess_and_frame_pick_match_the_reference_functions():
+    """f3 / a1: the oracle's get_frames chain vs outputs of the reference's own functional_video calls, and both
+    the oracle's and the product's 32-frame pick vs builder_utils.py:131-139 executed verbatim."""
+    from videotgb_amd import video
+    g = load_golden("preprocess")
+    for name in "abc":
+        raw = g[f"raw_{name}"]
+        ff = O.preprocess_frames(raw, 224)
+        assert ff.shape == (raw.shape[0], 3, 224, 224)
+        assert torch.equal(ff[:, :, ::7, ::5], g[f"probe_{name}"])          # same ATen kernels: bit-exact
+        assert torch.allclose(ff.double().sum(dim=(2, 3)), g[f"sum_{name}"], rtol=0, atol=1e-6)
+    for row in g["picks"].tolist():
+        vlen, want = row[0], row[1:]
+        assert O.candidate_frame_ids(vlen) == want
+        assert video.candidate_frame_ids(vlen) == want
+    t = load_golden("integer_tables")
+    for row in t["sample_frames"].tolist():
+        vlen, n, fix = row[:3]
+        want = [x for x in row[3:] if x >= 0]
+        assert video.sample_frames(n, vlen, "uniform", float(fix)) == want

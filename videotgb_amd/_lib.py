@@ -28,6 +28,7 @@ EXPORTS = [
     "vtgb_layernorm", "vtgb_prof_enable", "vtgb_prof_reset", "vtgb_prof_summary",
     "vtgb_llm_rmsnorm", "vtgb_llm_rope_cache", "vtgb_llm_decode_attention", "vtgb_llm_silu_mul",
     "vtgb_raft_update_workspace_bytes", "vtgb_raft_update", "vtgb_raft_encoder_workspace_bytes", "vtgb_raft_encoder",
+    "vtgb_preprocess_frames",
 ]
 
 i32, i64, f32, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -49,6 +50,11 @@ class SpanToFramesArgs(C.Structure):
 class GatherFramesArgs(C.Structure):
     _fields_ = [("pixel_values", vp), ("frame_idx", vp), ("out", vp), ("B", i32), ("N", i32), ("nframe", i32),
                 ("frame_elems", i64)]
+
+
+class PreprocessArgs(C.Structure):
+    _fields_ = [("raw", vp), ("frame_idx", vp), ("out", vp), ("T", i32), ("H0", i32), ("W0", i32), ("n_out", i32), ("size", i32),
+                ("mean", f32 * 3), ("std", f32 * 3)]
 
 
 class VitArgs(C.Structure):

@@ -127,3 +127,48 @@ extern "C" int vtgb_gather_frames(const vtgb_gather_frames_args* a, vtgb_stream_
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// f3: frame preprocessing (builder_utils.py:117-128).  HBM-bound: 3 B read per source pixel (gathered four
+// at a time), 12 B written per output pixel.  The arithmetic follows ATen's CPU bilinear kernel (source
+// index = scale * (dst + 0.5) - 0.5 clamped at 0, lambda clamped to [0, 1], rows interpolated first), the
+// result is truncated to an integer exactly as `.to(torch.uint8)` does, then /255 and normalised.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_kernel(const vtgb_preprocess_args a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = a.size;
+    if (i >= (int64_t)a.n_out * S * S) return;
+    const int x = (int)(i % S), y = (int)((i / S) % S);
+    const int64_t f = i / ((int64_t)S * S);
+    const int64_t t = a.frame_idx ? a.frame_idx[f] : f;
+    const float sy = (float)a.H0 / (float)S, sx = (float)a.W0 / (float)S;
+    const float ry = fmaxf(sy * ((float)y + 0.5f) - 0.5f, 0.f), rx = fmaxf(sx * ((float)x + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)floorf(ry), a.H0 - 1), x0 = min((int)floorf(rx), a.W0 - 1);
+    const int y1 = min(y0 + 1, a.H0 - 1), x1 = min(x0 + 1, a.W0 - 1);
+    const float ly = fminf(fmaxf(ry - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(rx - (float)x0, 0.f), 1.f);
+    const float wy0 = 1.f - ly, wx0 = 1.f - lx;
+    const uint8_t* base = a.raw + t * (int64_t)a.H0 * a.W0 * 3;
+    const uint8_t* p00 = base + ((int64_t)y0 * a.W0 + x0) * 3;
+    const uint8_t* p01 = base + ((int64_t)y0 * a.W0 + x1) * 3;
+    const uint8_t* p10 = base + ((int64_t)y1 * a.W0 + x0) * 3;
+    const uint8_t* p11 = base + ((int64_t)y1 * a.W0 + x1) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float r0 = (float)p00[c] * wx0 + (float)p01[c] * lx;
+        const float r1 = (float)p10[c] * wx0 + (float)p11[c] * lx;
+        const float v = r0 * wy0 + r1 * ly;
+        const float q = (float)(int)v;                                  // .to(torch.uint8): truncation (0 <= v <= 255)
+        a.out[((f * 3 + c) * S + y) * S + x] = (q / 255.0f - a.mean[c]) / a.std[c];
+    }
+}
+
+extern "C" int vtgb_preprocess_frames(const vtgb_preprocess_args* a, vtgb_stream_t stream) {
+    VTGB_REQUIRE(a && a->raw && a->out, VTGB_EINVAL, "preprocess_frames: NULL argument");
+    VTGB_REQUIRE(a->T > 0 && a->H0 > 0 && a->W0 > 0 && a->n_out > 0 && a->size > 0, VTGB_EINVAL, "preprocess_frames: T=%d H0=%d W0=%d n_out=%d size=%d",
+                 a->T, a->H0, a->W0, a->n_out, a->size);
+    VTGB_REQUIRE(a->std[0] != 0.f && a->std[1] != 0.f && a->std[2] != 0.f, VTGB_EINVAL, "preprocess_frames: zero std");
+    const int64_t n = (int64_t)a->n_out * a->size * a->size;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *a);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}

@@ -119,6 +119,27 @@ def gather_frames(pixel_values: Tensor, frame_idx: Tensor) -> Tensor:
     return out
 
 
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def preprocess_frames(raw: Tensor, frame_idx: Optional[Tensor] = None, size: int = 224, mean=CLIP_MEAN, std=CLIP_STD) -> Tensor:
+    """raw [T, H0, W0, 3] uint8 decoded frames -> [n_out, 3, size, size] fp32: bilinear resize, truncation to uint8, /255,
+    (x - mean) / std (get_frames, eval/utils/builder_utils.py:117-128); frame_idx [n_out] int64 picks source frames."""
+    _need_cuda(raw)
+    if raw.dtype != torch.uint8 or raw.dim() != 4 or raw.shape[-1] != 3:
+        raise TypeError("clip tensor should have data type uint8 and shape [T, H, W, 3]. Got %s %s" % (raw.dtype, tuple(raw.shape)))
+    raw = raw.contiguous()
+    T, H0, W0, _ = raw.shape
+    fi = None if frame_idx is None else frame_idx.to(device=raw.device, dtype=torch.int64).contiguous()
+    n_out = T if fi is None else fi.numel()
+    out = torch.empty(n_out, 3, size, size, dtype=torch.float32, device=raw.device)
+    a = L.PreprocessArgs(raw.data_ptr(), None if fi is None else fi.data_ptr(), out.data_ptr(), T, H0, W0, n_out, size,
+                         (C.c_float * 3)(*mean), (C.c_float * 3)(*std))
+    L.check(L.lib().vtgb_preprocess_frames(C.byref(a), _stream()))
+    return out
+
+
 # ----------------------------------------------------------------------------- building blocks
 def gemm(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, epilogue: int = L.EPI_STORE, resid: Optional[Tensor] = None,
          K: Optional[int] = None) -> Tensor:
