@@ -107,6 +107,41 @@ typedef struct {
 } vtgb_preprocess_args;
 int vtgb_preprocess_frames(const vtgb_preprocess_args* a, vtgb_stream_t stream);
 
+/* ---- a14: loss side of the LoRA training step (config C5) --------------------------------
+ * vtgb_concat_text_io replaces LSTPModule.concat_text_input_output and the label construction around it
+ * (src/models/LSTP_Vicuna_IVT_module.py:692-718 and :284-291): per row n = sum(input_atts),
+ * llm = [input[:n] | output[1:] | input[n:]] (ids and attention mask), labels = -100 for the prefix_len visual
+ * positions, for the first n text positions and for pad tokens, else the token id. */
+typedef struct {
+    const int64_t* input_ids;    /* [B, Li]  question tokens (right-padded)                  */
+    const int64_t* input_atts;   /* [B, Li]                                                  */
+    const int64_t* output_ids;   /* [B, Lo]  answer tokens (first one, BOS, is dropped)      */
+    const int64_t* output_atts;  /* [B, Lo]                                                  */
+    int64_t* llm_ids;            /* [B, Li + Lo - 1]                                         */
+    int64_t* llm_atts;           /* [B, Li + Lo - 1]                                         */
+    int64_t* input_len;          /* [B] or NULL: the n of each row (input_part_targets_len)  */
+    int64_t* labels;             /* [B, prefix_len + Li + Lo - 1] or NULL                    */
+    int64_t pad_id;
+    int32_t B, Li, Lo, prefix_len;
+} vtgb_concat_text_io_args;
+int vtgb_concat_text_io(const vtgb_concat_text_io_args* a, vtgb_stream_t stream);
+
+/* Shifted cross-entropy (LSTP_Vicuna_IVT_module.py:297-299, :325-326: logits[..., :-1, :] against labels[..., 1:],
+ * CrossEntropyLoss(reduction="mean"), ignore_index -100) without the shifted copies: forward reads the logits once
+ * (rows whose target is ignored are skipped), backward writes d loss / d logits for all S positions. */
+typedef struct {
+    int32_t dtype, B, S, V;      /* logits dtype VTGB_F32 / VTGB_BF16                        */
+    const void* logits;          /* [B, S, V]                                                */
+    const int64_t* labels;       /* [B, S]                                                   */
+    float* lse;                  /* [B, S-1] log-sum-exp per scored row (kept for backward)  */
+    float* row_loss;             /* [B, S-1] scratch                                         */
+    float* loss;                 /* [2]: mean loss, number of scored rows                    */
+    const float* grad_out;       /* [1] upstream gradient (backward)                         */
+    void* dlogits;               /* [B, S, V] same dtype as logits (backward)                */
+} vtgb_shifted_ce_args;
+int vtgb_shifted_ce_forward(const vtgb_shifted_ce_args* a, vtgb_stream_t stream);
+int vtgb_shifted_ce_backward(const vtgb_shifted_ce_args* a, vtgb_stream_t stream);
+
 /* ---- K1-K6: EVA-ViT-g vision tower ----------------------------------------------------
  * Replaces InstructBlipVisionModel.forward, src/models/components/xinstructblip.py:515-558
  * (embeddings :113-122, 39 x encoder layer :233-269 with attention :162-204 and MLP

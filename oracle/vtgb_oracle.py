@@ -599,3 +599,50 @@ def lstp_prefix(sd: SD, *, arch: str, frames: Tensor, nframe: int, sampler_ids: 
     prefix = pool_project(sd, "model.language_projection", qo, [nframe] * b, pool)
     return dict(of=of, tgb_seq=seq, tgb_logits=logits, sel=sel, cand_index=idx, sampled=sampled,
                 image_embeds=img, query_out=qo, prefix=prefix)
+
+
+# ----------------------------------------------------------------------------
+# a14: loss side of the LoRA training step (config C5)
+# ----------------------------------------------------------------------------
+def concat_text_input_output(input_ids: Tensor, input_atts: Tensor, output_ids: Tensor, output_atts: Tensor):
+    """src/models/LSTP_Vicuna_IVT_module.py:692-718: per row, the answer (without its first token) is spliced in
+    right after the question's real tokens, the question's padding moves to the end."""
+    ids, atts, lens = [], [], []
+    for i in range(input_ids.size(0)):
+        n = int(input_atts[i].sum())
+        lens.append(n)
+        ids.append(torch.cat([input_ids[i][:n], output_ids[i][1:], input_ids[i][n:]]))
+        atts.append(torch.cat([input_atts[i][:n], output_atts[i][1:], input_atts[i][n:]]))
+    return {"input_ids": torch.stack(ids), "attention_mask": torch.stack(atts)}, lens
+
+
+def lm_labels(llm_ids: Tensor, input_len: Sequence[int], pad_id: int, prefix_len: int) -> Tensor:
+    """LSTP_Vicuna_IVT_module.py:284-291: pad -> -100, the question part -> -100, -100 for the visual prefix."""
+    labels = llm_ids.masked_fill(llm_ids == pad_id, -100)
+    for i, l in enumerate(input_len):
+        labels[i][:l] = -100
+    empty = torch.full((llm_ids.shape[0], prefix_len), -100, dtype=torch.long)
+    return torch.cat([empty, labels], dim=1)
+
+
+def shifted_cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
+    """LSTP_Vicuna_IVT_module.py:297-299, :325-326: position t scores token t+1; mean over targets != -100."""
+    V = logits.shape[-1]
+    shift_logits = logits[..., :-1, :].contiguous()
+    shift_labels = labels[..., 1:].contiguous()
+    return F.cross_entropy(shift_logits.view(-1, V).float(), shift_labels.view(-1), reduction="mean")
+
+
+def lora_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], lora_A: Tensor, lora_B: Tensor, alpha: float, r: int) -> Tensor:
+    """peft 0.4.0 (pinned, requirement.txt:233; not vendored) tuners/lora.py Linear.forward in eval mode (dropout
+    off): F.linear(x, W, b) + lora_B(lora_A(x)) * (alpha / r)."""
+    return F.linear(x, weight, bias) + F.linear(F.linear(x, lora_A), lora_B) * (alpha / r)
+
+
+def cosine_schedule_lambda(step: int, num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.5) -> float:
+    """transformers.get_cosine_schedule_with_warmup's lr lambda (pinned 4.36.0), as configured by
+    LSTP_Vicuna_IVT_module.py:661-665 (max_steps = trainer.max_steps, which is -1 under max_epochs)."""
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))

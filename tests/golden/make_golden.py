@@ -12,6 +12,7 @@ unused heavy imports, build the reference modules at a tiny configuration, load 
 state_dict (videotgb_amd.synth) with strict key checking (which also pins the state_dict
 layout of Appendix A), call .eval(), inject recorded Gumbel noise, and record.
 """
+import importlib.machinery
 import inspect
 import os
 import sys
@@ -57,10 +58,11 @@ def install_shim():
     for name in ("sentence_transformers", "peft", "av", "cv2", "decord", "ffmpeg"):
         if name not in sys.modules:
             sys.modules[name] = types.ModuleType(name)
+            sys.modules[name].__spec__ = importlib.machinery.ModuleSpec(name, None)   # transformers probes find_spec()
     st = sys.modules["sentence_transformers"]
     st.SentenceTransformer = object
     st.util = object
-    for n in ("get_peft_model", "LoraConfig", "TaskType"):
+    for n in ("get_peft_model", "LoraConfig", "TaskType", "PeftModel", "PeftMixedModel"):
         setattr(sys.modules["peft"], n, object)
     dec = sys.modules["decord"]
     dec.cpu = lambda *a, **k: None
@@ -415,11 +417,76 @@ def preprocess_fixture():
     save("preprocess", **out)
 
 
+def train_fixture():
+    """a14: concat_text_input_output (called as the reference's own unbound method), the label-masking lines and the
+    shifted cross-entropy lines of LSTPModule.forward (src/models/LSTP_Vicuna_IVT_module.py:284-299, :325-326)
+    executed verbatim on synthetic tokens / logits.  The LightningModule's imports that are absent here (lightning,
+    torchmetrics) are stubbed with empty classes: only plain methods of the class are used."""
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __getattr__(self, n): return _Any()
+    for name, attrs in (("lightning", ["LightningModule"]), ("torchmetrics", ["MaxMetric", "MeanMetric"]),
+                        ("torchmetrics.classification", []), ("torchmetrics.classification.accuracy", ["Accuracy"]),
+                        ("torchmetrics.text", []), ("torchmetrics.text.bleu", ["BLEUScore"]), ("torchmetrics.text.bert", ["BERTScore"]),
+                        ("torchmetrics.text.rouge", ["ROUGEScore"]), ("torchmetrics.text.perplexity", ["Perplexity"])):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for a_ in attrs:
+                setattr(m, a_, type(a_, (), {}))
+            m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+            sys.modules[name] = m
+    import src.models.LSTP_Vicuna_IVT_module as tm
+    cls = tm.LSTPModule
+    lines = textwrap.dedent(inspect.getsource(cls.forward)).split("\n")
+    def block(first, last):
+        lo = next(i for i, l in enumerate(lines) if l.strip().startswith(first))
+        hi = next(i for i, l in enumerate(lines) if i >= lo and l.strip().startswith(last))
+        return textwrap.dedent("\n".join(lines[lo:hi + 1]))
+    lab_src = block('labels = llm_tokens["input_ids"].masked_fill(', "labels = torch.cat([empty_labels, labels], dim=1)")
+    lab_src = lab_src.replace("self.processor.tokenizer.pad_token_id", "pad_id")
+    ce_src = block("shift_logits = logits[..., :-1, :].contiguous()", "shift_labels = labels[..., 1:].contiguous()") + "\n" + \
+        block('loss_fct = CrossEntropyLoss(reduction="mean")', "loss = loss_fct(")
+    ce_src = ce_src.replace("self.model.config.text_config.vocab_size", "V")
+    lab_code, ce_code = compile(lab_src, "<reference labels>", "exec"), compile(ce_src, "<reference shifted CE>", "exec")
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    pad_id = 0
+    for case, (B, Li, Lo, prefix, V) in enumerate(((4, 12, 7, 32, 97), (3, 20, 20, 8, 211), (1, 5, 3, 0, 50))):
+        qlen = torch.randint(1, Li + 1, (B,), generator=g)
+        alen = torch.randint(2, Lo + 1, (B,), generator=g)
+        qlen[0], alen[0] = Li, Lo                                         # one row without padding
+        q_ids = torch.randint(3, V, (B, Li), generator=g)
+        a_ids = torch.randint(3, V, (B, Lo), generator=g)
+        a_ids[:, 0] = 1                                                    # BOS, dropped by output_ids[i][1:]
+        q_att = (torch.arange(Li)[None] < qlen[:, None]).long()
+        a_att = (torch.arange(Lo)[None] < alen[:, None]).long()
+        q_ids = q_ids * q_att + pad_id * (1 - q_att)
+        a_ids = a_ids * a_att + pad_id * (1 - a_att)
+        llm_tokens, input_part_targets_len = cls.concat_text_input_output(None, q_ids, q_att, a_ids, a_att)
+        env = dict(torch=torch, llm_tokens=llm_tokens, input_part_targets_len=input_part_targets_len, pad_id=pad_id,
+                   language_model_attention_mask=torch.ones(B, prefix, dtype=torch.long))
+        exec(lab_code, env)
+        labels = env["labels"]
+        S = labels.shape[1]
+        logits = torch.randn(B, S, V, generator=g) * 3.0
+        logits.requires_grad_(True)
+        env2 = dict(torch=torch, CrossEntropyLoss=torch.nn.CrossEntropyLoss, logits=logits, labels=labels, V=V)
+        exec(ce_code, env2)
+        loss = env2["loss"]
+        loss.backward()
+        out.update({f"q_ids_{case}": q_ids, f"q_att_{case}": q_att, f"a_ids_{case}": a_ids, f"a_att_{case}": a_att,
+                    f"llm_ids_{case}": llm_tokens["input_ids"], f"llm_att_{case}": llm_tokens["attention_mask"],
+                    f"input_len_{case}": torch.stack([x.reshape(()) for x in input_part_targets_len]), f"labels_{case}": labels,
+                    f"logits_{case}": logits.detach(), f"loss_{case}": loss.detach().reshape(1), f"dlogits_{case}": logits.grad,
+                    f"meta_{case}": torch.tensor([B, Li, Lo, prefix, V, pad_id])})
+    save("train_loss", **out)
+
+
 def main():
     install_shim()
     torch.manual_seed(0)
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["e2e", "int", "full", "pre"]
+    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train"]
     if "e2e" in which:
         ref_ib, cfg_ib, sd_ib = e2e_fixture("instructblip")
         ref_b2, cfg_b2, sd_b2 = e2e_fixture("blip2")
@@ -430,6 +497,8 @@ def main():
         fullsize_probes()
     if "pre" in which:
         preprocess_fixture()
+    if "train" in which:
+        train_fixture()
 
 
 if __name__ == "__main__":

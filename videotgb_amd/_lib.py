@@ -28,7 +28,7 @@ EXPORTS = [
     "vtgb_layernorm", "vtgb_prof_enable", "vtgb_prof_reset", "vtgb_prof_summary",
     "vtgb_llm_rmsnorm", "vtgb_llm_rope_cache", "vtgb_llm_decode_attention", "vtgb_llm_silu_mul",
     "vtgb_raft_update_workspace_bytes", "vtgb_raft_update", "vtgb_raft_encoder_workspace_bytes", "vtgb_raft_encoder",
-    "vtgb_preprocess_frames",
+    "vtgb_preprocess_frames", "vtgb_concat_text_io", "vtgb_shifted_ce_forward", "vtgb_shifted_ce_backward",
 ]
 
 i32, i64, f32, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -55,6 +55,16 @@ class GatherFramesArgs(C.Structure):
 class PreprocessArgs(C.Structure):
     _fields_ = [("raw", vp), ("frame_idx", vp), ("out", vp), ("T", i32), ("H0", i32), ("W0", i32), ("n_out", i32), ("size", i32),
                 ("mean", f32 * 3), ("std", f32 * 3)]
+
+
+class ConcatTextIoArgs(C.Structure):
+    _fields_ = [("input_ids", vp), ("input_atts", vp), ("output_ids", vp), ("output_atts", vp), ("llm_ids", vp), ("llm_atts", vp),
+                ("input_len", vp), ("labels", vp), ("pad_id", i64), ("B", i32), ("Li", i32), ("Lo", i32), ("prefix_len", i32)]
+
+
+class ShiftedCeArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("S", i32), ("V", i32), ("logits", vp), ("labels", vp), ("lse", vp), ("row_loss", vp),
+                ("loss", vp), ("grad_out", vp), ("dlogits", vp)]
 
 
 class VitArgs(C.Structure):

@@ -1,0 +1,206 @@
+"""The LoRA training step of config C5: twins of the loss-side pieces of
+``src/models/LSTP_Vicuna_IVT_module.py`` around the frozen video->prefix path.
+
+* ``concat_text_input_output`` + label masking (:692-718, :284-291)  -> ``vtgb_concat_text_io`` (HIP, integer)
+* shifted cross-entropy (:297-299, :325-326)                        -> ``vtgb_shifted_ce_*`` (HIP, fwd + bwd)
+* LoRA (``peft.get_peft_model(LoraConfig(CAUSAL_LM, r=8, lora_alpha=32, lora_dropout=0.1))``, :183-186; peft 0.4.0 is
+  third-party and not vendored by the reference): ``LoraLinear`` keeps its parameter names
+  (``q_proj.weight``, ``q_proj.lora_A.default.weight``, ``q_proj.lora_B.default.weight``) and arithmetic
+* ``freeze_weights`` (:682-690), AdamW + the cosine schedule as the reference configures it (:634-679)
+* gradient exchange: one flat bucket, one all-reduce per optimizer step (``dist.FlatGradBucket``; RCCL on the GPU box)
+
+The language model itself, autograd through it and AdamW stay PyTorch, as they are third-party in the reference.
+"""
+import ctypes as C
+import math
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib as L
+from .ops import _need_cuda, _stream, dtype_code
+
+
+# ----------------------------------------------------------------------------- tokens and labels
+def concat_text_input_output(input_ids: Tensor, input_atts: Tensor, output_ids: Tensor, output_atts: Tensor,
+                             pad_token_id: Optional[int] = None, prefix_len: int = 0):
+    """LSTPModule.concat_text_input_output (LSTP_Vicuna_IVT_module.py:692-718) on the device, without the per-row host
+    syncs: returns ``(llm_tokens, input_part_targets_len)`` like the reference (the lengths as an int64 tensor), plus
+    ``labels`` [B, prefix_len + L] (:284-291) when ``pad_token_id`` is given."""
+    _need_cuda(input_ids, input_atts, output_ids, output_atts)
+    ii, ia = input_ids.long().contiguous(), input_atts.long().contiguous()
+    oi, oa = output_ids.long().contiguous(), output_atts.long().contiguous()
+    B, Li = ii.shape
+    Lo = oi.shape[1]
+    dev = ii.device
+    ids = torch.empty(B, Li + Lo - 1, dtype=torch.int64, device=dev)
+    atts = torch.empty_like(ids)
+    lens = torch.empty(B, dtype=torch.int64, device=dev)
+    labels = torch.empty(B, prefix_len + Li + Lo - 1, dtype=torch.int64, device=dev) if pad_token_id is not None else None
+    a = L.ConcatTextIoArgs(ii.data_ptr(), ia.data_ptr(), oi.data_ptr(), oa.data_ptr(), ids.data_ptr(), atts.data_ptr(), lens.data_ptr(),
+                           None if labels is None else labels.data_ptr(), 0 if pad_token_id is None else int(pad_token_id), B, Li, Lo, prefix_len)
+    L.check(L.lib().vtgb_concat_text_io(C.byref(a), _stream()))
+    out = ({"input_ids": ids, "attention_mask": atts}, lens)
+    return out + (labels,) if labels is not None else out
+
+
+class _ShiftedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits: Tensor, labels: Tensor):
+        _need_cuda(logits, labels)
+        lg = logits.contiguous()
+        lb = labels.long().contiguous()
+        B, S, V = lg.shape
+        lse = torch.empty(B, S - 1, dtype=torch.float32, device=lg.device)
+        row = torch.empty_like(lse)
+        loss = torch.empty(2, dtype=torch.float32, device=lg.device)
+        a = L.ShiftedCeArgs(dtype_code(lg.dtype), B, S, V, lg.data_ptr(), lb.data_ptr(), lse.data_ptr(), row.data_ptr(), loss.data_ptr(), None, None)
+        L.check(L.lib().vtgb_shifted_ce_forward(C.byref(a), _stream()))
+        ctx.save_for_backward(lg, lb, lse, loss)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        lg, lb, lse, loss = ctx.saved_tensors
+        B, S, V = lg.shape
+        g = grad_out.reshape(1).float().contiguous()
+        d = torch.empty_like(lg)
+        a = L.ShiftedCeArgs(dtype_code(lg.dtype), B, S, V, lg.data_ptr(), lb.data_ptr(), lse.data_ptr(), None, loss.data_ptr(), g.data_ptr(), d.data_ptr())
+        L.check(L.lib().vtgb_shifted_ce_backward(C.byref(a), _stream()))
+        return d, None
+
+
+def shifted_cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
+    """``CrossEntropyLoss(reduction="mean")(logits[..., :-1, :], labels[..., 1:])`` with ignore_index -100
+    (LSTP_Vicuna_IVT_module.py:297-299, :325-326); logits [B, S, V] fp32 or bf16, labels [B, S] -> fp32 scalar."""
+    if logits.dim() != 3 or labels.shape != logits.shape[:2]:
+        raise ValueError(f"Expected logits [B, S, V] and labels [B, S], got {tuple(logits.shape)} and {tuple(labels.shape)}")
+    return _ShiftedCE.apply(logits, labels)
+
+
+# ----------------------------------------------------------------------------- LoRA
+class _Adapter(nn.ModuleDict):
+    """{"default": Linear} -- gives the parameters peft's names (``lora_A.default.weight``)."""
+
+
+class LoraLinear(nn.Linear):
+    """peft 0.4.0 ``tuners.lora.Linear``: the wrapped projection keeps ``weight`` / ``bias`` (frozen); the update is
+    ``lora_B(lora_A(dropout(x))) * (lora_alpha / r)``; A ~ kaiming_uniform(a=sqrt(5)), B = 0."""
+
+    def __init__(self, base: nn.Linear, r: int = 8, lora_alpha: int = 32, lora_dropout: float = 0.1):
+        super().__init__(base.in_features, base.out_features, bias=base.bias is not None, device=base.weight.device, dtype=base.weight.dtype)
+        self.weight, self.bias = base.weight, base.bias
+        self.weight.requires_grad = False
+        if self.bias is not None:
+            self.bias.requires_grad = False
+        self.r, self.lora_alpha, self.scaling = r, lora_alpha, lora_alpha / r
+        self.lora_dropout = nn.ModuleDict({"default": nn.Dropout(p=lora_dropout) if lora_dropout > 0.0 else nn.Identity()})
+        kw = dict(bias=False, device=base.weight.device, dtype=torch.float32)
+        self.lora_A = _Adapter({"default": nn.Linear(base.in_features, r, **kw)})
+        self.lora_B = _Adapter({"default": nn.Linear(r, base.out_features, **kw)})
+        nn.init.kaiming_uniform_(self.lora_A["default"].weight, a=math.sqrt(5))
+        nn.init.zeros_(self.lora_B["default"].weight)
+
+    def forward(self, x: Tensor) -> Tensor:
+        result = nn.functional.linear(x, self.weight, self.bias)
+        a = self.lora_A["default"]
+        xd = self.lora_dropout["default"](x.to(a.weight.dtype))
+        return result + (self.lora_B["default"](a(xd)) * self.scaling).to(result.dtype)
+
+
+def apply_lora(language_model: nn.Module, r: int = 8, lora_alpha: int = 32, lora_dropout: float = 0.1,
+               target_modules: Sequence[str] = ("q_proj", "v_proj")) -> List[nn.Parameter]:
+    """``get_peft_model(language_model, LoraConfig(task_type=CAUSAL_LM, r=8, lora_alpha=32, lora_dropout=0.1))``
+    (LSTP_Vicuna_IVT_module.py:183-186): peft's default targets for Llama are q_proj and v_proj; every other
+    parameter of the language model is frozen.  Returns the trainable (adapter) parameters
+    (Vicuna-7B: 32 layers x 2 x (4096*8 + 8*4096) = 4,194,304)."""
+    for p in language_model.parameters():
+        p.requires_grad = False
+    for parent in list(language_model.modules()):
+        for name, child in list(parent.named_children()):
+            if name in target_modules and isinstance(child, nn.Linear) and not isinstance(child, LoraLinear):
+                setattr(parent, name, LoraLinear(child, r, lora_alpha, lora_dropout))
+    return [p for n, p in language_model.named_parameters() if "lora_" in n]
+
+
+def freeze_weights(module: nn.Module) -> None:
+    """LSTPModule.freeze_weights (LSTP_Vicuna_IVT_module.py:682-690): RAFT, the vision tower and the TGB are frozen."""
+    for name in ("of_extractor", "temporal_encoder"):
+        sub = getattr(module, name, None)
+        if sub is not None:
+            for p in sub.parameters():
+                p.requires_grad = False
+    vm = getattr(getattr(module, "model", None), "vision_model", None)
+    if vm is not None:
+        for p in vm.parameters():
+            p.requires_grad = False
+
+
+# ----------------------------------------------------------------------------- optimizer
+def cosine_schedule_lambda(num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.5):
+    """The lr lambda of transformers.get_cosine_schedule_with_warmup (4.36.0)."""
+    def f(step: int) -> float:
+        if step < num_warmup_steps:
+            return float(step) / float(max(1, num_warmup_steps))
+        progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
+    return f
+
+
+def configure_optimizers(params: Iterable[nn.Parameter], lr: float = 1e-4, weight_decay: float = 0.0, max_steps: int = -1,
+                         warmup_ratio: float = 0.1, scheduler: Optional[str] = "cosine") -> Dict[str, object]:
+    """LSTPModule.configure_optimizers (:634-679): AdamW over the trainable set; "cosine" = transformers' warmup-cosine
+    with ``warmup = int(max_steps * ratio)`` where ``max_steps = trainer.max_steps`` (-1 when the run is bounded by
+    epochs, so warmup = 0 as in the reference); stepped once per EPOCH (``"interval": "epoch"``)."""
+    opt = torch.optim.AdamW([p for p in params if p.requires_grad], lr=lr, weight_decay=weight_decay)
+    if scheduler is None:
+        return {"optimizer": opt}
+    if scheduler != "cosine":
+        raise NotImplementedError("UNKONWN SCHEDULER")
+    warmup = int(max_steps * warmup_ratio)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, cosine_schedule_lambda(warmup, max_steps))
+    return {"optimizer": opt, "lr_scheduler": {"scheduler": sch, "monitor": "val/score", "interval": "epoch", "frequency": 1}}
+
+
+# ----------------------------------------------------------------------------- the step
+class LoraTrainStep:
+    """One C5 micro-batch: frozen prefix path (HIP, no grad) -> [prefix | question+answer embeddings] -> language model
+    with LoRA -> shifted CE (HIP) -> backward; every ``accumulate_grad_batches`` micro-batches the adapter gradients
+    are summed over the ranks in one flat bucket and AdamW steps
+    (configs/experiment/LSTP_instructblipvicuna7b_ivtinstruct.yaml:34 accumulate_grad_batches=4)."""
+
+    def __init__(self, lstp, pad_token_id: int, lr: float = 1e-4, weight_decay: float = 0.0, accumulate_grad_batches: int = 4):
+        from .dist import FlatGradBucket
+        self.m = lstp
+        self.lm = lstp.model.language_model
+        self.pad_token_id = pad_token_id
+        self.params = apply_lora(self.lm)
+        freeze_weights(lstp)
+        cfg = configure_optimizers(self.params, lr=lr, weight_decay=weight_decay)
+        self.optimizer, self.scheduler = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+        self.bucket = FlatGradBucket(self.params)
+        self.accumulate = accumulate_grad_batches
+        self.micro = 0
+
+    def loss(self, language_model_inputs: Tensor, question: Tensor, question_mask: Tensor, answer: Tensor, answer_mask: Tensor) -> Tensor:
+        """language_model_inputs [B, P, H] (the projected Q-Former prefix, LSTP_Vicuna_IVT_module.py:255-260) + tokens -> loss."""
+        B, P, _ = language_model_inputs.shape
+        llm_tokens, _, labels = concat_text_input_output(question, question_mask, answer, answer_mask, self.pad_token_id, P)
+        emb = self.lm.get_input_embeddings()(llm_tokens["input_ids"])
+        inputs_embeds = torch.cat([language_model_inputs.to(emb.dtype), emb], dim=1)
+        attention_mask = torch.cat([torch.ones(B, P, dtype=torch.long, device=emb.device), llm_tokens["attention_mask"]], dim=1)
+        logits = self.lm(inputs_embeds=inputs_embeds, attention_mask=attention_mask)[0]
+        return shifted_cross_entropy(logits, labels)
+
+    def step(self, language_model_inputs: Tensor, question: Tensor, question_mask: Tensor, answer: Tensor, answer_mask: Tensor) -> Tuple[Tensor, bool]:
+        loss = self.loss(language_model_inputs.detach(), question, question_mask, answer, answer_mask)
+        (loss / self.accumulate).backward()
+        self.micro += 1
+        stepped = False
+        if self.micro % self.accumulate == 0:
+            self.bucket.all_reduce(average=True)     # DDP semantics: mean over ranks
+            self.optimizer.step()
+            self.optimizer.zero_grad(set_to_none=False)
+            stepped = True
+        return loss.detach(), stepped
