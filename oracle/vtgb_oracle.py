@@ -646,3 +646,55 @@ def cosine_schedule_lambda(step: int, num_warmup_steps: int, num_training_steps:
         return float(step) / float(max(1, num_warmup_steps))
     progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
     return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
+
+
+# ----------------------------------------------------------------------------
+# f4: self-refinement pseudo labels
+# ----------------------------------------------------------------------------
+def rouge_n_list(gold: List[str], pred: List[str], ignore=(",", ".")) -> List[float]:
+    """src/gadgets/my_metrics.py:131-157 (list form, ignore given): per pair hits / counted gold tokens, then divided
+    by len(gold) -- the number of PAIRS (:154-155)."""
+    out = []
+    for g, p in zip(gold, pred):
+        g, p = g.split(), p.split()
+        toks = [t for t in g if t not in ignore]
+        r = (sum(1 for t in toks if t in p) / len(toks)) if toks else 0
+        out.append(r / len(gold) if len(gold) > 0 else r)
+    return out
+
+
+def monotone_span(score: Sequence[float]) -> Tuple[int, int]:
+    """src/models/LSTP_SF_module.py:246-261 restated as the definition it implements: over all windows [s, e] of the
+    scores, maximise (e - s + 1) * min(score[s..e]); the stack pops candidates in increasing right edge, so among
+    equal areas the first one popped wins; if no window has positive area the default (0, n - 1) stays."""
+    n = len(score)
+    bs, best = 0, (0, n - 1)
+    sc = [0] + list(score) + [0]
+    stack: List[int] = []
+    for i in range(len(sc)):
+        while stack and sc[stack[-1]] > sc[i]:
+            tmp = stack.pop()
+            area = (i - stack[-1] - 1) * sc[tmp]
+            if area > bs:
+                bs, best = area, (stack[-1], i - 2)
+        stack.append(i)
+    return best
+
+
+def pseudo_span_targets(scores: Tensor, flow_lengths: Sequence[int]) -> Tuple[List[int], List[int]]:
+    """LSTP_SF_module.py:246-265."""
+    b, n = scores.shape
+    st, en = [], []
+    for i in range(b):
+        s, e = monotone_span(scores[i].tolist())
+        st.append(int(s / (n - 1) * (flow_lengths[i] - 1)))
+        en.append(int(e / (n - 1) * (flow_lengths[i] - 1)))
+    return st, en
+
+
+def mrc_loss(of_logits: Tensor, start_targets: Tensor, end_targets: Tensor) -> Tensor:
+    """LSTP_SF_module.py:285-298."""
+    L_ = of_logits.shape[1]
+    s = F.cross_entropy(of_logits[..., 0], start_targets.clamp(0, L_), ignore_index=L_)
+    e = F.cross_entropy(of_logits[..., 1], end_targets.clamp(0, L_), ignore_index=L_)
+    return (s + e) / 2

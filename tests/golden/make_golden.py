@@ -422,9 +422,12 @@ def train_fixture():
     shifted cross-entropy lines of LSTPModule.forward (src/models/LSTP_Vicuna_IVT_module.py:284-299, :325-326)
     executed verbatim on synthetic tokens / logits.  The LightningModule's imports that are absent here (lightning,
     torchmetrics) are stubbed with empty classes: only plain methods of the class are used."""
-    class _Any:
-        def __init__(self, *a, **k): pass
-        def __getattr__(self, n): return _Any()
+    train_stubs()
+    import src.models.LSTP_Vicuna_IVT_module as tm
+    return _train_fixture_body(tm)
+
+
+def train_stubs():
     for name, attrs in (("lightning", ["LightningModule"]), ("torchmetrics", ["MaxMetric", "MeanMetric"]),
                         ("torchmetrics.classification", []), ("torchmetrics.classification.accuracy", ["Accuracy"]),
                         ("torchmetrics.text", []), ("torchmetrics.text.bleu", ["BLEUScore"]), ("torchmetrics.text.bert", ["BERTScore"]),
@@ -435,7 +438,9 @@ def train_fixture():
                 setattr(m, a_, type(a_, (), {}))
             m.__spec__ = importlib.machinery.ModuleSpec(name, None)
             sys.modules[name] = m
-    import src.models.LSTP_Vicuna_IVT_module as tm
+
+
+def _train_fixture_body(tm):
     cls = tm.LSTPModule
     lines = textwrap.dedent(inspect.getsource(cls.forward)).split("\n")
     def block(first, last):
@@ -482,11 +487,65 @@ def train_fixture():
     save("train_loss", **out)
 
 
+def refine_fixture():
+    """f4: rouge_n as imported from the reference (src/gadgets/my_metrics.py; torchmetrics stubbed), and the
+    monotone-stack / rescale / MRC-loss lines of LSTPSFModule.forward (src/models/LSTP_SF_module.py:239-298) executed
+    verbatim on synthetic strings, scores and logits."""
+    train_stubs()
+    tm_mod = sys.modules["torchmetrics"]
+    if not hasattr(tm_mod, "Metric"):
+        tm_mod.Metric = type("Metric", (), {})
+    from src.gadgets.my_metrics import rouge_n
+    import src.models.LSTP_SF_module as sf
+    lines = textwrap.dedent(inspect.getsource(sf.LSTPSFModule.forward)).split("\n")
+    def block(first, last):
+        lo = next(i for i, l in enumerate(lines) if l.strip().startswith(first))
+        hi = next(i for i, l in enumerate(lines) if i >= lo and l.strip().startswith(last))
+        return textwrap.dedent("\n".join(lines[lo:hi + 1]))
+    span_code = compile(block("scores = torch.tensor(scores, dtype=torch.float)", "end_targets = [int(end_targets[ii]"), "<reference span>", "exec")
+    loss_code = compile(block("start_logits, end_logits = of_logits.split(1, dim=-1)", "mrc_loss = (start_loss + end_loss) / 2"),
+                        "<reference mrc loss>", "exec")
+    rng = np.random.default_rng(11)
+    vocab = ["a", "man", "is", "riding", "horse", "the", "dog", "runs", ",", ".", "yes", "no", "two", "people", "cooking"]
+    out, texts = {}, []
+    B, N = 4, 32
+    gold = [" ".join(rng.choice(vocab, size=int(rng.integers(1, 7)))) for _ in range(B)]
+    pred = [" ".join(rng.choice(vocab, size=int(rng.integers(0, 8)))) for _ in range(B * N)]
+    target = [gold[int(idx // N)] for idx in range(len(pred))]
+    scores = rouge_n(target, pred)
+    flow_lengths = [96, 34, 256, 5]
+    env = dict(torch=torch, scores=list(scores), batch_size=B, num_frames=N, batch={"of_lengths": flow_lengths})
+    exec(span_code, env)
+    out["rouge"] = np.array(scores, dtype=np.float64)
+    out["start_targets"] = np.array(env["start_targets"], dtype=np.int64)
+    out["end_targets"] = np.array(env["end_targets"], dtype=np.int64)
+    out["flow_lengths"] = np.array(flow_lengths, dtype=np.int64)
+    # hand-made score rows: plateaus, ties, all-zero, single peak
+    rows = [[0.0] * 32, [0.5] * 32, [0.0] * 10 + [0.3] * 5 + [0.0] * 17, [0.1] * 8 + [0.9] + [0.1] * 23,
+            list(np.round(rng.random(32), 2)), [0.2, 0.2, 0.8, 0.8, 0.8, 0.1] + [0.0] * 26, list(np.round(rng.random(32), 1))]
+    env = dict(torch=torch, scores=[x for r in rows for x in r], batch_size=len(rows), num_frames=32,
+               batch={"of_lengths": [96, 96, 40, 32, 100, 7, 256]})
+    exec(span_code, env)
+    out["rows"] = np.array(rows, dtype=np.float32)
+    out["rows_lengths"] = np.array([96, 96, 40, 32, 100, 7, 256], dtype=np.int64)
+    out["rows_start"] = np.array(env["start_targets"], dtype=np.int64)
+    out["rows_end"] = np.array(env["end_targets"], dtype=np.int64)
+    g = torch.Generator().manual_seed(4)
+    of_logits = torch.randn(7, 96, 2, generator=g)
+    st = torch.tensor([0, 5, 95, 96, 200, 17, 3]); en = torch.tensor([95, 9, 95, 120, 300, 40, 3])
+    env = dict(torch=torch, CrossEntropyLoss=torch.nn.CrossEntropyLoss, of_logits=of_logits, start_targets=st.clone(), end_targets=en.clone())
+    exec(loss_code, env)
+    out.update(of_logits=of_logits, mrc_start=st, mrc_end=en, mrc_loss=env["mrc_loss"].reshape(1))
+    save("refine", **out)
+    with open(os.path.join(OUT, "refine_text.txt"), "w") as fh:      # the synthetic strings (data, one per line)
+        fh.write("\n".join(gold + pred) + "\n")
+
+
 def main():
     install_shim()
     torch.manual_seed(0)
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train"]
+    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train", "refine"]
     if "e2e" in which:
         ref_ib, cfg_ib, sd_ib = e2e_fixture("instructblip")
         ref_b2, cfg_b2, sd_b2 = e2e_fixture("blip2")
@@ -499,6 +558,8 @@ def main():
         preprocess_fixture()
     if "train" in which:
         train_fixture()
+    if "refine" in which:
+        refine_fixture()
 
 
 if __name__ == "__main__":
