@@ -353,7 +353,8 @@ int vtgb_raft_update(const vtgb_raft_update_args* a, vtgb_stream_t stream);
  *   image, channel = dX*12 + py*6 + px*3 + c (48, zero-padded to 64), ky = 2 tY + py - 1, kx = 2 dX + px - 1,
  *   scaled by 2/255 (raw 0..255 pixels enter the GEMM) [1] conv1.bias - 127.5 * sum(packed weights); per block b (layer1.0, 1.1, 2.0, 2.1, 3.0, 3.1) at
  *   2 + 6 b: conv1.weight bf16 [C, 3,3,Cin_pad] , conv1.bias, conv2.weight [C, 3,3,C_pad], conv2.bias,
- *   downsample.0.weight [C, Cin_pad] or NULL, downsample.0.bias or NULL  (96-channel stages: C_pad = 128, zero-filled);
+ *   downsample.0.weight [C, Cin_pad] or NULL, downsample.0.bias or NULL  (96-channel stages: C_pad = 128, zero-filled; with norm = 1 the
+ *   OUTPUT rows and biases of those stages are padded to C_pad as well: the GEMM stores bf16 activations directly);
  *   [38] conv2.weight bf16 [256, 128] [39] conv2.bias */
 #define VTGB_RAFT_ENC_NW 40
 typedef struct {

@@ -120,6 +120,11 @@ struct GemmDesc {
     // aux[m][n - gate_from] (bf16, ldaux) and stored to out2[m][n - gate_from] (bf16, ldo2) -- SepConvGRU's
     // r * h straight from the z|r convolution.  gate_from % 8 == 0; 0 = off.
     int gate_from;
+    // EPI_STORE (bf16, whole-row stores): out = [relu](act(acc + bias) + resid_bf16[m][n]) -- a ResidualBlock's
+    // tail (x + relu(conv)) -> relu with the skip operand in bf16 (row stride ldrb, 8-aligned)
+    const void* resid_bf16;
+    int64_t ldrb;
+    int post_relu;
 };
 #define VTGB_EPI_GRU 4
 int launch_gemm(const GemmDesc& d, hipStream_t s);

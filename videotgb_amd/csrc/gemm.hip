@@ -573,6 +573,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
 #pragma unroll
                         for (int e = 0; e < 8; e++) o[e] = (bf16_t)((float)a[e] * (float)g[e]);
                         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.out2) + (int64_t)m * p.ldo2 + ng) = o;
+                    } else if (EPI == EPI_STORE && p.resid_bf16) {
+                        const bf16x8 r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.resid_bf16) + (int64_t)m * p.ldrb + n);
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, v);
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            const float t = (float)a[e] + (float)r[e];
+                            o[e] = (bf16_t)(p.post_relu ? fmaxf(t, 0.f) : t);
+                        }
+                        *reinterpret_cast<bf16x8*>(outp + map_row(p.o_map, m) * p.ldo + n) = o;
                     } else {
                         *reinterpret_cast<uint4*>(outp + map_row(p.o_map, m) * p.ldo + n) = v;
                     }
@@ -866,6 +876,9 @@ int launch_conv_gemm(const GemmDesc& d, hipStream_t s) {
         VTGB_REQUIRE(d.epi == EPI_STORE && (d.gate_from % 8) == 0 && (d.N % 8) == 0 && (d.ldo % 8) == 0 && d.aux && d.out2 && (d.ldaux % 8) == 0 &&
                          (d.ldo2 % 8) == 0,
                      VTGB_EINVAL, "conv gemm: gated store needs 8-aligned bf16 rows, aux and out2");
+    if (d.resid_bf16)
+        VTGB_REQUIRE(d.epi == EPI_STORE && d.gate_from == 0 && (d.N % 8) == 0 && (d.ldo % 8) == 0 && (d.ldrb % 8) == 0, VTGB_EINVAL,
+                     "conv gemm: bf16 residual needs 8-aligned bf16 rows");
     if (d.col_stats)
         VTGB_REQUIRE(d.epi == EPI_STORE_F32 && d.stats_rows >= L_BM && (d.N % 4) == 0 && (d.ldo % 4) == 0 && d.act == 0 && d.out_scale == 0.f,
                      VTGB_EINVAL, "conv gemm: column statistics need fp32 whole-row stores and images of >= 256 rows");

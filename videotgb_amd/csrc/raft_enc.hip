@@ -184,8 +184,9 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
         float* sf = stats_for(stats, H2 * W2, 64);
         GemmDesc d = enc_conv((int)M2, 64, H2, W2, 1, 64, 1, H2, W2, act1, w[0], F(w[1]), cf, 64, pad_page, sf);
         d.conv_KH = 4; d.K = 256; d.ldw = 256;
+        if (!inorm) { d.epi = VTGB_EPI_STORE; d.act = 1; d.out = act0; }        // relu(bn1(conv1(x))) straight to bf16
         VTGB_TRY(launch_conv_gemm(d, s));
-        VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, sf != nullptr));
+        if (inorm) VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, sf != nullptr));
     }
     // ---- six residual blocks
     struct Stage { int C, Cpad, stride, Ho, Wo; };
@@ -194,31 +195,56 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     bf16_t* t1 = act1;
     bf16_t* t2 = act2;
     int Cin_pad = 64, Hi = H2, Wi = W2;
+    // cnet (norm == 1, BatchNorm folded): no statistics are needed, so ReLU, the skip connection and the bf16 cast
+    // live in the convolution's epilogue and the fp32 round trip + norm pass disappear (the packed weights carry
+    // C_pad output rows, the padded ones zero, so the padded channels come out as zeros)
+    auto conv_bn = [&](int64_t Mo, const Stage& g, int K, int Cin, int stride, int Hi_, int Wi_, const bf16_t* A, const void* Wt, const float* bias,
+                       int relu, const bf16_t* resid, int post_relu, bf16_t* out) -> int {
+        GemmDesc d = enc_conv((int)Mo, g.Cpad, g.Ho, g.Wo, K, Cin, stride, Hi_, Wi_, A, Wt, bias, nullptr, g.Cpad, zero, nullptr);
+        d.epi = VTGB_EPI_STORE; d.act = relu; d.out = out;
+        d.resid_bf16 = resid; d.ldrb = g.Cpad; d.post_relu = post_relu;
+        return launch_conv_gemm(d, s);
+    };
     for (int b = 0; b < 6; b++) {
         const Stage& g = st[b];
         const void* const* bw = w + 2 + 6 * b;
         const int64_t Mo = (int64_t)n * g.Ho * g.Wo;
         const int HWo = g.Ho * g.Wo;
-        float* sf = stats_for(stats, HWo, g.C);
-        VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), cf, g.Cpad, zero, sf), s));
-        VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t1, 1, 0, stats, sf != nullptr));  // y = relu(norm1(conv1(x)))
-        sf = stats_for(stats, HWo, g.C);
-        VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), cf, g.Cpad, zero, sf), s));
-        const bf16_t* res = x;
-        if (g.stride != 1) {                                                                      // x = norm3(downsample(x))
-            VTGB_REQUIRE(bw[4] && bw[5], VTGB_EINVAL, "raft_encoder: block %d lacks its downsample weights", b);
-            float* sf2 = stats_for(stats2, HWo, g.C);
-            VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 1, Cin_pad, g.stride, Hi, Wi, x, bw[4], F(bw[5]), cf2, g.Cpad, zero, sf2), s));
-            VTGB_TRY(norm(cf2, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t2, 0, 0, stats2, sf2 != nullptr));
-            res = t2;
+        if (g.stride != 1) VTGB_REQUIRE(bw[4] && bw[5], VTGB_EINVAL, "raft_encoder: block %d lacks its downsample weights", b);
+        bf16_t* outb;
+        if (!inorm) {
+            VTGB_TRY(conv_bn(Mo, g, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), 1, nullptr, 0, t1));        // y = relu(bn1(conv1(x)))
+            const bf16_t* res = x;
+            outb = t2;                                                                                          // conv2 reads t1: it cannot be the output
+            if (g.stride != 1) {                                                                                // x = bn3(downsample(x))
+                VTGB_TRY(conv_bn(Mo, g, 1, Cin_pad, g.stride, Hi, Wi, x, bw[4], F(bw[5]), 0, nullptr, 0, t2));
+                res = t2;
+                outb = x;                                                                                       // the block input is dead from here on
+            }
+            VTGB_TRY(conv_bn(Mo, g, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), 1, res, 1, outb));             // relu(x + relu(bn2(conv2(y))))
+        } else {
+            float* sf = stats_for(stats, HWo, g.C);
+            VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), cf, g.Cpad, zero, sf), s));
+            VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t1, 1, 0, stats, sf != nullptr));  // y = relu(norm1(conv1(x)))
+            sf = stats_for(stats, HWo, g.C);
+            VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), cf, g.Cpad, zero, sf), s));
+            const bf16_t* res = x;
+            if (g.stride != 1) {                                                                      // x = norm3(downsample(x))
+                float* sf2 = stats_for(stats2, HWo, g.C);
+                VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 1, Cin_pad, g.stride, Hi, Wi, x, bw[4], F(bw[5]), cf2, g.Cpad, zero, sf2), s));
+                VTGB_TRY(norm(cf2, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t2, 0, 0, stats2, sf2 != nullptr));
+                res = t2;
+            }
+            outb = t1;
+            // out = relu(x + relu(norm2(conv2(y))))   -- t1 is free once conv2 has consumed it (stream order)
+            VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, res, outb, 1, 1, stats, sf != nullptr));
         }
-        bf16_t* outb = t1;
-        // out = relu(x + relu(norm2(conv2(y))))   -- t1 is free once conv2 has consumed it (stream order)
-        VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, res, outb, 1, 1, stats, sf != nullptr));
-        // rotate buffers: the block output becomes the next input
-        bf16_t* old = x;
-        x = outb;
-        t1 = old;
+        // rotate buffers: the block output becomes the next input, the other two are scratch
+        bf16_t* all3[3] = {x, t1, t2};
+        bf16_t* rest[2];
+        int k = 0;
+        for (int i = 0; i < 3; i++) if (all3[i] != outb) rest[k++] = all3[i];
+        x = outb; t1 = rest[0]; t2 = rest[1];
         Cin_pad = g.Cpad; Hi = g.Ho; Wi = g.Wo;
     }
     // ---- head: 1x1, 128 -> 256 (no norm)

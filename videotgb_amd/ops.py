@@ -516,12 +516,18 @@ class RaftEncoderWeights(_WeightTable):
                 b = (b - sd[p + bn + ".running_mean"].float()) * g + sd[p + bn + ".bias"].float()
             return w, b
 
-        def packed(w, cin_pad):
+        def packed(w, cin_pad, cout_pad=None):
             co, ci, kh, kw = w.shape
             w = w.permute(0, 2, 3, 1)
             if cin_pad != ci:
                 w = torch.nn.functional.pad(w, (0, cin_pad - ci))
-            return conv_k_order(w)
+            w = conv_k_order(w)
+            if batch_norm and cout_pad and cout_pad != co:        # cnet stores bf16 straight from the GEMM: padded channels = 0
+                w = torch.nn.functional.pad(w, (0, 0, 0, cout_pad - co))
+            return w
+
+        def pbias(b, cout_pad):
+            return torch.nn.functional.pad(b, (0, cout_pad - b.numel())) if batch_norm and cout_pad != b.numel() else b
 
         # stem as a 4x1 convolution over the space-to-depth image (raft_enc.hip): [co][tY][dX, py, px, c | pad to 64],
         # ky = 2 tY + py - 1, kx = 2 dX + px - 1; raw 0..255 pixels: w' = w * 2/255, b' = b - 127.5 * sum(w')
@@ -546,12 +552,12 @@ class RaftEncoderWeights(_WeightTable):
             for bi in range(2):
                 bp = f"{li}.{bi}."
                 w1, b1 = folded(bp + "conv1", bp + "norm1")
-                self.add(packed(w1, cin_pad), True); self.add(b1)
+                self.add(packed(w1, cin_pad, cpad), True); self.add(pbias(b1, cpad))
                 w2, b2 = folded(bp + "conv2", bp + "norm2")
-                self.add(packed(w2, cpad), True); self.add(b2)
+                self.add(packed(w2, cpad, cpad), True); self.add(pbias(b2, cpad))
                 if (p + bp + "downsample.0.weight") in sd:
                     wd, bd = folded(bp + "downsample.0", bp + "norm3")
-                    self.add(packed(wd, cin_pad), True); self.add(bd)
+                    self.add(packed(wd, cin_pad, cpad), True); self.add(pbias(bd, cpad))
                 else:
                     self.add(None); self.add(None)
                 cin_pad = cpad
