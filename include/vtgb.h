@@ -336,14 +336,27 @@ typedef struct {
     int32_t n_pairs, H8, W8, iters;
     const float* net;           /* [n_pairs, 128, H8, W8] tanh(cnet[:, :128])   (xraft.py:126-127) */
     const float* inp;           /* [n_pairs, 128, H8, W8] relu(cnet[:, 128:])                      */
-    const float* corr[4];       /* pyramid level l: [n_pairs*H8*W8, H8>>l, W8>>l] fp32 (corr.py:19-27) */
+    const void* corr[4];        /* pyramid level l: [n_pairs*H8*W8, H8>>l, W8>>l] (corr.py:19-27), fp32 or fp16 (corr_f16) */
     const void* const* weights; /* host array                                                      */
     float* flow_up;             /* [n_pairs, 2, 8*H8, 8*W8]                                        */
     void* workspace;
     size_t workspace_bytes;
+    int32_t corr_f16;           /* 0: fp32 pyramid; 1: IEEE half (vtgb_raft_corr_pyramid), half the lookup's HBM reads */
 } vtgb_raft_update_args;
 size_t vtgb_raft_update_workspace_bytes(const vtgb_raft_update_args* a);
 int vtgb_raft_update(const vtgb_raft_update_args* a, vtgb_stream_t stream);
+
+/* CorrBlock.__init__ after the all-pairs matmul (raft_utils/corr.py:17-27, :52-60): corr / sqrt(dim), then three
+ * avg_pool2d(2, stride 2), in ONE pass over the fp32 correlation volume; the four levels are written as IEEE half
+ * (values are O(1..100): 11 significant bits against the bf16 features they feed). */
+typedef struct {
+    const float* corr;          /* [n_maps, H8, W8] fp32: <fmap1[p], fmap2[q]> for every pixel p (one map each)   */
+    void* levels[4];            /* level l: [n_maps, H8>>l, W8>>l] fp16                                            */
+    int64_t n_maps;
+    int32_t H8, W8;
+    float scale;                /* 1 / sqrt(dim) = 1/16                                                            */
+} vtgb_raft_corr_pyramid_args;
+int vtgb_raft_corr_pyramid(const vtgb_raft_corr_pyramid_args* a, vtgb_stream_t stream);
 
 /* RAFT BasicEncoder (raft_utils/extractor.py:116-189): stem 7x7/2, six ResidualBlocks, 1x1 head; the input
  * scaling 2*(x/255)-1 of RAFT.forward (xraft.py:105-106) is applied inside.  norm = 0: InstanceNorm2d (fnet);

@@ -100,3 +100,20 @@ def test_raft_all_hip_clip_path_vs_reference(dev, tiny_sd):
     e = rel_rms(flow, g["flow_iters20"])
     print(f"[raft all-HIP] rel_rms={e:.3e}")
     assert e <= 5e-2
+
+
+@pytest.mark.parametrize("h8,w8", [(28, 28), (16, 16), (9, 13)])
+def test_corr_pyramid_vs_torch(dev, h8, w8):
+    """corr / sqrt(dim) + three avg_pool2d (corr.py:17-27, :60) in one pass, stored as half: every level within
+    half-precision rounding (2^-11 relative) of the fp32 PyTorch chain, odd sizes floored like avg_pool2d."""
+    import torch.nn.functional as F
+    from videotgb_amd import ops
+    n = 37
+    corr = torch.randn(n, h8 * w8, generator=torch.Generator().manual_seed(h8)) * 40.0
+    got = ops.raft_corr_pyramid(corr.to(dev), h8, w8)
+    ref = (corr / 16.0).view(n, 1, h8, w8)
+    for l in range(4):
+        assert got[l].shape == ref.shape and got[l].dtype == torch.float16
+        assert (got[l].float().cpu() - ref).abs().max() <= 2.0 ** -11 * ref.abs().max() + 1e-6
+        if l < 3:
+            ref = F.avg_pool2d(ref, 2, stride=2)

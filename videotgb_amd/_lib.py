@@ -28,7 +28,7 @@ EXPORTS = [
     "vtgb_layernorm", "vtgb_prof_enable", "vtgb_prof_reset", "vtgb_prof_summary",
     "vtgb_llm_rmsnorm", "vtgb_llm_rope_cache", "vtgb_llm_decode_attention", "vtgb_llm_silu_mul",
     "vtgb_raft_update_workspace_bytes", "vtgb_raft_update", "vtgb_raft_encoder_workspace_bytes", "vtgb_raft_encoder",
-    "vtgb_preprocess_frames", "vtgb_concat_text_io", "vtgb_shifted_ce_forward", "vtgb_shifted_ce_backward",
+    "vtgb_raft_corr_pyramid", "vtgb_preprocess_frames", "vtgb_concat_text_io", "vtgb_shifted_ce_forward", "vtgb_shifted_ce_backward",
 ]
 
 i32, i64, f32, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -96,7 +96,11 @@ class TgbArgs(C.Structure):
 
 class RaftUpdateArgs(C.Structure):
     _fields_ = [("n_pairs", i32), ("H8", i32), ("W8", i32), ("iters", i32), ("net", vp), ("inp", vp), ("corr", vp * 4),
-                ("weights", C.POINTER(vp)), ("flow_up", vp), ("workspace", vp), ("workspace_bytes", sz)]
+                ("weights", C.POINTER(vp)), ("flow_up", vp), ("workspace", vp), ("workspace_bytes", sz), ("corr_f16", i32)]
+
+
+class RaftCorrPyramidArgs(C.Structure):
+    _fields_ = [("corr", vp), ("levels", vp * 4), ("n_maps", i64), ("H8", i32), ("W8", i32), ("scale", f32)]
 
 
 class RaftEncoderArgs(C.Structure):

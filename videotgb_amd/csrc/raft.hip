@@ -43,50 +43,63 @@ __global__ void raft_init_kernel(const float* __restrict__ net, const float* __r
 // NB the reference adds stack(meshgrid(dy, dx)) to (x, y): the x coordinate receives the ROW offset of
 // the 9x9 window (corr.py:36-43) -- replicated as is.
 // ---------------------------------------------------------------------------------------
-struct CorrPyr { const float* lvl[4]; int h[4], w[4]; };
+struct CorrPyr { const void* lvl[4]; int h[4], w[4]; };
 
+constexpr int CL_PIX = 8;   // pixels per wave (the per-lane tap tables are built once and reused)
+template <typename CT>
 __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr, const float* __restrict__ flow, bf16_t* __restrict__ out,
                                                                int64_t M, int H8, int W8) {
     __shared__ float win[4][4][104];   // [wave][level][10 x 10 window | wx | wy | pad]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int64_t m = (int64_t)blockIdx.x * 4 + wave;
-    const bool valid = m < M;
-    if (!valid) m = M - 1;
-    const int p = (int)(m % (H8 * W8));
-    const float cx = (float)(p % W8) + flow[m * 2], cy = (float)(p / W8) + flow[m * 2 + 1];
     const int wy0 = lane / 10, wx0 = lane - wy0 * 10;                 // window element `lane`
     const int wy1 = (lane + 64) / 10, wx1 = lane + 64 - wy1 * 10;     // window element `lane + 64` (< 100 for lane < 36)
-#pragma unroll
-    for (int l = 0; l < 4; l++) {
-        const int hl = pyr.h[l], wl = pyr.w[l];
-        const float* img = pyr.lvl[l] + m * (int64_t)(hl * wl);
-        const float sc = 1.0f / (float)(1 << l);
-        const float xs = cx * sc, ys = cy * sc, x0f = floorf(xs), y0f = floorf(ys);
-        const int x0 = (int)x0f - 4, y0 = (int)y0f - 4;
-        {
-            const int y = y0 + wy0, x = x0 + wx0;
-            win[wave][l][lane] = ((unsigned)y < (unsigned)hl && (unsigned)x < (unsigned)wl) ? img[y * wl + x] : 0.f;
-        }
-        if (lane < 36) {
-            const int y = y0 + wy1, x = x0 + wx1;
-            win[wave][l][lane + 64] = ((unsigned)y < (unsigned)hl && (unsigned)x < (unsigned)wl) ? img[y * wl + x] : 0.f;
-        }
-        if (lane == 63) { win[wave][l][100] = xs - x0f; win[wave][l][101] = ys - y0f; }
-    }
-    __syncthreads();
-    if (!valid) return;
+    // output k = kk * 64 + lane = level * 81 + i * 9 + j  (i: x offset, j: y offset): LDS offsets, fixed per lane
+    int tap_off[6], frac_off[6];
 #pragma unroll
     for (int kk = 0; kk < 6; kk++) {
         const int k = kk * 64 + lane;
-        float v = 0.f;
-        if (k < 324) {
-            const int l = k / 81, t = k - l * 81, i = t / 9, j = t - i * 9;   // i: x offset, j: y offset
-            const float* wn = win[wave][l];
-            const float wx = wn[100], wy = wn[101];
-            const float* q = wn + j * 10 + i;
-            v = (1.f - wy) * ((1.f - wx) * q[0] + wx * q[1]) + wy * ((1.f - wx) * q[10] + wx * q[11]);
+        const int l = k / 81, t = k - l * 81, i = t / 9, j = t - i * 9;
+        tap_off[kk] = k < 324 ? l * 104 + j * 10 + i : -1;
+        frac_off[kk] = l * 104 + 100;
+    }
+    const float* wv = &win[wave][0][0];
+    const int HW = H8 * W8;
+    const int64_t m_first = ((int64_t)blockIdx.x * 4 + wave) * CL_PIX;
+    for (int pi = 0; pi < CL_PIX; pi++) {
+        const int64_t m = m_first + pi;
+        if (m >= M) break;                                            // wave-uniform
+        const int p = (int)(m % HW);
+        const float2 fl = *reinterpret_cast<const float2*>(flow + m * 2);
+        const float cx = (float)(p % W8) + fl.x, cy = (float)(p / W8) + fl.y;
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            const int hl = pyr.h[l], wl = pyr.w[l];
+            const CT* img = reinterpret_cast<const CT*>(pyr.lvl[l]) + m * (int64_t)(hl * wl);
+            const float sc = 1.0f / (float)(1 << l);
+            const float xs = cx * sc, ys = cy * sc, x0f = floorf(xs), y0f = floorf(ys);
+            const int x0 = (int)x0f - 4, y0 = (int)y0f - 4;
+            {
+                const int y = y0 + wy0, x = x0 + wx0;
+                win[wave][l][lane] = ((unsigned)y < (unsigned)hl && (unsigned)x < (unsigned)wl) ? (float)img[y * wl + x] : 0.f;
+            }
+            if (lane < 36) {
+                const int y = y0 + wy1, x = x0 + wx1;
+                win[wave][l][lane + 64] = ((unsigned)y < (unsigned)hl && (unsigned)x < (unsigned)wl) ? (float)img[y * wl + x] : 0.f;
+            }
+            if (lane == 63) { win[wave][l][100] = xs - x0f; win[wave][l][101] = ys - y0f; }
         }
-        out[m * 384 + k] = (bf16_t)v;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the windows are private to this wave
+#pragma unroll
+        for (int kk = 0; kk < 6; kk++) {
+            float v = 0.f;
+            if (tap_off[kk] >= 0) {
+                const float wx = wv[frac_off[kk]], wy = wv[frac_off[kk] + 1];
+                const float* q = wv + tap_off[kk];
+                v = (1.f - wy) * ((1.f - wx) * q[0] + wx * q[1]) + wy * ((1.f - wx) * q[10] + wx * q[11]);
+            }
+            out[m * 384 + kk * 64 + lane] = (bf16_t)v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // before the next pixel overwrites the windows
     }
 }
 
@@ -223,6 +236,59 @@ __global__ void raft_upsample_kernel(const float* __restrict__ flow, const float
 }
 
 // ---------------------------------------------------------------------------------------
+// correlation pyramid (corr.py:17-27 after the matmul): one wave per pixel's map; the scaled level 0 sits in LDS
+// as fp32, levels 1..3 are 2x2 means of the fp32 level above (avg_pool2d floors odd sizes: 7 -> 3), every level
+// is stored as half.  One read of the volume (3 KB per map) instead of the five PyTorch passes.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void raft_corr_pyramid_kernel(const vtgb_raft_corr_pyramid_args a) {
+    extern __shared__ float pyr_sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t m = (int64_t)blockIdx.x * 4 + wave;
+    const int H = a.H8, W = a.W8, n0 = H * W;
+    float* l0 = pyr_sm + wave * (n0 + n0 / 4 + n0 / 16 + 64);
+    if (m < a.n_maps) {
+        const float* src = a.corr + m * n0;
+        _Float16* o0 = reinterpret_cast<_Float16*>(a.levels[0]) + m * n0;
+        for (int i = lane; i < n0; i += 64) {
+            const float v = src[i] * a.scale;
+            l0[i] = v;
+            o0[i] = (_Float16)v;
+        }
+    }
+    __syncthreads();
+    const float* prev = l0;
+    int ph = H, pw = W;
+    float* cur = l0 + n0;
+    for (int l = 1; l < 4; l++) {
+        const int ch = ph / 2, cw = pw / 2;
+        if (m < a.n_maps) {
+            _Float16* o = reinterpret_cast<_Float16*>(a.levels[l]) + m * (int64_t)(ch * cw);
+            for (int i = lane; i < ch * cw; i += 64) {
+                const int y = i / cw, x = i - y * cw;
+                const float* q = prev + (2 * y) * pw + 2 * x;
+                const float v = (q[0] + q[1] + q[pw] + q[pw + 1]) * 0.25f;
+                cur[i] = v;
+                o[i] = (_Float16)v;
+            }
+        }
+        __syncthreads();
+        prev = cur; cur += ch * cw; ph = ch; pw = cw;
+    }
+}
+
+extern "C" int vtgb_raft_corr_pyramid(const vtgb_raft_corr_pyramid_args* a, vtgb_stream_t stream) {
+    VTGB_REQUIRE(a && a->corr && a->levels[0] && a->levels[1] && a->levels[2] && a->levels[3], VTGB_EINVAL, "raft_corr_pyramid: NULL argument");
+    VTGB_REQUIRE(a->n_maps > 0 && a->H8 >= 8 && a->W8 >= 8, VTGB_EINVAL, "raft_corr_pyramid: n=%lld H8=%d W8=%d", (long long)a->n_maps, a->H8, a->W8);
+    const int n0 = a->H8 * a->W8;
+    const size_t lds = 4 * (size_t)(n0 + n0 / 4 + n0 / 16 + 64) * sizeof(float);
+    VTGB_REQUIRE(lds <= 160 * 1024, VTGB_EUNSUPPORTED, "raft_corr_pyramid: %d x %d maps exceed the LDS tile", a->H8, a->W8);
+    if (lds > 64 * 1024) VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_pyramid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(raft_corr_pyramid_kernel, dim3((unsigned)((a->n_maps + 3) / 4)), dim3(256), lds, stream, *a);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------
 static GemmDesc conv_desc(int M, int N, int H, int W, int KH, int KW, int Cin, int split, const void* A, int64_t lda, const void* A2,
@@ -281,7 +347,10 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     auto F = [](const void* p) { return (const float*)p; };
     for (int it = 0; it < a->iters; it++) {
         // ---- BasicMotionEncoder (update.py:88-97)
-        hipLaunchKernelGGL(raft_corr_lookup_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, pyr, flow, corrf, M, H8, W8);
+        if (a->corr_f16)
+            hipLaunchKernelGGL(raft_corr_lookup_kernel<_Float16>, dim3((unsigned)((M + 4 * CL_PIX - 1) / (4 * CL_PIX))), dim3(256), 0, s, pyr, flow, corrf, M, H8, W8);
+        else
+            hipLaunchKernelGGL(raft_corr_lookup_kernel<float>, dim3((unsigned)((M + 4 * CL_PIX - 1) / (4 * CL_PIX))), dim3(256), 0, s, pyr, flow, corrf, M, H8, W8);
         {
             GemmDesc d = conv_desc(Mi, 256, H8, W8, 0, 0, 0, 0, corrf, 384, nullptr, 0, w[0], F(w[1]), VTGB_EPI_STORE, 1, c1, 256, zero);
             d.K = 384; d.ldw = 384;

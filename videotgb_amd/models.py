@@ -272,11 +272,7 @@ class Raft(nn.Module):
         cmap = ops.raft_encoder(cw, frames[:, :-1].reshape(b * (t - 1), 3, h, w))             # [n, HW, 256]
         n = b * (t - 1)
         corr = torch.matmul(fmap[:, :-1].reshape(n, h8 * w8, 256), fmap[:, 1:].reshape(n, h8 * w8, 256).transpose(1, 2))
-        corr = (corr / 16.0).reshape(n * h8 * w8, 1, h8, w8)                                   # / sqrt(256)  (corr.py:60)
-        pyr = [corr]
-        for _ in range(3):
-            corr = F.avg_pool2d(corr, 2, stride=2)
-            pyr.append(corr)
+        pyr = ops.raft_corr_pyramid(corr.view(n * h8 * w8, h8 * w8), h8, w8)                   # / sqrt(256) + 3 avg-pools, fp16
         cm = cmap.view(n, h8, w8, 256).permute(0, 3, 1, 2)
         net, inp = torch.tanh(cm[:, :128]).contiguous(), torch.relu(cm[:, 128:]).contiguous()
         return ops.raft_update(upd, net, inp, pyr, iters).view(b, t - 1, 2, h, w)

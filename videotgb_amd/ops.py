@@ -486,17 +486,33 @@ def raft_update(w: RaftWeights, net: Tensor, inp: Tensor, pyramid: Sequence[Tens
     _need_cuda(net, inp, *pyramid)
     net, inp = net.contiguous().float(), inp.contiguous().float()
     n, _, H8, W8 = net.shape
-    lv = [t.contiguous().float() for t in pyramid]
-    if len(lv) != 4:
+    if len(pyramid) != 4:
         raise ValueError("raft_update: the correlation pyramid has 4 levels")
+    half = all(t.dtype == torch.float16 for t in pyramid)
+    lv = [t.contiguous() if half else t.contiguous().float() for t in pyramid]
     out = torch.empty(n, 2, 8 * H8, 8 * W8, dtype=torch.float32, device=net.device)
     a = L.RaftUpdateArgs(n, H8, W8, iters, net.data_ptr(), inp.data_ptr(), (C.c_void_p * 4)(*[t.data_ptr() for t in lv]),
-                         C.cast(w.array, C.POINTER(C.c_void_p)), out.data_ptr(), None, 0)
+                         C.cast(w.array, C.POINTER(C.c_void_p)), out.data_ptr(), None, 0, 1 if half else 0)
     need = L.lib().vtgb_raft_update_workspace_bytes(C.byref(a))
     ws = _ws.get(need, net.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     L.check(L.lib().vtgb_raft_update(C.byref(a), _stream()))
     return out
+
+
+def raft_corr_pyramid(corr: Tensor, H8: int, W8: int, scale: float = 1.0 / 16.0) -> List[Tensor]:
+    """corr [n_maps, H8*W8] fp32 (fmap1 . fmap2 for every pixel) -> the 4-level pyramid of CorrBlock (corr.py:17-27) in fp16:
+    level l is [n_maps, 1, H8 >> l, W8 >> l]."""
+    _need_cuda(corr)
+    corr = corr.contiguous().float()
+    n = corr.numel() // (H8 * W8)
+    lv, h, w = [], H8, W8
+    for _ in range(4):
+        lv.append(torch.empty(n, 1, h, w, dtype=torch.float16, device=corr.device))
+        h, w = h // 2, w // 2
+    a = L.RaftCorrPyramidArgs(corr.data_ptr(), (C.c_void_p * 4)(*[t.data_ptr() for t in lv]), n, H8, W8, scale)
+    L.check(L.lib().vtgb_raft_corr_pyramid(C.byref(a), _stream()))
+    return lv
 
 
 class RaftEncoderWeights(_WeightTable):
