@@ -42,7 +42,7 @@ def pmc_traffic(family="gemm"):
     """Mean HBM-side bytes per launch of the dominant kernel family from the committed PMC passes (FETCH_SIZE x2 per
     the gfx950 correction + WRITE_SIZE).  gemm: profiles/r01_pmc_traffic_gemm.json (tools/gemm_pmc.py, the four ViT-g
     layer shapes at 31 clips); conv: profiles/r01_pmc_traffic_conv.json (tools/conv_pmc.py, one RAFT pass over the
-    bench's 32-clip batch).  None if the file is absent."""
+    bench's 31-clip RAFT batch).  None if the file is absent."""
     path = os.path.join(REPO, "profiles", f"r01_pmc_traffic_{family}.json")
     try:
         ks = json.load(open(path))["kernels"]
@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step (default: 32 with --flow raft, 62 with precomputed flow)")
+    ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step (default: 124 with --flow raft, 62 with precomputed flow)")
     ap.add_argument("--T", type=int, default=96, help="flow frames per clip")
     ap.add_argument("--nframe", type=int, default=8)
     ap.add_argument("--flow", choices=["precomputed", "raft"], default="raft",
@@ -75,7 +75,9 @@ def parse():
                     help="RAFT fnet/cnet: libvtgb.so (bf16 MFMA implicit-GEMM convolutions, fnet once per distinct frame) or MIOpen")
     ap.add_argument("--raft-update", choices=["hip", "torch"], default="hip",
                     help="RAFT refinement loop: libvtgb.so (bf16 MFMA implicit-GEMM convolutions) or PyTorch-ROCm/MIOpen ops")
-    ap.add_argument("--raft-clips", type=int, default=32, help="clips per RAFT call (pairs of that many clips form one batch)")
+    ap.add_argument("--raft-clips", type=int, default=31,
+                    help="clips per RAFT call (pairs of that many clips form one batch; 31 clips = 249 ViT m-tiles / 9020 RAFT m-tiles: "
+                         "few idle CUs in the last round of 256-row tiles)")
     ap.add_argument("--overlap", action="store_true",
                     help="two HIP streams: the prefix stage of batch i+1 over the LLM decode of batch i (measured +7 % clips/s; off by "
                          "default because concurrent kernels inflate the per-launch durations the roofline object is computed from)")
@@ -220,7 +222,9 @@ def main():
     m.load_state_dict(sd, strict=False)
     m.to(dev)
     lm.to(torch.bfloat16)
-    B, T, nframe = (args.clips or (32 if args.flow == "raft" else 62)), args.T, args.nframe
+    # 124 clips per step: 4 RAFT batches of 31, one ViT / Q-Former pass over 992 frames, one decode batch (the decode step
+    # streams the 13.5 GB of LLM weights once per token whatever the batch: 3.4 ms per clip at 32 clips, 1.6 at 124)
+    B, T, nframe = (args.clips or (124 if args.flow == "raft" else 62)), args.T, args.nframe
     batches = [synth_batch(rank, i, B, T, args.flow, dev, cfg) for i in range(2)]
     torch.cuda.synchronize()
     if rank == 0:

@@ -3,10 +3,10 @@
 R=${1:-r01}
 O=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-# 1. PMC: HBM traffic of the conv family (one RAFT pass, 32 clips) and of the plain GEMMs; one counter per pass
+# 1. PMC: HBM traffic of the conv family (one RAFT pass, 31 clips = the bench batch) and of the plain GEMMs; one counter per pass
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pc_$c /tmp/pg_$c
-  timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/pc_$c -- python3 $GRAFT_REPO_ROOT/tools/conv_pmc.py 32 > /tmp/pc_$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/pc_$c -- python3 $GRAFT_REPO_ROOT/tools/conv_pmc.py 31 > /tmp/pc_$c.log 2>&1
   timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pg_$c -- python3 $GRAFT_REPO_ROOT/tools/gemm_pmc.py > /tmp/pg_$c.log 2>&1
 done
 python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py /tmp/pc_FETCH_SIZE /tmp/pc_WRITE_SIZE $O/${R}_pmc_traffic_conv.json conv > /dev/null

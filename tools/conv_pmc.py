@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from videotgb_amd import models, synth
 dev = torch.device("cuda:0")
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 31
 r = models.Raft(torch.float32, hip_update=True)
 sd = {k[len("of_extractor."):]: v for k, v in synth.synth_state_dict(synth.raft_shapes("of_extractor."), 0).items()}
 for k in list(sd):
