@@ -1,13 +1,14 @@
 // raft.hip -- the recurrent part of RAFT on gfx950: per refinement iteration the
 // correlation-pyramid lookup (the reference's missing `alt_cuda_corr`, raft_utils/corr.py:29-50,63-91),
 // BasicMotionEncoder, SepConvGRU and FlowHead (raft_utils/update.py:39-144), then the mask head and the
-// convex 8x upsample of the last iteration (xraft.py:88-99).  The two CNN encoders and the all-pairs
-// correlation matmul stay with the caller (MIOpen / rocBLAS through PyTorch).
+// convex 8x upsample of the last iteration (xraft.py:88-99), plus the fused correlation pyramid (scale +
+// three average pools, corr.py:17-27).  The two CNN encoders are raft_enc.hip; only the all-pairs correlation
+// matmul itself stays with the caller (one batched rocBLAS GEMM through PyTorch).
 //
 // Layout: every activation is NHWC ("pixel-major") bf16, so each convolution is an implicit GEMM on the
 // MFMA kernel of gemm.hip (LDS-DMA gathers the k-tile of the shifted pixel directly; out-of-image taps read
 // a zero page; channel concatenations [h | inp | motion | flow] are virtual: two base pointers, no copies).
-// The hidden state h, the flow / coordinates and the correlation pyramid stay fp32; GEMM operands are bf16
+// The hidden state h and the flow / coordinates stay fp32, the correlation pyramid is fp16 (or fp32); GEMM operands are bf16
 // with fp32 accumulation, gates (sigmoid / tanh) are evaluated in fp32 in the GEMM epilogue.
 #include <math.h>
 #include <string.h>
