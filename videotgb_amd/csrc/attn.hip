@@ -48,7 +48,7 @@ __device__ __forceinline__ bf16x8 rope8(bf16x8 v, const float* tab_row, int d0, 
 }
 
 template <int HD, int NKP>
-__global__ __launch_bounds__(NKP <= 9 ? 512 : 256, NKP <= 9 ? 2 : 1) void attn_bf16_kernel(const AttnDesc p, const int tiles_per_split) {
+__global__ __launch_bounds__(NKP <= 9 ? 576 : 256) void attn_bf16_kernel(const AttnDesc p, const int tiles_per_split) {
     using C = AttnCfg<HD, NKP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
@@ -64,7 +64,50 @@ __global__ __launch_bounds__(NKP <= 9 ? 512 : 256, NKP <= 9 ? 2 : 1) void attn_b
     constexpr int CH = HD / 8;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    // ---- stage K [key][d] (rope applied), zero padded
+    // ---- stage K [key][d] (rope applied, zero padded) and V^T [d][key].  All global loads of a thread are issued
+    // before the first LDS write: the naive load -> write loop serialised ~14 dependent HBM round trips per thread
+    // (about two thirds of the kernel at 257 keys); the whole K / V of a head is 90 KB, i.e. <= 8 + 8 loads per thread.
+    constexpr int TMIN = NKP <= 9 ? 512 : 256;                                           // workgroup size of the full-size launches
+    constexpr int KI = (C::NK * CH + TMIN - 1) / TMIN, VI = ((C::NK / 2) * CH + TMIN - 1) / TMIN;
+    if (nthreads >= TMIN) {
+        bf16x8 kreg[KI], v0r[VI], v1r[VI];
+#pragma unroll
+        for (int i = 0; i < KI; i++) {
+            const int idx = tid + i * nthreads, key = idx / CH, c = idx - key * CH;
+            kreg[i] = zero8;
+            if (idx < C::NK * CH && key < p.s_kv && c * 8 < hd) kreg[i] = *reinterpret_cast<const bf16x8*>(K + (int64_t)key * p.kv_tok + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < VI; i++) {
+            const int idx = tid + i * nthreads, c = idx / (C::NK / 2), key = (idx - c * (C::NK / 2)) * 2;
+            v0r[i] = zero8; v1r[i] = zero8;
+            if (idx < (C::NK / 2) * CH && c * 8 < hd) {
+                if (key < p.s_kv) v0r[i] = *reinterpret_cast<const bf16x8*>(V + (int64_t)key * p.kv_tok + c * 8);
+                if (key + 1 < p.s_kv) v1r[i] = *reinterpret_cast<const bf16x8*>(V + (int64_t)(key + 1) * p.kv_tok + c * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KI; i++) {
+            const int idx = tid + i * nthreads, key = idx / CH, c = idx - key * CH;
+            if (idx < C::NK * CH) {
+                bf16x8 val = kreg[i];
+                if (p.rope_k && key < p.s_kv && c * 8 < hd) val = rope8(val, p.rope_k + (int64_t)key * hd, c * 8, hd);
+                *reinterpret_cast<bf16x8*>(Ks + key * C::KS + c * 16) = val;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VI; i++) {
+            const int idx = tid + i * nthreads, c = idx / (C::NK / 2), key = (idx - c * (C::NK / 2)) * 2;
+            if (idx < (C::NK / 2) * CH) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                    bf16x2 pr = {v0r[i][e], v1r[i][e]};
+                    *reinterpret_cast<bf16x2*>(Vt + (c * 8 + e) * C::VS + key * 2) = pr;
+                }
+            }
+        }
+    } else {
     for (int idx = tid; idx < C::NK * CH; idx += nthreads) {
         const int key = idx / CH, c = idx - key * CH;
         bf16x8 val = zero8;
@@ -89,6 +132,7 @@ __global__ __launch_bounds__(NKP <= 9 ? 512 : 256, NKP <= 9 ? 2 : 1) void attn_b
             bf16x2 pr = {v0[i], v1[i]};
             *reinterpret_cast<bf16x2*>(Vt + (c * 8 + i) * C::VS + key * 2) = pr;
         }
+    }
     }
     for (int key = tid; key < C::NK; key += nthreads) {
         float m = -INFINITY;
@@ -295,8 +339,11 @@ static int launch_bf16(const AttnDesc& d, hipStream_t s) {
     int splits = 1;
     while ((int64_t)d.batch * d.heads * splits < 256 && splits * 2 <= n_qt && splits < 4) splits *= 2;
     const int tps = (n_qt + splits - 1) / splits;
-    const int max_waves = NKP <= 9 ? 8 : 4;
-    const int waves = tps < max_waves ? tps : max_waves;
+    // waves per workgroup: the fewest rounds over the 16-query tiles with at most 9 (NKP <= 9) waves, then the fewest
+    // waves for that many rounds (257 tokens = 17 tiles: 2 rounds of 9 waves instead of 3 rounds of 8)
+    const int max_waves = NKP <= 9 ? 9 : 4;
+    const int rounds = (tps + max_waves - 1) / max_waves;
+    const int waves = (tps + rounds - 1) / rounds;
     ProfScope prof(VTGB_PROF_ATTN, 4.0 * d.batch * d.heads * (double)d.s_q * d.s_kv * d.head_dim, s);
     hipLaunchKernelGGL((attn_bf16_kernel<HD, NKP>), dim3(splits, d.heads, d.batch), dim3(64 * waves), C::LDS, s, d, tps);
     VTGB_HIP(hipGetLastError());
