@@ -324,7 +324,10 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"InstructBLIP-Vicuna-7B + TGB, T={T}->{nframe} of 32 frames, 224x224, greedy {args.max_new_tokens} new tokens "
-                                      f"(BASELINE.json configs[2])", "flow": args.flow if args.flow == "precomputed" else f"raft inline (update={args.raft_update}, encoders={args.raft_encoders if args.raft_update == 'hip' else 'torch'}/{args.raft_dtype})",
+                                      f"(BASELINE.json configs[2])", "flow": args.flow if args.flow == "precomputed" else (
+                              f"raft inline, all HIP (bf16 MFMA convolutions, fp32 state / accumulation), {args.raft_clips} clips per RAFT batch"
+                              if (args.raft_update == "hip" and args.raft_encoders == "hip") else
+                              f"raft inline (update={args.raft_update}, encoders={args.raft_encoders if args.raft_update == 'hip' else 'torch'}/{args.raft_dtype})"),
                           "clips_per_gpu_per_step": B,
                           "global_batch": B * world, "parallelism": f"clip-parallel x{world} (no data-path collective)",
                           "llm": f"HF LlamaForCausalLM {args.llm} geometry, random init, KV cache, decode={args.decode}",
