@@ -341,7 +341,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     constexpr int W_OP = T_BN * 128;     // bytes per weight slot
     constexpr int WI = NWN;              // weight DMA instructions per wave and k-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const smem_w = smem + L_A_SLOTS * L_OP_BYTES;
+    // activation ring: 3 slots; 2 for the 64-wide tile, whose 80 KiB then let TWO workgroups share a CU (these tiles
+    // have few k-tiles -- K = 576 for RAFT's 64-channel 3x3 convolutions -- so prologue and epilogue are a third of
+    // a tile's life and overlap with the other workgroup's k-loop instead of idling the CU)
+    constexpr int A_SLOTS = NWN == 1 ? 2 : 3;
+    char* const smem_w = smem + A_SLOTS * L_OP_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- XCD-aware tile assignment
@@ -436,9 +440,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         L_ISSUE_A(1, L_BK)
         L_ISSUE_W(1, L_BK)
     }
-    if (nk > 2) L_ISSUE_A(2, 2 * L_BK)
-    if (nk > 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (8 + WI));        // vmcnt(8 + WI): A(0), W(0) landed
-    else if (nk == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (4 + WI));  // vmcnt(4 + WI)
+    if (A_SLOTS == 3 && nk > 2) L_ISSUE_A(2, 2 * L_BK)
+    if (A_SLOTS == 3 && nk > 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (8 + WI));        // vmcnt(8 + WI): A(0), W(0) landed
+    else if (nk >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (4 + WI));                  // vmcnt(4 + WI)
     else __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
     __builtin_amdgcn_s_barrier();
 
@@ -467,12 +471,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     if (!wave_active) {
         // same DMA issues, waits and barriers as the active waves, nothing else
         for (int kt = 0; kt + 1 < nk; kt++) {
-            if (kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4)
-            else __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+            if (A_SLOTS == 3 && kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4)
+            else __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0)
             __builtin_amdgcn_s_barrier();
             if (kt + 2 < nk) { L_ISSUE_W(kt & 1, (kt + 2) * L_BK) }
-            if (kt + 3 < nk) { L_ISSUE_A(a_slot, (kt + 3) * L_BK) }
-            a_slot = a_slot == 2 ? 0 : a_slot + 1;
+            if (kt + A_SLOTS < nk) { L_ISSUE_A(a_slot, (kt + A_SLOTS) * L_BK) }
+            a_slot = a_slot == A_SLOTS - 1 ? 0 : a_slot + 1;
         }
         if constexpr (EPI == EPI_STORE || EPI == EPI_GELU) {
             if (staged_store) __builtin_amdgcn_s_barrier();   // the barrier in front of the LDS-staged stores
@@ -491,17 +495,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     for (int kt = 0; kt + 1 < nk; kt++) {     // every iteration has a successor tile (no join before the MFMAs)
         const char* as = smem + a_slot * L_OP_BYTES;
         const char* ws = smem_w + (kt & 1) * W_OP;
-        const int a_nxt = a_slot == 2 ? 0 : a_slot + 1;
+        const int a_nxt = a_slot == A_SLOTS - 1 ? 0 : a_slot + 1;
         L_READ(wf1, xf1, as, ws, 1)
         L_MFMA(wf0, xf0)
         if constexpr (!(ABL & 8)) {
-            if (kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4) lgkmcnt(0): all but A(t+2) landed
-            else __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0)
+            if (A_SLOTS == 3 && kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4) lgkmcnt(0): all but A(t+2) landed
+            else __builtin_amdgcn_s_waitcnt(0x0070);                               // vmcnt(0) lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
         }
         if constexpr (!(ABL & 1)) {
             if (kt + 2 < nk) { L_ISSUE_W(kt & 1, (kt + 2) * L_BK) }
-            if (kt + 3 < nk) { L_ISSUE_A(a_slot, (kt + 3) * L_BK) }
+            if (kt + A_SLOTS < nk) { L_ISSUE_A(a_slot, (kt + A_SLOTS) * L_BK) }
         }
         L_READ(wf0, xf0, smem + a_nxt * L_OP_BYTES, smem_w + ((kt + 1) & 1) * W_OP, 0)
         L_MFMA(wf1, xf1)
@@ -836,7 +840,7 @@ static int launch_epi(const GemmDesc& d, hipStream_t s) {
 // kernel.  d.conv_KH == 0: plain GEMM through the same kernel (RAFT's 1x1 convolutions).
 template <int EPI, bool CONV, int NWN>
 static int launch_large_nwn(const GemmDesc& d, hipStream_t s) {
-    constexpr int T_BN = 64 * NWN, LDS = L_A_SLOTS * L_OP_BYTES + L_W_SLOTS * T_BN * 128;
+    constexpr int T_BN = 64 * NWN, LDS = (NWN == 1 ? 2 : 3) * L_OP_BYTES + L_W_SLOTS * T_BN * 128;
     const int m_tiles = (d.M + L_BM - 1) / L_BM, n_tiles = (d.N + T_BN - 1) / T_BN;
     const int G = n_tiles <= 8 ? 2 : 8;
     const int mx = (m_tiles + 7) / 8, groups = (mx + G - 1) / G;
