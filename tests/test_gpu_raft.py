@@ -74,6 +74,23 @@ def test_raft_encoder_vs_oracle(dev, tiny_sd, net, kind):
     assert e <= 2e-2
 
 
+@pytest.mark.parametrize("size,n", [(224, 3), (96, 2)])
+def test_raft_context_encoder_image_sizes(dev, tiny_sd, size, n):
+    """cnet (BatchNorm folded): ReLU, the skip connection and the bf16 cast live in the convolution epilogues (two
+    workgroups per CU on the 64-wide tiles, padded 96 -> 128 output rows in stage 2): other sizes than the golden 128."""
+    from oracle import vtgb_oracle as O
+    from videotgb_amd import ops
+    sd = tiny_sd["instructblip"][1]
+    fr = torch.randint(0, 256, (n, 3, size, size), generator=torch.Generator().manual_seed(size + 1)).float()
+    ref = O.raft_encoder(sd, "of_extractor.cnet.", 2 * (fr / 255.0) - 1.0, "batch")
+    rsd = {k[len("of_extractor."):]: v.to(dev) for k, v in sd.items() if k.startswith("of_extractor.")}
+    w = ops.RaftEncoderWeights(rsd, "cnet.", True)
+    out = ops.raft_encoder(w, fr.to(dev)).cpu().view(n, size // 8, size // 8, 256).permute(0, 3, 1, 2)
+    e = rel_rms(out, ref)
+    print(f"[raft cnet {size}x{size}] rel_rms={e:.3e}")
+    assert e <= 1e-2
+
+
 @pytest.mark.parametrize("size,n", [(224, 5), (64, 3), (96, 2)])
 def test_raft_encoder_image_sizes(dev, tiny_sd, size, n):
     """InstanceNorm moments come from the convolution epilogue: 224 -> 28x28 = 784-row images straddle the
