@@ -98,7 +98,20 @@ __global__ __launch_bounds__(256) void llm_decode_attn_kernel(const T* __restric
     for (int key = lane; key < n_keys; key += 64) {
         const T* k = kr + (int64_t)key * hd;
         float dot = 0.f;
-        for (int d = 0; d < hd; d++) dot = fmaf(qs[d], (float)k[d], dot);
+        if constexpr (sizeof(T) == 2) {
+            // a lane owns a key row: 16-byte loads (8 elements) instead of 2-byte ones, same summation order
+            if ((hd & 7) == 0) {
+                for (int d = 0; d < hd; d += 8) {
+                    const bf16x8 kv = *reinterpret_cast<const bf16x8*>(k + d);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) dot = fmaf(qs[d + e], (float)kv[e], dot);
+                }
+            } else {
+                for (int d = 0; d < hd; d++) dot = fmaf(qs[d], (float)k[d], dot);
+            }
+        } else {
+            for (int d = 0; d < hd; d++) dot = fmaf(qs[d], (float)k[d], dot);
+        }
         dot *= scale;
         sc[key] = dot;
         mx = fmaxf(mx, dot);
