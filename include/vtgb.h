@@ -350,11 +350,12 @@ int vtgb_raft_update(const vtgb_raft_update_args* a, vtgb_stream_t stream);
  * avg_pool2d(2, stride 2), in ONE pass over the fp32 correlation volume; the four levels are written as IEEE half
  * (values are O(1..100): 11 significant bits against the bf16 features they feed). */
 typedef struct {
-    const float* corr;          /* [n_maps, H8, W8] fp32: <fmap1[p], fmap2[q]> for every pixel p (one map each)   */
+    const void* corr;           /* [n_maps, H8, W8] fp32 (or IEEE half if corr_in_f16): <fmap1[p], fmap2[q]> for every pixel p */
     void* levels[4];            /* level l: [n_maps, H8>>l, W8>>l] fp16                                            */
     int64_t n_maps;
     int32_t H8, W8;
     float scale;                /* 1 / sqrt(dim) = 1/16                                                            */
+    int32_t corr_in_f16;        /* the volume comes from a half-precision GEMM (fp32 accumulation, half output)    */
 } vtgb_raft_corr_pyramid_args;
 int vtgb_raft_corr_pyramid(const vtgb_raft_corr_pyramid_args* a, vtgb_stream_t stream);
 

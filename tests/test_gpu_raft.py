@@ -134,3 +134,11 @@ def test_corr_pyramid_vs_torch(dev, h8, w8):
         assert (got[l].float().cpu() - ref).abs().max() <= 2.0 ** -11 * ref.abs().max() + 1e-6
         if l < 3:
             ref = F.avg_pool2d(ref, 2, stride=2)
+    # half-precision volume in (the output of the fp16 correlation GEMM): same chain on the rounded values
+    ch = corr.half()
+    got = ops.raft_corr_pyramid(ch.to(dev), h8, w8)
+    ref = (ch.float() / 16.0).view(n, 1, h8, w8)
+    for l in range(4):
+        assert (got[l].float().cpu() - ref).abs().max() <= 2.0 ** -11 * ref.abs().max() + 1e-6
+        if l < 3:
+            ref = F.avg_pool2d(ref, 2, stride=2)

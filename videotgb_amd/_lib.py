@@ -100,7 +100,7 @@ class RaftUpdateArgs(C.Structure):
 
 
 class RaftCorrPyramidArgs(C.Structure):
-    _fields_ = [("corr", vp), ("levels", vp * 4), ("n_maps", i64), ("H8", i32), ("W8", i32), ("scale", f32)]
+    _fields_ = [("corr", vp), ("levels", vp * 4), ("n_maps", i64), ("H8", i32), ("W8", i32), ("scale", f32), ("corr_in_f16", i32)]
 
 
 class RaftEncoderArgs(C.Structure):

@@ -241,6 +241,7 @@ __global__ void raft_upsample_kernel(const float* __restrict__ flow, const float
 // as fp32, levels 1..3 are 2x2 means of the fp32 level above (avg_pool2d floors odd sizes: 7 -> 3), every level
 // is stored as half.  One read of the volume (3 KB per map) instead of the five PyTorch passes.
 // ---------------------------------------------------------------------------------------
+template <typename IT>
 __global__ __launch_bounds__(256) void raft_corr_pyramid_kernel(const vtgb_raft_corr_pyramid_args a) {
     extern __shared__ float pyr_sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -248,10 +249,10 @@ __global__ __launch_bounds__(256) void raft_corr_pyramid_kernel(const vtgb_raft_
     const int H = a.H8, W = a.W8, n0 = H * W;
     float* l0 = pyr_sm + wave * (n0 + n0 / 4 + n0 / 16 + 64);
     if (m < a.n_maps) {
-        const float* src = a.corr + m * n0;
+        const IT* src = reinterpret_cast<const IT*>(a.corr) + m * n0;
         _Float16* o0 = reinterpret_cast<_Float16*>(a.levels[0]) + m * n0;
         for (int i = lane; i < n0; i += 64) {
-            const float v = src[i] * a.scale;
+            const float v = (float)src[i] * a.scale;
             l0[i] = v;
             o0[i] = (_Float16)v;
         }
@@ -283,8 +284,14 @@ extern "C" int vtgb_raft_corr_pyramid(const vtgb_raft_corr_pyramid_args* a, vtgb
     const int n0 = a->H8 * a->W8;
     const size_t lds = 4 * (size_t)(n0 + n0 / 4 + n0 / 16 + 64) * sizeof(float);
     VTGB_REQUIRE(lds <= 160 * 1024, VTGB_EUNSUPPORTED, "raft_corr_pyramid: %d x %d maps exceed the LDS tile", a->H8, a->W8);
-    if (lds > 64 * 1024) VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_pyramid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(raft_corr_pyramid_kernel, dim3((unsigned)((a->n_maps + 3) / 4)), dim3(256), lds, stream, *a);
+    if (lds > 64 * 1024) {
+        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_pyramid_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_pyramid_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (a->corr_in_f16)
+        hipLaunchKernelGGL(raft_corr_pyramid_kernel<_Float16>, dim3((unsigned)((a->n_maps + 3) / 4)), dim3(256), lds, stream, *a);
+    else
+        hipLaunchKernelGGL(raft_corr_pyramid_kernel<float>, dim3((unsigned)((a->n_maps + 3) / 4)), dim3(256), lds, stream, *a);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }

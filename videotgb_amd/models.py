@@ -271,7 +271,11 @@ class Raft(nn.Module):
         fmap = ops.raft_encoder(fw, frames.reshape(b * t, 3, h, w)).view(b, t, h8 * w8, 256)
         cmap = ops.raft_encoder(cw, frames[:, :-1].reshape(b * (t - 1), 3, h, w))             # [n, HW, 256]
         n = b * (t - 1)
-        corr = torch.matmul(fmap[:, :-1].reshape(n, h8 * w8, 256), fmap[:, 1:].reshape(n, h8 * w8, 256).transpose(1, 2))
+        # all-pairs correlation (corr.py:52-60) as ONE half-precision batched GEMM (fp32 accumulation in the MFMA; the
+        # features are O(1): 11 significant bits on inputs and outputs against the bf16 features the lookup emits),
+        # a tenth of the fp32 GEMM's time and half the volume's traffic
+        fh = fmap.to(torch.float16)
+        corr = torch.matmul(fh[:, :-1].reshape(n, h8 * w8, 256), fh[:, 1:].reshape(n, h8 * w8, 256).transpose(1, 2))
         pyr = ops.raft_corr_pyramid(corr.view(n * h8 * w8, h8 * w8), h8, w8)                   # / sqrt(256) + 3 avg-pools, fp16
         cm = cmap.view(n, h8, w8, 256).permute(0, 3, 1, 2)
         net, inp = torch.tanh(cm[:, :128]).contiguous(), torch.relu(cm[:, 128:]).contiguous()

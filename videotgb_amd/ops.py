@@ -501,16 +501,17 @@ def raft_update(w: RaftWeights, net: Tensor, inp: Tensor, pyramid: Sequence[Tens
 
 
 def raft_corr_pyramid(corr: Tensor, H8: int, W8: int, scale: float = 1.0 / 16.0) -> List[Tensor]:
-    """corr [n_maps, H8*W8] fp32 (fmap1 . fmap2 for every pixel) -> the 4-level pyramid of CorrBlock (corr.py:17-27) in fp16:
+    """corr [n_maps, H8*W8] fp32 or fp16 (fmap1 . fmap2 for every pixel) -> the 4-level pyramid of CorrBlock (corr.py:17-27) in fp16:
     level l is [n_maps, 1, H8 >> l, W8 >> l]."""
     _need_cuda(corr)
-    corr = corr.contiguous().float()
+    half_in = corr.dtype == torch.float16
+    corr = corr.contiguous() if half_in else corr.contiguous().float()
     n = corr.numel() // (H8 * W8)
     lv, h, w = [], H8, W8
     for _ in range(4):
         lv.append(torch.empty(n, 1, h, w, dtype=torch.float16, device=corr.device))
         h, w = h // 2, w // 2
-    a = L.RaftCorrPyramidArgs(corr.data_ptr(), (C.c_void_p * 4)(*[t.data_ptr() for t in lv]), n, H8, W8, scale)
+    a = L.RaftCorrPyramidArgs(corr.data_ptr(), (C.c_void_p * 4)(*[t.data_ptr() for t in lv]), n, H8, W8, scale, 1 if half_in else 0)
     L.check(L.lib().vtgb_raft_corr_pyramid(C.byref(a), _stream()))
     return lv
 
