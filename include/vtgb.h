@@ -342,6 +342,8 @@ typedef struct {
     void* workspace;
     size_t workspace_bytes;
     int32_t corr_f16;           /* 0: fp32 pyramid; 1: IEEE half (vtgb_raft_corr_pyramid), half the lookup's HBM reads */
+    const float* cnet_nhwc;     /* optional: the context encoder's raw output [n_pairs*H8*W8, 256] (vtgb_raft_encoder layout);
+                                   net = tanh(first 128), inp = relu(last 128) are then taken from it and net/inp may be NULL */
 } vtgb_raft_update_args;
 size_t vtgb_raft_update_workspace_bytes(const vtgb_raft_update_args* a);
 int vtgb_raft_update(const vtgb_raft_update_args* a, vtgb_stream_t stream);

@@ -96,7 +96,7 @@ class TgbArgs(C.Structure):
 
 class RaftUpdateArgs(C.Structure):
     _fields_ = [("n_pairs", i32), ("H8", i32), ("W8", i32), ("iters", i32), ("net", vp), ("inp", vp), ("corr", vp * 4),
-                ("weights", C.POINTER(vp)), ("flow_up", vp), ("workspace", vp), ("workspace_bytes", sz), ("corr_f16", i32)]
+                ("weights", C.POINTER(vp)), ("flow_up", vp), ("workspace", vp), ("workspace_bytes", sz), ("corr_f16", i32), ("cnet_nhwc", vp)]
 
 
 class RaftCorrPyramidArgs(C.Structure):

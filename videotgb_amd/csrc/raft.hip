@@ -18,17 +18,21 @@
 // ---------------------------------------------------------------------------------------
 // state init: NCHW fp32 -> pixel-major buffers
 // ---------------------------------------------------------------------------------------
-__global__ void raft_init_kernel(const float* __restrict__ net, const float* __restrict__ inp, float* __restrict__ h32,
-                                 bf16_t* __restrict__ hb, bf16_t* __restrict__ X, float* __restrict__ flow, int64_t M, int HW) {
+__global__ void raft_init_kernel(const float* __restrict__ net, const float* __restrict__ inp, const float* __restrict__ cnet_nhwc,
+                                 float* __restrict__ h32, bf16_t* __restrict__ hb, bf16_t* __restrict__ X, float* __restrict__ flow, int64_t M,
+                                 int HW) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * 128) return;
     const int64_t m = i >> 7;
     const int c = (int)(i & 127);
     const int64_t n = m / HW, p = m % HW;
-    const float hv = net[(n * 128 + c) * HW + p];
+    // net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:]) (xraft.py:126-127), either precomputed NCHW or straight
+    // from the context encoder's pixel-major output
+    const float hv = cnet_nhwc ? tanhf(cnet_nhwc[m * 256 + c]) : net[(n * 128 + c) * HW + p];
+    const float iv = cnet_nhwc ? fmaxf(cnet_nhwc[m * 256 + 128 + c], 0.f) : inp[(n * 128 + c) * HW + p];
     h32[i] = hv;
     hb[i] = (bf16_t)hv;
-    X[m * 256 + c] = (bf16_t)inp[(n * 128 + c) * HW + p];
+    X[m * 256 + c] = (bf16_t)iv;
     if (c < 2) {
         flow[m * 2 + c] = 0.f;
         X[m * 256 + 254 + c] = (bf16_t)0.f;
@@ -332,7 +336,7 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     void* zero = ws.take(256);
     if (ws.dry) return VTGB_OK;
     VTGB_REQUIRE(ws.ok(), VTGB_EWORKSPACE, "raft_update: workspace %zu < %zu bytes", ws.size, ws.used);
-    VTGB_REQUIRE(a->net && a->inp && a->weights && a->flow_up, VTGB_EINVAL, "raft_update: NULL operand");
+    VTGB_REQUIRE(((a->net && a->inp) || a->cnet_nhwc) && a->weights && a->flow_up, VTGB_EINVAL, "raft_update: NULL operand");
     const void* const* w = a->weights;
     for (int i = 0; i < VTGB_RAFT_NW; i++) VTGB_REQUIRE(w[i], VTGB_EINVAL, "raft_update: weights[%d] is NULL", i);
     CorrPyr pyr;
@@ -343,7 +347,7 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
         hl /= 2; wl /= 2;
     }
     VTGB_HIP(hipMemsetAsync(zero, 0, 256, s));
-    hipLaunchKernelGGL(raft_init_kernel, dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, s, a->net, a->inp, h32, hb, X, flow, M, HW);
+    hipLaunchKernelGGL(raft_init_kernel, dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, h32, hb, X, flow, M, HW);
     const int Mi = (int)M;
     const size_t cf1_lds = 128 * CF1_LD * 2 + 4 * 4096;
     static bool cf1_attr = false;

@@ -277,9 +277,8 @@ class Raft(nn.Module):
         fh = fmap.to(torch.float16)
         corr = torch.matmul(fh[:, :-1].reshape(n, h8 * w8, 256), fh[:, 1:].reshape(n, h8 * w8, 256).transpose(1, 2))
         pyr = ops.raft_corr_pyramid(corr.view(n * h8 * w8, h8 * w8), h8, w8)                   # / sqrt(256) + 3 avg-pools, fp16
-        cm = cmap.view(n, h8, w8, 256).permute(0, 3, 1, 2)
-        net, inp = torch.tanh(cm[:, :128]).contiguous(), torch.relu(cm[:, 128:]).contiguous()
-        return ops.raft_update(upd, net, inp, pyr, iters).view(b, t - 1, 2, h, w)
+        # net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:]) (xraft.py:126-127) are taken from the pixel-major cnet output inside
+        return ops.raft_update(upd, None, None, pyr, iters, cnet_nhwc=cmap, hw=(h8, w8)).view(b, t - 1, 2, h, w)
 
     def _c(self, name, x, stride=1, padding=0):
         m = self.get_submodule(name)

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -481,20 +481,30 @@ class RaftWeights(_WeightTable):
         self.finish()
 
 
-def raft_update(w: RaftWeights, net: Tensor, inp: Tensor, pyramid: Sequence[Tensor], iters: int = 20) -> Tensor:
-    """net/inp [n, 128, H8, W8] fp32 (tanh / relu applied), pyramid: 4 fp32 levels [n*H8*W8, 1, h, w] -> flow_up [n, 2, 8H8, 8W8]."""
-    _need_cuda(net, inp, *pyramid)
-    net, inp = net.contiguous().float(), inp.contiguous().float()
-    n, _, H8, W8 = net.shape
+def raft_update(w: RaftWeights, net: Optional[Tensor], inp: Optional[Tensor], pyramid: Sequence[Tensor], iters: int = 20,
+                cnet_nhwc: Optional[Tensor] = None, hw: Optional[Tuple[int, int]] = None) -> Tensor:
+    """net/inp [n, 128, H8, W8] fp32 (tanh / relu applied) -- or ``cnet_nhwc`` [n, H8*W8, 256], the context encoder's
+    pixel-major output, with ``hw=(H8, W8)`` (tanh / relu are then applied inside); pyramid: 4 levels
+    [n*H8*W8, 1, h, w] fp32 or fp16 -> flow_up [n, 2, 8H8, 8W8]."""
+    if cnet_nhwc is not None:
+        _need_cuda(cnet_nhwc, *pyramid)
+        cnet_nhwc = cnet_nhwc.contiguous().float()
+        n, (H8, W8) = cnet_nhwc.shape[0], hw
+    else:
+        _need_cuda(net, inp, *pyramid)
+        net, inp = net.contiguous().float(), inp.contiguous().float()
+        n, _, H8, W8 = net.shape
     if len(pyramid) != 4:
         raise ValueError("raft_update: the correlation pyramid has 4 levels")
     half = all(t.dtype == torch.float16 for t in pyramid)
     lv = [t.contiguous() if half else t.contiguous().float() for t in pyramid]
-    out = torch.empty(n, 2, 8 * H8, 8 * W8, dtype=torch.float32, device=net.device)
-    a = L.RaftUpdateArgs(n, H8, W8, iters, net.data_ptr(), inp.data_ptr(), (C.c_void_p * 4)(*[t.data_ptr() for t in lv]),
-                         C.cast(w.array, C.POINTER(C.c_void_p)), out.data_ptr(), None, 0, 1 if half else 0)
+    dev = lv[0].device
+    out = torch.empty(n, 2, 8 * H8, 8 * W8, dtype=torch.float32, device=dev)
+    a = L.RaftUpdateArgs(n, H8, W8, iters, None if net is None else net.data_ptr(), None if inp is None else inp.data_ptr(),
+                         (C.c_void_p * 4)(*[t.data_ptr() for t in lv]), C.cast(w.array, C.POINTER(C.c_void_p)), out.data_ptr(), None, 0,
+                         1 if half else 0, None if cnet_nhwc is None else cnet_nhwc.data_ptr())
     need = L.lib().vtgb_raft_update_workspace_bytes(C.byref(a))
-    ws = _ws.get(need, net.device)
+    ws = _ws.get(need, dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     L.check(L.lib().vtgb_raft_update(C.byref(a), _stream()))
     return out
