@@ -53,6 +53,29 @@ def test_argument_validation_without_gpu(lib):
     assert L.vtgb_vit_patch_kpad(lib.BF16, 14) == 640 and L.vtgb_vit_patch_kpad(lib.F32, 14) == 588
 
 
+def test_argument_validation_of_the_wider_rows(lib):
+    """RAFT, preprocessing, training-loss and pyramid entry points reject bad arguments on the host (no GPU needed)."""
+    L = lib.lib()
+    EINVAL, EWS = -1, -2
+    assert C.sizeof(lib.RaftUpdateArgs) == 4 * 4 + 2 * 8 + 4 * 8 + 4 * 8 + 8 + 8                       # incl. corr_f16 (+pad) and cnet_nhwc
+    r = lib.RaftUpdateArgs(0, 28, 28, 20, None, None, (C.c_void_p * 4)(), None, None, None, 0, 1, None)
+    assert L.vtgb_raft_update_workspace_bytes(C.byref(r)) == 0 and b"bad dims" in L.vtgb_last_error()
+    r.n_pairs = 95
+    need = L.vtgb_raft_update_workspace_bytes(C.byref(r))
+    assert 0.4e9 < need < 1.2e9                                                                        # ~7 KB per coarse pixel
+    assert L.vtgb_raft_update(C.byref(r), None) == EWS
+    e = lib.RaftEncoderArgs(4, 60, 224, 0, None, None, None, None, 0)
+    assert L.vtgb_raft_encoder_workspace_bytes(C.byref(e)) == 0 and b"bad dims" in L.vtgb_last_error()
+    pp = lib.PreprocessArgs(None, None, None, 4, 240, 320, 4, 224, (C.c_float * 3)(0, 0, 0), (C.c_float * 3)(1, 1, 1))
+    assert L.vtgb_preprocess_frames(C.byref(pp), None) == EINVAL and b"NULL" in L.vtgb_last_error()
+    ct = lib.ConcatTextIoArgs(None, None, None, None, None, None, None, None, 0, 2, 8, 4, 32)
+    assert L.vtgb_concat_text_io(C.byref(ct), None) == EINVAL
+    ce = lib.ShiftedCeArgs(lib.BF16, 2, 1, 32000, None, None, None, None, None, None, None)
+    assert L.vtgb_shifted_ce_forward(C.byref(ce), None) == EINVAL and L.vtgb_shifted_ce_backward(C.byref(ce), None) == EINVAL
+    cp = lib.RaftCorrPyramidArgs(None, (C.c_void_p * 4)(), 10, 28, 28, 1 / 16.0, 0)
+    assert L.vtgb_raft_corr_pyramid(C.byref(cp), None) == EINVAL
+
+
 def test_product_path_has_no_cpu_fallback(lib):
     import torch
     from videotgb_amd import ops
