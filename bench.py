@@ -68,13 +68,9 @@ def parse():
     ap.add_argument("--llm", default="vicuna-7b")
     ap.add_argument("--decode", choices=["graph", "hf"], default="graph",
                     help="graph: videotgb_amd.decode.GreedyDecoder (one hipGraph replay per token); hf: HF generate, eager")
-    ap.add_argument("--raft-dtype", choices=["fp32", "bf16"], default="fp32",
-                    help="precision of the RAFT convolutions in --flow raft mode (reference: fp32; bf16 keeps coords/correlation in fp32)")
-    ap.add_argument("--raft-channels-last", action="store_true", help="NHWC activations for the MIOpen encoder convolutions of RAFT")
-    ap.add_argument("--raft-encoders", choices=["hip", "torch"], default="hip",
-                    help="RAFT fnet/cnet: libvtgb.so (bf16 MFMA implicit-GEMM convolutions, fnet once per distinct frame) or MIOpen")
-    ap.add_argument("--raft-update", choices=["hip", "torch"], default="hip",
-                    help="RAFT refinement loop: libvtgb.so (bf16 MFMA implicit-GEMM convolutions) or PyTorch-ROCm/MIOpen ops")
+    ap.add_argument("--raft-dtype", choices=["bf16", "f32"], default="bf16",
+                    help="arithmetic of RAFT in --flow raft mode: bf16 MFMA implicit-GEMM convolutions (default) or the fp32 exactness "
+                         "mode (the reference's arithmetic; fp32 FMAs)")
     ap.add_argument("--raft-clips", type=int, default=31,
                     help="clips per RAFT call (pairs of that many clips form one batch; 31 clips = 249 ViT m-tiles / 9020 RAFT m-tiles: "
                          "few idle CUs in the last round of 256-row tiles)")
@@ -215,18 +211,10 @@ def main():
     dev = torch.device("cuda", local)
     from videotgb_amd import _lib, llm, models, synth
     _lib.lib()
-    if args.flow == "raft" and not (args.raft_encoders == "hip" and args.raft_update == "hip"):
-        # RAFT (partly) on MIOpen: let it search its solvers once, in the warm-up
-        # (without this several RAFT convolutions fall back to MIOpen's naive kernel, 45 % of the stage)
-        torch.backends.cudnn.benchmark = True
     cfg = synth.full_cfg("instructblip")
     t_setup = time.time()
     lm = llm.build_llama(args.llm, torch.bfloat16, dev, seed=0)
-    m = models.LSTP(cfg, dev, language_model=lm, compute_dtype="bf16",
-                    raft_dtype=torch.bfloat16 if args.raft_dtype == "bf16" else torch.float32,
-                    raft_hip_update=(args.raft_update == "hip"))
-    m.of_extractor.channels_last = args.raft_channels_last
-    m.of_extractor.hip_encoders = (args.raft_encoders == "hip" and args.raft_update == "hip")
+    m = models.LSTP(cfg, dev, language_model=lm, compute_dtype="bf16", raft_dtype=args.raft_dtype)
     m.flow_clips_per_call = args.raft_clips
     sd = synth.path_state_dict(cfg, seed=0, with_raft=True)
     m.load_state_dict(sd, strict=False)
@@ -335,9 +323,8 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"InstructBLIP-Vicuna-7B + TGB, T={T}->{nframe} of 32 frames, 224x224, greedy {args.max_new_tokens} new tokens "
                                       f"(BASELINE.json configs[2])", "flow": args.flow if args.flow == "precomputed" else (
-                              f"raft inline, all HIP (bf16 MFMA convolutions, fp32 state / accumulation), {args.raft_clips} clips per RAFT batch"
-                              if (args.raft_update == "hip" and args.raft_encoders == "hip") else
-                              f"raft inline (update={args.raft_update}, encoders={args.raft_encoders if args.raft_update == 'hip' else 'torch'}/{args.raft_dtype})"),
+                              f"raft inline, all HIP ({'bf16 MFMA convolutions, fp32 state / accumulation' if args.raft_dtype == 'bf16' else 'fp32 exactness mode'}), "
+                              f"{args.raft_clips} clips per RAFT batch"),
                           "clips_per_gpu_per_step": B,
                           "global_batch": B * world, "parallelism": f"clip-parallel x{world} (no data-path collective)",
                           "llm": f"HF LlamaForCausalLM {args.llm} geometry, random init, KV cache, decode={args.decode}",

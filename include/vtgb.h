@@ -31,7 +31,7 @@ extern "C" {
 
 typedef struct ihipStream_t* vtgb_stream_t; /* == hipStream_t */
 
-#define VTGB_VERSION 100
+#define VTGB_VERSION 200
 
 #define VTGB_OK 0
 #define VTGB_EINVAL (-1)       /* bad argument (NULL pointer, unsupported size, bad mode) */
@@ -313,27 +313,33 @@ typedef struct {
 } vtgb_layernorm_args;
 int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream);
 
-/* ---- a2 / f1: RAFT recurrent update ---------------------------------------------------------
- * Replaces the refinement loop of RAFT.forward, src/models/components/xraft.py:135-156: per iteration
- * CorrBlock.__call__ (raft_utils/corr.py:29-50; the reference's optional `alt_cuda_corr`, corr.py:63-91,
- * is the CUDA counterpart of the lookup kernel), BasicUpdateBlock (raft_utils/update.py:123-144:
- * BasicMotionEncoder :75-97, SepConvGRU :39-65, FlowHead :6-18), then the mask head and upsample_flow
- * (xraft.py:88-99) of the last iteration.  The two encoders and the all-pairs correlation stay with the
- * caller.  Convolutions are bf16 MFMA implicit GEMMs with fp32 accumulation; hidden state, flow and the
- * correlation pyramid stay fp32 (a reduced-precision mode: the reference runs RAFT in fp32).
- * weights (host array of device pointers; conv weights bf16 packed [C_out, C_in/64, KH, KW, 64]: K runs 64-channel
- * chunk major, tap minor -- written [C_out, KH,KW,C_in] below for the shapes only):
+/* ---- a2 / f1: RAFT (src/models/components/xraft.py:102-156) --------------------------------------
+ * Three entry points cover RAFT.forward: vtgb_raft_encoder (fnet / cnet), vtgb_raft_corr (CorrBlock.__init__) and
+ * vtgb_raft_update (the refinement loop, mask head and convex upsample).  `dtype` selects the arithmetic of all
+ * three: VTGB_BF16 = bf16 MFMA implicit-GEMM convolutions over NHWC bf16 activations, fp32 accumulation, fp32
+ * hidden state / flow / norms, IEEE-half correlation pyramid (a reduced-precision mode the reference does not have);
+ * VTGB_F32 = fp32 operands and FMAs everywhere, k summed in order -- the exactness mode, which is how the reference
+ * runs RAFT (xraft.py:118-119).  Convolution weights are packed [C_out, K] in `dtype` with K running 64-channel chunk
+ * major, tap minor, channel-in-chunk innermost (written [C_out, KH,KW,C_in] below for the shapes only).
+ *
+ * vtgb_raft_update replaces the refinement loop xraft.py:135-156: per iteration CorrBlock.__call__
+ * (raft_utils/corr.py:29-50; the reference's optional `alt_cuda_corr`, corr.py:63-91, is the CUDA counterpart of the
+ * lookup kernel), BasicUpdateBlock (raft_utils/update.py:123-144: BasicMotionEncoder :75-97, SepConvGRU :39-65,
+ * FlowHead :6-18), then the mask head and upsample_flow (xraft.py:88-99) of the last iteration.
+ * weights (host array of device pointers):
  *   [0] encoder.convc1.weight [256, 384] (324 input channels zero-padded to 384) [1] .bias
- *   [2] encoder.convc2.weight [192, 3,3,256] [3] .bias   [4] encoder.convf1.weight bf16 [128, 56 taps, {x,y,x,y}] (49 taps zero-padded) [5] .bias
+ *   [2] encoder.convc2.weight [192, 3,3,256] [3] .bias
+ *   [4] encoder.convf1.weight -- VTGB_BF16: bf16 [128, 56 taps, {x,y,x,y}] (49 taps zero-padded; the flow enters as a
+ *       bf16 head + bf16 remainder); VTGB_F32: fp32 [98, 128] (k = c*49 + ky*7 + kx, output channel minor)   [5] .bias
  *   [6] encoder.convf2.weight [64, 3,3,128]  [7] .bias   [8] encoder.conv.weight [126, 3,3,256]     [9] .bias
  *   [10] gru.convz1|convr1.weight [256, 1,5,384] [11] bias [256]  [12] gru.convq1.weight [128, 1,5,384] [13] .bias
  *   [14] gru.convz2|convr2.weight [256, 5,1,384] [15] bias [256]  [16] gru.convq2.weight [128, 5,1,384] [17] .bias
- *   [18] flow_head.conv1.weight [256, 3,3,128] [19] .bias  [20] flow_head.conv2.weight bf16 [32, 256], row tap*2+o (18 rows zero-padded) [21] .bias
+ *   [18] flow_head.conv1.weight [256, 3,3,128] [19] .bias  [20] flow_head.conv2.weight [32, 256], row tap*2+o (18 rows zero-padded) [21] .bias
  *   [22] mask.0.weight [256, 3,3,128] [23] .bias           [24] mask.2.weight [576, 256] [25] .bias
  * Biases fp32.  GRU input channels are [h(128) | inp(128) | motion(126) | flow(2)] as in the reference. */
 #define VTGB_RAFT_NW 26
 typedef struct {
-    int32_t n_pairs, H8, W8, iters;
+    int32_t dtype, n_pairs, H8, W8, iters;
     const float* net;           /* [n_pairs, 128, H8, W8] tanh(cnet[:, :128])   (xraft.py:126-127) */
     const float* inp;           /* [n_pairs, 128, H8, W8] relu(cnet[:, 128:])                      */
     const void* corr[4];        /* pyramid level l: [n_pairs*H8*W8, H8>>l, W8>>l] (corr.py:19-27), fp32 or fp16 (corr_f16) */
@@ -341,40 +347,47 @@ typedef struct {
     float* flow_up;             /* [n_pairs, 2, 8*H8, 8*W8]                                        */
     void* workspace;
     size_t workspace_bytes;
-    int32_t corr_f16;           /* 0: fp32 pyramid; 1: IEEE half (vtgb_raft_corr_pyramid), half the lookup's HBM reads */
+    int32_t corr_f16;           /* 0: fp32 pyramid; 1: IEEE half (what vtgb_raft_corr writes in VTGB_BF16 mode)  */
     const float* cnet_nhwc;     /* optional: the context encoder's raw output [n_pairs*H8*W8, 256] (vtgb_raft_encoder layout);
                                    net = tanh(first 128), inp = relu(last 128) are then taken from it and net/inp may be NULL */
+    const float* flow_init;     /* optional [n_pairs, 2, H8, W8]: coords1 = coords0 + flow_init (xraft.py:131-132)    */
 } vtgb_raft_update_args;
 size_t vtgb_raft_update_workspace_bytes(const vtgb_raft_update_args* a);
 int vtgb_raft_update(const vtgb_raft_update_args* a, vtgb_stream_t stream);
 
-/* CorrBlock.__init__ after the all-pairs matmul (raft_utils/corr.py:17-27, :52-60): corr / sqrt(dim), then three
- * avg_pool2d(2, stride 2), in ONE pass over the fp32 correlation volume; the four levels are written as IEEE half
- * (values are O(1..100): 11 significant bits against the bf16 features they feed). */
+/* CorrBlock.__init__ (raft_utils/corr.py:12-27; the all-pairs product :52-60): for every pair the correlation of each
+ * pixel of image 1 with every pixel of image 2 over the `dim` = 256 features, divided by sqrt(dim), and its three
+ * avg_pool2d(2, stride 2) -- one kernel, the four levels are its only output.  Pair n uses the feature maps of images
+ * (n / pairs_per_clip) * frames_per_clip + n % pairs_per_clip + {first_off, second_off}: consecutive frames of whole
+ * clips are (T-1, T, 0, 1); separate image1 / image2 batches of N encoded as cat([image1, image2]) are (N, N, 0, N).
+ * VTGB_BF16: half-precision MFMA on an fp16 copy of the features (made in the workspace), fp32 accumulate and scale,
+ * levels IEEE half; VTGB_F32: fp32 FMAs, levels fp32. */
 typedef struct {
-    const void* corr;           /* [n_maps, H8, W8] fp32 (or IEEE half if corr_in_f16): <fmap1[p], fmap2[q]> for every pixel p */
-    void* levels[4];            /* level l: [n_maps, H8>>l, W8>>l] fp16                                            */
-    int64_t n_maps;
-    int32_t H8, W8;
+    int32_t dtype, n_pairs, H8, W8, dim;
+    int32_t pairs_per_clip, frames_per_clip, first_off, second_off, n_images;
     float scale;                /* 1 / sqrt(dim) = 1/16                                                            */
-    int32_t corr_in_f16;        /* the volume comes from a half-precision GEMM (fp32 accumulation, half output)    */
-} vtgb_raft_corr_pyramid_args;
-int vtgb_raft_corr_pyramid(const vtgb_raft_corr_pyramid_args* a, vtgb_stream_t stream);
+    const float* fmap;          /* [n_images, H8*W8, dim] fp32 (vtgb_raft_encoder output)                           */
+    void* levels[4];            /* level l: [n_pairs*H8*W8, H8>>l, W8>>l] half (VTGB_BF16) or fp32 (VTGB_F32)       */
+    void* workspace;
+    size_t workspace_bytes;
+} vtgb_raft_corr_args;
+size_t vtgb_raft_corr_workspace_bytes(const vtgb_raft_corr_args* a);
+int vtgb_raft_corr(const vtgb_raft_corr_args* a, vtgb_stream_t stream);
 
 /* RAFT BasicEncoder (raft_utils/extractor.py:116-189): stem 7x7/2, six ResidualBlocks, 1x1 head; the input
  * scaling 2*(x/255)-1 of RAFT.forward (xraft.py:105-106) is applied inside.  norm = 0: InstanceNorm2d (fnet);
  * norm = 1: the caller has folded the eval-mode BatchNorm2d that follows every convolution into the packed
  * weights and biases (cnet).  Output: NHWC features [n_images * H/8 * W/8, 256] fp32.
- * weights: [0] conv1.weight bf16 [64, 4 (tY), 64]: the stem as a 4x1 convolution over the 2x2 space-to-depth
+ * weights (`dtype`): [0] conv1.weight [64, 4 (tY), 64]: the stem as a 4x1 convolution over the 2x2 space-to-depth
  *   image, channel = dX*12 + py*6 + px*3 + c (48, zero-padded to 64), ky = 2 tY + py - 1, kx = 2 dX + px - 1,
- *   scaled by 2/255 (raw 0..255 pixels enter the GEMM) [1] conv1.bias - 127.5 * sum(packed weights); per block b (layer1.0, 1.1, 2.0, 2.1, 3.0, 3.1) at
- *   2 + 6 b: conv1.weight bf16 [C, 3,3,Cin_pad] , conv1.bias, conv2.weight [C, 3,3,C_pad], conv2.bias,
+ *   scaled by 2/255 (raw pixels enter the GEMM) [1] conv1.bias - 127.5 * sum(packed weights); per block b (layer1.0, 1.1, 2.0, 2.1, 3.0, 3.1) at
+ *   2 + 6 b: conv1.weight [C, 3,3,Cin_pad] , conv1.bias, conv2.weight [C, 3,3,C_pad], conv2.bias,
  *   downsample.0.weight [C, Cin_pad] or NULL, downsample.0.bias or NULL  (96-channel stages: C_pad = 128, zero-filled; with norm = 1 the
- *   OUTPUT rows and biases of those stages are padded to C_pad as well: the GEMM stores bf16 activations directly);
- *   [38] conv2.weight bf16 [256, 128] [39] conv2.bias */
+ *   OUTPUT rows and biases of those stages are padded to C_pad as well: the GEMM stores the activations directly);
+ *   [38] conv2.weight [256, 128] [39] conv2.bias */
 #define VTGB_RAFT_ENC_NW 40
 typedef struct {
-    int32_t n_images, H, W, norm;
+    int32_t dtype, n_images, H, W, norm;
     const float* images;        /* [n_images, 3, H, W] fp32 */
     const void* const* weights; /* host array              */
     float* out;                 /* [n_images * H/8 * W/8, 256] fp32 */

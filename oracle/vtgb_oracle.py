@@ -511,7 +511,7 @@ def _raft_update(sd: SD, p: str, net: Tensor, inp: Tensor, corr: Tensor, flow: T
     return net, mask, delta
 
 
-def raft_forward(sd: SD, p: str, image1: Tensor, image2: Tensor, iters: int = 20) -> Tensor:
+def raft_forward(sd: SD, p: str, image1: Tensor, image2: Tensor, iters: int = 20, flow_init: Optional[Tensor] = None) -> Tensor:
     """RAFT.forward xraft.py:102-156, test_mode=True -> last flow_up [B, 2, H, W].
     Only the last iteration's upsample is materialised (earlier ones are discarded by
     the reference, :154-156)."""
@@ -527,6 +527,8 @@ def raft_forward(sd: SD, p: str, image1: Tensor, image2: Tensor, iters: int = 20
     ys, xs = torch.meshgrid(torch.arange(h // 8), torch.arange(w // 8), indexing="ij")
     coords0 = torch.stack([xs, ys], dim=0).float()[None].repeat(n, 1, 1, 1)   # coords_grid utils.py:75-78
     coords1 = coords0.clone()
+    if flow_init is not None:                                                   # xraft.py:131-132
+        coords1 = coords1 + flow_init
     mask = None
     for it in range(iters):
         corr = raft_corr_lookup(pyr, coords1)

@@ -25,7 +25,7 @@ def test_exports_match_header(lib):
     L = lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.vtgb_version() == 100
+    assert L.vtgb_version() == 200
 
 
 def test_struct_sizes_follow_header(lib):
@@ -57,23 +57,34 @@ def test_argument_validation_of_the_wider_rows(lib):
     """RAFT, preprocessing, training-loss and pyramid entry points reject bad arguments on the host (no GPU needed)."""
     L = lib.lib()
     EINVAL, EWS = -1, -2
-    assert C.sizeof(lib.RaftUpdateArgs) == 4 * 4 + 2 * 8 + 4 * 8 + 4 * 8 + 8 + 8                       # incl. corr_f16 (+pad) and cnet_nhwc
-    r = lib.RaftUpdateArgs(0, 28, 28, 20, None, None, (C.c_void_p * 4)(), None, None, None, 0, 1, None)
+    assert C.sizeof(lib.RaftUpdateArgs) == 5 * 4 + 4 + 2 * 8 + 4 * 8 + 4 * 8 + 8 + 8 + 8                # dtype first; corr_f16 (+pad), cnet_nhwc, flow_init
+    r = lib.RaftUpdateArgs(lib.BF16, 0, 28, 28, 20, None, None, (C.c_void_p * 4)(), None, None, None, 0, 1, None, None)
     assert L.vtgb_raft_update_workspace_bytes(C.byref(r)) == 0 and b"bad dims" in L.vtgb_last_error()
     r.n_pairs = 95
     need = L.vtgb_raft_update_workspace_bytes(C.byref(r))
     assert 0.4e9 < need < 1.2e9                                                                        # ~7 KB per coarse pixel
     assert L.vtgb_raft_update(C.byref(r), None) == EWS
-    e = lib.RaftEncoderArgs(4, 60, 224, 0, None, None, None, None, 0)
+    r.dtype = 7
+    assert L.vtgb_raft_update_workspace_bytes(C.byref(r)) == 0 and b"bad dtype" in L.vtgb_last_error()
+    r.dtype = lib.F32                                                                                  # exactness mode: fp32 activations
+    assert need < L.vtgb_raft_update_workspace_bytes(C.byref(r)) < 2 * need
+    e = lib.RaftEncoderArgs(lib.BF16, 4, 60, 224, 0, None, None, None, None, 0)
     assert L.vtgb_raft_encoder_workspace_bytes(C.byref(e)) == 0 and b"bad dims" in L.vtgb_last_error()
+    e = lib.RaftEncoderArgs(lib.F32, 4, 224, 224, 0, None, None, None, None, 0)
+    assert L.vtgb_raft_encoder_workspace_bytes(C.byref(e)) > 0 and L.vtgb_raft_encoder(C.byref(e), None) == EWS
     pp = lib.PreprocessArgs(None, None, None, 4, 240, 320, 4, 224, (C.c_float * 3)(0, 0, 0), (C.c_float * 3)(1, 1, 1))
     assert L.vtgb_preprocess_frames(C.byref(pp), None) == EINVAL and b"NULL" in L.vtgb_last_error()
     ct = lib.ConcatTextIoArgs(None, None, None, None, None, None, None, None, 0, 2, 8, 4, 32)
     assert L.vtgb_concat_text_io(C.byref(ct), None) == EINVAL
     ce = lib.ShiftedCeArgs(lib.BF16, 2, 1, 32000, None, None, None, None, None, None, None)
     assert L.vtgb_shifted_ce_forward(C.byref(ce), None) == EINVAL and L.vtgb_shifted_ce_backward(C.byref(ce), None) == EINVAL
-    cp = lib.RaftCorrPyramidArgs(None, (C.c_void_p * 4)(), 10, 28, 28, 1 / 16.0, 0)
-    assert L.vtgb_raft_corr_pyramid(C.byref(cp), None) == EINVAL
+    cp = lib.RaftCorrArgs(lib.BF16, 95, 28, 28, 256, 95, 96, 0, 1, 96, 1 / 16.0, None, (C.c_void_p * 4)(), None, 0)
+    assert L.vtgb_raft_corr_workspace_bytes(C.byref(cp)) == 96 * 784 * 256 * 2                          # the fp16 copy of the feature maps
+    assert L.vtgb_raft_corr(C.byref(cp), None) == EINVAL and b"NULL" in L.vtgb_last_error()
+    cp.n_images = 95                                                                                   # the last pair would read image 95
+    assert L.vtgb_raft_corr_workspace_bytes(C.byref(cp)) == 0 and b"pair -> image map" in L.vtgb_last_error()
+    cp.n_images, cp.dim = 96, 128
+    assert L.vtgb_raft_corr(C.byref(cp), None) == EINVAL and b"bad dims" in L.vtgb_last_error()
 
 
 def test_product_path_has_no_cpu_fallback(lib):

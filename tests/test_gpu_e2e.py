@@ -1,8 +1,9 @@
 """-m gpu: the whole path (LSTP.generate / LSTP_blip2.generate twins) against the vectors
-recorded from the reference's own generate() on a tiny configuration, RAFT inline, noise
-injected.  fp32 mode: frame indices and greedy token ids bit-exact, tensors to 1e-3 of their
-scale (RAFT runs 20 recurrent iterations through MIOpen on the GPU vs. the CPU reference);
-bf16 mode: indices equal, tensors to the bf16 tolerance of test_gpu_stages.py."""
+recorded from the reference's own generate() on a tiny configuration, RAFT inline (in libvtgb.so,
+like every other stage), noise injected; HF generate and the hipGraph decoder of the bench both run.
+fp32 mode: frame indices and greedy token ids bit-exact, tensors to 2e-4 of their scale (summation
+order only; RAFT runs 20 recurrent iterations); bf16 mode: indices equal, tensors to the stated
+bf16 tolerances."""
 import pytest
 import torch
 
@@ -41,7 +42,9 @@ class BE(dict):
 
 @pytest.mark.parametrize("arch", ["instructblip", "blip2"])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_generate_vs_reference(dev, tiny_sd, arch, dtype):
+@pytest.mark.parametrize("fast_decode", [False, True])
+def test_generate_vs_reference(dev, tiny_sd, arch, dtype, fast_decode):
+    """fast_decode=True + bf16 is the configuration bench.py times (all-HIP RAFT, graph-replayed greedy decode)."""
     m, cfg = build(arch, tiny_sd, dev, dtype)
     g = load_golden(f"tiny_{arch}_e2e")
     te = BE(input_ids=g["prompt_ids"].to(dev), attention_mask=g["prompt_mask"].to(dev))
@@ -51,15 +54,18 @@ def test_generate_vs_reference(dev, tiny_sd, arch, dtype):
     se = BE(input_ids=g["sampler_ids"].to(dev), attention_mask=g["sampler_mask"].to(dev))
     ids, cand, st = m.generate(deq(g, "frames_q8").to(dev), deq(g, "flow_frames_q8").to(dev), int(g["nframe"]), te, se,
                                do_sample=False, temperature=None, max_new_tokens=6, use_cache=False, noise=g["noise"].to(dev),
-                               return_stages=True)
+                               return_stages=True, fast_decode=fast_decode)
 
-    def chk(name, got, ref, tol):
+    def chk(name, got, ref, tol, rms_tol=None):
         got, ref = got.float().cpu(), ref.float()
         err, scale = (got - ref).abs().max().item(), ref.abs().max().item()
-        print(f"[e2e {arch} {dtype}] {name}: max|diff|={err:.3e} max|ref|={scale:.3e}")
+        rms = float((got - ref).double().pow(2).mean().sqrt() / ref.double().pow(2).mean().sqrt())
+        print(f"[e2e {arch} {dtype}] {name}: max|diff|={err:.3e} rel_rms={rms:.3e} max|ref|={scale:.3e}")
         assert err <= tol * scale, name
-    tol = 1e-3 if dtype == "f32" else 6e-2
-    chk("raft flow", st["of"][0, :-1], g["raft_flow"], 1e-3)
+        assert rms_tol is None or rms <= rms_tol, name
+    tol = 2e-4 if dtype == "f32" else 6e-2
+    # bf16 RAFT (a mode the reference does not have): 20 recurrent iterations of bf16 convolutions; observed rel-RMS 6e-3
+    chk("raft flow", st["of"][0, :-1], g["raft_flow"], 2e-4 if dtype == "f32" else 6e-2, None if dtype == "f32" else 1.5e-2)
     assert torch.equal(st["of"][0, -1], st["of"][0, -2])            # last flow repeated (eval/utils/model.py:82)
     chk("tgb logits", st["tgb_logits"], g["tgb_logits"], tol)
     assert cand.cpu().tolist() == g["cand_index"].tolist()

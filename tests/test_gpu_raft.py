@@ -1,7 +1,12 @@
-"""-m gpu: the HIP RAFT update block (bf16 MFMA implicit-GEMM convolutions, row f1) against the fp32 oracle
-and the vectors recorded from the reference RAFT.  Tolerance: this is a reduced-precision mode (the
-reference runs RAFT in fp32) iterated 5 / 20 times -> relative RMS error of the final flow <= 1e-2 (observed 2.6e-3);
-the fp32 PyTorch-ROCm path (hip_update=False) is held to 1e-3."""
+"""-m gpu: RAFT in libvtgb.so (encoders, all-pairs correlation + pyramid, refinement loop, convex upsample; row a2 / f1)
+against the vectors recorded from the reference RAFT and against the fp32 oracle, in both arithmetic modes.
+
+Tolerances (relative RMS error of the compared tensor):
+  VTGB_F32  (the reference's arithmetic, fp32 FMAs): flow after 5 / 20 iterations <= 1e-4 (observed ~1e-6: summation
+            order only, through 20 recurrent iterations); encoders <= 1e-5; correlation levels <= 1e-5 of the level's max.
+  VTGB_BF16 (bf16 MFMA convolutions, half-precision correlation -- a mode the reference does not have): final flow
+            <= 1e-2 (observed 2.6e-3 ... 3.6e-3), one iteration <= 2e-2, encoders <= 2e-2, correlation levels within
+            half-precision rounding of inputs and outputs."""
 import pytest
 import torch
 
@@ -23,43 +28,73 @@ def rel_rms(a, b):
     return float(((a.double() - b.double()).pow(2).mean().sqrt()) / b.double().pow(2).mean().sqrt())
 
 
-def make(dev, tiny_sd, hip):
+def make(dev, tiny_sd, dtype):
     from videotgb_amd import models
     sd = {k[len("of_extractor."):]: v for k, v in tiny_sd["instructblip"][1].items() if k.startswith("of_extractor.")}
-    r = models.Raft(torch.float32, hip_update=hip)
+    r = models.Raft(dtype)
     r.load_state_dict(sd, strict=True)
     return r.to(dev)
 
 
+FLOW_TOL = {"f32": 1e-4, "bf16": 1e-2}
+ENC_TOL = {"f32": 1e-5, "bf16": 2e-2}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("iters", [5, 20])
-def test_raft_update_vs_reference(dev, tiny_sd, iters):
+def test_raft_pairs_vs_reference(dev, tiny_sd, dtype, iters):
+    """of_extractor(image1, image2) -- the reference-shaped entry (xraft.py:102) -- vs the reference's flows."""
     g = load_golden("tiny_raft")
     fr = deq(g, "frames_q8").to(dev)
     ref = g[f"flow_iters{iters}"]
-    fp32 = make(dev, tiny_sd, False)(fr[:-1], fr[1:], iters=iters).cpu()
-    hip = make(dev, tiny_sd, True)(fr[:-1], fr[1:], iters=iters).cpu()
-    e32, ehip = rel_rms(fp32, ref), rel_rms(hip, ref)
-    print(f"[raft iters={iters}] rel_rms torch-fp32={e32:.3e} hip-bf16={ehip:.3e} max|ref|={ref.abs().max():.3e}")
-    assert e32 <= 1e-3
-    assert ehip <= 1e-2
+    got = make(dev, tiny_sd, dtype)(fr[:-1], fr[1:], iters=iters).cpu()
+    e = rel_rms(got, ref)
+    print(f"[raft {dtype} iters={iters}] rel_rms={e:.3e} max|diff|={(got - ref).abs().max():.3e} max|ref|={ref.abs().max():.3e}")
+    assert e <= FLOW_TOL[dtype]
 
 
-def test_raft_update_single_iteration_pieces(dev, tiny_sd):
-    """One iteration isolates the kernels from the recurrence: flow after 1 step vs the oracle."""
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_raft_clip_path_vs_reference(dev, tiny_sd, dtype):
+    """forward_clips (what LSTP.flow uses): fnet once per distinct frame; same flows as the pair entry."""
+    g = load_golden("tiny_raft")
+    fr = deq(g, "frames_q8").to(dev)
+    r = make(dev, tiny_sd, dtype)
+    flow = r.forward_clips(fr[None], iters=20)[0].cpu()          # [2, 2, 128, 128]
+    e = rel_rms(flow, g["flow_iters20"])
+    print(f"[raft clips {dtype}] rel_rms={e:.3e}")
+    assert e <= FLOW_TOL[dtype]
+    if dtype == "f32":   # encoding each frame once is the same arithmetic as encoding cat(image1, image2)
+        pair = r(fr[:-1], fr[1:], iters=20).cpu()
+        assert (pair - flow).abs().max() <= 1e-5 * flow.abs().max()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_raft_single_iteration_and_flow_init(dev, tiny_sd, dtype):
+    """One iteration isolates the kernels from the recurrence; flow_init = coords1 - coords0 offset (xraft.py:131-132)."""
     from oracle import vtgb_oracle as O
     g = load_golden("tiny_raft")
     fr = deq(g, "frames_q8")
     sd = tiny_sd["instructblip"][1]
+    r = make(dev, tiny_sd, dtype)
     ref = O.raft_forward(sd, "of_extractor.", fr[:-1], fr[1:], iters=1)
-    hip = make(dev, tiny_sd, True)(fr[:-1].to(dev), fr[1:].to(dev), iters=1).cpu()
-    e = rel_rms(hip, ref)
-    print(f"[raft 1 iteration] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
-    assert e <= 2e-2
+    got = r(fr[:-1].to(dev), fr[1:].to(dev), iters=1).cpu()
+    e = rel_rms(got, ref)
+    print(f"[raft {dtype} 1 iteration] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
+    assert e <= (1e-5 if dtype == "f32" else 2e-2)
+    fi = torch.randn(2, 2, 16, 16, generator=torch.Generator().manual_seed(3)) * 0.5
+    ref = O.raft_forward(sd, "of_extractor.", fr[:-1], fr[1:], iters=2, flow_init=fi)
+    got = r(fr[:-1].to(dev), fr[1:].to(dev), iters=2, flow_init=fi.to(dev)).cpu()
+    e = rel_rms(got, ref)
+    print(f"[raft {dtype} flow_init] rel_rms={e:.3e}")
+    assert e <= (1e-5 if dtype == "f32" else 2e-2)
+    with pytest.raises(NotImplementedError):
+        r(fr[:-1].to(dev), fr[1:].to(dev), test_mode=False)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("net,kind", [("fnet.", "instance"), ("cnet.", "batch")])
-def test_raft_encoder_vs_oracle(dev, tiny_sd, net, kind):
-    """BasicEncoder in HIP (bf16 MFMA implicit-GEMM convs, fp32 norms) vs the fp32 oracle."""
+def test_raft_encoder_vs_oracle(dev, tiny_sd, net, kind, dtype):
+    """BasicEncoder in HIP vs the fp32 oracle."""
     from oracle import vtgb_oracle as O
     from videotgb_amd import ops
     sd = tiny_sd["instructblip"][1]
@@ -67,16 +102,17 @@ def test_raft_encoder_vs_oracle(dev, tiny_sd, net, kind):
     fr = deq(g, "frames_q8")                                   # [3, 3, 128, 128]
     ref = O.raft_encoder(sd, "of_extractor." + net, 2 * (fr / 255.0) - 1.0, kind)       # [3, 256, 16, 16]
     rsd = {k[len("of_extractor."):]: v.to(dev) for k, v in sd.items() if k.startswith("of_extractor.")}
-    w = ops.RaftEncoderWeights(rsd, net, kind == "batch")
+    w = ops.RaftEncoderWeights(rsd, net, kind == "batch", ops.dtype_code(dtype))
     out = ops.raft_encoder(w, fr.to(dev)).cpu().view(3, 16, 16, 256).permute(0, 3, 1, 2)
     e = rel_rms(out, ref)
-    print(f"[raft encoder {net}] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
-    assert e <= 2e-2
+    print(f"[raft encoder {net} {dtype}] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
+    assert e <= ENC_TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("size,n", [(224, 3), (96, 2)])
-def test_raft_context_encoder_image_sizes(dev, tiny_sd, size, n):
-    """cnet (BatchNorm folded): ReLU, the skip connection and the bf16 cast live in the convolution epilogues (two
+def test_raft_context_encoder_image_sizes(dev, tiny_sd, size, n, dtype):
+    """cnet (BatchNorm folded): ReLU, the skip connection and the cast live in the convolution epilogues (two
     workgroups per CU on the 64-wide tiles, padded 96 -> 128 output rows in stage 2): other sizes than the golden 128."""
     from oracle import vtgb_oracle as O
     from videotgb_amd import ops
@@ -84,16 +120,17 @@ def test_raft_context_encoder_image_sizes(dev, tiny_sd, size, n):
     fr = torch.randint(0, 256, (n, 3, size, size), generator=torch.Generator().manual_seed(size + 1)).float()
     ref = O.raft_encoder(sd, "of_extractor.cnet.", 2 * (fr / 255.0) - 1.0, "batch")
     rsd = {k[len("of_extractor."):]: v.to(dev) for k, v in sd.items() if k.startswith("of_extractor.")}
-    w = ops.RaftEncoderWeights(rsd, "cnet.", True)
+    w = ops.RaftEncoderWeights(rsd, "cnet.", True, ops.dtype_code(dtype))
     out = ops.raft_encoder(w, fr.to(dev)).cpu().view(n, size // 8, size // 8, 256).permute(0, 3, 1, 2)
     e = rel_rms(out, ref)
-    print(f"[raft cnet {size}x{size}] rel_rms={e:.3e}")
-    assert e <= 1e-2
+    print(f"[raft cnet {size}x{size} {dtype}] rel_rms={e:.3e}")
+    assert e <= (1e-5 if dtype == "f32" else 1e-2)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("size,n", [(224, 5), (64, 3), (96, 2)])
-def test_raft_encoder_image_sizes(dev, tiny_sd, size, n):
-    """InstanceNorm moments come from the convolution epilogue: 224 -> 28x28 = 784-row images straddle the
+def test_raft_encoder_image_sizes(dev, tiny_sd, size, n, dtype):
+    """InstanceNorm moments come from the convolution epilogue (bf16 mode): 224 -> 28x28 = 784-row images straddle the
     256-row GEMM tiles, 64 -> 8x8 images are below the fused path's minimum (separate statistics pass)."""
     from oracle import vtgb_oracle as O
     from videotgb_amd import ops
@@ -101,44 +138,63 @@ def test_raft_encoder_image_sizes(dev, tiny_sd, size, n):
     fr = torch.randint(0, 256, (n, 3, size, size), generator=torch.Generator().manual_seed(size)).float()
     ref = O.raft_encoder(sd, "of_extractor.fnet.", 2 * (fr / 255.0) - 1.0, "instance")
     rsd = {k[len("of_extractor."):]: v.to(dev) for k, v in sd.items() if k.startswith("of_extractor.")}
-    w = ops.RaftEncoderWeights(rsd, "fnet.", False)
+    w = ops.RaftEncoderWeights(rsd, "fnet.", False, ops.dtype_code(dtype))
     out = ops.raft_encoder(w, fr.to(dev)).cpu().view(n, size // 8, size // 8, 256).permute(0, 3, 1, 2)
     e = rel_rms(out, ref)
-    print(f"[raft encoder {size}x{size}] rel_rms={e:.3e}")
-    assert e <= 2e-2
+    print(f"[raft encoder {size}x{size} {dtype}] rel_rms={e:.3e}")
+    assert e <= ENC_TOL[dtype]
 
 
-def test_raft_all_hip_clip_path_vs_reference(dev, tiny_sd):
-    """forward_clips: encoders + update in HIP, fnet once per distinct frame; vs the reference flows."""
-    g = load_golden("tiny_raft")
-    fr = deq(g, "frames_q8").to(dev)
-    r = make(dev, tiny_sd, True)
-    flow = r.forward_clips(fr[None], iters=20)[0].cpu()          # [2, 2, 128, 128]
-    e = rel_rms(flow, g["flow_iters20"])
-    print(f"[raft all-HIP] rel_rms={e:.3e}")
-    assert e <= 5e-2
+def test_raft_float_valued_frames(dev, tiny_sd):
+    """The eval path feeds RAFT CLIP-normalised floats (eval/inference.py:68 -> eval/utils/model.py:79), not 0..255
+    integers: after 2*(x/255)-1 the image is -1 +- 0.02.  fp32 mode must still match the oracle; the bf16 mode rounds the
+    raw pixel to 8 significant bits before the stem (stated in DESIGN.md) and is held to the bf16 tolerance."""
+    from oracle import vtgb_oracle as O
+    sd = tiny_sd["instructblip"][1]
+    fr = torch.randn(3, 3, 128, 128, generator=torch.Generator().manual_seed(12))
+    ref = O.raft_forward(sd, "of_extractor.", fr[:-1], fr[1:], iters=6)
+    for dtype, tol in (("f32", 1e-4), ("bf16", 2e-2)):
+        got = make(dev, tiny_sd, dtype)(fr[:-1].to(dev), fr[1:].to(dev), iters=6).cpu()
+        e = rel_rms(got, ref)
+        print(f"[raft normalised frames {dtype}] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
+        assert e <= tol
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("h8,w8", [(28, 28), (16, 16), (9, 13)])
-def test_corr_pyramid_vs_torch(dev, h8, w8):
-    """corr / sqrt(dim) + three avg_pool2d (corr.py:17-27, :60) in one pass, stored as half: every level within
-    half-precision rounding (2^-11 relative) of the fp32 PyTorch chain, odd sizes floored like avg_pool2d."""
-    import torch.nn.functional as F
+def test_corr_pyramid_vs_oracle(dev, h8, w8, dtype):
+    """CorrBlock.__init__ (corr.py:12-27, :52-60) in one kernel: all-pairs product / sqrt(dim) + three avg_pool2d, odd sizes
+    floored like avg_pool2d; both pair -> image maps (consecutive frames of clips; cat(image1, image2))."""
+    from oracle import vtgb_oracle as O
     from videotgb_amd import ops
-    n = 37
-    corr = torch.randn(n, h8 * w8, generator=torch.Generator().manual_seed(h8)) * 40.0
-    got = ops.raft_corr_pyramid(corr.to(dev), h8, w8)
-    ref = (corr / 16.0).view(n, 1, h8, w8)
+    g = torch.Generator().manual_seed(h8 * 31 + w8)
+    b, t = 2, 3
+    fm = torch.randn(b * t, h8 * w8, 256, generator=g) * 1.5
+    code = ops.dtype_code(dtype)
+    got = ops.raft_corr(fm.to(dev), b * (t - 1), h8, w8, t - 1, t, 0, 1, code)
+    nchw = fm.view(b, t, h8, w8, 256).permute(0, 1, 4, 2, 3)
+    f1, f2 = nchw[:, :-1].reshape(-1, 256, h8, w8), nchw[:, 1:].reshape(-1, 256, h8, w8)
+    ref = O.raft_corr_pyramid(f1, f2)
+    tol = 1e-5 if dtype == "f32" else 3 * 2.0 ** -11
     for l in range(4):
-        assert got[l].shape == ref.shape and got[l].dtype == torch.float16
-        assert (got[l].float().cpu() - ref).abs().max() <= 2.0 ** -11 * ref.abs().max() + 1e-6
-        if l < 3:
-            ref = F.avg_pool2d(ref, 2, stride=2)
-    # half-precision volume in (the output of the fp16 correlation GEMM): same chain on the rounded values
-    ch = corr.half()
-    got = ops.raft_corr_pyramid(ch.to(dev), h8, w8)
-    ref = (ch.float() / 16.0).view(n, 1, h8, w8)
+        assert got[l].shape == ref[l].shape and got[l].dtype == (torch.float32 if dtype == "f32" else torch.float16)
+        err = (got[l].float().cpu() - ref[l]).abs().max().item()
+        print(f"[corr {dtype} {h8}x{w8}] level {l}: max|diff|={err:.3e} max|ref|={ref[l].abs().max():.3e}")
+        assert err <= tol * ref[l].abs().max().item()
+    # cat(image1, image2) map: pair n = images n and N + n
+    n = 3
+    got2 = ops.raft_corr(fm.to(dev), n, h8, w8, n, n, 0, n, code)
+    ref2 = O.raft_corr_pyramid(nchw.reshape(-1, 256, h8, w8)[:n], nchw.reshape(-1, 256, h8, w8)[n:2 * n])
     for l in range(4):
-        assert (got[l].float().cpu() - ref).abs().max() <= 2.0 ** -11 * ref.abs().max() + 1e-6
-        if l < 3:
-            ref = F.avg_pool2d(ref, 2, stride=2)
+        assert (got2[l].float().cpu() - ref2[l]).abs().max().item() <= tol * ref2[l].abs().max().item()
+    with pytest.raises(ValueError):
+        ops.raft_corr(fm.to(dev), b * t, h8, w8, t, t, 0, 1, code)          # the last pair would read past the feature maps
+
+
+def test_corr_large_features_do_not_overflow(dev):
+    """The 1/sqrt(dim) scale is applied to the fp32 accumulator: raw dot products beyond the half range (65504) still give
+    finite half-precision levels (trained RAFT features are not bounded by the synthetic N(0, 0.02) weights)."""
+    from videotgb_amd import ops
+    fm = torch.full((2, 64, 256), 20.0)                     # raw dot product 256 * 400 = 102400 > 65504; scaled 6400
+    got = ops.raft_corr(fm.to(dev), 1, 8, 8, 1, 2, 0, 1, ops.BF16)
+    assert torch.isfinite(got[0].float()).all() and abs(got[0].float().mean().item() - 6400.0) < 4.0

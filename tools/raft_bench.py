@@ -9,12 +9,12 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 NWN = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # > 0 forces the conv tile width (4 = 256 wide for every conv)
 from videotgb_amd import _lib
 _lib.lib().vtgb_debug_set_conv_nwn(NWN)
-r = models.Raft(torch.float32, hip_update=True)
+r = models.Raft(os.environ.get('RAFT_DTYPE', 'bf16'))
 sd = {k[len("of_extractor."):]: v for k, v in synth.synth_state_dict(synth.raft_shapes("of_extractor."), 0).items()}
 for k in list(sd):
     if ".downsample.1." in k:
         sd[k] = sd[k.replace(".downsample.1.", ".norm3.")]
-r.load_state_dict(sd, strict=True); r.to(dev); r.hip_encoders = True
+r.load_state_dict(sd, strict=True); r.to(dev)
 g = torch.Generator(device=dev).manual_seed(0)
 frames = torch.randn(B, 96, 3, 224, 224, generator=g, device=dev)
 for _ in range(2): r.forward_clips(frames)

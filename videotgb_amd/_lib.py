@@ -28,7 +28,7 @@ EXPORTS = [
     "vtgb_layernorm", "vtgb_prof_enable", "vtgb_prof_reset", "vtgb_prof_summary",
     "vtgb_llm_rmsnorm", "vtgb_llm_rope_cache", "vtgb_llm_decode_attention", "vtgb_llm_silu_mul",
     "vtgb_raft_update_workspace_bytes", "vtgb_raft_update", "vtgb_raft_encoder_workspace_bytes", "vtgb_raft_encoder",
-    "vtgb_raft_corr_pyramid", "vtgb_preprocess_frames", "vtgb_concat_text_io", "vtgb_shifted_ce_forward", "vtgb_shifted_ce_backward",
+    "vtgb_raft_corr_workspace_bytes", "vtgb_raft_corr", "vtgb_preprocess_frames", "vtgb_concat_text_io", "vtgb_shifted_ce_forward", "vtgb_shifted_ce_backward",
 ]
 
 i32, i64, f32, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -95,16 +95,19 @@ class TgbArgs(C.Structure):
 
 
 class RaftUpdateArgs(C.Structure):
-    _fields_ = [("n_pairs", i32), ("H8", i32), ("W8", i32), ("iters", i32), ("net", vp), ("inp", vp), ("corr", vp * 4),
-                ("weights", C.POINTER(vp)), ("flow_up", vp), ("workspace", vp), ("workspace_bytes", sz), ("corr_f16", i32), ("cnet_nhwc", vp)]
+    _fields_ = [("dtype", i32), ("n_pairs", i32), ("H8", i32), ("W8", i32), ("iters", i32), ("net", vp), ("inp", vp), ("corr", vp * 4),
+                ("weights", C.POINTER(vp)), ("flow_up", vp), ("workspace", vp), ("workspace_bytes", sz), ("corr_f16", i32), ("cnet_nhwc", vp),
+                ("flow_init", vp)]
 
 
-class RaftCorrPyramidArgs(C.Structure):
-    _fields_ = [("corr", vp), ("levels", vp * 4), ("n_maps", i64), ("H8", i32), ("W8", i32), ("scale", f32), ("corr_in_f16", i32)]
+class RaftCorrArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("n_pairs", i32), ("H8", i32), ("W8", i32), ("dim", i32), ("pairs_per_clip", i32), ("frames_per_clip", i32),
+                ("first_off", i32), ("second_off", i32), ("n_images", i32), ("scale", f32), ("fmap", vp), ("levels", vp * 4),
+                ("workspace", vp), ("workspace_bytes", sz)]
 
 
 class RaftEncoderArgs(C.Structure):
-    _fields_ = [("n_images", i32), ("H", i32), ("W", i32), ("norm", i32), ("images", vp), ("weights", C.POINTER(vp)), ("out", vp),
+    _fields_ = [("dtype", i32), ("n_images", i32), ("H", i32), ("W", i32), ("norm", i32), ("images", vp), ("weights", C.POINTER(vp)), ("out", vp),
                 ("workspace", vp), ("workspace_bytes", sz)]
 
 
@@ -161,6 +164,10 @@ def lib() -> C.CDLL:
     L.vtgb_raft_encoder.restype = C.c_int
     L.vtgb_raft_encoder_workspace_bytes.argtypes = [C.POINTER(RaftEncoderArgs)]
     L.vtgb_raft_encoder_workspace_bytes.restype = sz
+    L.vtgb_raft_corr.argtypes = [C.POINTER(RaftCorrArgs), vp]
+    L.vtgb_raft_corr.restype = C.c_int
+    L.vtgb_raft_corr_workspace_bytes.argtypes = [C.POINTER(RaftCorrArgs)]
+    L.vtgb_raft_corr_workspace_bytes.restype = sz
     L.vtgb_llm_rmsnorm.argtypes = [C.c_int, vp, vp, vp, vp, i64, i32, f32, vp]
     L.vtgb_llm_rope_cache.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.vtgb_llm_decode_attention.argtypes = [C.c_int, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]

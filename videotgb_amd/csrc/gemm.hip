@@ -867,15 +867,18 @@ static int launch_large_forced(const GemmDesc& d, hipStream_t s) {
     return launch_large_nwn<EPI, CONV, 4>(d, s);
 }
 
+int launch_conv_f32(const GemmDesc& d, hipStream_t s);   // conv_f32.hip: the exactness mode of this entry
+
 int launch_conv_gemm(const GemmDesc& d, hipStream_t s) {
-    VTGB_REQUIRE(d.dtype == VTGB_BF16 && d.A && d.W && d.out && d.M > 0 && d.N > 0, VTGB_EINVAL, "conv gemm: bad argument");
-    VTGB_REQUIRE((d.K % L_BK) == 0 && (d.lda % 8) == 0 && (d.ldw % 8) == 0, VTGB_EUNSUPPORTED, "conv gemm: K=%d must be a multiple of 64", d.K);
+    VTGB_REQUIRE((d.dtype == VTGB_BF16 || d.dtype == VTGB_F32) && d.A && d.W && d.out && d.M > 0 && d.N > 0, VTGB_EINVAL, "conv gemm: bad argument");
     const bool conv = d.conv_KH > 0;
     if (conv) {
         VTGB_REQUIRE(d.zero_page && (d.conv_Cin % L_BK) == 0 && (d.conv_split % L_BK) == 0 && d.K == d.conv_KH * d.conv_KW * d.conv_Cin &&
                          (d.M % (d.conv_H * d.conv_W)) == 0 && (d.conv_split == d.conv_Cin || d.A2),
                      VTGB_EINVAL, "conv gemm: inconsistent convolution geometry");
     }
+    if (d.dtype == VTGB_F32) return launch_conv_f32(d, s);
+    VTGB_REQUIRE((d.K % L_BK) == 0 && (d.lda % 8) == 0 && (d.ldw % 8) == 0, VTGB_EUNSUPPORTED, "conv gemm: K=%d must be a multiple of 64", d.K);
     if (d.gate_from > 0)
         VTGB_REQUIRE(d.epi == EPI_STORE && (d.gate_from % 8) == 0 && (d.N % 8) == 0 && (d.ldo % 8) == 0 && d.aux && d.out2 && (d.ldaux % 8) == 0 &&
                          (d.ldo2 % 8) == 0,

@@ -1,15 +1,16 @@
 // raft.hip -- the recurrent part of RAFT on gfx950: per refinement iteration the
 // correlation-pyramid lookup (the reference's missing `alt_cuda_corr`, raft_utils/corr.py:29-50,63-91),
 // BasicMotionEncoder, SepConvGRU and FlowHead (raft_utils/update.py:39-144), then the mask head and the
-// convex 8x upsample of the last iteration (xraft.py:88-99), plus the fused correlation pyramid (scale +
-// three average pools, corr.py:17-27).  The two CNN encoders are raft_enc.hip; only the all-pairs correlation
-// matmul itself stays with the caller (one batched rocBLAS GEMM through PyTorch).
+// convex 8x upsample of the last iteration (xraft.py:88-99).  The two CNN encoders are raft_enc.hip, the all-pairs
+// correlation + pyramid is raft_corr.hip.
 //
 // Layout: every activation is NHWC ("pixel-major") bf16, so each convolution is an implicit GEMM on the
 // MFMA kernel of gemm.hip (LDS-DMA gathers the k-tile of the shifted pixel directly; out-of-image taps read
 // a zero page; channel concatenations [h | inp | motion | flow] are virtual: two base pointers, no copies).
 // The hidden state h and the flow / coordinates stay fp32, the correlation pyramid is fp16 (or fp32); GEMM operands are bf16
 // with fp32 accumulation, gates (sigmoid / tanh) are evaluated in fp32 in the GEMM epilogue.
+// VTGB_F32 (exactness mode): the same launch sequence with every bf16 buffer in fp32 and the convolutions on
+// conv_f32.hip's FMA kernel (launch_conv_gemm dispatches on GemmDesc::dtype).
 #include <math.h>
 #include <string.h>
 
@@ -18,9 +19,10 @@
 // ---------------------------------------------------------------------------------------
 // state init: NCHW fp32 -> pixel-major buffers
 // ---------------------------------------------------------------------------------------
+template <typename T>
 __global__ void raft_init_kernel(const float* __restrict__ net, const float* __restrict__ inp, const float* __restrict__ cnet_nhwc,
-                                 float* __restrict__ h32, bf16_t* __restrict__ hb, bf16_t* __restrict__ X, float* __restrict__ flow, int64_t M,
-                                 int HW) {
+                                 float* __restrict__ h32, T* __restrict__ hb, T* __restrict__ X, float* __restrict__ flow,
+                                 const float* __restrict__ flow_init, int64_t M, int HW) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * 128) return;
     const int64_t m = i >> 7;
@@ -31,11 +33,12 @@ __global__ void raft_init_kernel(const float* __restrict__ net, const float* __r
     const float hv = cnet_nhwc ? tanhf(cnet_nhwc[m * 256 + c]) : net[(n * 128 + c) * HW + p];
     const float iv = cnet_nhwc ? fmaxf(cnet_nhwc[m * 256 + 128 + c], 0.f) : inp[(n * 128 + c) * HW + p];
     h32[i] = hv;
-    hb[i] = (bf16_t)hv;
-    X[m * 256 + c] = (bf16_t)iv;
-    if (c < 2) {
-        flow[m * 2 + c] = 0.f;
-        X[m * 256 + 254 + c] = (bf16_t)0.f;
+    hb[i] = (T)hv;
+    X[m * 256 + c] = (T)iv;
+    if (c < 2) {   // flow = coords1 - coords0: zero, or flow_init [n, 2, H8, W8] (xraft.py:131-132)
+        const float f0 = flow_init ? flow_init[(n * 2 + c) * HW + p] : 0.f;
+        flow[m * 2 + c] = f0;
+        X[m * 256 + 254 + c] = (T)f0;
     }
 }
 
@@ -51,8 +54,8 @@ __global__ void raft_init_kernel(const float* __restrict__ net, const float* __r
 struct CorrPyr { const void* lvl[4]; int h[4], w[4]; };
 
 constexpr int CL_PIX = 8;   // pixels per wave (the per-lane tap tables are built once and reused)
-template <typename CT>
-__global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr, const float* __restrict__ flow, bf16_t* __restrict__ out,
+template <typename CT, typename OT>
+__global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr, const float* __restrict__ flow, OT* __restrict__ out,
                                                                int64_t M, int H8, int W8) {
     __shared__ float win[4][4][104];   // [wave][level][10 x 10 window | wx | wy | pad]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr
                 const float* q = wv + tap_off[kk];
                 v = (1.f - wy) * ((1.f - wx) * q[0] + wx * q[1]) + wy * ((1.f - wx) * q[10] + wx * q[11]);
             }
-            out[m * 384 + kk * 64 + lane] = (bf16_t)v;
+            out[m * 384 + kk * 64 + lane] = (OT)v;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // before the next pixel overwrites the windows
     }
@@ -182,6 +185,32 @@ __global__ __launch_bounds__(256) void raft_convf1_kernel(const float* __restric
     }
 }
 
+// Exactness mode of convf1: the 7x7 convolution of the 2-channel flow as plain fp32 FMAs (98 taps per output); weights
+// [98][128] (k = c * 49 + ky * 7 + kx, output channel minor).  Two pixels per workgroup, one thread per output channel.
+__global__ __launch_bounds__(256) void raft_convf1_f32_kernel(const float* __restrict__ flow, const float* __restrict__ wt, const float* __restrict__ b,
+                                                              float* __restrict__ f1, float* __restrict__ X, int64_t M, int H8, int W8) {
+    __shared__ float win[2][100];
+    const int tid = threadIdx.x, HW = H8 * W8;
+    if (tid < 196) {
+        const int px = tid / 98, k = tid - px * 98, c = k / 49, t = k - c * 49, ky = t / 7, kx = t - ky * 7;
+        const int64_t m = (int64_t)blockIdx.x * 2 + px;
+        float v = 0.f;
+        if (m < M) {
+            const int pix = (int)(m % HW), y = pix / W8 + ky - 3, x = pix % W8 + kx - 3;
+            if ((unsigned)y < (unsigned)H8 && (unsigned)x < (unsigned)W8) v = flow[(m + (ky - 3) * W8 + (kx - 3)) * 2 + c];
+        }
+        win[px][k] = v;
+    }
+    __syncthreads();
+    const int px = tid >> 7, co = tid & 127;
+    const int64_t m = (int64_t)blockIdx.x * 2 + px;
+    if (m >= M) return;
+    float acc = b[co];
+    for (int k = 0; k < 98; k++) acc = fmaf(win[px][k], wt[k * 128 + co], acc);
+    f1[m * 128 + co] = fmaxf(acc, 0.f);
+    if (co < 2) X[m * 256 + 254 + co] = flow[m * 2 + co];
+}
+
 // FlowHead.conv2 (3x3, 256 -> 2; update.py:14,18) + coords1 += delta (xraft.py:145).  The convolution is a
 // GEMM with the taps moved to the OUTPUT side: P[m][tap*2 + o] = <FH[m], w[o][tap]> for every pixel (one pass
 // over FH on the MFMA kernel, N = 18 padded to 32), then delta[m][o] = sum_tap P[m + offset(tap)][tap*2 + o]
@@ -241,73 +270,13 @@ __global__ void raft_upsample_kernel(const float* __restrict__ flow, const float
 }
 
 // ---------------------------------------------------------------------------------------
-// correlation pyramid (corr.py:17-27 after the matmul): one wave per pixel's map; the scaled level 0 sits in LDS
-// as fp32, levels 1..3 are 2x2 means of the fp32 level above (avg_pool2d floors odd sizes: 7 -> 3), every level
-// is stored as half.  One read of the volume (3 KB per map) instead of the five PyTorch passes.
-// ---------------------------------------------------------------------------------------
-template <typename IT>
-__global__ __launch_bounds__(256) void raft_corr_pyramid_kernel(const vtgb_raft_corr_pyramid_args a) {
-    extern __shared__ float pyr_sm[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t m = (int64_t)blockIdx.x * 4 + wave;
-    const int H = a.H8, W = a.W8, n0 = H * W;
-    float* l0 = pyr_sm + wave * (n0 + n0 / 4 + n0 / 16 + 64);
-    if (m < a.n_maps) {
-        const IT* src = reinterpret_cast<const IT*>(a.corr) + m * n0;
-        _Float16* o0 = reinterpret_cast<_Float16*>(a.levels[0]) + m * n0;
-        for (int i = lane; i < n0; i += 64) {
-            const float v = (float)src[i] * a.scale;
-            l0[i] = v;
-            o0[i] = (_Float16)v;
-        }
-    }
-    __syncthreads();
-    const float* prev = l0;
-    int ph = H, pw = W;
-    float* cur = l0 + n0;
-    for (int l = 1; l < 4; l++) {
-        const int ch = ph / 2, cw = pw / 2;
-        if (m < a.n_maps) {
-            _Float16* o = reinterpret_cast<_Float16*>(a.levels[l]) + m * (int64_t)(ch * cw);
-            for (int i = lane; i < ch * cw; i += 64) {
-                const int y = i / cw, x = i - y * cw;
-                const float* q = prev + (2 * y) * pw + 2 * x;
-                const float v = (q[0] + q[1] + q[pw] + q[pw + 1]) * 0.25f;
-                cur[i] = v;
-                o[i] = (_Float16)v;
-            }
-        }
-        __syncthreads();
-        prev = cur; cur += ch * cw; ph = ch; pw = cw;
-    }
-}
-
-extern "C" int vtgb_raft_corr_pyramid(const vtgb_raft_corr_pyramid_args* a, vtgb_stream_t stream) {
-    VTGB_REQUIRE(a && a->corr && a->levels[0] && a->levels[1] && a->levels[2] && a->levels[3], VTGB_EINVAL, "raft_corr_pyramid: NULL argument");
-    VTGB_REQUIRE(a->n_maps > 0 && a->H8 >= 8 && a->W8 >= 8, VTGB_EINVAL, "raft_corr_pyramid: n=%lld H8=%d W8=%d", (long long)a->n_maps, a->H8, a->W8);
-    const int n0 = a->H8 * a->W8;
-    const size_t lds = 4 * (size_t)(n0 + n0 / 4 + n0 / 16 + 64) * sizeof(float);
-    VTGB_REQUIRE(lds <= 160 * 1024, VTGB_EUNSUPPORTED, "raft_corr_pyramid: %d x %d maps exceed the LDS tile", a->H8, a->W8);
-    if (lds > 64 * 1024) {
-        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_pyramid_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_pyramid_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    if (a->corr_in_f16)
-        hipLaunchKernelGGL(raft_corr_pyramid_kernel<_Float16>, dim3((unsigned)((a->n_maps + 3) / 4)), dim3(256), lds, stream, *a);
-    else
-        hipLaunchKernelGGL(raft_corr_pyramid_kernel<float>, dim3((unsigned)((a->n_maps + 3) / 4)), dim3(256), lds, stream, *a);
-    VTGB_HIP(hipGetLastError());
-    return VTGB_OK;
-}
-
-// ---------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------
-static GemmDesc conv_desc(int M, int N, int H, int W, int KH, int KW, int Cin, int split, const void* A, int64_t lda, const void* A2,
+static GemmDesc conv_desc(int dt, int M, int N, int H, int W, int KH, int KW, int Cin, int split, const void* A, int64_t lda, const void* A2,
                           int64_t lda2, const void* Wt, const float* bias, int epi, int act, void* out, int64_t ldo, const void* zero) {
     GemmDesc d;
     memset(&d, 0, sizeof(d));
-    d.dtype = VTGB_BF16; d.M = M; d.N = N; d.K = KH * KW * Cin; d.epi = epi; d.act = act;
+    d.dtype = dt; d.M = M; d.N = N; d.K = KH * KW * Cin; d.epi = epi; d.act = act;
     d.A = A; d.lda = lda; d.A2 = A2; d.lda2 = lda2; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = out; d.ldo = ldo;
     d.conv_H = H; d.conv_W = W; d.conv_KH = KH; d.conv_KW = KW; d.conv_Cin = Cin; d.conv_split = split; d.zero_page = zero;
     return d;
@@ -315,21 +284,26 @@ static GemmDesc conv_desc(int M, int N, int H, int W, int KH, int KW, int Cin, i
 
 static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     VTGB_REQUIRE(a, VTGB_EINVAL, "raft_update: NULL args");
+    VTGB_REQUIRE(a->dtype == VTGB_BF16 || a->dtype == VTGB_F32, VTGB_EINVAL, "raft_update: bad dtype %d", a->dtype);
     VTGB_REQUIRE(a->n_pairs > 0 && a->H8 >= 8 && a->W8 >= 8 && a->iters > 0, VTGB_EINVAL, "raft_update: bad dims n=%d H8=%d W8=%d iters=%d",
                  a->n_pairs, a->H8, a->W8, a->iters);
+    const int dt = a->dtype;
+    const bool f32 = dt == VTGB_F32;
+    const size_t es = dtype_size(dt);
     const int H8 = a->H8, W8 = a->W8, HW = H8 * W8;
     const int64_t M = (int64_t)a->n_pairs * HW;
     VTGB_REQUIRE(M < (1ll << 31), VTGB_EUNSUPPORTED, "raft_update: too many pixels");
+    // activations: bf16 (VTGB_BF16) or fp32 (VTGB_F32); typed access through char* + element size
     float* h32 = (float*)ws.take(M * 128 * 4);
-    bf16_t* hb = (bf16_t*)ws.take(M * 128 * 2);
-    bf16_t* X = (bf16_t*)ws.take(M * 256 * 2);
-    bf16_t* corrf = (bf16_t*)ws.take(M * 384 * 2);
-    bf16_t* c1 = (bf16_t*)ws.take(M * 256 * 2);
-    bf16_t* CF = (bf16_t*)ws.take(M * 256 * 2);
-    bf16_t* f1 = (bf16_t*)ws.take(M * 128 * 2);
-    bf16_t* ZR = (bf16_t*)ws.take(M * 256 * 2);
-    bf16_t* RH = (bf16_t*)ws.take(M * 128 * 2);
-    bf16_t* FH = (bf16_t*)ws.take(M * 256 * 2);
+    char* hb = (char*)ws.take(M * 128 * es);
+    char* X = (char*)ws.take(M * 256 * es);
+    char* corrf = (char*)ws.take(M * 384 * es);
+    char* c1 = (char*)ws.take(M * 256 * es);
+    char* CF = (char*)ws.take(M * 256 * es);
+    char* f1 = (char*)ws.take(M * 128 * es);
+    char* ZR = (char*)ws.take(M * 256 * es);
+    char* RH = (char*)ws.take(M * 128 * es);
+    char* FH = (char*)ws.take(M * 256 * es);
     float* flow = (float*)ws.take(M * 2 * 4);
     float* mask = (float*)ws.take(M * 576 * 4);
     float* P2 = mask;   // [M, 32] per-tap partial products of FlowHead.conv2 (the mask buffer is idle until the last iteration)
@@ -337,6 +311,7 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     if (ws.dry) return VTGB_OK;
     VTGB_REQUIRE(ws.ok(), VTGB_EWORKSPACE, "raft_update: workspace %zu < %zu bytes", ws.size, ws.used);
     VTGB_REQUIRE(((a->net && a->inp) || a->cnet_nhwc) && a->weights && a->flow_up, VTGB_EINVAL, "raft_update: NULL operand");
+    VTGB_REQUIRE(!(f32 && a->corr_f16), VTGB_EINVAL, "raft_update: the exactness mode takes an fp32 correlation pyramid");
     const void* const* w = a->weights;
     for (int i = 0; i < VTGB_RAFT_NW; i++) VTGB_REQUIRE(w[i], VTGB_EINVAL, "raft_update: weights[%d] is NULL", i);
     CorrPyr pyr;
@@ -347,55 +322,63 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
         hl /= 2; wl /= 2;
     }
     VTGB_HIP(hipMemsetAsync(zero, 0, 256, s));
-    hipLaunchKernelGGL(raft_init_kernel, dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, h32, hb, X, flow, M, HW);
+    const dim3 init_grid((unsigned)((M * 128 + 255) / 256));
+    if (f32)
+        hipLaunchKernelGGL(raft_init_kernel<float>, init_grid, dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, h32, (float*)hb, (float*)X, flow, a->flow_init, M, HW);
+    else
+        hipLaunchKernelGGL(raft_init_kernel<bf16_t>, init_grid, dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, h32, (bf16_t*)hb, (bf16_t*)X, flow, a->flow_init, M, HW);
     const int Mi = (int)M;
     const size_t cf1_lds = 128 * CF1_LD * 2 + 4 * 4096;
-    static bool cf1_attr = false;
-    if (!cf1_attr) {
+    if (!f32)
         VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_convf1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cf1_lds));
-        cf1_attr = true;
-    }
     const int64_t cf1_groups = (M + 15) / 16, cf1_grid = cf1_groups < 4 * 512 ? (cf1_groups + 3) / 4 : 512;
     auto F = [](const void* p) { return (const float*)p; };
+    auto E = [es](char* p, int64_t elems) { return (void*)(p + elems * (int64_t)es); };   // element offset into an activation buffer
+    const dim3 lk_grid((unsigned)((M + 4 * CL_PIX - 1) / (4 * CL_PIX)));
     for (int it = 0; it < a->iters; it++) {
         // ---- BasicMotionEncoder (update.py:88-97)
-        if (a->corr_f16)
-            hipLaunchKernelGGL(raft_corr_lookup_kernel<_Float16>, dim3((unsigned)((M + 4 * CL_PIX - 1) / (4 * CL_PIX))), dim3(256), 0, s, pyr, flow, corrf, M, H8, W8);
+        if (f32)
+            hipLaunchKernelGGL((raft_corr_lookup_kernel<float, float>), lk_grid, dim3(256), 0, s, pyr, flow, (float*)corrf, M, H8, W8);
+        else if (a->corr_f16)
+            hipLaunchKernelGGL((raft_corr_lookup_kernel<_Float16, bf16_t>), lk_grid, dim3(256), 0, s, pyr, flow, (bf16_t*)corrf, M, H8, W8);
         else
-            hipLaunchKernelGGL(raft_corr_lookup_kernel<float>, dim3((unsigned)((M + 4 * CL_PIX - 1) / (4 * CL_PIX))), dim3(256), 0, s, pyr, flow, corrf, M, H8, W8);
+            hipLaunchKernelGGL((raft_corr_lookup_kernel<float, bf16_t>), lk_grid, dim3(256), 0, s, pyr, flow, (bf16_t*)corrf, M, H8, W8);
         {
-            GemmDesc d = conv_desc(Mi, 256, H8, W8, 0, 0, 0, 0, corrf, 384, nullptr, 0, w[0], F(w[1]), VTGB_EPI_STORE, 1, c1, 256, zero);
+            GemmDesc d = conv_desc(dt, Mi, 256, H8, W8, 0, 0, 0, 0, corrf, 384, nullptr, 0, w[0], F(w[1]), VTGB_EPI_STORE, 1, c1, 256, zero);
             d.K = 384; d.ldw = 384;
             VTGB_TRY(launch_conv_gemm(d, s));
         }
-        VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 192, H8, W8, 3, 3, 256, 256, c1, 256, nullptr, 0, w[2], F(w[3]), VTGB_EPI_STORE, 1, CF, 256, zero), s));
-        hipLaunchKernelGGL(raft_convf1_kernel, dim3((unsigned)cf1_grid), dim3(256), cf1_lds, s, flow, (const bf16_t*)w[4], F(w[5]), f1, X, M, H8, W8);
-        VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 64, H8, W8, 3, 3, 128, 128, f1, 128, nullptr, 0, w[6], F(w[7]), VTGB_EPI_STORE, 1, CF + 192, 256, zero), s));
-        VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 126, H8, W8, 3, 3, 256, 256, CF, 256, nullptr, 0, w[8], F(w[9]), VTGB_EPI_STORE, 1, X + 128, 256, zero), s));
+        VTGB_TRY(launch_conv_gemm(conv_desc(dt, Mi, 192, H8, W8, 3, 3, 256, 256, c1, 256, nullptr, 0, w[2], F(w[3]), VTGB_EPI_STORE, 1, CF, 256, zero), s));
+        if (f32)
+            hipLaunchKernelGGL(raft_convf1_f32_kernel, dim3((unsigned)((M + 1) / 2)), dim3(256), 0, s, flow, F(w[4]), F(w[5]), (float*)f1, (float*)X, M, H8, W8);
+        else
+            hipLaunchKernelGGL(raft_convf1_kernel, dim3((unsigned)cf1_grid), dim3(256), cf1_lds, s, flow, (const bf16_t*)w[4], F(w[5]), (bf16_t*)f1, (bf16_t*)X, M, H8, W8);
+        VTGB_TRY(launch_conv_gemm(conv_desc(dt, Mi, 64, H8, W8, 3, 3, 128, 128, f1, 128, nullptr, 0, w[6], F(w[7]), VTGB_EPI_STORE, 1, E(CF, 192), 256, zero), s));
+        VTGB_TRY(launch_conv_gemm(conv_desc(dt, Mi, 126, H8, W8, 3, 3, 256, 256, CF, 256, nullptr, 0, w[8], F(w[9]), VTGB_EPI_STORE, 1, E(X, 128), 256, zero), s));
         // ---- SepConvGRU (update.py:50-65): horizontal (1x5) then vertical (5x1)
         for (int half = 0; half < 2; half++) {
             const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1, wi = 10 + 4 * half;
-            // z -> ZR[:, :128]; r is multiplied by h (bf16) in the epilogue and lands in RH (update.py:55,62)
-            GemmDesc zr = conv_desc(Mi, 256, H8, W8, kh, kw, 384, 128, hb, 128, X, 256, w[wi], F(w[wi + 1]), VTGB_EPI_STORE, 2, ZR, 256, zero);
+            // z -> ZR[:, :128]; r is multiplied by h in the epilogue and lands in RH (update.py:55,62)
+            GemmDesc zr = conv_desc(dt, Mi, 256, H8, W8, kh, kw, 384, 128, hb, 128, X, 256, w[wi], F(w[wi + 1]), VTGB_EPI_STORE, 2, ZR, 256, zero);
             zr.gate_from = 128; zr.aux = hb; zr.ldaux = 128; zr.out2 = RH; zr.ldo2 = 128;
             VTGB_TRY(launch_conv_gemm(zr, s));
-            GemmDesc q = conv_desc(Mi, 128, H8, W8, kh, kw, 384, 128, RH, 128, X, 256, w[wi + 2], F(w[wi + 3]), VTGB_EPI_GRU, 0, h32, 128, zero);
+            GemmDesc q = conv_desc(dt, Mi, 128, H8, W8, kh, kw, 384, 128, RH, 128, X, 256, w[wi + 2], F(w[wi + 3]), VTGB_EPI_GRU, 0, h32, 128, zero);
             q.resid = h32; q.ldr = 128; q.aux = ZR; q.ldaux = 256; q.out2 = hb; q.ldo2 = 128;
             VTGB_TRY(launch_conv_gemm(q, s));
         }
         // ---- FlowHead (update.py:10-18) and coords1 += delta_flow (xraft.py:145)
-        VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 256, H8, W8, 3, 3, 128, 128, hb, 128, nullptr, 0, w[18], F(w[19]), VTGB_EPI_STORE, 1, FH, 256, zero), s));
+        VTGB_TRY(launch_conv_gemm(conv_desc(dt, Mi, 256, H8, W8, 3, 3, 128, 128, hb, 128, nullptr, 0, w[18], F(w[19]), VTGB_EPI_STORE, 1, FH, 256, zero), s));
         {
-            GemmDesc d = conv_desc(Mi, 32, H8, W8, 0, 0, 0, 0, FH, 256, nullptr, 0, w[20], nullptr, VTGB_EPI_STORE_F32, 0, P2, 32, zero);
+            GemmDesc d = conv_desc(dt, Mi, 32, H8, W8, 0, 0, 0, 0, FH, 256, nullptr, 0, w[20], nullptr, VTGB_EPI_STORE_F32, 0, P2, 32, zero);
             d.K = 256; d.ldw = 256;
             VTGB_TRY(launch_conv_gemm(d, s));
         }
         hipLaunchKernelGGL(raft_flow_head2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, P2, F(w[21]), flow, M, H8, W8);
     }
     // ---- mask head of the last iteration (update.py:129-132,143) and convex upsample (xraft.py:88-99)
-    VTGB_TRY(launch_conv_gemm(conv_desc(Mi, 256, H8, W8, 3, 3, 128, 128, hb, 128, nullptr, 0, w[22], F(w[23]), VTGB_EPI_STORE, 1, FH, 256, zero), s));
+    VTGB_TRY(launch_conv_gemm(conv_desc(dt, Mi, 256, H8, W8, 3, 3, 128, 128, hb, 128, nullptr, 0, w[22], F(w[23]), VTGB_EPI_STORE, 1, FH, 256, zero), s));
     {
-        GemmDesc d = conv_desc(Mi, 576, H8, W8, 0, 0, 0, 0, FH, 256, nullptr, 0, w[24], F(w[25]), VTGB_EPI_STORE_F32, 0, mask, 576, zero);
+        GemmDesc d = conv_desc(dt, Mi, 576, H8, W8, 0, 0, 0, 0, FH, 256, nullptr, 0, w[24], F(w[25]), VTGB_EPI_STORE_F32, 0, mask, 576, zero);
         d.K = 256; d.ldw = 256; d.out_scale = 0.25f;
         VTGB_TRY(launch_conv_gemm(d, s));
     }

@@ -1,0 +1,197 @@
+// raft_corr.hip -- CorrBlock.__init__ of RAFT (raft_utils/corr.py:12-27 with the all-pairs product :52-60) in ONE
+// kernel: for a 16-pixel tile of image 1 the dot products with every pixel of image 2 (K = 256 features), the
+// 1/sqrt(dim) scale and the three 2x2 average pools, straight into the four pyramid levels.  The correlation
+// volume never exists in any other form: the reference's matmul output (233 MB per T=96 clip in fp32) plus the
+// three pooled copies are written once, as the lookup kernel reads them.
+//
+// A workgroup (4 waves) owns 16 rows p of one pair.  Its slice of the volume S[16][HW] lives in LDS as fp32:
+//   VTGB_BF16: v_mfma_f32_16x16x32_f16 on an IEEE-half copy of the features (11 significant bits on the inputs,
+//              fp32 accumulation; the scale is applied to the fp32 accumulator, so there is no half-precision
+//              overflow however large the raw dot product is); image 2's rows are the MFMA "A" operand read
+//              straight from L2 (400 KB per image, shared by the 49 workgroups of a pair), image 1's tile is the
+//              "B" operand in LDS; levels are stored as half.
+//   VTGB_F32 : fp32 FMAs, features summed in order; levels are stored as fp32 (the exactness mode).
+// Level l+1 is the 2x2 mean of the fp32 level l kept in LDS (avg_pool2d floors odd sizes: 7 -> 3).
+#include "common.h"
+
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+typedef __attribute__((ext_vector_type(4))) _Float16 half4;
+
+__global__ void cast_f16_kernel(const float* __restrict__ x, half_t* __restrict__ y, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    *reinterpret_cast<half4*>(y + i * 4) = half4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+}
+
+constexpr int CORR_D = 256;
+constexpr int CORR_F1H_LD = CORR_D + 8;    // half elements per LDS row of the image-1 tile (528 B: 16 rows -> 16 bank groups)
+constexpr int CORR_F1F_LD = CORR_D + 4;    // fp32 variant
+
+struct CorrLds { int ldS, n1, n2, n3; size_t bytes; };
+static inline CorrLds corr_lds(int H8, int W8, bool f32) {
+    CorrLds c;
+    const int HW = H8 * W8;
+    c.ldS = (HW + 15) / 16 * 16 + 4;
+    c.n1 = (H8 / 2) * (W8 / 2);
+    c.n2 = (H8 / 4) * (W8 / 4);
+    c.n3 = (H8 / 8) * (W8 / 8);
+    c.bytes = (size_t)16 * (c.ldS + c.n1 + c.n2) * 4 + (f32 ? 16 * CORR_F1F_LD * 4 : 16 * CORR_F1H_LD * 2);
+    return c;
+}
+
+template <bool F32, typename OT>
+__global__ __launch_bounds__(256) void raft_corr_kernel(const vtgb_raft_corr_args a, const half_t* __restrict__ fh, const int ldS, const int n1,
+                                                        const int n2) {
+    extern __shared__ __attribute__((aligned(16))) char corr_sm[];
+    const int H = a.H8, W = a.W8, HW = H * W;
+    float* const S = reinterpret_cast<float*>(corr_sm);
+    float* const S1 = S + 16 * ldS;
+    float* const S2 = S1 + 16 * n1;
+    char* const f1s = reinterpret_cast<char*>(S2 + 16 * n2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n = blockIdx.y;
+    const int p0 = blockIdx.x * 16;
+    const int64_t img = (n / a.pairs_per_clip) * a.frames_per_clip + n % a.pairs_per_clip;
+    const int64_t i1 = img + a.first_off, i2 = img + a.second_off;
+    // ---- image-1 tile -> LDS (rows past the image: the last row again; their outputs are never stored)
+    if constexpr (F32) {
+        const float* f1 = a.fmap + i1 * HW * CORR_D;
+        float* dst = reinterpret_cast<float*>(f1s);
+        for (int i = tid; i < 16 * (CORR_D / 4); i += 256) {
+            const int r = i / (CORR_D / 4), c = i - r * (CORR_D / 4);
+            const int p = min(p0 + r, HW - 1);
+            *reinterpret_cast<float4*>(dst + r * CORR_F1F_LD + c * 4) = *reinterpret_cast<const float4*>(f1 + (int64_t)p * CORR_D + c * 4);
+        }
+    } else {
+        const half_t* f1 = fh + i1 * HW * CORR_D;
+        half_t* dst = reinterpret_cast<half_t*>(f1s);
+        for (int i = tid; i < 16 * (CORR_D / 8); i += 256) {
+            const int r = i / (CORR_D / 8), c = i - r * (CORR_D / 8);
+            const int p = min(p0 + r, HW - 1);
+            *reinterpret_cast<half8*>(dst + r * CORR_F1H_LD + c * 8) = *reinterpret_cast<const half8*>(f1 + (int64_t)p * CORR_D + c * 8);
+        }
+    }
+    __syncthreads();
+    // ---- S[p][q] = scale * <f1[p], f2[q]>
+    if constexpr (F32) {
+        const float* f2 = a.fmap + i2 * HW * CORR_D;
+        const float* f1l = reinterpret_cast<const float*>(f1s);
+        for (int q = tid; q < HW; q += 256) {
+            const float* row = f2 + (int64_t)q * CORR_D;
+            float acc[16];
+#pragma unroll
+            for (int p = 0; p < 16; p++) acc[p] = 0.f;
+            for (int d = 0; d < CORR_D; d += 4) {
+                const float4 b = *reinterpret_cast<const float4*>(row + d);
+#pragma unroll
+                for (int p = 0; p < 16; p++) {
+                    const float4 x = *reinterpret_cast<const float4*>(f1l + p * CORR_F1F_LD + d);   // same address in every lane: broadcast
+                    acc[p] = fmaf(x.x, b.x, acc[p]);
+                    acc[p] = fmaf(x.y, b.y, acc[p]);
+                    acc[p] = fmaf(x.z, b.z, acc[p]);
+                    acc[p] = fmaf(x.w, b.w, acc[p]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 16; p++) S[p * ldS + q] = acc[p] * a.scale;
+        }
+    } else {
+        const half_t* f2 = fh + i2 * HW * CORR_D;
+        const half_t* f1l = reinterpret_cast<const half_t*>(f1s);
+        const int fr = lane & 15, fg = lane >> 4;
+        half8 bfrag[CORR_D / 32];
+#pragma unroll
+        for (int ks = 0; ks < CORR_D / 32; ks++) bfrag[ks] = *reinterpret_cast<const half8*>(f1l + fr * CORR_F1H_LD + ks * 32 + fg * 8);
+        const int n_qt = (HW + 15) >> 4;
+        for (int qt = wave; qt < n_qt; qt += 4) {
+            const int q = min(qt * 16 + fr, HW - 1);
+            const half_t* row = f2 + (int64_t)q * CORR_D + fg * 8;
+            half8 afrag[CORR_D / 32];
+#pragma unroll
+            for (int ks = 0; ks < CORR_D / 32; ks++) afrag[ks] = *reinterpret_cast<const half8*>(row + ks * 32);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < CORR_D / 32; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[ks], bfrag[ks], acc, 0, 0, 0);
+            // D: rows fg * 4 + r = q within the tile, column fr = p
+            *reinterpret_cast<f32x4*>(S + fr * ldS + qt * 16 + fg * 4) = acc * a.scale;
+        }
+    }
+    __syncthreads();
+    // ---- the four levels.  Row p of level l is [n * HW + p0 + p][n_l]: the tile's outputs are one contiguous span.
+    const int rows = min(16, HW - p0);
+    OT* const o0 = reinterpret_cast<OT*>(a.levels[0]) + (n * HW + p0) * (int64_t)HW;
+    for (int i = tid; i < rows * HW; i += 256) {
+        const int p = i / HW, q = i - p * HW;
+        o0[i] = (OT)S[p * ldS + q];
+    }
+    const int w1 = W / 2, w2 = W / 4, w3 = W / 8, n3 = (H / 8) * w3;
+    OT* const o1 = reinterpret_cast<OT*>(a.levels[1]) + (n * HW + p0) * (int64_t)n1;
+    for (int i = tid; i < rows * n1; i += 256) {
+        const int p = i / n1, r = i - p * n1, y = r / w1, x = r - y * w1;
+        const float* s = S + p * ldS + (2 * y) * W + 2 * x;
+        const float v = (((s[0] + s[1]) + s[W]) + s[W + 1]) * 0.25f;
+        S1[i] = v;
+        o1[i] = (OT)v;
+    }
+    __syncthreads();
+    OT* const o2 = reinterpret_cast<OT*>(a.levels[2]) + (n * HW + p0) * (int64_t)n2;
+    for (int i = tid; i < rows * n2; i += 256) {
+        const int p = i / n2, r = i - p * n2, y = r / w2, x = r - y * w2;
+        const float* s = S1 + p * n1 + (2 * y) * w1 + 2 * x;
+        const float v = (((s[0] + s[1]) + s[w1]) + s[w1 + 1]) * 0.25f;
+        S2[i] = v;
+        o2[i] = (OT)v;
+    }
+    __syncthreads();
+    OT* const o3 = reinterpret_cast<OT*>(a.levels[3]) + (n * HW + p0) * (int64_t)n3;
+    for (int i = tid; i < rows * n3; i += 256) {
+        const int p = i / n3, r = i - p * n3, y = r / w3, x = r - y * w3;
+        const float* s = S2 + p * n2 + (2 * y) * w2 + 2 * x;
+        o3[i] = (OT)((((s[0] + s[1]) + s[w2]) + s[w2 + 1]) * 0.25f);
+    }
+}
+
+static int corr_check(const vtgb_raft_corr_args* a) {
+    VTGB_REQUIRE(a, VTGB_EINVAL, "raft_corr: NULL args");
+    VTGB_REQUIRE(a->dtype == VTGB_BF16 || a->dtype == VTGB_F32, VTGB_EINVAL, "raft_corr: bad dtype %d", a->dtype);
+    VTGB_REQUIRE(a->n_pairs <= 65535, VTGB_EUNSUPPORTED, "raft_corr: at most 65535 pairs per call (got %d)", a->n_pairs);
+    VTGB_REQUIRE(a->n_pairs > 0 && a->H8 >= 8 && a->W8 >= 8 && a->dim == CORR_D && a->pairs_per_clip > 0 && a->frames_per_clip > 0 && a->n_images > 0,
+                 VTGB_EINVAL, "raft_corr: bad dims n_pairs=%d H8=%d W8=%d dim=%d", a->n_pairs, a->H8, a->W8, a->dim);
+    const int64_t last = ((int64_t)(a->n_pairs - 1) / a->pairs_per_clip) * a->frames_per_clip + (a->n_pairs - 1) % a->pairs_per_clip;
+    VTGB_REQUIRE(a->first_off >= 0 && a->second_off >= 0 && last + a->first_off < a->n_images && last + a->second_off < a->n_images, VTGB_EINVAL,
+                 "raft_corr: pair -> image map leaves the %d feature maps", a->n_images);
+    const CorrLds c = corr_lds(a->H8, a->W8, a->dtype == VTGB_F32);
+    VTGB_REQUIRE(c.bytes <= 160 * 1024, VTGB_EUNSUPPORTED, "raft_corr: %d x %d maps exceed the LDS tile", a->H8, a->W8);
+    return VTGB_OK;
+}
+
+extern "C" size_t vtgb_raft_corr_workspace_bytes(const vtgb_raft_corr_args* a) {
+    if (corr_check(a) != VTGB_OK) return 0;
+    if (a->dtype == VTGB_F32) return 256;
+    return align_up((size_t)a->n_images * a->H8 * a->W8 * CORR_D * sizeof(half_t), 256);
+}
+
+extern "C" int vtgb_raft_corr(const vtgb_raft_corr_args* a, vtgb_stream_t stream) {
+    VTGB_TRY(corr_check(a));
+    VTGB_REQUIRE(a->fmap && a->levels[0] && a->levels[1] && a->levels[2] && a->levels[3], VTGB_EINVAL, "raft_corr: NULL operand");
+    const bool f32 = a->dtype == VTGB_F32;
+    const CorrLds c = corr_lds(a->H8, a->W8, f32);
+    const int HW = a->H8 * a->W8;
+    const dim3 grid((unsigned)((HW + 15) / 16), (unsigned)a->n_pairs);
+    if (f32) {
+        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_kernel<true, float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.bytes));
+        hipLaunchKernelGGL((raft_corr_kernel<true, float>), grid, dim3(256), c.bytes, stream, *a, nullptr, c.ldS, c.n1, c.n2);
+    } else {
+        const size_t need = vtgb_raft_corr_workspace_bytes(a);
+        VTGB_REQUIRE(a->workspace && a->workspace_bytes >= need, VTGB_EWORKSPACE, "raft_corr: workspace %zu < %zu bytes", a->workspace_bytes, need);
+        half_t* fh = reinterpret_cast<half_t*>(a->workspace);
+        const int64_t n4 = (int64_t)a->n_images * HW * CORR_D / 4;
+        hipLaunchKernelGGL(cast_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a->fmap, fh, n4);
+        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_kernel<false, half_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.bytes));
+        hipLaunchKernelGGL((raft_corr_kernel<false, half_t>), grid, dim3(256), c.bytes, stream, *a, fh, c.ldS, c.n1, c.n2);
+    }
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}

@@ -17,16 +17,17 @@
 // Raw 0..255 integers are exact in bf16; the normalisation lives in the packed weights (w * 2/255) and bias
 // (b - 127.5 * sum w'), and out-of-image taps hold 127.5 (= normalised 0): horizontally in the packed tensor,
 // vertically through the convolution's padding page.
-__global__ __launch_bounds__(256) void raft_stem_pack_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, bf16_t* __restrict__ pad_page,
+template <typename T>
+__global__ __launch_bounds__(256) void raft_stem_pack_kernel(const float* __restrict__ img, T* __restrict__ out, T* __restrict__ pad_page,
                                                              int64_t n_px, int H, int W) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 128) pad_page[i] = (bf16_t)((i & 63) < 48 ? 127.5f : 0.f);
+    if (i < 64) pad_page[i] = (T)(i < 48 ? 127.5f : 0.f);
     if (i >= n_px * 4) return;
     const int64_t px_i = i >> 2;
     const int dX = (int)(i & 3), W2 = W >> 1, H2 = H >> 1;
     const int X = (int)(px_i % W2), Y = (int)((px_i / W2) % H2);
     const int64_t n = px_i / ((int64_t)W2 * H2);
-    bf16_t v[12];
+    T v[12];
 #pragma unroll
     for (int py = 0; py < 2; py++)
 #pragma unroll
@@ -34,15 +35,16 @@ __global__ __launch_bounds__(256) void raft_stem_pack_kernel(const float* __rest
             const int col = 2 * (X + dX - 2) + pxx, row = 2 * Y + py;
             const bool ok = (unsigned)col < (unsigned)W;
 #pragma unroll
-            for (int c = 0; c < 3; c++) v[py * 6 + pxx * 3 + c] = (bf16_t)(ok ? img[((n * 3 + c) * H + row) * W + col] : 127.5f);
+            for (int c = 0; c < 3; c++) v[py * 6 + pxx * 3 + c] = (T)(ok ? img[((n * 3 + c) * H + row) * W + col] : 127.5f);
         }
-    bf16_t* o = out + px_i * 64 + dX * 12;
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    T* o = out + px_i * 64 + dX * 12;
 #pragma unroll
-    for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4*>(o + q * 4) = bf16x4{v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+    for (int q = 0; q < 3; q++) *reinterpret_cast<T4*>(o + q * 4) = T4{v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
     if (dX == 3) {
-        const bf16x4 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        const T4 z = {(T)0.f, (T)0.f, (T)0.f, (T)0.f};
 #pragma unroll
-        for (int q = 0; q < 4; q++) *reinterpret_cast<bf16x4*>(out + px_i * 64 + 48 + q * 4) = z;
+        for (int q = 0; q < 4; q++) *reinterpret_cast<T4*>(out + px_i * 64 + 48 + q * 4) = z;
     }
 }
 
@@ -80,8 +82,10 @@ __global__ __launch_bounds__(256) void inorm_stats_kernel(const float* __restric
 
 // ---- y = [relu]((x - mean) * rstd); out = [relu](resid + y); bf16 NHWC with Cpad channels (pad = 0).
 // mean = sum / HW, rstd = 1 / sqrt(biased var + 1e-5) from the accumulated moments; 4 channels per thread.
-__global__ void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const bf16_t* __restrict__ resid,
-                                  bf16_t* __restrict__ out, int64_t M, int HW, int C, int Cpad, int ldx, int relu_inner, int relu_outer) {
+template <typename T>
+__global__ void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const T* __restrict__ resid,
+                                  T* __restrict__ out, int64_t M, int HW, int C, int Cpad, int ldx, int relu_inner, int relu_outer) {
+    typedef T T4 __attribute__((ext_vector_type(4)));
     const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int cp4 = Cpad >> 2;
     if (i4 >= M * cp4) return;
@@ -108,7 +112,7 @@ __global__ void norm_apply_kernel(const float* __restrict__ x, const float* __re
             for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
         }
         if (resid) {
-            const bf16x4 r = *reinterpret_cast<const bf16x4*>(resid + m * Cpad + c);
+            const T4 r = *reinterpret_cast<const T4*>(resid + m * Cpad + c);
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] += (float)r[e];
         }
@@ -117,15 +121,15 @@ __global__ void norm_apply_kernel(const float* __restrict__ x, const float* __re
             for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
         }
     }
-    const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-    *reinterpret_cast<bf16x4*>(out + m * Cpad + c) = o;
+    const T4 o = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+    *reinterpret_cast<T4*>(out + m * Cpad + c) = o;
 }
 
-static GemmDesc enc_conv(int Mo, int N, int Ho, int Wo, int K, int Cin, int stride, int Hi, int Wi, const void* A, const void* Wt, const float* bias,
+static GemmDesc enc_conv(int dt, int Mo, int N, int Ho, int Wo, int K, int Cin, int stride, int Hi, int Wi, const void* A, const void* Wt, const float* bias,
                          float* out, int ldo, const void* zero, float* col_stats) {
     GemmDesc d;
     memset(&d, 0, sizeof(d));
-    d.dtype = VTGB_BF16; d.M = Mo; d.N = N; d.K = K * K * Cin; d.epi = VTGB_EPI_STORE_F32;
+    d.dtype = dt; d.M = Mo; d.N = N; d.K = K * K * Cin; d.epi = VTGB_EPI_STORE_F32;
     d.A = A; d.lda = Cin; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = out; d.ldo = ldo;
     d.conv_H = Ho; d.conv_W = Wo; d.conv_KH = K; d.conv_KW = K; d.conv_Cin = Cin; d.conv_split = Cin;
     d.conv_stride = stride; d.conv_Hi = Hi; d.conv_Wi = Wi; d.zero_page = zero;
@@ -137,15 +141,17 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     VTGB_REQUIRE(a, VTGB_EINVAL, "raft_encoder: NULL args");
     VTGB_REQUIRE(a->n_images > 0 && a->H >= 64 && a->W >= 64 && (a->H % 8) == 0 && (a->W % 8) == 0 && (a->norm == 0 || a->norm == 1), VTGB_EINVAL,
                  "raft_encoder: bad dims n=%d H=%d W=%d", a->n_images, a->H, a->W);
-    const int n = a->n_images;
+    VTGB_REQUIRE(a->dtype == VTGB_BF16 || a->dtype == VTGB_F32, VTGB_EINVAL, "raft_encoder: bad dtype %d", a->dtype);
+    const int n = a->n_images, dt = a->dtype;
+    const size_t es = dtype_size(dt);
     const int H2 = a->H / 2, W2 = a->W / 2, H4 = a->H / 4, W4 = a->W / 4, H8 = a->H / 8, W8 = a->W / 8;
     const int64_t M2 = (int64_t)n * H2 * W2, M4 = (int64_t)n * H4 * W4, M8 = (int64_t)n * H8 * W8;
     VTGB_REQUIRE(M2 < (1ll << 31), VTGB_EUNSUPPORTED, "raft_encoder: too many pixels per call (chunk the images)");
     float* cf = (float*)ws.take(M2 * 64 * 4);          // fp32 conv output (largest stage; later stages reuse it)
     float* cf2 = (float*)ws.take(M4 * 128 * 4);        // fp32 output of the downsample branch
-    bf16_t* act0 = (bf16_t*)ws.take(M2 * 64 * 2);
-    bf16_t* act1 = (bf16_t*)ws.take(M2 * 64 * 2);
-    bf16_t* act2 = (bf16_t*)ws.take(M2 * 64 * 2);
+    void* act0 = ws.take(M2 * 64 * es);   // activations: bf16 (VTGB_BF16) or fp32 (VTGB_F32)
+    void* act1 = ws.take(M2 * 64 * es);
+    void* act2 = ws.take(M2 * 64 * es);
     float* stats = (float*)ws.take((int64_t)n * 128 * 2 * 4);
     float* stats2 = (float*)ws.take((int64_t)n * 128 * 2 * 4);   // the downsample branch's moments
     void* zero = ws.take(256);
@@ -159,30 +165,40 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     VTGB_HIP(hipMemsetAsync(zero, 0, 256, s));
 
     // `fused`: the convolution that produced x has already accumulated the moments (stats zeroed before it)
-    auto norm = [&](const float* x, int64_t M, int HW, int C, int Cpad, int ldx, const bf16_t* resid, bf16_t* out, int relu_in, int relu_out,
+    auto norm = [&](const float* x, int64_t M, int HW, int C, int Cpad, int ldx, const void* resid, void* out, int relu_in, int relu_out,
                     float* st, bool fused) -> int {
         if (inorm && !fused) {
             VTGB_HIP(hipMemsetAsync(st, 0, (size_t)n * C * 2 * sizeof(float), s));
             const int splits = HW >= 4096 ? 16 : HW >= 1024 ? 4 : 1;
             hipLaunchKernelGGL(inorm_stats_kernel, dim3(n, splits), dim3(256), 0, s, x, st, HW, C, ldx);
         }
-        hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)((M * (Cpad / 4) + 255) / 256)), dim3(256), 0, s, x, inorm ? st : nullptr, resid, out, M, HW,
-                           C, Cpad, ldx, relu_in, relu_out);
+        const dim3 grid((unsigned)((M * (Cpad / 4) + 255) / 256));
+        if (dt == VTGB_BF16)
+            hipLaunchKernelGGL(norm_apply_kernel<bf16_t>, grid, dim3(256), 0, s, x, inorm ? st : nullptr, (const bf16_t*)resid, (bf16_t*)out, M, HW, C, Cpad,
+                               ldx, relu_in, relu_out);
+        else
+            hipLaunchKernelGGL(norm_apply_kernel<float>, grid, dim3(256), 0, s, x, inorm ? st : nullptr, (const float*)resid, (float*)out, M, HW, C, Cpad,
+                               ldx, relu_in, relu_out);
         VTGB_HIP(hipGetLastError());
         return VTGB_OK;
     };
     // moments for a convolution output: zero the buffer and hand it to the GEMM epilogue when the image is
     // large enough for the two-images-per-tile bookkeeping, else leave it to the separate pass
     auto stats_for = [&](float* st, int HW, int C) -> float* {
-        if (!inorm || HW < 256) return nullptr;
+        if (!inorm || HW < 256 || dt != VTGB_BF16) return nullptr;   // (the fp32 kernel leaves the moments to the separate pass)
         (void)hipMemsetAsync(st, 0, (size_t)n * C * 2 * sizeof(float), s);
         return st;
     };
     // ---- stem: repack, then a 4x1 implicit-GEMM convolution whose epilogue also yields the InstanceNorm moments
-    hipLaunchKernelGGL(raft_stem_pack_kernel, dim3((unsigned)((M2 * 4 + 255) / 256)), dim3(256), 0, s, a->images, act1, (bf16_t*)pad_page, M2, a->H, a->W);
+    if (dt == VTGB_BF16)
+        hipLaunchKernelGGL(raft_stem_pack_kernel<bf16_t>, dim3((unsigned)((M2 * 4 + 255) / 256)), dim3(256), 0, s, a->images, (bf16_t*)act1, (bf16_t*)pad_page, M2,
+                           a->H, a->W);
+    else
+        hipLaunchKernelGGL(raft_stem_pack_kernel<float>, dim3((unsigned)((M2 * 4 + 255) / 256)), dim3(256), 0, s, a->images, (float*)act1, (float*)pad_page, M2,
+                           a->H, a->W);
     {
         float* sf = stats_for(stats, H2 * W2, 64);
-        GemmDesc d = enc_conv((int)M2, 64, H2, W2, 1, 64, 1, H2, W2, act1, w[0], F(w[1]), cf, 64, pad_page, sf);
+        GemmDesc d = enc_conv(dt, (int)M2, 64, H2, W2, 1, 64, 1, H2, W2, act1, w[0], F(w[1]), cf, 64, pad_page, sf);
         d.conv_KH = 4; d.K = 256; d.ldw = 256;
         if (!inorm) { d.epi = VTGB_EPI_STORE; d.act = 1; d.out = act0; }        // relu(bn1(conv1(x))) straight to bf16
         VTGB_TRY(launch_conv_gemm(d, s));
@@ -191,16 +207,16 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     // ---- six residual blocks
     struct Stage { int C, Cpad, stride, Ho, Wo; };
     const Stage st[6] = {{64, 64, 1, H2, W2}, {64, 64, 1, H2, W2}, {96, 128, 2, H4, W4}, {96, 128, 1, H4, W4}, {128, 128, 2, H8, W8}, {128, 128, 1, H8, W8}};
-    bf16_t* x = act0;
-    bf16_t* t1 = act1;
-    bf16_t* t2 = act2;
+    void* x = act0;
+    void* t1 = act1;
+    void* t2 = act2;
     int Cin_pad = 64, Hi = H2, Wi = W2;
     // cnet (norm == 1, BatchNorm folded): no statistics are needed, so ReLU, the skip connection and the bf16 cast
     // live in the convolution's epilogue and the fp32 round trip + norm pass disappear (the packed weights carry
     // C_pad output rows, the padded ones zero, so the padded channels come out as zeros)
-    auto conv_bn = [&](int64_t Mo, const Stage& g, int K, int Cin, int stride, int Hi_, int Wi_, const bf16_t* A, const void* Wt, const float* bias,
-                       int relu, const bf16_t* resid, int post_relu, bf16_t* out) -> int {
-        GemmDesc d = enc_conv((int)Mo, g.Cpad, g.Ho, g.Wo, K, Cin, stride, Hi_, Wi_, A, Wt, bias, nullptr, g.Cpad, zero, nullptr);
+    auto conv_bn = [&](int64_t Mo, const Stage& g, int K, int Cin, int stride, int Hi_, int Wi_, const void* A, const void* Wt, const float* bias,
+                       int relu, const void* resid, int post_relu, void* out) -> int {
+        GemmDesc d = enc_conv(dt, (int)Mo, g.Cpad, g.Ho, g.Wo, K, Cin, stride, Hi_, Wi_, A, Wt, bias, nullptr, g.Cpad, zero, nullptr);
         d.epi = VTGB_EPI_STORE; d.act = relu; d.out = out;
         d.resid_bf16 = resid; d.ldrb = g.Cpad; d.post_relu = post_relu;
         return launch_conv_gemm(d, s);
@@ -211,10 +227,10 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
         const int64_t Mo = (int64_t)n * g.Ho * g.Wo;
         const int HWo = g.Ho * g.Wo;
         if (g.stride != 1) VTGB_REQUIRE(bw[4] && bw[5], VTGB_EINVAL, "raft_encoder: block %d lacks its downsample weights", b);
-        bf16_t* outb;
+        void* outb;
         if (!inorm) {
             VTGB_TRY(conv_bn(Mo, g, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), 1, nullptr, 0, t1));        // y = relu(bn1(conv1(x)))
-            const bf16_t* res = x;
+            const void* res = x;
             outb = t2;                                                                                          // conv2 reads t1: it cannot be the output
             if (g.stride != 1) {                                                                                // x = bn3(downsample(x))
                 VTGB_TRY(conv_bn(Mo, g, 1, Cin_pad, g.stride, Hi, Wi, x, bw[4], F(bw[5]), 0, nullptr, 0, t2));
@@ -224,14 +240,14 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
             VTGB_TRY(conv_bn(Mo, g, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), 1, res, 1, outb));             // relu(x + relu(bn2(conv2(y))))
         } else {
             float* sf = stats_for(stats, HWo, g.C);
-            VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), cf, g.Cpad, zero, sf), s));
+            VTGB_TRY(launch_conv_gemm(enc_conv(dt, (int)Mo, g.C, g.Ho, g.Wo, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), cf, g.Cpad, zero, sf), s));
             VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t1, 1, 0, stats, sf != nullptr));  // y = relu(norm1(conv1(x)))
             sf = stats_for(stats, HWo, g.C);
-            VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), cf, g.Cpad, zero, sf), s));
-            const bf16_t* res = x;
+            VTGB_TRY(launch_conv_gemm(enc_conv(dt, (int)Mo, g.C, g.Ho, g.Wo, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), cf, g.Cpad, zero, sf), s));
+            const void* res = x;
             if (g.stride != 1) {                                                                      // x = norm3(downsample(x))
                 float* sf2 = stats_for(stats2, HWo, g.C);
-                VTGB_TRY(launch_conv_gemm(enc_conv((int)Mo, g.C, g.Ho, g.Wo, 1, Cin_pad, g.stride, Hi, Wi, x, bw[4], F(bw[5]), cf2, g.Cpad, zero, sf2), s));
+                VTGB_TRY(launch_conv_gemm(enc_conv(dt, (int)Mo, g.C, g.Ho, g.Wo, 1, Cin_pad, g.stride, Hi, Wi, x, bw[4], F(bw[5]), cf2, g.Cpad, zero, sf2), s));
                 VTGB_TRY(norm(cf2, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t2, 0, 0, stats2, sf2 != nullptr));
                 res = t2;
             }
@@ -240,8 +256,8 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
             VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, res, outb, 1, 1, stats, sf != nullptr));
         }
         // rotate buffers: the block output becomes the next input, the other two are scratch
-        bf16_t* all3[3] = {x, t1, t2};
-        bf16_t* rest[2];
+        void* all3[3] = {x, t1, t2};
+        void* rest[2];
         int k = 0;
         for (int i = 0; i < 3; i++) if (all3[i] != outb) rest[k++] = all3[i];
         x = outb; t1 = rest[0]; t2 = rest[1];
@@ -251,7 +267,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     {
         GemmDesc d;
         memset(&d, 0, sizeof(d));
-        d.dtype = VTGB_BF16; d.M = (int)M8; d.N = 256; d.K = 128; d.epi = VTGB_EPI_STORE_F32;
+        d.dtype = dt; d.M = (int)M8; d.N = 256; d.K = 128; d.epi = VTGB_EPI_STORE_F32;
         d.A = x; d.lda = 128; d.W = w[38]; d.ldw = 128; d.bias = F(w[39]); d.out = a->out; d.ldo = 256;
         VTGB_TRY(launch_conv_gemm(d, s));
     }

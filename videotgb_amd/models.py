@@ -11,7 +11,7 @@ library or without a GPU the forwards raise.
   QFormer            <- InstructBlipQFormerModel / Blip2QFormerModel (xinstructblip.py:1049-1242, xblip2.py:988-1174)
   LanguageProjection <- nn.Linear language_projection                (xinstructblip.py:1266)
   TemporalEncoder    <- RopeBertModel                                (xropebert.py:929-1178)
-  Raft               <- RAFT (host torch ops on the GPU for now) (xraft.py:51-156)
+  Raft               <- RAFT                                        (xraft.py:51-156, raft_utils/*)
   LSTP / LSTP_blip2  <- eval/utils/model.py:19-235 / :238-445
 """
 from __future__ import annotations
@@ -234,141 +234,76 @@ class InputPadder:
 
 
 class Raft(nn.Module):
-    """RAFT-large with the reference's parameter names.  First pass: stock
-    PyTorch-ROCm ops (MIOpen convolutions, rocBLAS all-pairs correlation) on the GPU, in
-    ``raft_dtype`` (fp32 by default as in the reference, xraft.py:118-119).  Only the last
-    iteration's upsampled flow is materialised."""
+    """RAFT-large (xraft.py:51-156) with the reference's parameter names; every forward runs in libvtgb.so:
+    vtgb_raft_encoder (fnet, cnet) -> vtgb_raft_corr (all-pairs correlation + pyramid) -> vtgb_raft_update (refinement
+    loop, mask head, convex upsample).  ``compute_dtype``: "bf16" = MFMA implicit-GEMM convolutions (a reduced-precision
+    mode the reference does not have), "f32" = fp32 FMAs, the reference's arithmetic (xraft.py:118-119).
+    Only the last iteration's upsampled flow is materialised (``test_mode=True``, what every caller on the path uses)."""
 
-    def __init__(self, raft_dtype=torch.float32, hip_update: bool = False):
+    def __init__(self, compute_dtype="bf16"):
         super().__init__()
         tree = ParamTree(synth.raft_shapes(""), "")
         for name, child in list(tree._modules.items()):
             self.add_module(name, child)
-        self.raft_dtype = raft_dtype
-        self.hip_update = hip_update     # run the 20 refinement iterations in libvtgb.so (bf16 MFMA implicit-GEMM convs)
-        self.channels_last = False       # NHWC activations for the MIOpen encoder convolutions
-        self.hip_encoders = False        # fnet / cnet in libvtgb.so as well (forward_clips)
+        self.code = ops.dtype_code(compute_dtype)
         self._table = None
 
     def _apply(self, fn, *a, **k):
         self._table = None
         return super()._apply(fn, *a, **k)
 
+    def load_state_dict(self, state_dict, *a, **k):
+        self._table = None
+        if any(key.startswith("module.") for key in state_dict):     # DataParallel checkpoint (raft_utils/utils.py:85-90)
+            state_dict = dp_state_to_normal(state_dict)
+        return super().load_state_dict(state_dict, *a, **k)
+
+    def set_compute_dtype(self, compute_dtype):
+        self.code = ops.dtype_code(compute_dtype)
+        self._table = None
+        return self
+
     def _hip_tables(self):
         if self._table is None:
             sd = {k: v for k, v in self.state_dict().items()}
-            self._table = (ops.RaftWeights(sd), ops.RaftEncoderWeights(sd, "fnet.", False), ops.RaftEncoderWeights(sd, "cnet.", True))
+            self._table = (ops.RaftWeights(sd, "update_block.", self.code), ops.RaftEncoderWeights(sd, "fnet.", False, self.code),
+                           ops.RaftEncoderWeights(sd, "cnet.", True, self.code))
         return self._table
 
     @torch.no_grad()
     def forward_clips(self, frames: Tensor, iters: int = 20) -> Tensor:
-        """All-HIP path for whole clips: frames [B, T, 3, H, W] -> flow [B, T-1, 2, H, W] between consecutive frames.
+        """Whole clips: frames [B, T, 3, H, W] -> flow [B, T-1, 2, H, W] between consecutive frames.
         fnet runs once per distinct frame (the reference encodes cat(image1, image2), i.e. every inner frame
         twice, with identical results since InstanceNorm is per image); cnet on frames[:, :-1]."""
         upd, fw, cw = self._hip_tables()
         b, t, _, h, w = frames.shape
         h8, w8 = h // 8, w // 8
-        fmap = ops.raft_encoder(fw, frames.reshape(b * t, 3, h, w)).view(b, t, h8 * w8, 256)
+        fmap = ops.raft_encoder(fw, frames.reshape(b * t, 3, h, w))                           # [b*t, HW, 256]
         cmap = ops.raft_encoder(cw, frames[:, :-1].reshape(b * (t - 1), 3, h, w))             # [n, HW, 256]
         n = b * (t - 1)
-        # all-pairs correlation (corr.py:52-60) as ONE half-precision batched GEMM (fp32 accumulation in the MFMA; the
-        # features are O(1): 11 significant bits on inputs and outputs against the bf16 features the lookup emits),
-        # a tenth of the fp32 GEMM's time and half the volume's traffic
-        fh = fmap.to(torch.float16)
-        corr = torch.matmul(fh[:, :-1].reshape(n, h8 * w8, 256), fh[:, 1:].reshape(n, h8 * w8, 256).transpose(1, 2))
-        pyr = ops.raft_corr_pyramid(corr.view(n * h8 * w8, h8 * w8), h8, w8)                   # / sqrt(256) + 3 avg-pools, fp16
+        pyr = ops.raft_corr(fmap, n, h8, w8, t - 1, t, 0, 1, self.code)
         # net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:]) (xraft.py:126-127) are taken from the pixel-major cnet output inside
         return ops.raft_update(upd, None, None, pyr, iters, cnet_nhwc=cmap, hw=(h8, w8)).view(b, t - 1, 2, h, w)
 
-    def _c(self, name, x, stride=1, padding=0):
-        m = self.get_submodule(name)
-        w = m.weight.to(x.dtype)
-        if self.channels_last:
-            w = w.contiguous(memory_format=torch.channels_last)
-        return F.conv2d(x, w, m.bias.to(x.dtype), stride=stride, padding=padding)
-
-    def _norm(self, name, x, kind):
-        if kind == "instance":
-            return F.instance_norm(x, eps=1e-5)
-        m = self.get_submodule(name)
-        return F.batch_norm(x, m.running_mean.to(x.dtype), m.running_var.to(x.dtype), m.weight.to(x.dtype),
-                            m.bias.to(x.dtype), training=False, eps=1e-5)
-
-    def _res(self, p, x, kind, stride):
-        y = F.relu(self._norm(p + "norm1", self._c(p + "conv1", x, stride, 1), kind))
-        y = F.relu(self._norm(p + "norm2", self._c(p + "conv2", y, 1, 1), kind))
-        if stride != 1:
-            x = self._norm(p + "norm3", self._c(p + "downsample.0", x, stride, 0), kind)
-        return F.relu(x + y)
-
-    def _encoder(self, p, x, kind):
-        x = F.relu(self._norm(p + "norm1", self._c(p + "conv1", x, 2, 3), kind))
-        for li, stride in (("layer1", 1), ("layer2", 2), ("layer3", 2)):
-            x = self._res(f"{p}{li}.0.", x, kind, stride)
-            x = self._res(f"{p}{li}.1.", x, kind, 1)
-        return self._c(p + "conv2", x)
-
     @torch.no_grad()
     def forward(self, image1, image2, iters=20, flow_init=None, upsample=True, test_mode=True):
-        dt = self.raft_dtype
-        image1 = (2 * (image1.float() / 255.0) - 1.0).contiguous().to(dt)
-        image2 = (2 * (image2.float() / 255.0) - 1.0).contiguous().to(dt)
+        """RAFT.forward (xraft.py:102-156): image1 / image2 [N, 3, H, W] (0..255 convention), H and W multiples of 8
+        (InputPadder) -> flow_up [N, 2, H, W]."""
+        if not (test_mode and upsample):
+            raise NotImplementedError("Raft: only test_mode=True, upsample=True (the last iteration's upsampled flow) is built")
+        upd, fw, cw = self._hip_tables()
         n, _, h, w = image1.shape
-        if self.channels_last:
-            image1 = image1.contiguous(memory_format=torch.channels_last)
-            image2 = image2.contiguous(memory_format=torch.channels_last)
-        f = self._encoder("fnet.", torch.cat([image1, image2], 0), "instance").float()
-        fmap1, fmap2 = f[:n], f[n:]
-        d, hh, ww = fmap1.shape[1:]
-        corr = torch.matmul(fmap1.view(n, d, hh * ww).transpose(1, 2), fmap2.view(n, d, hh * ww))
-        corr = (corr / torch.sqrt(torch.tensor(d).float())).reshape(n * hh * ww, 1, hh, ww)
-        pyr = [corr]
-        for _ in range(3):
-            corr = F.avg_pool2d(corr, 2, stride=2)
-            pyr.append(corr)
-        c = self._encoder("cnet.", image1, "batch")
-        net, inp = torch.tanh(c[:, :128]), torch.relu(c[:, 128:])
-        if self.hip_update and flow_init is None:
-            return ops.raft_update(self._hip_tables()[0], net.float(), inp.float(), pyr, iters)
-        ys, xs = torch.meshgrid(torch.arange(hh, device=image1.device), torch.arange(ww, device=image1.device), indexing="ij")
-        coords0 = torch.stack([xs, ys], 0).float()[None].repeat(n, 1, 1, 1)
-        coords1 = coords0.clone() if flow_init is None else coords0 + flow_init
-        r = 4
-        dx = torch.linspace(-r, r, 2 * r + 1, device=image1.device)
-        delta = torch.stack(torch.meshgrid(dx, dx, indexing="ij"), dim=-1).view(1, 2 * r + 1, 2 * r + 1, 2)
-        u = "update_block."
-        mask = None
-        for it in range(iters):
-            cp = coords1.permute(0, 2, 3, 1).reshape(n * hh * ww, 1, 1, 2)
-            outs = []
-            for i, cv in enumerate(pyr):                      # CorrBlock.__call__ corr.py:29-50
-                cl = cp / 2 ** i + delta
-                hc, wc = cv.shape[-2:]
-                grid = torch.cat([2 * cl[..., 0:1] / (wc - 1) - 1, 2 * cl[..., 1:2] / (hc - 1) - 1], dim=-1)
-                outs.append(F.grid_sample(cv, grid, align_corners=True).view(n, hh, ww, -1))
-            cfeat = torch.cat(outs, dim=-1).permute(0, 3, 1, 2).contiguous().to(dt)
-            flow = (coords1 - coords0).to(dt)
-            cor = F.relu(self._c(u + "encoder.convc1", cfeat))
-            cor = F.relu(self._c(u + "encoder.convc2", cor, 1, 1))
-            flo = F.relu(self._c(u + "encoder.convf1", flow, 1, 3))
-            flo = F.relu(self._c(u + "encoder.convf2", flo, 1, 1))
-            mf = F.relu(self._c(u + "encoder.conv", torch.cat([cor, flo], 1), 1, 1))
-            x = torch.cat([inp, mf, flow], 1)
-            for sfx, pad in (("1", (0, 2)), ("2", (2, 0))):
-                hx = torch.cat([net, x], 1)
-                z = torch.sigmoid(self._c(u + "gru.convz" + sfx, hx, 1, pad))
-                rr = torch.sigmoid(self._c(u + "gru.convr" + sfx, hx, 1, pad))
-                q = torch.tanh(self._c(u + "gru.convq" + sfx, torch.cat([rr * net, x], 1), 1, pad))
-                net = (1 - z) * net + z * q
-            dflow = self._c(u + "flow_head.conv2", F.relu(self._c(u + "flow_head.conv1", net, 1, 1)), 1, 1)
-            coords1 = coords1 + dflow.float()
-            if it == iters - 1:
-                mask = 0.25 * self._c(u + "mask.2", F.relu(self._c(u + "mask.0", net, 1, 1))).float()
-        flow = coords1 - coords0
-        m = torch.softmax(mask.view(n, 1, 9, 8, 8, hh, ww), dim=2)
-        up = F.unfold(8 * flow, [3, 3], padding=1).view(n, 2, 9, 1, 1, hh, ww)
-        up = torch.sum(m * up, dim=2).permute(0, 1, 4, 2, 5, 3)
-        return up.reshape(n, 2, 8 * hh, 8 * ww)
+        h8, w8 = h // 8, w // 8
+        fmap = ops.raft_encoder(fw, torch.cat([image1, image2], 0))                           # fnet([image1, image2]) (:115)
+        cmap = ops.raft_encoder(cw, image1)
+        pyr = ops.raft_corr(fmap, n, h8, w8, n, n, 0, n, self.code)
+        return ops.raft_update(upd, None, None, pyr, iters, cnet_nhwc=cmap, hw=(h8, w8), flow_init=flow_init)
+
+
+def dp_state_to_normal(state_dict):
+    """raft_utils/utils.py:85-90: strip the DataParallel ``module.`` prefix of a RAFT checkpoint (keys without it are dropped,
+    as in the reference)."""
+    return {k.replace("module.", ""): v for k, v in state_dict.items() if k.startswith("module")}
 
 
 class PathModel(nn.Module):
@@ -399,12 +334,13 @@ class _LSTPBase(nn.Module):
     MAP = "A"
 
     def __init__(self, cfg: synth.PathCfg, device="cuda", language_model: Optional[nn.Module] = None, compute_dtype="bf16",
-                 raft_dtype=torch.float32, raft_hip_update: bool = False):
+                 raft_dtype=None):
         super().__init__()
         self.cfg = cfg
         self.model = PathModel(cfg, language_model, compute_dtype)
         self.temporal_encoder = TemporalEncoder(cfg.tgb, compute_dtype)
-        self.of_extractor = Raft(raft_dtype, raft_hip_update)
+        self.of_extractor = Raft(raft_dtype or compute_dtype)      # raft_dtype: run RAFT in another mode than the rest
+        self._raft_follows = raft_dtype is None
         self.device = device
         self.fell_back = False
 
@@ -413,6 +349,8 @@ class _LSTPBase(nn.Module):
             m.set_compute_dtype(compute_dtype)
         self.model.language_projection.code = ops.dtype_code(compute_dtype)
         self.model.language_projection._packed = None
+        if self._raft_follows:
+            self.of_extractor.set_compute_dtype(compute_dtype)
         return self
 
     # ---- stages -------------------------------------------------------------------------------
@@ -430,12 +368,7 @@ class _LSTPBase(nn.Module):
             ff = flow_frames[c0:c0 + clips_per_call]
             ff = InputPadder(ff.shape).pad(ff.reshape(-1, *ff.shape[2:])).reshape(ff.shape[0], t, ff.shape[2], -1, ff.shape[4]) \
                 if (ff.shape[-1] % 8 or ff.shape[-2] % 8) else ff
-            if getattr(self.of_extractor, "hip_encoders", False):
-                fl = self.of_extractor.forward_clips(ff)
-            else:
-                i1 = ff[:, :-1].reshape(-1, *ff.shape[2:])
-                i2 = ff[:, 1:].reshape(-1, *ff.shape[2:])
-                fl = self.of_extractor(i1, i2).view(ff.shape[0], t - 1, 2, ff.shape[3], ff.shape[4])
+            fl = self.of_extractor.forward_clips(ff)
             outs.append(torch.cat([fl, fl[:, -1:]], dim=1))
         return torch.cat(outs, dim=0)
 

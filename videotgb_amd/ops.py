@@ -432,19 +432,19 @@ def tgb_forward(w: TgbWeights, of: Tensor, of_mask: Tensor, text_ids: Tensor, te
     return seq, logits
 
 
-# ----------------------------------------------------------------------------- RAFT recurrent update (f1)
+# ----------------------------------------------------------------------------- RAFT (a2 / f1)
 def conv_k_order(w: Tensor) -> Tensor:
-    """[co, kh, kw, ci] (ci % 64 == 0) -> [co, K] in the implicit-GEMM kernel's K order: 64-channel chunk major,
-    tap minor (the taps of one channel slab are gathered back to back, see gemm.hip)."""
+    """[co, kh, kw, ci] (ci % 64 == 0) -> [co, K] in the implicit-GEMM kernels' K order: 64-channel chunk major,
+    tap minor (the taps of one channel slab are gathered back to back, see gemm.hip / conv_f32.hip)."""
     co, kh, kw, ci = w.shape
     return w.reshape(co, kh * kw, ci // 64, 64).permute(0, 2, 1, 3).reshape(co, -1).contiguous()
 
 
 class RaftWeights(_WeightTable):
-    """of_extractor.update_block.* -> the packed table of vtgb_raft_update (bf16, [C_out, KH, KW, C_in])."""
+    """of_extractor.update_block.* -> the packed table of vtgb_raft_update ([C_out, KH, KW, C_in] in the compute dtype)."""
 
-    def __init__(self, sd: Dict[str, Tensor], prefix: str = "update_block."):
-        super().__init__(BF16)
+    def __init__(self, sd: Dict[str, Tensor], prefix: str = "update_block.", code: int = BF16):
+        super().__init__(code)
         p = prefix
 
         def conv(name, cin_pad=None):
@@ -461,10 +461,15 @@ class RaftWeights(_WeightTable):
 
         add_conv("encoder.convc1", 384)
         add_conv("encoder.convc2")
-        # convf1 on the matrix cores: k = tap * 4 + {x, y, x, y} (flow head | flow remainder), 49 taps padded to 56
-        wf = sd[p + "encoder.convf1.weight"].float().reshape(128, 2, 49).permute(0, 2, 1)             # [co, tap, c]
-        wf = torch.nn.functional.pad(torch.cat([wf, wf], 2), (0, 0, 0, 7))                            # [co, 56, 4]
-        self.add(wf.reshape(128, 224).contiguous(), True); self.add(sd[p + "encoder.convf1.bias"])
+        if code == BF16:
+            # convf1 on the matrix cores: k = tap * 4 + {x, y, x, y} (flow head | flow remainder), 49 taps padded to 56
+            wf = sd[p + "encoder.convf1.weight"].float().reshape(128, 2, 49).permute(0, 2, 1)         # [co, tap, c]
+            wf = torch.nn.functional.pad(torch.cat([wf, wf], 2), (0, 0, 0, 7))                        # [co, 56, 4]
+            self.add(wf.reshape(128, 224).contiguous(), True)
+        else:
+            # exactness mode: plain fp32 FMAs over the 98 taps; [98, 128], k = c * 49 + ky * 7 + kx
+            self.add(sd[p + "encoder.convf1.weight"].float().reshape(128, 98).t().contiguous(), True)
+        self.add(sd[p + "encoder.convf1.bias"])
         add_conv("encoder.convf2")
         add_conv("encoder.conv")
         for sfx in ("1", "2"):
@@ -482,10 +487,10 @@ class RaftWeights(_WeightTable):
 
 
 def raft_update(w: RaftWeights, net: Optional[Tensor], inp: Optional[Tensor], pyramid: Sequence[Tensor], iters: int = 20,
-                cnet_nhwc: Optional[Tensor] = None, hw: Optional[Tuple[int, int]] = None) -> Tensor:
+                cnet_nhwc: Optional[Tensor] = None, hw: Optional[Tuple[int, int]] = None, flow_init: Optional[Tensor] = None) -> Tensor:
     """net/inp [n, 128, H8, W8] fp32 (tanh / relu applied) -- or ``cnet_nhwc`` [n, H8*W8, 256], the context encoder's
     pixel-major output, with ``hw=(H8, W8)`` (tanh / relu are then applied inside); pyramid: 4 levels
-    [n*H8*W8, 1, h, w] fp32 or fp16 -> flow_up [n, 2, 8H8, 8W8]."""
+    [n*H8*W8, 1, h, w] fp32 or fp16 -> flow_up [n, 2, 8H8, 8W8].  ``flow_init`` [n, 2, H8, W8] as in xraft.py:131-132."""
     if cnet_nhwc is not None:
         _need_cuda(cnet_nhwc, *pyramid)
         cnet_nhwc = cnet_nhwc.contiguous().float()
@@ -499,10 +504,12 @@ def raft_update(w: RaftWeights, net: Optional[Tensor], inp: Optional[Tensor], py
     half = all(t.dtype == torch.float16 for t in pyramid)
     lv = [t.contiguous() if half else t.contiguous().float() for t in pyramid]
     dev = lv[0].device
+    if flow_init is not None:
+        flow_init = flow_init.contiguous().float()
     out = torch.empty(n, 2, 8 * H8, 8 * W8, dtype=torch.float32, device=dev)
-    a = L.RaftUpdateArgs(n, H8, W8, iters, None if net is None else net.data_ptr(), None if inp is None else inp.data_ptr(),
+    a = L.RaftUpdateArgs(w.code, n, H8, W8, iters, None if net is None else net.data_ptr(), None if inp is None else inp.data_ptr(),
                          (C.c_void_p * 4)(*[t.data_ptr() for t in lv]), C.cast(w.array, C.POINTER(C.c_void_p)), out.data_ptr(), None, 0,
-                         1 if half else 0, None if cnet_nhwc is None else cnet_nhwc.data_ptr())
+                         1 if half else 0, None if cnet_nhwc is None else cnet_nhwc.data_ptr(), _ptr(flow_init))
     need = L.lib().vtgb_raft_update_workspace_bytes(C.byref(a))
     ws = _ws.get(need, dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -510,19 +517,38 @@ def raft_update(w: RaftWeights, net: Optional[Tensor], inp: Optional[Tensor], py
     return out
 
 
-def raft_corr_pyramid(corr: Tensor, H8: int, W8: int, scale: float = 1.0 / 16.0) -> List[Tensor]:
-    """corr [n_maps, H8*W8] fp32 or fp16 (fmap1 . fmap2 for every pixel) -> the 4-level pyramid of CorrBlock (corr.py:17-27) in fp16:
-    level l is [n_maps, 1, H8 >> l, W8 >> l]."""
-    _need_cuda(corr)
-    half_in = corr.dtype == torch.float16
-    corr = corr.contiguous() if half_in else corr.contiguous().float()
-    n = corr.numel() // (H8 * W8)
+def raft_corr(fmap: Tensor, n_pairs: int, H8: int, W8: int, pairs_per_clip: int, frames_per_clip: int, first_off: int, second_off: int,
+              code: int = BF16) -> List[Tensor]:
+    """CorrBlock.__init__ (corr.py:12-27, :52-60): fmap [n_images, H8*W8, 256] fp32 (raft_encoder layout) -> the 4-level pyramid,
+    level l [n_pairs*H8*W8, 1, H8 >> l, W8 >> l] in fp16 (bf16 mode) or fp32 (exactness mode).  Pair n correlates images
+    (n // pairs_per_clip) * frames_per_clip + n % pairs_per_clip + first_off / + second_off."""
+    _need_cuda(fmap)
+    fmap = fmap.contiguous().float()
+    n_images = fmap.numel() // (H8 * W8 * 256)
+    odt = torch.float16 if code == BF16 else torch.float32
     lv, h, w = [], H8, W8
     for _ in range(4):
-        lv.append(torch.empty(n, 1, h, w, dtype=torch.float16, device=corr.device))
+        lv.append(torch.empty(n_pairs * H8 * W8, 1, h, w, dtype=odt, device=fmap.device))
         h, w = h // 2, w // 2
-    a = L.RaftCorrPyramidArgs(corr.data_ptr(), (C.c_void_p * 4)(*[t.data_ptr() for t in lv]), n, H8, W8, scale, 1 if half_in else 0)
-    L.check(L.lib().vtgb_raft_corr_pyramid(C.byref(a), _stream()))
+    done = 0
+    while done < n_pairs:   # the kernel's grid takes at most 65535 pairs; chunks must start on a clip boundary
+        per = n_pairs - done
+        if per > 65535:
+            per = max(65535 // pairs_per_clip, 1) * pairs_per_clip
+            if per > 65535:
+                raise NotImplementedError("raft_corr: more than 65535 pairs per clip")
+        img0 = (done // pairs_per_clip) * frames_per_clip
+        fm = fmap.view(n_images, -1)[img0:]
+        lvs = [t[done * H8 * W8:] for t in lv]
+        a = L.RaftCorrArgs(code, per, H8, W8, 256, pairs_per_clip, frames_per_clip, first_off, second_off, n_images - img0, 1.0 / 16.0,
+                           fm.data_ptr(), (C.c_void_p * 4)(*[t.data_ptr() for t in lvs]), None, 0)
+        need = L.lib().vtgb_raft_corr_workspace_bytes(C.byref(a))
+        if need == 0:
+            L.check(L.lib().vtgb_raft_corr(C.byref(a), _stream()))   # raises with the library's message
+        ws = _ws.get(need, fmap.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        L.check(L.lib().vtgb_raft_corr(C.byref(a), _stream()))
+        done += per
     return lv
 
 
@@ -530,8 +556,8 @@ class RaftEncoderWeights(_WeightTable):
     """of_extractor.{fnet,cnet}.* -> the packed table of vtgb_raft_encoder.  batch_norm=True folds the eval-mode
     BatchNorm2d that follows each convolution (extractor.py:20-24,124) into the convolution's weight and bias."""
 
-    def __init__(self, sd: Dict[str, Tensor], prefix: str, batch_norm: bool):
-        super().__init__(BF16)
+    def __init__(self, sd: Dict[str, Tensor], prefix: str, batch_norm: bool, code: int = BF16):
+        super().__init__(code)
         self.batch_norm = batch_norm
         p = prefix
 
@@ -549,7 +575,7 @@ class RaftEncoderWeights(_WeightTable):
             if cin_pad != ci:
                 w = torch.nn.functional.pad(w, (0, cin_pad - ci))
             w = conv_k_order(w)
-            if batch_norm and cout_pad and cout_pad != co:        # cnet stores bf16 straight from the GEMM: padded channels = 0
+            if batch_norm and cout_pad and cout_pad != co:        # cnet stores activations straight from the GEMM: padded channels = 0
                 w = torch.nn.functional.pad(w, (0, 0, 0, cout_pad - co))
             return w
 
@@ -557,7 +583,7 @@ class RaftEncoderWeights(_WeightTable):
             return torch.nn.functional.pad(b, (0, cout_pad - b.numel())) if batch_norm and cout_pad != b.numel() else b
 
         # stem as a 4x1 convolution over the space-to-depth image (raft_enc.hip): [co][tY][dX, py, px, c | pad to 64],
-        # ky = 2 tY + py - 1, kx = 2 dX + px - 1; raw 0..255 pixels: w' = w * 2/255, b' = b - 127.5 * sum(w')
+        # ky = 2 tY + py - 1, kx = 2 dX + px - 1; raw pixels enter: w' = w * 2/255, b' = b - 127.5 * sum(w')
         w, b = folded("conv1", "norm1")
         w = w * (2.0 / 255.0)
         wp = torch.zeros(64, 4, 4, 2, 2, 3, dtype=torch.float32, device=w.device)
@@ -572,8 +598,8 @@ class RaftEncoderWeights(_WeightTable):
                         if kx >= 0:
                             wp[:, tY, dX, py, px, :] = w[:, :, ky, kx]
         wp = torch.nn.functional.pad(wp.reshape(64, 4, 48), (0, 16)).reshape(64, 256)
-        wq = wp.to(torch.bfloat16).float()
-        self.add(wq.contiguous(), True); self.add(b - 127.5 * wq.sum(1))
+        wq = wp.to(torch.bfloat16).float() if code == BF16 else wp       # the weights the kernel will actually multiply by
+        self.add(wq.contiguous(), True); self.add(b - 127.5 * wq.double().sum(1).float())
         cin_pad = 64
         for li, c, cpad in (("layer1", 64, 64), ("layer2", 96, 128), ("layer3", 128, 128)):
             for bi in range(2):
@@ -599,9 +625,11 @@ def raft_encoder(w: RaftEncoderWeights, images: Tensor, max_images: int = 384) -
     images = images.contiguous().float()
     n, _, H, W = images.shape
     out = torch.empty(n, (H // 8) * (W // 8), 256, dtype=torch.float32, device=images.device)
+    if w.code == F32:
+        max_images = max(max_images // 2, 1)
     for i0 in range(0, n, max_images):
         chunk = images[i0:i0 + max_images]
-        a = L.RaftEncoderArgs(chunk.shape[0], H, W, 1 if w.batch_norm else 0, chunk.data_ptr(), C.cast(w.array, C.POINTER(C.c_void_p)),
+        a = L.RaftEncoderArgs(w.code, chunk.shape[0], H, W, 1 if w.batch_norm else 0, chunk.data_ptr(), C.cast(w.array, C.POINTER(C.c_void_p)),
                               out[i0:i0 + max_images].data_ptr(), None, 0)
         need = L.lib().vtgb_raft_encoder_workspace_bytes(C.byref(a))
         ws = _ws.get(need, images.device)
