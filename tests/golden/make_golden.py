@@ -541,11 +541,50 @@ def refine_fixture():
         fh.write("\n".join(gold + pred) + "\n")
 
 
+def refine_answers_fixture():
+    """f4 on the reference side: the per-frame answer loop of LSTPSFModule.forward (src/models/LSTP_SF_module.py:149-204,
+    sliced out of the live function and executed on the tiny InstructBLIP reference model) -- ViT over all candidate
+    frames, then nframe frames at a time through Q-Former + projection + language_model.generate(max_length=128) --
+    on the frames / question of the tiny e2e fixture.  Records the generated ids of every frame."""
+    train_stubs()
+    tm_mod = sys.modules["torchmetrics"]
+    if not hasattr(tm_mod, "Metric"):
+        tm_mod.Metric = type("Metric", (), {})
+    import src.models.LSTP_SF_module as sf
+    from videotgb_amd.synth import path_state_dict, tiny_cfg
+    cfg = tiny_cfg("instructblip")
+    cfg.vit.image = 56
+    ref, tc, _ = build_reference("instructblip", cfg, path_state_dict(cfg, seed=0))
+    lines = textwrap.dedent(inspect.getsource(sf.LSTPSFModule.forward)).split("\n")
+    lo = next(i for i, l in enumerate(lines) if l.strip().startswith("image_embeddings = self.model.vision_model("))
+    hi = next(i for i, l in enumerate(lines) if l.strip().startswith("predict.extend(self.processor.batch_decode("))
+    code = compile(textwrap.dedent("\n".join(lines[lo:hi + 1])), "<reference per-frame answers>", "exec")
+    z = np.load(os.path.join(OUT, "tiny_instructblip_e2e.npz"))
+    frames = torch.from_numpy(z["frames_q8"]).float() * float(z["q8_scale"])
+    rows = []
+    proc = types.SimpleNamespace(batch_decode=lambda ids, skip_special_tokens=True: (rows.extend(r.tolist() for r in ids), [""] * len(ids))[1])
+    batch = {"frames": frames, "qformer_text": torch.from_numpy(z["qformer_ids"]), "qformer_text_attention_mask": torch.from_numpy(z["qformer_mask"]),
+             "question": torch.from_numpy(z["prompt_ids"]), "question_attention_mask": torch.from_numpy(z["prompt_mask"])}
+    env = dict(torch=torch, self=types.SimpleNamespace(model=ref.model, processor=proc), batch=batch, batch_size=1,
+               num_frames=frames.shape[0], nframe=int(z["nframe"]))
+    pref = []
+    hook = ref.model.language_projection.register_forward_hook(lambda m, i, o: pref.append(o))
+    with torch.no_grad():
+        exec(code, env)
+    hook.remove()
+    assert len(rows) == frames.shape[0]
+    n = max(len(r) for r in rows)
+    ids = np.full((len(rows), n), -1, dtype=np.int64)
+    for i, r in enumerate(rows):
+        ids[i, :len(r)] = r
+    save("tiny_refine_answers", ids=ids, prefix_per_frame=torch.cat(pref, 0), eos_token_id=np.int64(tc.eos_token_id), pad_token_id=np.int64(tc.pad_token_id), max_length=np.int64(128))
+
+
 def main():
     install_shim()
     torch.manual_seed(0)
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train", "refine"]
+    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train", "refine", "answers"]
     if "e2e" in which:
         ref_ib, cfg_ib, sd_ib = e2e_fixture("instructblip")
         ref_b2, cfg_b2, sd_b2 = e2e_fixture("blip2")
@@ -560,6 +599,8 @@ def main():
         train_fixture()
     if "refine" in which:
         refine_fixture()
+    if "answers" in which:
+        refine_answers_fixture()
 
 
 if __name__ == "__main__":

@@ -25,8 +25,39 @@ def _check(device, use_graph, fused=True):
     assert out2.tolist() == ref2.tolist()
 
 
+def _check_eos(device, use_graph):
+    """No min_new_tokens on either side: rows stop at EOS, pad afterwards, and the output ends where the last row finished
+    (the fixed-length decoder emitted post-EOS continuations).  EOS = a token the model does emit early."""
+    from videotgb_amd.decode import GreedyDecoder
+    lm = _model(device)
+    g = torch.Generator().manual_seed(1)
+    emb = (torch.randn(5, 6, 32, generator=g) * 0.5).to(device)
+    am = torch.ones(5, 6, dtype=torch.long, device=device)
+    free = lm.generate(inputs_embeds=emb, attention_mask=am, do_sample=False, max_new_tokens=9, min_new_tokens=9, use_cache=True)
+    dec = GreedyDecoder(lm)
+    for eos in (int(free[0, 2]), int(free[1, 0]), int(free[2, 5])):
+        ref = lm.generate(inputs_embeds=emb, attention_mask=am, do_sample=False, max_new_tokens=9, eos_token_id=eos, pad_token_id=0, use_cache=True)
+        out = dec.generate(emb, 9, use_graph=use_graph, eos_token_id=eos, pad_token_id=0)
+        assert out.tolist() == ref.tolist(), (eos, out.tolist(), ref.tolist())
+        assert (ref == eos).any()
+        ref = lm.generate(inputs_embeds=emb, attention_mask=am, do_sample=False, max_new_tokens=9, min_new_tokens=4, eos_token_id=eos, pad_token_id=0,
+                          use_cache=True)
+        out = dec.generate(emb, 9, use_graph=use_graph, eos_token_id=eos, pad_token_id=0, min_new_tokens=4)
+        assert out.tolist() == ref.tolist(), ("min_new", eos, out.tolist(), ref.tolist())
+    # every row finishes at once -> shorter output, like HF
+    eos = int(free[0, 0])
+    e1 = emb[:1].repeat(3, 1, 1)
+    ref = lm.generate(inputs_embeds=e1, attention_mask=am[:3], do_sample=False, max_new_tokens=9, eos_token_id=eos, pad_token_id=0, use_cache=True)
+    out = dec.generate(e1, 9, use_graph=use_graph, eos_token_id=eos, pad_token_id=0)
+    assert out.shape == ref.shape == (3, 1) and out.tolist() == ref.tolist()
+
+
 def test_greedy_decoder_matches_hf_generate_cpu():
     _check("cpu", False)
+
+
+def test_greedy_decoder_eos_semantics_cpu():
+    _check_eos("cpu", False)
 
 
 @pytest.mark.gpu
@@ -36,3 +67,5 @@ def test_greedy_decoder_hipgraph_matches_hf_generate_gpu():
     _check("cuda:0", True)
     _check("cuda:0", False)
     _check("cuda:0", True, fused=False)
+    _check_eos("cuda:0", True)
+    _check_eos("cuda:0", False)

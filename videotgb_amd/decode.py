@@ -11,7 +11,12 @@ throughput harness the step is then HBM-bound (13.5 GB of bf16 weights per token
 
 Scope: Llama-architecture models, greedy, all-ones attention mask (no padding) -- the case of
 every benchmark configuration.  Anything else goes through HF generate (models.LSTP.generate).
-Greedy ids are checked token-for-token against HF generate at fp32 in tests/test_gpu_e2e.py.
+EOS handling is HF's (GenerationMixin._sample with EosTokenCriteria): a per-sequence finished flag
+lives on the device inside the captured step; a finished row emits ``pad_token_id`` from then on, and
+the returned ids end at the step where the last row finished.  ``min_new_tokens`` masks the EOS logit
+for the first steps like MinNewTokensLengthLogitsProcessor.  ``eos_token_id=None`` = fixed-length
+decode (the bench's "no EOS stopping, fixed work per clip" mode).
+Greedy ids are checked token-for-token against HF generate at fp32 (tests/test_decode.py, test_gpu_e2e.py).
 """
 from __future__ import annotations
 
@@ -92,8 +97,8 @@ class GreedyDecoder:
     def _head(self, x):
         return F.linear(_rms(x, self.lm.model.norm.weight, self.eps), self.lm.lm_head.weight)
 
-    def _state(self, B: int, P: int, N: int, device, dtype):
-        key = (B, P, N)
+    def _state(self, B: int, P: int, N: int, device, dtype, eos=None, pad=0, min_new=0):
+        key = (B, P, N, eos, pad, min_new)
         st = self.graphs.get(key)
         if st is None:
             tmax = P + N
@@ -103,7 +108,8 @@ class GreedyDecoder:
                       vc=[torch.zeros(B, self.nkv, tmax, self.hd, device=device, dtype=dtype) for _ in self.layers],
                       tok=torch.zeros(B, dtype=torch.long, device=device), pos=torch.zeros(1, dtype=torch.long, device=device),
                       step=torch.zeros(1, dtype=torch.long, device=device), out=torch.zeros(B, N, dtype=torch.long, device=device),
-                      ar=torch.arange(tmax, device=device), graph=None,
+                      ar=torch.arange(tmax, device=device), graph=None, eos=eos, pad=pad, min_new=min_new,
+                      fin=torch.zeros(B, dtype=torch.bool, device=device),
                       x=torch.zeros(B, self.cfg.hidden_size, device=device, dtype=dtype),
                       h=torch.zeros(B, self.cfg.hidden_size, device=device, dtype=dtype),
                       q=torch.zeros(B, self.nh * self.hd, device=device, dtype=dtype),
@@ -143,7 +149,24 @@ class GreedyDecoder:
             delta = F.linear(act, wd)
         L.check(lib.vtgb_llm_rmsnorm(code, x.data_ptr(), delta.data_ptr(), self.lm.model.norm.weight.data_ptr(), h.data_ptr(), B, H,
                                      self.eps, stream))
-        nxt = F.linear(h, self.lm.lm_head.weight).argmax(-1)
+        self._emit(st, F.linear(h, self.lm.lm_head.weight))
+
+    def _pick(self, st, logits: Tensor, step) -> Tensor:
+        """Greedy token of every row with HF's EOS semantics (device-side, capturable): EOS masked while step < min_new_tokens,
+        finished rows emit pad, a row finishes when it emits EOS."""
+        eos = st["eos"]
+        if eos is not None and st["min_new"] > 0:
+            blocked = (step < st["min_new"]) if isinstance(step, Tensor) else torch.tensor([step < st["min_new"]], device=logits.device)
+            logits = logits.clone()
+            logits[:, eos] = torch.where(blocked, torch.full_like(logits[:, eos], float("-inf")), logits[:, eos])
+        nxt = logits.argmax(-1)
+        if eos is not None:
+            nxt = torch.where(st["fin"], torch.full_like(nxt, st["pad"]), nxt)
+            st["fin"].logical_or_(nxt == eos)
+        return nxt
+
+    def _emit(self, st, logits: Tensor):
+        nxt = self._pick(st, logits, st["step"])
         st["tok"].copy_(nxt)
         st["out"].index_copy_(1, st["step"], nxt[:, None])
         st["pos"].add_(1)
@@ -161,19 +184,21 @@ class GreedyDecoder:
         mask = torch.where(st["ar"][None, None, None, :] <= pos, 0.0, neg).to(x.dtype)
         for li, w in enumerate(self.layers):
             x = self._layer(x, w, cos, sin, st["kc"][li], st["vc"][li], pos, mask)
-        nxt = self._head(x[:, -1]).argmax(-1)
-        st["tok"].copy_(nxt)
-        st["out"].index_copy_(1, st["step"], nxt[:, None])
-        st["pos"].add_(1)
-        st["step"].add_(1)
+        self._emit(st, self._head(x[:, -1]))
 
     @torch.no_grad()
-    def generate(self, inputs_embeds: Tensor, max_new_tokens: int, use_graph: bool = True) -> Tensor:
-        """inputs_embeds [B, P, H] (no padding) -> greedy ids [B, max_new_tokens]."""
+    def generate(self, inputs_embeds: Tensor, max_new_tokens: int, use_graph: bool = True, eos_token_id=None, pad_token_id: int = 0,
+                 min_new_tokens: int = 0) -> Tensor:
+        """inputs_embeds [B, P, H] (no padding) -> greedy ids [B, n <= max_new_tokens] (n < max_new_tokens only when every
+        row has emitted ``eos_token_id``, as HF generate returns them)."""
         B, P, _ = inputs_embeds.shape
         N = max_new_tokens
         dev, dt = inputs_embeds.device, inputs_embeds.dtype
-        st = self._state(B, P, N, dev, dt)
+        if isinstance(eos_token_id, (list, tuple)):
+            if len(eos_token_id) != 1:
+                raise NotImplementedError("GreedyDecoder: one eos_token_id")
+            eos_token_id = eos_token_id[0]
+        st = self._state(B, P, N, dev, dt, eos_token_id, int(pad_token_id if pad_token_id is not None else (eos_token_id or 0)), int(min_new_tokens or 0))
         # ---- prefill (eager: a handful of large GEMMs)
         x = inputs_embeds
         pidx = st["ar"][:P]
@@ -181,7 +206,10 @@ class GreedyDecoder:
         cos, sin = st["cos"][:P], st["sin"][:P]
         for li, w in enumerate(self.layers):
             x = self._layer(x, w, cos, sin, st["kc"][li], st["vc"][li], pidx, causal)
-        first = self._head(x[:, -1]).argmax(-1)
+        st["fin"].zero_()
+        if eos_token_id is not None:
+            st["out"].fill_(st["pad"])
+        first = self._pick(st, self._head(x[:, -1]), 0)
         st["tok"].copy_(first)
         st["out"][:, 0] = first
         st["pos"].fill_(P)
@@ -189,21 +217,29 @@ class GreedyDecoder:
         if N > 1:
             if use_graph and st["graph"] is None:
                 # warm up on a side stream (handles, workspaces), then capture one step
-                keep = (st["tok"].clone(), st["pos"].clone(), st["step"].clone(), st["out"].clone())
+                keep = (st["tok"].clone(), st["pos"].clone(), st["step"].clone(), st["out"].clone(), st["fin"].clone())
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
                     self._decode_step(st)
                 torch.cuda.current_stream().wait_stream(s)
-                st["tok"].copy_(keep[0]); st["pos"].copy_(keep[1]); st["step"].copy_(keep[2]); st["out"].copy_(keep[3])
+                st["tok"].copy_(keep[0]); st["pos"].copy_(keep[1]); st["step"].copy_(keep[2]); st["out"].copy_(keep[3]); st["fin"].copy_(keep[4])
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._decode_step(st)
                 st["graph"] = g
-                st["tok"].copy_(keep[0]); st["pos"].copy_(keep[1]); st["step"].copy_(keep[2]); st["out"].copy_(keep[3])
-            for _ in range(N - 1):
+                st["tok"].copy_(keep[0]); st["pos"].copy_(keep[1]); st["step"].copy_(keep[2]); st["out"].copy_(keep[3]); st["fin"].copy_(keep[4])
+            for i in range(N - 1):
+                if eos_token_id is not None and i % 16 == 0 and bool(st["fin"].all()):
+                    break          # every row has finished (one host read per 16 tokens)
                 if use_graph:
                     st["graph"].replay()
                 else:
                     self._decode_step(st)
-        return st["out"].clone()
+        out = st["out"].clone()
+        if eos_token_id is not None:
+            # HF stops at the step where the last row finished: keep the columns up to (and including) the last first-EOS
+            is_eos = out == eos_token_id
+            first_eos = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((B,), N, device=dev))
+            out = out[:, : int(first_eos.max().item())]
+        return out

@@ -439,7 +439,11 @@ class _LSTPBase(nn.Module):
             from .decode import GreedyDecoder
             if getattr(self, "_decoder", None) is None or self._decoder.lm is not lm:
                 self._decoder = GreedyDecoder(lm)
-            outputs = self._decoder.generate(inputs_embeds, max_new_tokens)
+            gc = getattr(lm, "generation_config", None)     # HF generate's defaults (eos / pad from the generation config)
+            outputs = self._decoder.generate(inputs_embeds, max_new_tokens,
+                                             eos_token_id=gen_kwargs.pop("eos_token_id", getattr(gc, "eos_token_id", None)),
+                                             pad_token_id=gen_kwargs.pop("pad_token_id", getattr(gc, "pad_token_id", None)),
+                                             min_new_tokens=gen_kwargs.pop("min_new_tokens", 0))
         else:
             outputs = lm.generate(inputs_embeds=inputs_embeds, attention_mask=attention_mask, do_sample=do_sample,
                                   temperature=temperature, max_new_tokens=max_new_tokens, use_cache=use_cache,

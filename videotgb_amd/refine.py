@@ -109,7 +109,8 @@ def frame_answers(lstp, frames: Tensor, batch_size: int, qformer_text: Optional[
     one batch: ViT -> Q-Former (the clip's instruction repeated per frame) -> language_projection (a "clip" of one frame)
     -> [prefix | question] -> greedy decode.  ``max_length`` counts prefix + question + new tokens, as
     ``generate(inputs_embeds=..., max_length=128)`` does in the pinned transformers.  Requires unpadded questions
-    (the graph decoder has no padding mask); returns ids [B*num_frames, n_new] with the LLaMA 0 -> 2 patch applied."""
+    (the graph decoder has no padding mask); returns ids [B*num_frames, <= n_new] (rows end at EOS and are padded, as HF
+    generate returns them) with the LLaMA 0 -> 2 patch applied."""
     from .decode import GreedyDecoder
     n_all = frames.shape[0]
     num_frames = n_all // batch_size
@@ -129,7 +130,8 @@ def frame_answers(lstp, frames: Tensor, batch_size: int, qformer_text: Optional[
         raise ValueError(f"max_length={max_length} leaves no room after the {emb.shape[1]}-token prompt")
     if getattr(lstp, "_decoder", None) is None or lstp._decoder.lm is not lm:
         lstp._decoder = GreedyDecoder(lm)
-    out = lstp._decoder.generate(emb, n_new)
+    gc = getattr(lm, "generation_config", None)     # HF generate's defaults: stop at EOS, pad afterwards
+    out = lstp._decoder.generate(emb, n_new, eos_token_id=getattr(gc, "eos_token_id", None), pad_token_id=getattr(gc, "pad_token_id", None) or 0)
     if lstp.model.config.text_config.architectures[0] == "LLaMAForCausalLM":
         out[out == 0] = 2
     return out
