@@ -541,6 +541,99 @@ def refine_fixture():
         fh.write("\n".join(gold + pred) + "\n")
 
 
+def bf16_reference_fixtures():
+    """What does the REFERENCE produce in its own bf16 mode?  Lightning `precision: bf16` (configs/trainer/default.yaml) is
+    torch.autocast(bfloat16) around the modules: linear / matmul / conv in bf16, LayerNorm and softmax in fp32, fp32
+    parameters.  Recorded here with torch.autocast("cpu", bfloat16) so that the bf16 tolerances of the GPU tests can be
+    stated against the reference's own bf16 numbers, not only against its fp32 numbers:
+      * tiny e2e (both flavours): TGB logits, ViT output, Q-Former queries, prefix -- RAFT kept in fp32 as the reference
+        does (xraft.py:113-119 wraps it in autocast(enabled=False) / .float());
+      * full size: ViT-g probes, Q-Former probes (on a seeded int8 image-token tensor, also recorded in fp32 so the stage
+        is tested in isolation), BERT-base TGB logits."""
+    from transformers import BertConfig, InstructBlipQFormerConfig, InstructBlipVisionConfig
+    from src.models.components.xinstructblip import InstructBlipQFormerModel, InstructBlipVisionModel
+    from src.models.components.xropebert import RopeBertModel
+    from videotgb_amd.synth import (QFormerCfg, TgbCfg, VitCfg, path_state_dict, qformer_shapes, synth_state_dict, synth_tensor,
+                                    tgb_shapes, tiny_cfg, vit_shapes)
+    ac = lambda: torch.autocast("cpu", dtype=torch.bfloat16)
+    # ---- tiny e2e
+    for arch in ("instructblip", "blip2"):
+        cfg = tiny_cfg(arch)
+        cfg.vit.image = 56
+        ref, tc, _ = build_reference(arch, cfg, path_state_dict(cfg, seed=0))
+        z = np.load(os.path.join(OUT, f"tiny_{arch}_e2e.npz"))
+        sc = float(z["q8_scale"])
+        frames, flow_frames = torch.from_numpy(z["frames_q8"]).float() * sc, torch.from_numpy(z["flow_frames_q8"]).float() * sc
+        noise = torch.from_numpy(z["noise"])
+        exps = [torch.exp(-noise[i]).unsqueeze(-1) for i in range(noise.shape[0])]      # g = -log(E)  ->  E = exp(-g)
+        raft_fwd = ref.of_extractor.forward
+
+        def raft_fp32(*a, **k):
+            with torch.autocast("cpu", enabled=False):
+                return raft_fwd(*[x.float() if torch.is_tensor(x) else x for x in a], **k)
+        ref.of_extractor.forward = raft_fp32
+        cap = {}
+        hooks = [
+            ref.temporal_encoder.register_forward_hook(lambda m, i, o: cap.update(tgb_logits=o[1])),
+            ref.model.vision_model.register_forward_hook(lambda m, i, o: cap.__setitem__("image_embeds", o.last_hidden_state)),
+            ref.model.qformer.register_forward_hook(lambda m, i, o: cap.__setitem__("qformer_seq", o[0])),
+            ref.model.language_projection.register_forward_hook(lambda m, i, o: cap.__setitem__("prefix", o)),
+        ]
+        te = BE(input_ids=torch.from_numpy(z["prompt_ids"]), attention_mask=torch.from_numpy(z["prompt_mask"]))
+        if arch == "instructblip":
+            te["qformer_input_ids"] = torch.from_numpy(z["qformer_ids"])
+            te["qformer_attention_mask"] = torch.from_numpy(z["qformer_mask"])
+        se = BE(input_ids=torch.from_numpy(z["sampler_ids"]), attention_mask=torch.from_numpy(z["sampler_mask"]))
+        with NoiseQueue(exps) as nq, ac():
+            ids, cand = ref.generate(frames, flow_frames, int(z["nframe"]), te, se, do_sample=False, temperature=None, max_new_tokens=6,
+                                     use_cache=False)
+        assert nq.used == 2 and "tgb_logits" in cap, "reference took its bare-except fallback"
+        for h in hooks:
+            h.remove()
+        save(f"tiny_{arch}_e2e_bf16ref", tgb_logits=cap["tgb_logits"].float(), cand_index=cand, image_embeds=cap["image_embeds"].float(),
+             query_out=cap["qformer_seq"][:, :cfg.qformer.n_query].float(), prefix=cap["prefix"].float(), greedy_ids=ids)
+    # ---- full size
+    g = torch.Generator().manual_seed(21)
+    old = np.load(os.path.join(OUT, "full_probes.npz"))
+    out = {}
+    vm = InstructBlipVisionModel(InstructBlipVisionConfig()).eval()
+    vm.load_state_dict(synth_state_dict(vit_shapes(VitCfg(), ""), 0), strict=True)
+    pix = torch.from_numpy(old["vit_pixel_q8"]).float() / 48
+    with torch.no_grad(), ac():
+        img16 = vm(pixel_values=pix, return_dict=True).last_hidden_state.float()
+    out["vit_probe_val_bf16ref"] = img16.flatten()[torch.from_numpy(old["vit_probe_idx"])]
+    del vm
+    qm = InstructBlipQFormerModel(InstructBlipQFormerConfig()).eval()
+    qm.load_state_dict(synth_state_dict(qformer_shapes(QFormerCfg(), ""), 0), strict=True)
+    qtok = synth_tensor("model.query_tokens", (1, 32, 768))
+    g2 = torch.Generator().manual_seed(33)
+    iq, img = q8((2, 257, 1408), g2, 1 / 64)                       # image tokens ~ U(-2, 2): the scale of a post-LayerNorm ViT output
+    qids = torch.randint(1000, 30000, (2, 9), generator=g2)
+    qmask = torch.ones(2, 9, dtype=torch.long)
+    qmask[1, 6:] = 0
+    am = torch.cat([torch.ones(2, 32, dtype=torch.long), qmask], 1)
+    kw = dict(input_ids=qids, attention_mask=am, query_embeds=qtok.expand(2, -1, -1), encoder_hidden_states=img,
+              encoder_attention_mask=torch.ones(2, 257, dtype=torch.long), return_dict=True)
+    with torch.no_grad():
+        q32 = qm(**kw).last_hidden_state[:, :32]
+        with ac():
+            q16 = qm(**kw).last_hidden_state[:, :32].float()
+    qidx = torch.randint(0, q32.numel(), (4096,), generator=g2)
+    out.update(qf2_image_q8=iq, qf2_ids=qids, qf2_mask=qmask, qf2_probe_idx=qidx, qf2_probe_val=q32.flatten()[qidx],
+               qf2_probe_val_bf16ref=q16.flatten()[qidx], qf2_q8_scale=np.float32(1 / 64))
+    del qm
+    tm = RopeBertModel(BertConfig(fusion_layer=6, encoder_width=768)).eval()
+    tm.load_state_dict(synth_state_dict(tgb_shapes(TgbCfg(), ""), 0), strict=True)
+    of = torch.from_numpy(old["tgb_of_q8"]).float() / 127
+    tids = torch.from_numpy(old["tgb_text_ids"])
+    with torch.no_grad(), ac():
+        for mode in ("multi_modal", "fusion"):
+            seq, logits = tm(encoder_embeds=of.clone(), attention_mask=torch.ones(1, 26, dtype=torch.long), encoder_hidden_states=tids,
+                             encoder_attention_mask=torch.ones_like(tids), mode=mode)
+            out[f"tgb_logits_{mode}_bf16ref"] = logits.float()
+    save("full_probes_bf16ref", **out)
+
+
 def refine_answers_fixture():
     """f4 on the reference side: the per-frame answer loop of LSTPSFModule.forward (src/models/LSTP_SF_module.py:149-204,
     sliced out of the live function and executed on the tiny InstructBLIP reference model) -- ViT over all candidate
@@ -584,7 +677,7 @@ def main():
     install_shim()
     torch.manual_seed(0)
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train", "refine", "answers"]
+    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train", "refine", "answers", "bf16"]
     if "e2e" in which:
         ref_ib, cfg_ib, sd_ib = e2e_fixture("instructblip")
         ref_b2, cfg_b2, sd_b2 = e2e_fixture("blip2")
@@ -601,6 +694,8 @@ def main():
         refine_fixture()
     if "answers" in which:
         refine_answers_fixture()
+    if "bf16" in which:
+        bf16_reference_fixtures()
 
 
 if __name__ == "__main__":

@@ -63,7 +63,7 @@ def test_generate_vs_reference(dev, tiny_sd, arch, dtype, fast_decode):
         print(f"[e2e {arch} {dtype}] {name}: max|diff|={err:.3e} rel_rms={rms:.3e} max|ref|={scale:.3e}")
         assert err <= tol * scale, name
         assert rms_tol is None or rms <= rms_tol, name
-    tol = 2e-4 if dtype == "f32" else 6e-2
+    tol = 2e-4 if dtype == "f32" else 1.5e-2      # bf16: 2 x observed (7e-3 of the logit scale, 2.3e-3 of the prefix scale)
     # bf16 RAFT (a mode the reference does not have): 20 recurrent iterations of bf16 convolutions; observed rel-RMS 6e-3
     chk("raft flow", st["of"][0, :-1], g["raft_flow"], 2e-4 if dtype == "f32" else 6e-2, None if dtype == "f32" else 1.5e-2)
     assert torch.equal(st["of"][0, -1], st["of"][0, -2])            # last flow repeated (eval/utils/model.py:82)
@@ -74,6 +74,21 @@ def test_generate_vs_reference(dev, tiny_sd, arch, dtype, fast_decode):
     chk("inputs_embeds", st["inputs_embeds"], g["inputs_embeds"], tol)
     if dtype == "f32":
         assert ids.cpu().tolist() == g["greedy_ids"].tolist()      # greedy token ids bit-exact at fp32
+    else:
+        # against the reference's OWN bf16 mode (torch.autocast(bfloat16), its Lightning `precision: bf16`; RAFT fp32 there):
+        # HIP-bf16 is at least as close to the reference's fp32 numbers as the reference's bf16 run is, and the two bf16
+        # runs agree to 2 x that distance (bounds = 2 x observed ratios; the numbers are printed)
+        from test_gpu_stages import rel_rms
+        r16 = load_golden(f"tiny_{arch}_e2e_bf16ref")
+        assert cand.cpu().tolist() == r16["cand_index"].tolist()
+        for name, key in (("tgb logits", "tgb_logits"), ("prefix", "prefix")):
+            hip = st[key].float().cpu()
+            e_ref, e32, e16 = rel_rms(r16[key], g[key]), rel_rms(hip, g[key]), rel_rms(hip, r16[key])
+            print(f"[e2e {arch} bf16] {name}: relRMS hip16~ref32={e32:.3e} hip16~ref16={e16:.3e} ref16~ref32={e_ref:.3e}; max|diff| "
+                  f"hip16~ref32={(hip - g[key]).abs().max():.3e} ref16~ref32={(r16[key] - g[key]).abs().max():.3e}")
+            assert e32 <= 1.5 * e_ref and e16 <= 2.0 * e_ref, name
+        if fast_decode is False:
+            assert ids.cpu().tolist() == r16["greedy_ids"].tolist()
 
 
 def test_precomputed_flow_and_concat_pool(dev, tiny_sd):

@@ -3,8 +3,9 @@ same seeded inputs, and against the vectors recorded from the reference (tests/g
 
 Tolerances (stated here, used below):
   fp32 mode : |diff| <= 2e-4 * max|ref|   (summation order only)
-  bf16 mode : relative RMS error <= 2e-2 and |diff| <= 6e-2 * max|ref| against the fp32 oracle
-              (bf16 operands, fp32 accumulate / residual / LayerNorm / softmax)
+  bf16 mode : tiny configurations: relative RMS error <= 6e-3 and |diff| <= 8e-3 * max|ref| against the reference's fp32
+              vectors (2 x the largest observed: 2.9e-3 / 3.3e-3; bf16 operands, fp32 accumulate / residual / LayerNorm /
+              softmax); full size: stated against the reference's own bf16-autocast run, see below
   integer / index outputs: bit-exact."""
 import pytest
 import torch
@@ -36,7 +37,7 @@ def check(name, got, ref, dtype):
     if dtype == "f32":
         assert err <= 2e-4 * scale, name
     else:
-        assert rms <= 2e-2 and err <= 6e-2 * scale, name
+        assert rms <= 6e-3 and err <= 8e-3 * scale, name
 
 
 DTYPES = ["f32", "bf16"]
@@ -117,28 +118,113 @@ def test_tgb_invalid_mode(dev, tiny_sd):
 
 
 # ----------------------------------------------------------------------------- full size
+# bf16 bounds at full size are stated against BOTH of the reference's own runs (tests/golden/make_golden.py):
+#   ref32 = the reference in fp32, ref16 = the reference under torch.autocast(bfloat16) (its Lightning `precision: bf16`).
+#   e_ref = relRMS(ref16, ref32) is what the reference's own bf16 mode costs; the HIP bf16 mode must satisfy
+#     relRMS(hip16, ref32) <= 1.25 * e_ref     (at least as close to the fp32 truth as the reference's bf16 mode;
+#                                               observed 0.55 ... 0.9 x e_ref: fp32 accumulation AND fp32 residual stream)
+#     relRMS(hip16, ref16) <= 1.6 * e_ref      (two bf16 roundings of the same computation; observed 1.1 ... 1.3 x e_ref)
+#   and max|diff| to ref32 may not exceed 2 x the reference's own bf16 max|diff|.
+#   The north-star figure "1e-3 at bf16" is NOT met by the reference's own bf16 mode at these depths
+#   (ViT-g: 7.6e-3 relRMS, 2.9e-2 abs on a 3.9 scale), so it cannot be the bound for ours; DESIGN.md section 2 has the table.
+def rel_rms(a, b):
+    return float(((a.double() - b.double()).pow(2).mean().sqrt()) / b.double().pow(2).mean().sqrt())
+
+
+def check_bf16_three_way(name, hip16, ref32, ref16):
+    hip16, ref32, ref16 = hip16.detach().float().cpu(), ref32.float(), ref16.float()
+    e_ref, e32, e16 = rel_rms(ref16, ref32), rel_rms(hip16, ref32), rel_rms(hip16, ref16)
+    m_ref, m32 = (ref16 - ref32).abs().max().item(), (hip16 - ref32).abs().max().item()
+    print(f"[{name} bf16] relRMS hip16~ref32={e32:.3e} hip16~ref16={e16:.3e} ref16~ref32={e_ref:.3e} | max|diff| hip16~ref32={m32:.3e} "
+          f"ref16~ref32={m_ref:.3e} (max|ref|={ref32.abs().max():.3e})")
+    assert e32 <= 1.25 * e_ref, name
+    assert e16 <= 1.6 * e_ref, name
+    assert m32 <= 2.0 * m_ref, name
+
+
 @pytest.fixture(scope="module")
 def full_probes():
-    return load_golden("full_probes")
+    p = load_golden("full_probes")
+    p.update(load_golden("full_probes_bf16ref"))
+    return p
+
+
+@pytest.fixture(scope="module")
+def vit_g(dev):
+    """EVA-ViT-g weight tables (both modes share the fp32 state_dict on the device)."""
+    from videotgb_amd.synth import VitCfg, synth_state_dict, vit_shapes
+    return to_dev(synth_state_dict(vit_shapes(VitCfg(), ""), 0), dev)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_vit_g_full_size_vs_reference_probes(dev, full_probes, dtype):
+def test_vit_g_full_size_vs_reference_probes(dev, full_probes, vit_g, dtype):
     """EVA-ViT-g (39 layers, 1408-d, 16x88 heads), 2 frames: probe elements recorded from the
-    reference's InstructBlipVisionModel with the same seeded weights."""
+    reference's InstructBlipVisionModel with the same seeded weights (fp32 and bf16-autocast runs)."""
     from videotgb_amd import ops
-    from videotgb_amd.synth import VitCfg, synth_state_dict, vit_shapes
     p = full_probes
-    sd = synth_state_dict(vit_shapes(VitCfg(), "v."), 0)
-    # same tensors as the fixture generator's prefix-less keys: regenerate under those names
-    sd = {k: v for k, v in synth_state_dict(vit_shapes(VitCfg(), ""), 0).items()}
-    w = ops.VitWeights(to_dev(sd, dev), "", ops.dtype_code(dtype), 16, 1e-6)
-    del sd
+    w = ops.VitWeights(vit_g, "", ops.dtype_code(dtype), 16, 1e-6)
     pix = p["vit_pixel_q8"].float() / 48
     out32, _ = ops.vit_forward(w, pix.to(dev))
     assert list(out32.shape) == p["vit_shape"].tolist()
     got = out32.flatten()[p["vit_probe_idx"].to(dev)]
-    check("vit-g probes", got, p["vit_probe_val"], dtype)
+    if dtype == "f32":
+        check("vit-g probes", got, p["vit_probe_val"], dtype)
+    else:
+        check_bf16_three_way("vit-g probes", got, p["vit_probe_val"], p["vit_probe_val_bf16ref"])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_qformer_full_size_vs_reference_probes(dev, full_probes, dtype):
+    """Q-Former at full size (12 layers, 12 x 64 heads, 1408-wide cross-attention K/V GEMMs, text branch with padding),
+    2 frames, on a seeded image-token tensor: probes from the reference's InstructBlipQFormerModel."""
+    from videotgb_amd import ops
+    from videotgb_amd.synth import QFormerCfg, qformer_shapes, synth_state_dict, synth_tensor
+    p = full_probes
+    sd = to_dev(synth_state_dict(qformer_shapes(QFormerCfg(), ""), 0), dev)
+    w = ops.QFormerWeights(sd, "", ops.dtype_code(dtype), 12)
+    img = (p["qf2_image_q8"].float() * float(p["qf2_q8_scale"])).to(dev)
+    qtok = synth_tensor("model.query_tokens", (1, 32, 768)).to(dev)
+    q = ops.qformer_forward(w, qtok, img, p["qf2_ids"].to(dev), p["qf2_mask"].to(dev))
+    got = q.flatten()[p["qf2_probe_idx"].to(dev)]
+    if dtype == "f32":
+        check("qformer full", got, p["qf2_probe_val"], dtype)
+    else:
+        check_bf16_three_way("qformer full", got, p["qf2_probe_val"], p["qf2_probe_val_bf16ref"])
+
+
+def test_vit_g_into_qformer_full_size_chain_fp32(dev, full_probes, vit_g):
+    """The two full-size stages chained (our ViT-g output feeds our Q-Former) against the probes the reference recorded
+    from its own chain (fixture `qf_probe_*`), fp32 mode."""
+    from videotgb_amd import ops
+    from videotgb_amd.synth import QFormerCfg, qformer_shapes, synth_state_dict, synth_tensor
+    p = full_probes
+    vw = ops.VitWeights(vit_g, "", ops.F32, 16, 1e-6)
+    img, _ = ops.vit_forward(vw, (p["vit_pixel_q8"].float() / 48).to(dev))
+    sd = to_dev(synth_state_dict(qformer_shapes(QFormerCfg(), ""), 0), dev)
+    w = ops.QFormerWeights(sd, "", ops.F32, 12)
+    q = ops.qformer_forward(w, synth_tensor("model.query_tokens", (1, 32, 768)).to(dev), img, p["qf_ids"].to(dev),
+                            torch.ones_like(p["qf_ids"]).to(dev))
+    check("vit-g -> qformer chain", q.flatten()[p["qf_probe_idx"].to(dev)], p["qf_probe_val"], "f32")
+    assert abs(q.abs().mean().item() - float(p["qf_absmean"])) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", ["multi_modal", "fusion"])
+def test_tgb_full_size_vs_reference(dev, full_probes, dtype, mode):
+    """BERT-base TGB (12 layers, 12 x 64 rotary heads, fusion_layer 6), T = 24: logits of the reference's RopeBertModel."""
+    from videotgb_amd import ops
+    from videotgb_amd.synth import TgbCfg, synth_state_dict, tgb_shapes
+    p = full_probes
+    sd = to_dev(synth_state_dict(tgb_shapes(TgbCfg(), ""), 0), dev)
+    w = ops.TgbWeights(sd, "", ops.dtype_code(dtype), 12, 6)
+    of = (p["tgb_of_q8"].float() / 127).to(dev)
+    tids = p["tgb_text_ids"].to(dev)
+    seq, logits = ops.tgb_forward(w, of, torch.ones(1, 26, dtype=torch.long, device=dev), tids, torch.ones_like(tids), mode)
+    if dtype == "f32":
+        check(f"tgb full {mode}", logits, p[f"tgb_logits_{mode}"], dtype)
+        assert abs(seq.abs().mean().item() - float(p[f"tgb_seq_absmean_{mode}"])) < 1e-4
+    else:
+        check_bf16_three_way(f"tgb full {mode}", logits, p[f"tgb_logits_{mode}"], p[f"tgb_logits_{mode}_bf16ref"])
 
 
 # ------------------------------------------------------------------------------------------ f3 preprocessing
