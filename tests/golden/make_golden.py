@@ -88,7 +88,18 @@ def save(name, **arrs):
 
 
 # ----------------------------------------------------------------------------- models
-def build_reference(arch, cfg, sd):
+def tiny_text_config(kind, hidden):
+    """The tiny third-party LLM of the fixtures: Llama (decoder-only) or T5 (seq2seq: the Flan-T5 hookup of configs C1 / C2)."""
+    from transformers import LlamaConfig, T5Config
+    if kind == "t5":
+        return T5Config(vocab_size=120, d_model=hidden, d_kv=16, d_ff=64, num_layers=2, num_decoder_layers=2, num_heads=2,
+                        feed_forward_proj="gated-gelu", tie_word_embeddings=False, decoder_start_token_id=0, pad_token_id=0, eos_token_id=1,
+                        architectures=["T5ForConditionalGeneration"])
+    return LlamaConfig(hidden_size=hidden, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+                       vocab_size=120, architectures=["LlamaForCausalLM"], bos_token_id=1, eos_token_id=2, pad_token_id=0)
+
+
+def build_reference(arch, cfg, sd, llm="llama", save_dir=None):
     """Reference eval-side module (eval/utils/model.py LSTP / LSTP_blip2) at the tiny config."""
     from transformers import (Blip2Config, Blip2QFormerConfig, Blip2VisionConfig, InstructBlipConfig,
                               InstructBlipQFormerConfig, InstructBlipVisionConfig, LlamaConfig)
@@ -99,9 +110,7 @@ def build_reference(arch, cfg, sd):
     qkw = dict(hidden_size=q.hidden, num_hidden_layers=q.layers, num_attention_heads=q.heads,
                intermediate_size=q.ffn, encoder_hidden_size=q.enc_hidden, vocab_size=q.vocab,
                max_position_embeddings=q.max_pos, cross_attention_frequency=q.cross_freq)
-    tc = LlamaConfig(hidden_size=cfg.llm_hidden, intermediate_size=64, num_hidden_layers=2,
-                     num_attention_heads=2, num_key_value_heads=2, vocab_size=120,
-                     architectures=["LlamaForCausalLM"], bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    tc = tiny_text_config(llm, cfg.llm_hidden)
     if arch == "instructblip":
         c = InstructBlipConfig(vision_config=InstructBlipVisionConfig(**vkw).to_dict(),
                                qformer_config=InstructBlipQFormerConfig(**qkw).to_dict(),
@@ -112,7 +121,7 @@ def build_reference(arch, cfg, sd):
                         qformer_config=Blip2QFormerConfig(**qkw).to_dict(),
                         text_config=tc.to_dict(), num_query_tokens=q.n_query)
         cls = em.LSTP_blip2
-    d = tempfile.mkdtemp()
+    d = save_dir or tempfile.mkdtemp()
     c.save_pretrained(d)
     # the reference hard-codes BertConfig(fusion_layer=6, encoder_width=768) for the TGB
     # (eval/utils/model.py:35); shrink it for the tiny fixture through the class it calls.
@@ -132,6 +141,9 @@ def build_reference(arch, cfg, sd):
     full = dict(sd)
     for k, p in ref.model.language_model.state_dict().items():
         full["model.language_model." + k] = synth_tensor("model.language_model." + k, tuple(p.shape))
+    for k in list(full):       # T5 ties encoder / decoder token embeddings to `shared`
+        if k.endswith("encoder.embed_tokens.weight") or k.endswith("decoder.embed_tokens.weight"):
+            full[k] = full[k.rsplit(".", 3)[0] + ".shared.weight"]
     ref_keys = set(ref.state_dict().keys())
     missing = ref_keys - set(full)
     extra = set(full) - ref_keys
@@ -634,6 +646,94 @@ def bf16_reference_fixtures():
     save("full_probes_bf16ref", **out)
 
 
+def up4(q):
+    """int8 [.., h, w] -> fp32 [.., 4h, 4w] by exact pixel replication (keeps the committed inputs small)."""
+    return q.float().repeat_interleave(4, -2).repeat_interleave(4, -1)
+
+
+def module_fixtures():
+    """The reference's LightningModules run THEIR OWN ``eval_forward`` (called as unbound functions on the reference's
+    eval-side model object, which has the attributes they touch: model / temporal_encoder / of_extractor / generate_configs;
+    lightning and torchmetrics are stubbed with empty classes, nothing of them is used by these methods):
+      * src.models.LSTP_module.LSTPModule.eval_forward        InstructBLIP, RAFT on the candidate frames (replicate-padded
+                                                              126 -> 128 is not possible with the TGB's fixed 224 x 224 flow
+                                                              input, so 224), multi_modal, V = N + 2, map A, concat
+      * src.models.LSTP_SF_module.LSTPSFModule.eval_forward   InstructBLIP, batch["of"] with ragged of_lengths, fusion, map B
+      * src.models.LSTP_blip2_module.LSTPModule.eval_forward  BLIP-2 + a seq2seq (T5) language model, no sampler  (config C1)
+      * src.models.LSTP_SF_blip2_module.LSTPSFModule.eval_forward  BLIP-2 + T5, batch["of"], fusion, map B          (config C2)
+    Inputs are int8 at 56 x 56 and replicated x4 to 224 x 224; outputs: generated ids, selected frames, of_logits, prefix."""
+    train_stubs()
+    tm_mod = sys.modules["torchmetrics"]
+    if not hasattr(tm_mod, "Metric"):
+        tm_mod.Metric = type("Metric", (), {})
+    import src.models.LSTP_module as m_ib
+    import src.models.LSTP_SF_module as m_sf
+    import src.models.LSTP_blip2_module as m_b2
+    import src.models.LSTP_SF_blip2_module as m_sfb2
+    from videotgb_amd.synth import path_state_dict, tiny_cfg
+    g = torch.Generator().manual_seed(41)
+    B, N, nframe = 2, 8, 4
+    fq = torch.randint(-127, 128, (B * N, 3, 56, 56), generator=g, dtype=torch.int32).to(torch.int8)
+    frames = up4(fq) / 48
+    L = 10
+    ofq = torch.randint(-127, 128, (B, L, 2, 56, 56), generator=g, dtype=torch.int32).to(torch.int8)
+    of = up4(ofq) / 127
+    of_lengths = [L, 7]
+    of_mask = torch.ones(B, L + 2, dtype=torch.long)
+    of_mask[1, 7 + 2:] = 0
+    common = dict(nframe=nframe, of_lengths=of_lengths, answer=torch.zeros(B, 1, dtype=torch.long), text_answer=[""] * B)
+    out = dict(frames_q8=fq, of_q8=ofq, of_mask=of_mask, of_lengths=np.array(of_lengths), nframe=nframe)
+    for tag, arch, llm, mod, cls_name, uses_of in (("ib", "instructblip", "llama", m_ib, "LSTPModule", False),
+                                                  ("sf", "instructblip", "llama", m_sf, "LSTPSFModule", True),
+                                                  ("b2", "blip2", "t5", m_b2, "LSTPModule", False),
+                                                  ("sfb2", "blip2", "t5", m_sfb2, "LSTPSFModule", True)):
+        cfg = tiny_cfg(arch)                                   # vit.image stays 224: the TGB's flow input is 224 x 224
+        ref, tc, _ = build_reference(arch, cfg, path_state_dict(cfg, seed=0), llm=llm)
+        ref.generate_configs = dict(do_sample=False, max_new_tokens=6)
+        samp = torch.randint(3, cfg.tgb.vocab, (B, 7), generator=g)
+        smask = torch.ones_like(samp)
+        smask[1, 5:] = 0
+        qf = torch.randint(3, cfg.qformer.vocab, (B, 6), generator=g)
+        qfm = torch.ones_like(qf)
+        qfm[1, 4:] = 0
+        quest = torch.randint(3, tc.vocab_size, (B, 5), generator=g)
+        qmask = torch.ones_like(quest)
+        batch = dict(common, frames=frames, sampler_question=samp, sampler_question_attention_mask=smask, qformer_text=qf,
+                     qformer_text_attention_mask=qfm, question=quest, question_attention_mask=qmask)
+        if uses_of:
+            batch.update(of=of, of_mask=of_mask)
+        T = L if uses_of else N
+        exps = [torch.empty(2 * B, T, 1).exponential_(generator=g) for _ in range(2)]
+        cap = {}
+        hooks = [ref.model.vision_model.register_forward_pre_hook(lambda m, a, k: cap.__setitem__("sampled", k["pixel_values"]), with_kwargs=True),
+                 ref.model.language_projection.register_forward_hook(lambda m, i, o: cap.__setitem__("proj", o)),
+                 ref.temporal_encoder.register_forward_hook(lambda m, i, o: cap.__setitem__("of_logits", o[1])),
+                 ref.of_extractor.register_forward_hook(lambda m, i, o: cap.setdefault("raft", []).append(o)),
+                 ref.model.language_model.lm_head.register_forward_hook(lambda m, i, o: cap.setdefault("lm_logits", []).append(o))]
+        with NoiseQueue(exps) as nq, torch.no_grad():
+            ids = getattr(mod, cls_name).eval_forward(ref, batch)
+        for h in hooks:
+            h.remove()
+        sampler_ran = "of_logits" in cap
+        assert nq.used == (2 if sampler_ran else 0)
+        # frame indices: match the selected frames back to the candidates (bit-exact copies)
+        sp = cap["sampled"].view(B, nframe, -1)
+        pv = frames.view(B, N, -1)
+        idx = torch.stack([torch.stack([(pv[b] == sp[b, i]).all(1).float().argmax() for i in range(nframe)]) for b in range(B)])
+        assert all(torch.equal(pv[b, idx[b, i]], sp[b, i]) for b in range(B) for i in range(nframe))
+        rec = {f"{tag}_ids": ids, f"{tag}_frame_idx": idx, f"{tag}_first_logits": cap["lm_logits"][0][:, -1].float(), f"{tag}_prefix": cap["proj"].reshape(B, -1, cap["proj"].shape[-1]),
+               f"{tag}_sampler_ids": samp, f"{tag}_sampler_mask": smask, f"{tag}_qformer_ids": qf, f"{tag}_qformer_mask": qfm,
+               f"{tag}_question": quest, f"{tag}_question_mask": qmask}
+        if sampler_ran:
+            rec[f"{tag}_of_logits"] = cap["of_logits"]
+            rec[f"{tag}_noise"] = torch.stack([-e.log().squeeze(-1) for e in exps])
+        if "raft" in cap:
+            rec[f"{tag}_raft_flow"] = torch.stack(cap["raft"])                       # [B, N-1, 2, 224, 224] -> subsample for size
+            rec[f"{tag}_raft_flow"] = rec[f"{tag}_raft_flow"][:, :, :, ::7, ::5].contiguous()
+        out.update(rec)
+    save("tiny_modules", **out)
+
+
 def refine_answers_fixture():
     """f4 on the reference side: the per-frame answer loop of LSTPSFModule.forward (src/models/LSTP_SF_module.py:149-204,
     sliced out of the live function and executed on the tiny InstructBLIP reference model) -- ViT over all candidate
@@ -677,7 +777,7 @@ def main():
     install_shim()
     torch.manual_seed(0)
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train", "refine", "answers", "bf16"]
+    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train", "refine", "answers", "bf16", "modules"]
     if "e2e" in which:
         ref_ib, cfg_ib, sd_ib = e2e_fixture("instructblip")
         ref_b2, cfg_b2, sd_b2 = e2e_fixture("blip2")
@@ -696,6 +796,8 @@ def main():
         refine_answers_fixture()
     if "bf16" in which:
         bf16_reference_fixtures()
+    if "modules" in which:
+        module_fixtures()
 
 
 if __name__ == "__main__":

@@ -16,6 +16,7 @@ library or without a GPU the forwards raise.
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -306,13 +307,54 @@ def dp_state_to_normal(state_dict):
     return {k.replace("module.", ""): v for k, v in state_dict.items() if k.startswith("module")}
 
 
+def path_cfg_from_hf(hf_config, arch: str) -> synth.PathCfg:
+    """InstructBlipConfig / Blip2Config (transformers; what ``*.from_pretrained(base_model_path)`` parses out of the
+    directory's config.json, eval/utils/model.py:33,252) -> the dims of the hot-path stages."""
+    v, q, t = hf_config.vision_config, hf_config.qformer_config, hf_config.text_config
+    n_query = getattr(hf_config, "num_query_tokens", 32)
+    llm_hidden = getattr(t, "hidden_size", None) or getattr(t, "d_model")
+    return synth.PathCfg(
+        arch,
+        synth.VitCfg(hidden=v.hidden_size, layers=v.num_hidden_layers, heads=v.num_attention_heads, mlp=v.intermediate_size,
+                     image=v.image_size, patch=v.patch_size, eps=v.layer_norm_eps),
+        synth.QFormerCfg(hidden=q.hidden_size, layers=q.num_hidden_layers, heads=q.num_attention_heads, ffn=q.intermediate_size,
+                         enc_hidden=q.encoder_hidden_size, n_query=n_query, vocab=q.vocab_size, max_pos=q.max_position_embeddings,
+                         cross_freq=q.cross_attention_frequency, has_text=(arch == "instructblip"), eps=q.layer_norm_eps),
+        synth.TgbCfg(),                                            # BertConfig(fusion_layer=6, encoder_width=768): BERT-base
+        llm_hidden)
+
+
+def load_hf_config(base_model_path: str, arch: str):
+    from transformers import Blip2Config, InstructBlipConfig
+    return (InstructBlipConfig if arch == "instructblip" else Blip2Config).from_pretrained(base_model_path)
+
+
+def build_language_model(hf_config, dtype=torch.float32, device=None) -> nn.Module:
+    """The third-party LLM of the path, random-init from ``text_config`` exactly as the reference's
+    ``InstructBlipForConditionalGeneration(config=...)`` does (xinstructblip.py:1268-1273, xblip2.py:1551-1556): a causal LM
+    when ``use_decoder_only_language_model`` else a seq2seq LM (Flan-T5).  The checkpoint's state_dict then fills it."""
+    from transformers import AutoModelForCausalLM, AutoModelForSeq2SeqLM
+    auto = AutoModelForCausalLM if hf_config.use_decoder_only_language_model else AutoModelForSeq2SeqLM
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        if device is not None:
+            with torch.device(device):
+                lm = auto.from_config(hf_config.text_config)
+        else:
+            lm = auto.from_config(hf_config.text_config)
+    finally:
+        torch.set_default_dtype(prev)
+    return lm.eval()
+
+
 class PathModel(nn.Module):
     """The ``self.model`` object of the reference modules (InstructBlip/Blip2ForConditionalGeneration)
     restricted to what the path touches: vision_model, qformer, query_tokens, language_projection,
     temporal_projection (dead weight, must exist), language_model (third-party HF), config."""
 
     def __init__(self, cfg: synth.PathCfg, language_model: Optional[nn.Module] = None, compute_dtype="bf16",
-                 llm_architectures=("LlamaForCausalLM",), decoder_only: bool = True):
+                 llm_architectures=None, decoder_only: Optional[bool] = None, hf_config=None):
         super().__init__()
         self.vision_model = VisionModel(cfg.vit, compute_dtype)
         self.qformer = QFormer(cfg.qformer, compute_dtype)
@@ -320,9 +362,17 @@ class PathModel(nn.Module):
         self.language_projection = LanguageProjection(cfg.qformer.hidden, cfg.llm_hidden, compute_dtype)
         self.temporal_projection = nn.Linear(cfg.qformer.hidden, cfg.llm_hidden)
         self.language_model = language_model
-        self.config = SimpleNamespace(use_decoder_only_language_model=decoder_only,
-                                      text_config=SimpleNamespace(architectures=list(llm_architectures),
-                                                                  vocab_size=getattr(getattr(language_model, "config", None), "vocab_size", 0)))
+        lm_cfg = getattr(language_model, "config", None)
+        if hf_config is not None:
+            self.config = hf_config                                 # the reference's own config object (transformers)
+        else:
+            if decoder_only is None:
+                decoder_only = not bool(getattr(lm_cfg, "is_encoder_decoder", False))
+            if llm_architectures is None:
+                llm_architectures = getattr(lm_cfg, "architectures", None) or ["LlamaForCausalLM"]
+            self.config = SimpleNamespace(use_decoder_only_language_model=decoder_only,
+                                          text_config=SimpleNamespace(architectures=list(llm_architectures),
+                                                                      vocab_size=getattr(lm_cfg, "vocab_size", 0)))
 
     def get_input_embeddings(self):
         return self.language_model.get_input_embeddings()
@@ -333,16 +383,53 @@ class _LSTPBase(nn.Module):
     TGB_MODE = "multi_modal"
     MAP = "A"
 
-    def __init__(self, cfg: synth.PathCfg, device="cuda", language_model: Optional[nn.Module] = None, compute_dtype="bf16",
-                 raft_dtype=None):
+    def __init__(self, base_model_path, device="cuda", lora: bool = False, language_model: Optional[nn.Module] = None,
+                 compute_dtype="bf16", raft_dtype=None, lm_dtype=None, tgb_cfg: Optional[synth.TgbCfg] = None):
+        """Reference signature (eval/utils/model.py:21-45, :240-264): ``LSTP(base_model_path, device, lora=False)`` -- the
+        HF config in ``base_model_path`` sizes the vision tower, Q-Former and language model (random init, the checkpoint
+        fills them), the TGB is BERT-base with fusion_layer 6, RAFT is RAFT-large.  ``base_model_path`` may also be a
+        ``synth.PathCfg`` (``from_cfg``): then ``language_model`` is the caller's.  Keyword extensions: ``compute_dtype``
+        ("bf16" / "f32") of the HIP stages, ``raft_dtype`` to run RAFT in another mode, ``lm_dtype`` of the built LLM
+        (default: bf16 with compute_dtype "bf16", else fp32), ``tgb_cfg`` to size the TGB differently from BERT-base (tests)."""
         super().__init__()
+        hf_config = None
+        if isinstance(base_model_path, synth.PathCfg):
+            cfg = base_model_path
+        else:
+            hf_config = load_hf_config(base_model_path, self.ARCH)
+            cfg = path_cfg_from_hf(hf_config, self.ARCH)
+            if tgb_cfg is not None:
+                cfg.tgb = tgb_cfg
+            if language_model is None:
+                if lm_dtype is None:
+                    lm_dtype = torch.bfloat16 if ops.dtype_code(compute_dtype) == ops.BF16 else torch.float32
+                language_model = build_language_model(hf_config, lm_dtype)
         self.cfg = cfg
-        self.model = PathModel(cfg, language_model, compute_dtype)
+        self.model = PathModel(cfg, language_model, compute_dtype, hf_config=hf_config)
         self.temporal_encoder = TemporalEncoder(cfg.tgb, compute_dtype)
         self.of_extractor = Raft(raft_dtype or compute_dtype)      # raft_dtype: run RAFT in another mode than the rest
         self._raft_follows = raft_dtype is None
         self.device = device
         self.fell_back = False
+        if lora:
+            # the reference wraps the LLM with peft (r=8, alpha=32, dropout 0.1, inference mode; eval/utils/model.py:40-44);
+            # same adapter arithmetic and parameter names here (videotgb_amd.train.LoraLinear), without peft's
+            # ``base_model.model.`` wrapper level -- load_state_dict strips it from a reference checkpoint's keys
+            from .train import apply_lora
+            apply_lora(self.model.language_model, r=8, lora_alpha=32, lora_dropout=0.1)
+            self.model.language_model.eval()
+
+    @classmethod
+    def from_cfg(cls, cfg: synth.PathCfg, device="cuda", language_model: Optional[nn.Module] = None, compute_dtype="bf16", raft_dtype=None):
+        return cls(cfg, device, False, language_model, compute_dtype, raft_dtype)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        """Accepts a reference (Lightning) checkpoint's ``state_dict`` as is: peft's ``language_model.base_model.model.``
+        level is flattened, the dead ``position_ids`` buffers older transformers versions persisted are tolerated."""
+        lp = "model.language_model.base_model.model."
+        if any(k.startswith(lp) for k in state_dict):
+            state_dict = {("model.language_model." + k[len(lp):] if k.startswith(lp) else k): v for k, v in state_dict.items()}
+        return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def set_compute_dtype(self, compute_dtype):
         for m in (self.model.vision_model, self.model.qformer, self.temporal_encoder):

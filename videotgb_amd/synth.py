@@ -24,7 +24,7 @@ import torch
 
 Shapes = Dict[str, Tuple[int, ...]]
 
-_LN_W = re.compile(r"(LayerNorm|layernorm|layer_norm\d|post_layernorm|\.ln|norm\d)\.weight$")
+_LN_W = re.compile(r"(LayerNorm|layernorm|layer_norm\d?|post_layernorm|\.ln|norm\d)\.weight$")
 
 
 def rope_table(n_pos: int, dim: int) -> torch.Tensor:
