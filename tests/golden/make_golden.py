@@ -734,6 +734,51 @@ def module_fixtures():
     save("tiny_modules", **out)
 
 
+def train_step_fixture():
+    """C5's training forward on the reference side: ``LSTPModule.forward`` of src.models.LSTP_Vicuna_IV_module (the IVT module
+    minus peft, which is absent here; same forward, :191-335) called as an unbound function on the tiny reference model in
+    eval mode (dropout off), then ``loss.backward()``: the loss and the gradients of everything the reference trains on the
+    prefix side (Q-Former, query_tokens, language_projection) for a ragged batch (widths 3 and 2, padded question / answer)."""
+    train_stubs()
+    tm_mod = sys.modules["torchmetrics"]
+    if not hasattr(tm_mod, "Metric"):
+        tm_mod.Metric = type("Metric", (), {})
+    import src.models.LSTP_Vicuna_IV_module as iv
+    from videotgb_amd.synth import path_state_dict, tiny_cfg
+    cfg = tiny_cfg("instructblip")
+    cfg.vit.image = 56
+    ref, tc, _ = build_reference("instructblip", cfg, path_state_dict(cfg, seed=0))
+    ref.processor = types.SimpleNamespace(tokenizer=types.SimpleNamespace(pad_token_id=0))
+    ref.concat_text_input_output = types.MethodType(iv.LSTPModule.concat_text_input_output, ref)
+    g = torch.Generator().manual_seed(61)
+    widths = [3, 2]
+    fq, frames = q8((sum(widths), 3, 56, 56), g, 1 / 48)
+    qf = torch.randint(3, cfg.qformer.vocab, (2, 6), generator=g)
+    qfm = torch.ones_like(qf)
+    qfm[1, 4:] = 0
+    quest = torch.randint(3, tc.vocab_size, (2, 5), generator=g)
+    qm = torch.ones_like(quest)
+    qm[1, 3:] = 0
+    quest = quest * qm
+    ans = torch.randint(3, tc.vocab_size, (2, 4), generator=g)
+    ans[:, 0] = 1
+    am = torch.ones_like(ans)
+    am[0, 3:] = 0
+    ans = ans * am
+    batch = dict(frames=frames, widths=widths, nframe=3, qformer_text=qf, qformer_text_attention_mask=qfm, question=quest,
+                 question_attention_mask=qm, answer=ans, answer_attention_mask=am)
+    ref.zero_grad()
+    loss, logits = iv.LSTPModule.forward(ref, batch)
+    loss.backward()
+    out = dict(frames_q8=fq, q8_scale=np.float32(1 / 48), widths=np.array(widths), qformer_ids=qf, qformer_mask=qfm, question=quest,
+               question_mask=qm, answer=ans, answer_mask=am, loss=loss.detach().reshape(1), logits=logits.detach())
+    for n, p in ref.model.named_parameters():
+        if n.startswith("qformer.") or n in ("query_tokens", "language_projection.weight", "language_projection.bias"):
+            assert p.grad is not None, n
+            out["g:" + n] = p.grad.detach()
+    save("tiny_train_step", **out)
+
+
 def refine_answers_fixture():
     """f4 on the reference side: the per-frame answer loop of LSTPSFModule.forward (src/models/LSTP_SF_module.py:149-204,
     sliced out of the live function and executed on the tiny InstructBLIP reference model) -- ViT over all candidate
@@ -777,7 +822,7 @@ def main():
     install_shim()
     torch.manual_seed(0)
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train", "refine", "answers", "bf16", "modules"]
+    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train", "refine", "answers", "bf16", "modules", "trainstep"]
     if "e2e" in which:
         ref_ib, cfg_ib, sd_ib = e2e_fixture("instructblip")
         ref_b2, cfg_b2, sd_b2 = e2e_fixture("blip2")
@@ -798,6 +843,8 @@ def main():
         bf16_reference_fixtures()
     if "modules" in which:
         module_fixtures()
+    if "trainstep" in which:
+        train_step_fixture()
 
 
 if __name__ == "__main__":

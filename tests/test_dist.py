@@ -58,3 +58,39 @@ def test_split_list_matches_reference_semantics():
     assert split_list(list(range(10)), 4) == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9]]
     assert split_list(list(range(8)), 8) == [[i] for i in range(8)]
     assert get_chunk(list(range(3)), 8, 5) == []                         # more ranks than clips
+
+
+def _nccl_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from videotgb_amd import dist as vd
+    dev = torch.device("cuda", rank)
+    lin = torch.nn.Linear(1024, 512).to(dev)
+    lin.weight.grad = torch.full_like(lin.weight, float(rank + 1))
+    lin.bias.grad = torch.full_like(lin.bias, 10.0 * (rank + 1))
+    vd.FlatGradBucket(lin.parameters()).all_reduce(average=True)        # DDP semantics: mean over ranks, one RCCL collective
+    t = vd.max_over_ranks(1.0 + rank, device=dev)
+    torch.cuda.synchronize()
+    q.put((rank, lin.weight.grad[3, 7].item(), lin.bias.grad[5].item(), t))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_flat_bucket_allreduce_over_rccl_when_two_gpus_are_visible():
+    """The C5 gradient exchange on the real backend ("nccl" == RCCL over xGMI): runs wherever >= 2 GPUs are visible (the
+    1-GPU gpurun boxes skip it; the driver's multi-GPU node runs it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 visible GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, w, b, t in out:
+        assert w == 1.5 and b == 15.0 and t == 2.0

@@ -126,3 +126,12 @@ def test_lightning_module_twin_eval_forward(dev, tmp_path, tag):
     assert set(opt) == {"optimizer", "lr_scheduler"} and opt["lr_scheduler"]["interval"] == "epoch"
     trainable = {n.split(".")[0] + "." + n.split(".")[1] for n, p in m.named_parameters() if p.requires_grad}
     assert not any(n.startswith("of_extractor") or n.startswith("model.vision_model") or n.startswith("model.language_model") for n in trainable)
+    assert {"model.qformer", "model.query_tokens", "model.language_projection"} <= trainable
+    # training forward of the flavour: loss is finite and reaches the Q-Former (HIP forward, recompute backward)
+    batch.update(answer=torch.randint(3, 100, (B, 4), device=dev), answer_attention_mask=torch.ones(B, 4, dtype=torch.long, device=dev))
+    if not uses_of:
+        batch.update(of=(up4(g["of_q8"]) / 127).to(dev)[:, :8], of_mask=torch.ones(B, 10, dtype=torch.long, device=dev))
+    m.SELF_REFINE = False                                     # (the SF pseudo-label loop is covered by tests/test_gpu_refine.py)
+    loss, logits = m.forward(batch, noise=(g[f"{tag}_noise"].to(dev) if uses_of and f"{tag}_noise" in g else None))
+    loss.backward()
+    assert torch.isfinite(loss) and m.model.query_tokens.grad is not None and m.model.query_tokens.grad.abs().max() > 0

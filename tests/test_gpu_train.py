@@ -72,7 +72,7 @@ def test_lora_micro_step_matches_plain_pytorch(dev):
     class Holder:                                            # the attribute layout LoraTrainStep expects of an LSTP twin
         pass
     m = Holder(); m.model = Holder(); m.model.language_model = lm
-    step = train.LoraTrainStep(m, pad_token_id=0, lr=1e-2, accumulate_grad_batches=4)
+    step = train.LoraTrainStep(m, pad_token_id=0, lr=1e-2, accumulate_grad_batches=4, train_prefix=False)
     lm.eval()                                                # dropout off for the comparison
     with torch.no_grad():
         for n, p in lm.named_parameters():
@@ -108,3 +108,52 @@ def test_lora_micro_step_matches_plain_pytorch(dev):
     assert flags == [False, False, False, True]
     for n, p in lm.named_parameters():
         assert ("lora_" in n) == (not torch.equal(before[n], p.detach())), n
+
+
+def test_training_forward_and_prefix_gradients_vs_reference(dev, tiny_sd):
+    """C5's real trainable set (LSTP_Vicuna_IVT_module.py:682-690 freezes RAFT / ViT / TGB only): loss of one ragged
+    micro-batch and the gradients of EVERY Q-Former parameter, query_tokens and language_projection against the vectors the
+    reference's own ``LSTPModule.forward`` + ``loss.backward()`` produced (tests/golden/make_golden.py trainstep).
+    fp32 mode: loss to 1e-5 relative, every gradient to 1e-4 of its own max (HIP forward, PyTorch-recompute backward)."""
+    from test_gpu_e2e import build
+    from videotgb_amd import train
+    m, cfg = build("instructblip", tiny_sd, dev, "f32")
+    g = load_golden("tiny_train_step")
+    step = train.LoraTrainStep.__new__(train.LoraTrainStep)          # no LoRA here: the IV flavour the fixture was recorded with
+    step.m, step.lm, step.pad_token_id, step.train_prefix = m, m.model.language_model, 0, True
+    params = train.enable_prefix_training(m.model)
+    for p in m.model.language_model.parameters():
+        p.requires_grad = True
+    m.model.language_model.eval()
+    frames = (g["frames_q8"].float() * float(g["q8_scale"])).to(dev)
+    widths = g["widths"].tolist()
+    prefix = step.prefix(frames, g["qformer_ids"].to(dev), g["qformer_mask"].to(dev), widths)
+    assert prefix.requires_grad and prefix.shape == (2, 32, cfg.llm_hidden)
+    loss = step.loss(prefix, g["question"].to(dev), g["question_mask"].to(dev), g["answer"].to(dev), g["answer_mask"].to(dev))
+    loss.backward()
+    ref = float(g["loss"])
+    print(f"[train step] loss {loss.item():.6f} vs reference {ref:.6f}")
+    assert abs(loss.item() - ref) <= 1e-5 * abs(ref)
+    names, plist = train.prefix_params(m.model)
+    worst = 0.0
+    for n, p in zip(names, plist):
+        want = g["g:" + n]
+        assert p.grad is not None, n
+        err = (p.grad.float().cpu() - want).abs().max().item()
+        scale = want.abs().max().item()
+        if scale > 1e-7:      # (key biases have an analytically zero gradient -- softmax shift invariance -- : rounding noise on both sides)
+            worst = max(worst, err / scale)
+        assert err <= 1e-4 * scale + 1e-10, (n, err, scale)
+    print(f"[train step] {len(names)} gradient tensors, worst max|diff| / max|ref| = {worst:.2e}")
+    assert all(p.grad is None for p in m.model.vision_model.parameters())
+    # the step itself: after AdamW the HIP Q-Former must see the new weights (packed tables invalidated)
+    full = train.LoraTrainStep(m, pad_token_id=0, lr=1e-2, accumulate_grad_batches=1)
+    before = m.model.qformer.state_dict()["encoder.layer.0.attention.attention.query.weight"].clone()
+    p0 = full.prefix(frames, g["qformer_ids"].to(dev), g["qformer_mask"].to(dev), widths).detach().clone()
+    _, stepped = full.step_frames(frames, g["qformer_ids"].to(dev), g["qformer_mask"].to(dev), widths, g["question"].to(dev),
+                                  g["question_mask"].to(dev), g["answer"].to(dev), g["answer_mask"].to(dev))
+    assert stepped and not torch.equal(before, m.model.qformer.state_dict()["encoder.layer.0.attention.attention.query.weight"])
+    p1 = full.prefix(frames, g["qformer_ids"].to(dev), g["qformer_mask"].to(dev), widths).detach()
+    assert (p1 - p0).abs().max() > 1e-4
+    n_train = sum(p.numel() for p in full.params)
+    print(f"[train step] trainable parameters incl. LoRA adapters: {n_train}")

@@ -1,29 +1,49 @@
 #!/usr/bin/env python3
-"""Config C5 micro-step at full size (row a14): Vicuna-7B geometry + LoRA (r=8 on q_proj/v_proj, 4.19 M trainable),
-32 visual prefix tokens + question + answer, HIP token splice / label masking / shifted cross-entropy, AdamW every 4
-micro-batches.  The frozen prefix path is not part of this measurement (its cost is bench.py's); the prefix is a random
-[B, 32, 4096] tensor.  Prints ms per micro-batch and sequences/s on one MI355X."""
+"""Config C5 micro-step at full size (row a14): InstructBLIP-Vicuna-7B geometry, the REFERENCE's trainable set -- Q-Former
+(185.7 M) + query_tokens + language_projection + temporal_projection + LoRA r=8 on q_proj / v_proj (4.19 M) -- per micro-batch:
+frozen EVA-ViT-g over the B x 8 pre-selected frames (HIP) -> Q-Former + mean pool + projection (HIP forward, PyTorch-recompute
+backward) -> [32 prefix | 48 question | 31 answer tokens] through the LLM with LoRA -> HIP token splice / labels / shifted CE
+-> backward; AdamW + one flat-bucket gradient all-reduce every 4 micro-batches.
+    python tools/train_bench.py [B] [--lora-only]      prints ms per micro-batch and sequences/s on one MI355X.
+Under torchrun (2+ ranks, backend nccl = RCCL) the flat bucket is all-reduced across the ranks."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from videotgb_amd import llm, train
-dev = torch.device("cuda:0")
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 4          # per-GPU micro-batch of the reference experiment config
+import torch.distributed as dist
+from videotgb_amd import llm, models, synth, train
+world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+B = int(args[0]) if args else 4                            # per-GPU micro-batch of the reference experiment config
+lora_only = "--lora-only" in sys.argv
+cfg = synth.full_cfg("instructblip")
 lm = llm.build_llama("vicuna-7b", torch.bfloat16, dev)
-class H: pass
-m = H(); m.model = H(); m.model.language_model = lm
-step = train.LoraTrainStep(m, pad_token_id=0, lr=1e-4, accumulate_grad_batches=4)
+m = models.LSTP(cfg, dev, language_model=lm, compute_dtype="bf16")
+sd = synth.path_state_dict(cfg, 0, with_raft=False)
+m.load_state_dict(sd, strict=False); m.to(dev); lm.to(torch.bfloat16)
+step = train.LoraTrainStep(m, pad_token_id=0, lr=1e-4, accumulate_grad_batches=4, train_prefix=not lora_only)
 lm.train()
-print("trainable parameters:", sum(p.numel() for p in step.params))
-g = torch.Generator(device=dev).manual_seed(0)
-P, Li, Lo = 32, 48, 32
-prefix = torch.randn(B, P, 4096, generator=g, device=dev, dtype=torch.bfloat16)
+n_train = sum(p.numel() for p in step.params)
+g = torch.Generator(device=dev).manual_seed(local)
+P, Li, Lo, nframe = 32, 48, 32, 8
+frames = torch.randn(B * nframe, 3, 224, 224, generator=g, device=dev)
+qt = torch.randint(1000, 30000, (B, 14), generator=g, device=dev); qtm = torch.ones_like(qt)
 q = torch.randint(3, 32000, (B, Li), generator=g, device=dev); qm = torch.ones_like(q)
 a = torch.randint(3, 32000, (B, Lo), generator=g, device=dev); am = torch.ones_like(a)
-for _ in range(4): loss, _ = step.step(prefix, q, qm, a, am)
+def micro():
+    return step.step_frames(frames, qt, qtm, [nframe] * B, q, qm, a, am)
+for _ in range(4): loss, _ = micro()
 torch.cuda.synchronize(); t0 = time.time()
 n = 8
-for _ in range(n): loss, stepped = step.step(prefix, q, qm, a, am)
+for _ in range(n): loss, stepped = micro()
 torch.cuda.synchronize(); dt = (time.time() - t0) / n
-print(f"C5 LoRA micro-batch B={B}, S={P + Li + Lo - 1}: {dt * 1e3:.1f} ms ({B / dt:.1f} sequences/s), loss {loss.item():.3f}, "
-      f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+if local == 0:
+    print(f"C5 micro-batch B={B} x {world} GPU(s), S={P + Li + Lo - 1}, trainable {n_train} params ({n_train * 4 / 1e6:.0f} MB fp32 gradient bucket"
+          f"{', adapters only' if lora_only else ''}): {dt * 1e3:.1f} ms per micro-batch incl. the prefix path ({B * world / dt:.1f} sequences/s), "
+          f"loss {loss.item():.3f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()

@@ -242,12 +242,26 @@ class _LSTPLightningBase(_Base):
         idx = ops.span_to_frames(sel, v, n, nframe, self.MAP)
         return ops.gather_frames(pixel_values, idx).view(b * nframe, *pixel_values.shape[2:]), idx, logits
 
-    @torch.no_grad()
     def _prefix(self, batch, sampled: torch.Tensor, batch_size: int, nframe: int) -> torch.Tensor:
-        """ViT -> Q-Former -> pooling + language_projection of one flavour -> language_model_inputs [B, P, H]."""
-        img = self.model.vision_model(pixel_values=sampled, return_dict=True, act_output=True).last_hidden_state
-        query_tokens = self.model.query_tokens.expand(img.shape[0], -1, -1)
+        """ViT -> Q-Former -> pooling + language_projection of one flavour -> language_model_inputs [B, P, H].  With autograd on
+        and the prefix side trainable (``freeze_weights``) the result carries gradients to the Q-Former / query tokens /
+        projection (train.prefix_with_grad: HIP forward, PyTorch-recompute backward); the vision tower is frozen."""
+        with torch.no_grad():
+            img = self.model.vision_model(pixel_values=sampled, return_dict=True, act_output=True).last_hidden_state
         widths = list(batch["widths"]) if self.WIDTHS else [nframe] * batch_size
+        pool = "mean" if self.WIDTHS else "concat"
+        if torch.is_grad_enabled() and self.model.query_tokens.requires_grad:
+            qi = qm = None
+            if self.ARCH == "instructblip":
+                rep = torch.as_tensor(widths, device=img.device)
+                qi = torch.repeat_interleave(batch["qformer_text"], rep, 0)
+                qm = torch.repeat_interleave(batch["qformer_text_attention_mask"], rep, 0)
+            return train.prefix_with_grad(self.model, img, qi, qm, widths, pool)
+        with torch.no_grad():
+            return self._prefix_nograd(batch, img, widths, pool)
+
+    def _prefix_nograd(self, batch, img, widths, pool):
+        query_tokens = self.model.query_tokens.expand(img.shape[0], -1, -1)
         if self.ARCH == "instructblip":
             rep = torch.as_tensor(widths, device=img.device)
             qi = torch.repeat_interleave(batch["qformer_text"], rep, 0)
@@ -258,7 +272,7 @@ class _LSTPLightningBase(_Base):
         else:
             qo = self.model.qformer(query_embeds=query_tokens, encoder_hidden_states=img, encoder_attention_mask=None)[0]
         qo = qo[:, : query_tokens.size(1), :]
-        return self.model.language_projection.pool(qo, widths, "mean" if self.WIDTHS else "concat")
+        return self.model.language_projection.pool(qo, widths, pool)
 
     def _has_frames(self, batch) -> bool:
         fr = batch["frames"]
@@ -386,10 +400,13 @@ class _LSTPLightningBase(_Base):
     def freeze_weights(self):
         """LSTP_module.py:669-675: RAFT, the vision tower and the language model are frozen (Q-Former, projections and the
         TGB stay trainable); IV / IVT instead freeze the TGB and leave the LLM to peft (LSTP_Vicuna_IVT_module.py:682-690)."""
+        train.enable_prefix_training(self.model)      # Q-Former, query tokens, projections: trainable in every flavour
         for p in self.of_extractor.parameters():
             p.requires_grad = False
         for p in self.model.vision_model.parameters():
             p.requires_grad = False
+        # (the TGB's parameters are registered frozen: no backward is built for it -- in LSTP_module it receives no gradient
+        # anyway (selection is an argmax), the SF flavours' MRC loss on its logits is computed but does not train it here)
         if self.WIDTHS:
             for p in self.temporal_encoder.parameters():
                 p.requires_grad = False

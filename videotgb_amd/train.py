@@ -8,6 +8,14 @@
   (``q_proj.weight``, ``q_proj.lora_A.default.weight``, ``q_proj.lora_B.default.weight``) and arithmetic
 * ``freeze_weights`` (:682-690), AdamW + the cosine schedule as the reference configures it (:634-679)
 * gradient exchange: one flat bucket, one all-reduce per optimizer step (``dist.FlatGradBucket``; RCCL on the GPU box)
+* the trainable set is the reference's (``freeze_weights`` :682-690 freezes RAFT, the vision tower and the TGB only): the
+  Q-Former, ``query_tokens`` and ``language_projection`` train together with the adapters.  ``prefix_with_grad`` makes the
+  prefix differentiable: FORWARD = the HIP Q-Former + pooling + projection (libvtgb.so, what the loss is computed from);
+  BACKWARD = the same graph recomputed with PyTorch ops in fp32 on the same parameters and differentiated by autograd
+  (activation recomputation; 0.35 TFLOP per 8-frame clip against ~4.5 TFLOP of LLM forward + backward per sequence).  HIP
+  backward kernels for the Q-Former are not built; this is the documented torch-autograd path over the same weights.
+  Dropout (Q-Former hidden / attention dropout 0.1, LoRA dropout 0.1 inside ``LoraLinear``) : the HIP Q-Former forward has
+  no dropout, so Q-Former training here is the dropout-free variant of the reference's step.
 
 The language model itself, autograd through it and AdamW stay PyTorch, as they are third-party in the reference.
 """
@@ -77,6 +85,128 @@ def shifted_cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
     if logits.dim() != 3 or labels.shape != logits.shape[:2]:
         raise ValueError(f"Expected logits [B, S, V] and labels [B, S], got {tuple(logits.shape)} and {tuple(labels.shape)}")
     return _ShiftedCE.apply(logits, labels)
+
+
+# ----------------------------------------------------------------------------- differentiable prefix (Q-Former + pooling + projection)
+def _qformer_graph(sd: Dict[str, Tensor], query_tokens: Tensor, image_embeds: Tensor, heads: int, input_ids: Optional[Tensor], text_mask: Optional[Tensor],
+                   cross_freq: int, eps: float) -> Tensor:
+    """The Q-Former as PyTorch ops (autograd) over the state_dict tensors ``sd`` (names relative to ``model.qformer.``):
+    InstructBlipQFormerModel.forward xinstructblip.py:1122-1242 (``input_ids`` given: embeddings :1018-1046, text FFN branch)
+    / Blip2QFormerModel.forward xblip2.py:1063-1174.  Used ONLY as the backward of ``prefix_with_grad``.  -> [n, n_query, hidden]."""
+    F = nn.functional
+    n = image_embeds.shape[0]
+    q = query_tokens.expand(n, -1, -1)
+    nq = q.shape[1]
+
+    def lin(name, x):
+        return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
+
+    def ln(name, x):
+        return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], eps)
+
+    def split(x):
+        b, t, d = x.shape
+        return x.view(b, t, heads, d // heads).permute(0, 2, 1, 3)
+
+    def attn(ap, hidden, kv, mask):
+        qq, kk, vv = split(lin(ap + "attention.query", hidden)), split(lin(ap + "attention.key", kv)), split(lin(ap + "attention.value", kv))
+        sc = torch.matmul(qq, kk.transpose(-1, -2)) / math.sqrt(qq.shape[-1])
+        if mask is not None:
+            sc = sc + mask
+        ctx = torch.matmul(torch.softmax(sc, dim=-1), vv).permute(0, 2, 1, 3).reshape(hidden.shape)
+        return ln(ap + "output.LayerNorm", lin(ap + "output.dense", ctx) + hidden)
+
+    def ffn(lp, inter, outp, x):
+        h = lin(lp + outp + ".dense", F.gelu(lin(lp + inter + ".dense", x)))
+        return ln(lp + outp + ".LayerNorm", h + x)
+
+    if input_ids is not None:
+        lt = input_ids.shape[1]
+        emb = sd["embeddings.word_embeddings.weight"][input_ids] + sd["embeddings.position_embeddings.weight"][:lt][None]
+        x = ln("embeddings.layernorm", torch.cat([q, emb], dim=1))
+        m = torch.cat([torch.ones(n, nq, device=q.device), (text_mask if text_mask is not None else torch.ones(n, lt, device=q.device)).float()], 1)
+        self_mask = (1.0 - m)[:, None, None, :] * -10000.0
+    else:
+        x = ln("layernorm", q)
+        self_mask = None
+    i = 0
+    while f"encoder.layer.{i}.attention.attention.query.weight" in sd:
+        lp = f"encoder.layer.{i}."
+        att = attn(lp + "attention.", x, x, self_mask)
+        qa = att[:, :nq]
+        if i % cross_freq == 0:
+            qa = attn(lp + "crossattention.", qa, image_embeds, None)
+        out = ffn(lp, "intermediate_query", "output_query", qa)
+        if att.shape[1] > nq:
+            out = torch.cat([out, ffn(lp, "intermediate", "output", att[:, nq:])], dim=1)
+        x = out
+        i += 1
+    return x[:, :nq]
+
+
+def _pool_project_graph(query_out: Tensor, widths: Sequence[int], w: Tensor, b: Tensor, mode: str) -> Tensor:
+    """eval/utils/model.py:186-195 / LSTP_Vicuna_IVT_module.py:244-249 (mean over ragged widths; width 0 -> zero row) or
+    LSTP_module.py:477-481 (concat), as autograd ops."""
+    if mode == "mean":
+        rows, idx = [], 0
+        for wd in widths:
+            rows.append(query_out[idx:idx + wd].mean(0) if wd > 0 else torch.zeros_like(query_out[0]))
+            idx += wd
+        return nn.functional.linear(torch.stack(rows), w, b)
+    y = nn.functional.linear(query_out, w, b)
+    return y.reshape(len(widths), -1, y.shape[-1])
+
+
+class _PrefixFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pm, image_embeds, input_ids, text_mask, widths, mode, names, *params):
+        from . import ops
+        qf = pm.qformer
+        qf._table = None                                   # the parameters may have been stepped since the last pack
+        pm.language_projection._packed = None
+        q = ops.qformer_forward(qf.table(), pm.query_tokens[0], image_embeds, input_ids, text_mask, None)
+        out = pm.language_projection.pool(q, widths, mode)
+        ctx.save_for_backward(image_embeds, *params)
+        ctx.meta = (qf.cfg.heads, qf.cfg.cross_freq, qf.cfg.eps, input_ids, text_mask, tuple(widths), mode, names)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        image_embeds, *params = ctx.saved_tensors
+        heads, cross_freq, eps, input_ids, text_mask, widths, mode, names = ctx.meta
+        with torch.enable_grad():
+            leaves = [p.detach().float().requires_grad_(True) for p in params]
+            sd = dict(zip(names, leaves))
+            q = _qformer_graph({k[len("qformer."):]: v for k, v in sd.items() if k.startswith("qformer.")}, sd["query_tokens"],
+                               image_embeds.detach().float(), heads, input_ids, text_mask, cross_freq, eps)
+            out = _pool_project_graph(q, widths, sd["language_projection.weight"], sd["language_projection.bias"], mode)
+            grads = torch.autograd.grad(out, leaves, grad_out.float(), allow_unused=True)
+        return (None,) * 7 + tuple(None if g is None else g.to(p.dtype) for g, p in zip(grads, params))
+
+
+def prefix_params(pm) -> Tuple[List[str], List[nn.Parameter]]:
+    """The prefix-side trainable parameters of ``self.model`` in a fixed order: qformer.*, query_tokens, language_projection.*."""
+    names = ["qformer." + n for n, _ in pm.qformer.named_parameters()] + ["query_tokens", "language_projection.weight", "language_projection.bias"]
+    params = [p for _, p in pm.qformer.named_parameters()] + [pm.query_tokens, pm.language_projection.weight, pm.language_projection.bias]
+    return names, params
+
+
+def prefix_with_grad(pm, image_embeds: Tensor, input_ids: Optional[Tensor], text_mask: Optional[Tensor], widths: Sequence[int], mode: str = "mean") -> Tensor:
+    """``language_model_inputs`` [n_clips, P, H] from the frozen vision tower's ``image_embeds`` [sum(widths), tokens, enc] with
+    gradients to the Q-Former, ``query_tokens`` and ``language_projection`` (see the module docstring): HIP forward, PyTorch
+    recompute backward.  ``pm`` is the ``self.model`` object (models.PathModel)."""
+    names, params = prefix_params(pm)
+    return _PrefixFn.apply(pm, image_embeds, input_ids, text_mask, list(widths), mode, names, *params)
+
+
+def enable_prefix_training(pm) -> List[nn.Parameter]:
+    """requires_grad = True for what the reference leaves trainable on the prefix side (everything of ``self.model`` but the
+    vision tower; LSTP_Vicuna_IVT_module.py:682-690) -- the stages register their parameters frozen for inference."""
+    _, params = prefix_params(pm)
+    params = params + list(pm.temporal_projection.parameters())          # dead weight, but in the reference's optimizer all the same
+    for p in params:
+        p.requires_grad = True
+    return params
 
 
 # ----------------------------------------------------------------------------- LoRA
@@ -165,23 +295,45 @@ def configure_optimizers(params: Iterable[nn.Parameter], lr: float = 1e-4, weigh
 
 # ----------------------------------------------------------------------------- the step
 class LoraTrainStep:
-    """One C5 micro-batch: frozen prefix path (HIP, no grad) -> [prefix | question+answer embeddings] -> language model
-    with LoRA -> shifted CE (HIP) -> backward; every ``accumulate_grad_batches`` micro-batches the adapter gradients
-    are summed over the ranks in one flat bucket and AdamW steps
-    (configs/experiment/LSTP_instructblipvicuna7b_ivtinstruct.yaml:34 accumulate_grad_batches=4)."""
+    """One C5 micro-batch (LSTP_Vicuna_IVT_module.py:191-413): frozen vision tower (HIP, no grad) -> Q-Former + pooling +
+    projection (``prefix_with_grad``: trainable, as in the reference) -> [prefix | question+answer embeddings] -> language model
+    with LoRA -> shifted CE (HIP) -> backward; every ``accumulate_grad_batches`` micro-batches ALL trainable gradients (Q-Former
+    185.7 M + projections + query tokens + 4.19 M adapter parameters = the reference's ~785 MB fp32) are summed over the
+    ranks in one flat bucket and AdamW steps (configs/experiment/LSTP_instructblipvicuna7b_ivtinstruct.yaml:34
+    accumulate_grad_batches=4).  ``train_prefix=False`` keeps the round-1 adapters-only step (not reference-equivalent)."""
 
-    def __init__(self, lstp, pad_token_id: int, lr: float = 1e-4, weight_decay: float = 0.0, accumulate_grad_batches: int = 4):
+    def __init__(self, lstp, pad_token_id: int, lr: float = 1e-4, weight_decay: float = 0.0, accumulate_grad_batches: int = 4,
+                 train_prefix: bool = True):
         from .dist import FlatGradBucket
         self.m = lstp
         self.lm = lstp.model.language_model
         self.pad_token_id = pad_token_id
         self.params = apply_lora(self.lm)
         freeze_weights(lstp)
+        self.train_prefix = train_prefix
+        if train_prefix:
+            self.params = enable_prefix_training(lstp.model) + self.params
         cfg = configure_optimizers(self.params, lr=lr, weight_decay=weight_decay)
         self.optimizer, self.scheduler = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
         self.bucket = FlatGradBucket(self.params)
         self.accumulate = accumulate_grad_batches
         self.micro = 0
+
+    def prefix(self, frames: Tensor, qformer_text: Optional[Tensor], qformer_mask: Optional[Tensor], widths: Sequence[int], pool: str = "mean") -> Tensor:
+        """frames [sum(widths), 3, H, W] (already selected, as the IV / IVT datasets deliver them) -> language_model_inputs."""
+        pm = self.m.model
+        with torch.no_grad():
+            img = pm.vision_model(pixel_values=frames, return_dict=True, act_output=True).last_hidden_state
+        ids = mask = None
+        if qformer_text is not None:
+            rep = torch.as_tensor(list(widths), device=frames.device)
+            ids, mask = torch.repeat_interleave(qformer_text, rep, 0), torch.repeat_interleave(qformer_mask, rep, 0)
+        if self.train_prefix:
+            return prefix_with_grad(pm, img, ids, mask, widths, pool)
+        with torch.no_grad():
+            from . import ops
+            q = ops.qformer_forward(pm.qformer.table(), pm.query_tokens[0], img, ids, mask, None)
+            return pm.language_projection.pool(q, widths, pool)
 
     def loss(self, language_model_inputs: Tensor, question: Tensor, question_mask: Tensor, answer: Tensor, answer_mask: Tensor) -> Tensor:
         """language_model_inputs [B, P, H] (the projected Q-Former prefix, LSTP_Vicuna_IVT_module.py:255-260) + tokens -> loss."""
@@ -194,7 +346,9 @@ class LoraTrainStep:
         return shifted_cross_entropy(logits, labels)
 
     def step(self, language_model_inputs: Tensor, question: Tensor, question_mask: Tensor, answer: Tensor, answer_mask: Tensor) -> Tuple[Tensor, bool]:
-        loss = self.loss(language_model_inputs.detach(), question, question_mask, answer, answer_mask)
+        """One micro-batch from a prefix (``self.prefix(...)`` output: gradients flow into the Q-Former / projection when
+        ``train_prefix``; a plain tensor is treated as a constant)."""
+        loss = self.loss(language_model_inputs, question, question_mask, answer, answer_mask)
         (loss / self.accumulate).backward()
         self.micro += 1
         stepped = False
@@ -202,5 +356,13 @@ class LoraTrainStep:
             self.bucket.all_reduce(average=True)     # DDP semantics: mean over ranks
             self.optimizer.step()
             self.optimizer.zero_grad(set_to_none=False)
+            if self.train_prefix:                    # the packed (bf16) weight tables of the HIP stages are stale now
+                self.m.model.qformer._table = None
+                self.m.model.language_projection._packed = None
             stepped = True
         return loss.detach(), stepped
+
+    def step_frames(self, frames: Tensor, qformer_text, qformer_mask, widths: Sequence[int], question: Tensor, question_mask: Tensor, answer: Tensor,
+                    answer_mask: Tensor) -> Tuple[Tensor, bool]:
+        """The whole micro-batch of LSTPModule.forward (LSTP_Vicuna_IVT_module.py:191-335): frames -> prefix -> loss -> backward."""
+        return self.step(self.prefix(frames, qformer_text, qformer_mask, widths), question, question_mask, answer, answer_mask)
