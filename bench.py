@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """clips/s of the VideoTGB video -> LLM hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--clips B] [--flow precomputed|raft]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--clips B] [--flow precomputed|raft]     (N > 1 without a launcher: spawns the ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (config.workload): InstructBLIP-Vicuna-7B + TGB, T = 96 flow frames -> 8 of 32 candidate
@@ -15,9 +15,12 @@ Clips shard across ranks with no data-path collective (weak scaling: B clips per
 Weights are random-init (seeded N(0, 0.02)), data synthetic: there is no network here.
 
 The JSON line also carries
-  roofline     for the dominant kernel family (gemm_bf16_kernel, the ViT/Q-Former/TGB GEMMs):
-               algorithmic FLOPs / summed launch time, both recorded per launch with HIP events on
-               the launch stream inside the timed region (include/vtgb.h, vtgb_prof_*);
+  roofline     for the dominant kernel family: algorithmic FLOPs / summed launch time, both recorded per
+               launch with HIP events on the launch stream (include/vtgb.h, vtgb_prof_*) in a short pass
+               AFTER the timed region (the headline is timed without the event records);
+  companions   the same path at 32 clips per step, one clip at a time (latency), with host-resident
+               inputs uploaded over PCIe under compute, with RAFT in the fp32 exactness mode, and with
+               the flow precomputed;
   cpu_baseline the CPU oracle (a port: the reference's Python cannot travel) timed on this box's
                host cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -39,17 +42,20 @@ VIT_GFLOP_PER_FRAME = 520.72   # SURVEY.md 8d / BASELINE.md 2
 
 
 def pmc_traffic(family="gemm"):
-    """Mean HBM-side bytes per launch of the dominant kernel family from the committed PMC passes (FETCH_SIZE x2 per
-    the gfx950 correction + WRITE_SIZE).  gemm: profiles/r01_pmc_traffic_gemm.json (tools/gemm_pmc.py, the four ViT-g
-    layer shapes at 31 clips); conv: profiles/r01_pmc_traffic_conv.json (tools/conv_pmc.py, one RAFT pass over the
-    bench's 31-clip RAFT batch).  None if the file is absent."""
-    path = os.path.join(REPO, "profiles", f"r01_pmc_traffic_{family}.json")
+    """(bytes, source): mean HBM-side bytes per launch of the dominant kernel family from the COMMITTED PMC passes
+    (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE) -- NOT measured in this run (counters need their own
+    rocprofv3 --pmc passes): gemm = tools/gemm_pmc.py, the four ViT-g layer shapes at 31 clips; conv = tools/conv_pmc.py,
+    one RAFT pass over the bench's 31-clip RAFT batch.  The newest profiles/rNN_pmc_traffic_<family>.json is used."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r??_pmc_traffic_{family}.json")))
+    if not files:
+        return None, None
     try:
-        ks = json.load(open(path))["kernels"]
+        ks = json.load(open(files[-1]))["kernels"]
         tot = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ks.values())
-        return int(tot / sum(v["launches"] for v in ks.values()))
+        return int(tot / sum(v["launches"] for v in ks.values())), "profiles/" + os.path.basename(files[-1])
     except Exception:
-        return None
+        return None, None
 
 
 def parse():
@@ -63,7 +69,9 @@ def parse():
     ap.add_argument("--flow", choices=["precomputed", "raft"], default="raft",
                     help="raft: RAFT runs inline on the T frames inside the timed step, as eval/utils/model.py:76-84 does (default); "
                          "precomputed: the batch['of'] contract of the LightningModules (src/models/LSTP_SF_module.py:476)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the short precomputed-flow leg reported next to the inline-RAFT value")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short companion legs reported next to the headline value (precomputed flow, 32-clip steps, single-clip "
+                         "latency, host-resident inputs over PCIe, fp32-RAFT exactness mode)")
     ap.add_argument("--max-new-tokens", type=int, default=16)
     ap.add_argument("--llm", default="vicuna-7b")
     ap.add_argument("--decode", choices=["graph", "hf"], default="graph",
@@ -78,7 +86,8 @@ def parse():
                     help="two HIP streams: the prefix stage of batch i+1 over the LLM decode of batch i (measured +7 % clips/s; off by "
                          "default because concurrent kernels inflate the per-launch durations the roofline object is computed from)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prof", action="store_true", help="do not record per-launch HIP events")
+    ap.add_argument("--no-prof", action="store_true", help="skip the (untimed) roofline pass that records per-launch HIP events")
+    ap.add_argument("--prof-steps", type=int, default=2, help="steps of the untimed roofline pass")
     ap.add_argument("--stage-times", action="store_true", help="print a per-stage breakdown to stderr")
     return ap.parse_args()
 
@@ -198,8 +207,81 @@ def cpu_baseline(cfg, T, nframe, seed_sd, inline_raft=True, raft_pairs=4):
                       f"in fp32 on {cores} host threads, {dt:.1f} s; LLM decode excluded"}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run as a CHILD process (nothing
+    in this process has touched the GPU yet) and exit with its code; rank 0 of the child prints the JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def timed_steps(fn, steps, barrier, dev, world):
+    """K calls of fn(i) bracketed by barrier + synchronize on both sides; returns the MAX over ranks of the wall time."""
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def host_resident_leg(m, rank, B, T, nframe, max_new_tokens, decoder, dev, steps, barrier, world):
+    """The same step with the clip tensors starting in PINNED HOST memory (what a decoder process hands over): a copy stream
+    uploads batch i+1 (frames 19.3 MB + flow frames 57.8 MB per clip at T=96) while batch i computes; the upload of the first
+    batch is inside the timed region."""
+    host = []
+    for i in range(2):
+        d = synth_batch(rank, 200 + i, B, T, "raft", dev, None)
+        host.append({k: (v.cpu().pin_memory() if k in ("frames", "flow_frames") else v) for k, v in d.items()})
+        del d
+    torch.cuda.empty_cache()
+    copy = torch.cuda.Stream()
+    dbuf = [{k: torch.empty_like(v, device=dev) for k, v in h.items() if k in ("frames", "flow_frames")} for h in host]
+    ready = [torch.cuda.Event() for _ in range(2)]
+    free = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(i):
+        with torch.cuda.stream(copy):
+            copy.wait_event(free[i % 2])
+            for k, v in dbuf[i % 2].items():
+                v.copy_(host[i % 2][k], non_blocking=True)
+            ready[i % 2].record(copy)
+
+    def run(n):
+        main = torch.cuda.current_stream()
+        for e in free:
+            e.record(main)
+        upload(0)
+        for i in range(n):
+            if i + 1 < n:
+                upload(i + 1)
+            main.wait_event(ready[i % 2])
+            d = dict(host[i % 2], **dbuf[i % 2])
+            run_step(m, d, B, nframe, max_new_tokens, None, decoder)
+            free[i % 2].record(main)
+    run(2)
+    el = timed_steps(lambda i: run(steps) if i == 0 else None, 1, barrier, dev, world)
+    gb = sum(v.numel() * 4 for v in dbuf[0].values()) / 1e9
+    del host, dbuf
+    return {"inputs": "pinned host memory, uploaded on a copy stream under the previous batch's compute (PCIe inclusive)",
+            "clips_per_gpu_per_step": B, "steps": steps, "value": round(B * steps * world / el, 3), "unit": "clips/s",
+            "ms_per_step": round(el / steps * 1e3, 2), "h2d_gb_per_step": round(gb, 2)}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -210,7 +292,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from videotgb_amd import _lib, llm, models, synth
-    _lib.lib()
+    L = _lib.lib()
     cfg = synth.full_cfg("instructblip")
     t_setup = time.time()
     lm = llm.build_llama(args.llm, torch.bfloat16, dev, seed=0)
@@ -240,53 +322,56 @@ def main():
         decoder = GreedyDecoder(lm)
     for i in range(max(args.warmup, 1 if decoder else 0)):   # the first graph-decode call captures the graph
         run_step(m, batches[i % 2], B, nframe, args.max_new_tokens, None, decoder)
-    prof = not args.no_prof
-    L = _lib.lib()
-    L.vtgb_prof_reset()
-    L.vtgb_prof_enable(1 if prof else 0)
+    # ---- the timed region: K steps, per-launch event recording OFF (it would add two hipEventRecord per GEMM launch)
+    L.vtgb_prof_enable(0)
     stage_ev = []
     overlap = args.overlap and not args.stage_times
     side = torch.cuda.Stream(priority=-1) if overlap else None   # decode stream: high priority, short memory-bound kernels
     if overlap:   # one untimed overlapped pass so that both streams have their handles / graph ready
         run_steps_overlapped(m, batches, 2, B, nframe, args.max_new_tokens, decoder, side)
-        L.vtgb_prof_reset()
-    barrier()
-    t0 = time.perf_counter()
     if overlap:
-        run_steps_overlapped(m, batches, args.steps, B, nframe, args.max_new_tokens, decoder, side)
+        elapsed = timed_steps(lambda i: run_steps_overlapped(m, batches, args.steps, B, nframe, args.max_new_tokens, decoder, side) if i == 0 else None,
+                              1, barrier, dev, world)
     else:
-        for i in range(args.steps):
+        def one(i):
             ev = [] if args.stage_times else None
             run_step(m, batches[i % 2], B, nframe, args.max_new_tokens, ev, decoder)
             if ev:
                 stage_ev.append(ev)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    L.vtgb_prof_enable(0)
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        elapsed = timed_steps(one, args.steps, barrier, dev, world)
     total_clips = B * args.steps * world
     value = total_clips / elapsed
 
+    # ---- roofline pass (untimed): the same step with HIP events around every GEMM / convolution / attention launch
     roofline = None
-    if prof:
+    if not args.no_prof:
+        L.vtgb_prof_reset()
+        L.vtgb_prof_enable(1)
+        for i in range(args.prof_steps):
+            run_step(m, batches[i % 2], B, nframe, args.max_new_tokens, None, decoder)
+        torch.cuda.synchronize()
+        L.vtgb_prof_enable(0)
+
         def fam(kind, name):
             n, ms, fl = _lib.prof_summary(kind)
             if not n or ms <= 0:
                 return None
             ach = fl / (ms * 1e-3) / 1e12
             return {"kernel": name, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                    "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "ms_per_step": round(ms / args.steps, 3),
-                    "gflop_per_step": round(fl / args.steps / 1e9, 1)}
+                    "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "ms_per_step": round(ms / args.prof_steps, 3),
+                    "gflop_per_step": round(fl / args.prof_steps / 1e9, 1)}
         gemm = fam(0, "gemm_bf16_large_kernel<EPI,0,false> / gemm_bf16_kernel: plain bf16 MFMA GEMMs (ViT-g, Q-Former, TGB, projection)")
         conv = fam(2, "gemm_bf16_large_kernel<EPI,0,true>: the same MFMA kernel as implicit-GEMM convolution (RAFT encoders + update block)")
         attn = fam(1, "attn_bf16_kernel")
         fams = [f for f in (gemm, conv) if f]
         if fams:
             dom = max(fams, key=lambda f: f["ms_per_step"])          # the family the step spends most time in
-            roofline = {"bound": "mfma", **dom, "traffic": pmc_traffic("gemm" if dom is gemm else "conv"),
+            traffic, src = pmc_traffic("gemm" if dom is gemm else "conv")
+            roofline = {"bound": "mfma", **dom, "traffic": traffic,
+                        "traffic_source": (f"{src} (committed rocprofv3 --pmc passes of the same kernels at the bench's batch; not "
+                                           f"collected in this run)") if src else None,
+                        "measured_in": f"{args.prof_steps} untimed steps after the timed region (HIP events per launch; the timed region runs "
+                                       f"without them)",
                         "other": [f for f in (gemm, conv, attn) if f and f is not dom]}
     if stage_ev and rank == 0:
         acc = {}
@@ -295,28 +380,36 @@ def main():
                 acc[n1] = acc.get(n1, 0.0) + e0.elapsed_time(e1)
         print("[bench] ms/step by stage: " + ", ".join(f"{k}={v / len(stage_ev):.1f}" for k, v in acc.items()), file=sys.stderr)
 
-    secondary = None
+    # ---- companion legs (short, untimed w.r.t. the headline; each has its own barrier-bracketed timing)
+    legs = {}
     if args.flow == "raft" and not args.no_secondary:
-        # the same path with the flow precomputed (the training-time / LightningModule contract): RAFT is the only
-        # stage left out.  Short separate leg, outside the timed region above; reported next to `value`.
         del batches
         torch.cuda.empty_cache()
-        B2 = 62
-        b2 = [synth_batch(rank, 100 + i, B2, T, "precomputed", dev, cfg) for i in range(2)]
-        for i in range(2):
-            run_step(m, b2[i % 2], B2, nframe, args.max_new_tokens, None, decoder)
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(3):
-            run_step(m, b2[i % 2], B2, nframe, args.max_new_tokens, None, decoder)
-        barrier()
-        e2 = time.perf_counter() - t1
-        t2 = torch.tensor([e2], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-        secondary = {"flow": "precomputed (batch['of'] contract)", "clips_per_gpu_per_step": B2, "steps": 3,
-                     "value": round(B2 * 3 * world / float(t2.item()), 3), "unit": "clips/s", "ms_per_step": round(float(t2.item()) / 3 * 1e3, 2)}
-        del b2
+
+        def leg(name, Bn, flow, steps, note, raft_dtype=None, tokens=None):
+            if raft_dtype:
+                m.of_extractor.set_compute_dtype(raft_dtype)
+            bs = [synth_batch(rank, 100 + i, Bn, T, flow, dev, cfg) for i in range(2)]
+            ntok = tokens or args.max_new_tokens
+            for i in range(2):
+                run_step(m, bs[i % 2], Bn, nframe, ntok, None, decoder)
+            el = timed_steps(lambda i: run_step(m, bs[i % 2], Bn, nframe, ntok, None, decoder), steps, barrier, dev, world)
+            if raft_dtype:
+                m.of_extractor.set_compute_dtype(args.raft_dtype)
+            legs[name] = {"what": note, "clips_per_gpu_per_step": Bn, "steps": steps, "value": round(Bn * steps * world / el, 3),
+                          "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 2)}
+            del bs
+            torch.cuda.empty_cache()
+        # the same path with the flow precomputed (the training-time / LightningModule contract): RAFT is the only stage left out
+        leg("precomputed_flow", 62, "precomputed", 3, "flow precomputed (the batch['of'] contract of the LightningModules): every stage but RAFT")
+        leg("clips32", 32, "raft", 3, "the headline path at 32 clips per step (one RAFT batch)")
+        leg("single_clip", 1, "raft", 5, "the headline path one clip at a time (the reference's eval loop is batch 1): ms_per_step = end-to-end "
+                                       "latency of one clip")
+        legs["single_clip"]["latency_ms_per_clip"] = legs["single_clip"]["ms_per_step"]
+        if args.raft_dtype == "bf16":
+            leg("raft_fp32_exactness", 8, "raft", 1, "the headline path with RAFT in the fp32 exactness mode (the reference's RAFT arithmetic; "
+                                                     "tests/test_gpu_selection.py: the selected frames are identical for 64/64 clips at T=96)", raft_dtype="f32")
+        legs["host_resident_inputs"] = host_resident_leg(m, rank, 32, T, nframe, args.max_new_tokens, decoder, dev, 3, barrier, world)
     if rank == 0:
         out = {"metric": "clips/sec end-to-end VideoQA (96->8 frames)", "value": round(value, 3), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
@@ -325,13 +418,15 @@ def main():
                                       f"(BASELINE.json configs[2])", "flow": args.flow if args.flow == "precomputed" else (
                               f"raft inline, all HIP ({'bf16 MFMA convolutions, fp32 state / accumulation' if args.raft_dtype == 'bf16' else 'fp32 exactness mode'}), "
                               f"{args.raft_clips} clips per RAFT batch"),
-                          "clips_per_gpu_per_step": B,
+                          "clips_per_gpu_per_step": B, "inputs": "resident in HBM when the timed region starts",
                           "global_batch": B * world, "parallelism": f"clip-parallel x{world} (no data-path collective)",
-                          "llm": f"HF LlamaForCausalLM {args.llm} geometry, random init, KV cache, decode={args.decode}",
+                          "llm": f"HF LlamaForCausalLM {args.llm} geometry, random init, KV cache, decode={args.decode}, no EOS stop (fixed work)",
                           "streams": "2 (prefix of batch i+1 over LLM decode of batch i)" if overlap else "1", "weights": "seeded N(0,0.02) random init"},
                "roofline": roofline}
-        if secondary:
-            out["precomputed_flow"] = secondary
+        if legs:
+            out["precomputed_flow"] = legs.pop("precomputed_flow", None)
+            out["latency_ms_per_clip"] = legs["single_clip"]["latency_ms_per_clip"]
+            out["companions"] = legs
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(cfg, T, nframe, sd, inline_raft=(args.flow == "raft"))
