@@ -3,6 +3,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+# (the vtgb_debug_* knobs exist only in a library built with VTGB_DEBUG_HOOKS=1 python -m videotgb_amd.build --force)
 from videotgb_amd import _lib as L, ops
 dev = torch.device("cuda:0"); lib = L.lib()
 lib.vtgb_debug_set_gemm_large_min_tiles(0); lib.vtgb_debug_set_gemm_large_variant(0)

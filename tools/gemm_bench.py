@@ -7,12 +7,15 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+# (the vtgb_debug_* knobs exist only in a library built with VTGB_DEBUG_HOOKS=1 python -m videotgb_amd.build --force)
 
 from videotgb_amd import _lib as L, ops
 
 dev = torch.device("cuda:0")
 lib = L.lib()
-lib.vtgb_debug_set_gemm_large_min_tiles.argtypes = [C.c_int]
+HOOKS = hasattr(lib, "vtgb_debug_set_gemm_large_min_tiles")
+if HOOKS:
+    lib.vtgb_debug_set_gemm_large_min_tiles.argtypes = [C.c_int]
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 M = 257 * frames
 shapes = [("qkv", M, 4224, 1408, L.EPI_STORE), ("proj", M, 1408, 1408, L.EPI_RESID_F32), ("fc1", M, 6144, 1408, L.EPI_GELU),
@@ -29,9 +32,10 @@ for name, m, n, k, epi in shapes:
         ref = torch.nn.functional.gelu(ref)
     if resid is not None:
         ref = ref + resid[:4096]
-    for variant, thr, var in (("v1", 1 << 30, 0), ("L", 0, 0)):
-        lib.vtgb_debug_set_gemm_large_min_tiles(thr)
-        lib.vtgb_debug_set_gemm_large_variant(var)
+    for variant, thr, var in ((("v1", 1 << 30, 0), ("L", 0, 0)) if HOOKS else (("L", 0, 0),)):
+        if HOOKS:
+            lib.vtgb_debug_set_gemm_large_min_tiles(thr)
+            lib.vtgb_debug_set_gemm_large_variant(var)
         out = ops.gemm(A, W, bias, epi, resid)
         err = (out[:4096].float() - ref).abs().max().item() / ref.abs().max().item()
         tail = (out[-300:].float() - ((A[-300:].float() @ W.float().t() + bias) if epi != L.EPI_GELU else torch.nn.functional.gelu(A[-300:].float() @ W.float().t() + bias)) - (resid[-300:] if resid is not None else 0)).abs().max().item()

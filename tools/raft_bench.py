@@ -3,12 +3,13 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+# (the vtgb_debug_* knobs exist only in a library built with VTGB_DEBUG_HOOKS=1 python -m videotgb_amd.build --force)
 from videotgb_amd import models, synth
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 NWN = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # > 0 forces the conv tile width (4 = 256 wide for every conv)
 from videotgb_amd import _lib
-_lib.lib().vtgb_debug_set_conv_nwn(NWN)
+if hasattr(_lib.lib(), 'vtgb_debug_set_conv_nwn'): _lib.lib().vtgb_debug_set_conv_nwn(NWN)
 r = models.Raft(os.environ.get('RAFT_DTYPE', 'bf16'))
 sd = {k[len("of_extractor."):]: v for k, v in synth.synth_state_dict(synth.raft_shapes("of_extractor."), 0).items()}
 for k in list(sd):

@@ -33,6 +33,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                "-I", os.path.join(REPO, "include"), "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        if os.environ.get("VTGB_DEBUG_HOOKS") == "1":      # experiment knobs + timing-only ablation kernels (tools/gemm_ablate.py)
+            cmd.insert(1, "-DVTGB_DEBUG_HOOKS")
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
     for src, p in procs:

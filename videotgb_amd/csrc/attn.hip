@@ -329,12 +329,8 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnDesc p) {
 template <int HD, int NKP>
 static int launch_bf16(const AttnDesc& d, hipStream_t s) {
     using C = AttnCfg<HD, NKP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel<HD, NKP>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
-        attr_set = true;
-    }
+    static DeviceOnce attr_set;
+    VTGB_FUNC_LDS_ONCE(attr_set, (attn_bf16_kernel<HD, NKP>), C::LDS);
     const int n_qt = (d.s_q + 15) / 16;
     int splits = 1;
     while ((int64_t)d.batch * d.heads * splits < 256 && splits * 2 <= n_qt && splits < 4) splits *= 2;

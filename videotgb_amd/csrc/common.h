@@ -60,6 +60,28 @@ __host__ __device__ static inline int64_t map_row(const RowMap& m, int64_t r) {
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// "once per device" flag for per-function attributes (hipFuncSetAttribute is per device): need() is true until mark() has
+// been called while that device was current.  Thread-safe: a second thread may repeat the idempotent attribute call, it can
+// never skip it before it has completed.
+#include <atomic>
+struct DeviceOnce {
+    std::atomic<uint64_t> done{0};
+    static uint64_t bit() {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        return 1ull << (dev & 63);
+    }
+    bool need() const { return !(done.load(std::memory_order_acquire) & bit()); }
+    void mark() { done.fetch_or(bit(), std::memory_order_acq_rel); }
+};
+#define VTGB_FUNC_LDS_ONCE(flag, kernel, bytes)                                                                              \
+    do {                                                                                                                     \
+        if ((flag).need()) {                                                                                                 \
+            VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+            (flag).mark();                                                                                                   \
+        }                                                                                                                    \
+    } while (0)
 static inline size_t dtype_size(int dtype) { return dtype == VTGB_BF16 ? 2 : 4; }
 
 // bump allocator over the caller's workspace

@@ -186,6 +186,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmDesc p) {
     }
 }
 
+// tanh for the GRU candidate (bf16 mode): 1 - 2 / (exp(2x) + 1) with the hardware exp / rcp (~1e-6 relative, far below
+// the bf16 rounding of the inputs) instead of libm tanhf's ~90 instructions per element, which made the GRU epilogue a
+// VALU-bound tail as long as a third of the k-loop.  The exactness mode (conv_f32.hip) keeps tanhf.
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float e = __expf(2.0f * x);                 // inf for large x -> 1 - 0 = 1; 0 for very negative x -> -1
+    return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
     if (act == 2) return 1.0f / (1.0f + __expf(-v));
@@ -244,7 +252,7 @@ __device__ __forceinline__ void store4(const GemmDesc& p, int m, int n0, f32x4 v
 #pragma unroll
         for (int i = 0; i < 4; i++)
             if (n0 + i < p.N) {
-                const float z = (float)zp[i], h = hp[i], q = tanhf(v[i]);
+                const float z = (float)zp[i], h = hp[i], q = tanh_fast(v[i]);
                 const float hn = (1.0f - z) * h + z * q;
                 o[i] = hn;
                 o2[i] = (bf16_t)hn;
@@ -310,6 +318,7 @@ constexpr int L_LDS = (L_A_SLOTS + L_W_SLOTS) * L_OP_BYTES;   // 160 KiB
 // debug: shader-clock cycles and 100 MHz reference ticks spent inside the large kernel (summed over
 // workgroups), so that tools/gemm_ablate.py can report the clock the chip actually holds under each variant
 __device__ unsigned long long g_clk[2];
+#ifdef VTGB_DEBUG_HOOKS
 extern "C" void vtgb_debug_read_clk(unsigned long long* out, int reset) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(g_clk));
     if (reset) {
@@ -317,6 +326,7 @@ extern "C" void vtgb_debug_read_clk(unsigned long long* out, int reset) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, sizeof(z));
     }
 }
+#endif
 struct ClkScope {
     unsigned long long c0, r0;
     bool on;
@@ -331,10 +341,14 @@ struct ClkScope {
     }
 };
 
-template <int EPI, int ABL = 0, bool CONV = false, int NWN = 4>
+// NXF (activation fragments per wave, default 2 NWN): NWN = 2 with NXF = 8 is a 512 x 128 tile -- waves 4(M) x 2(N) of
+// 128 x 64, the SAME wave tile (and LDS-read : MFMA ratio, 12 fragment reads per 32 MFMAs) as the 256 x 256 tile, for
+// 128-channel outputs with many rows (RAFT's GRU q convolution, the 126-channel motion-encoder output, the stage 2 / 3
+// encoder convolutions); its activation slot is 64 KiB, so the ring is 2 activation + 2 weight slots = 160 KiB.
+template <int EPI, int ABL = 0, bool CONV = false, int NWN = 4, int NXF = 2 * NWN>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G) {
     ClkScope clk(ABL != 0);
-    constexpr int NX = 2 * NWN;          // activation fragments per wave: wave tile = (16 NX) x 64
+    constexpr int NX = NXF;              // activation fragments per wave: wave tile = (16 NX) x 64
     constexpr int WROWS = 16 * NX;       // rows of the wave tile
     constexpr int MW = 8 / NWN;          // waves along M
     constexpr int T_BN = 64 * NWN;       // tile width
@@ -344,8 +358,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     // activation ring: 3 slots; 2 for the 64-wide tile, whose 80 KiB then let TWO workgroups share a CU (these tiles
     // have few k-tiles -- K = 576 for RAFT's 64-channel 3x3 convolutions -- so prologue and epilogue are a third of
     // a tile's life and overlap with the other workgroup's k-loop instead of idling the CU)
-    constexpr int A_SLOTS = NWN == 1 ? 2 : 3;
-    char* const smem_w = smem + A_SLOTS * L_OP_BYTES;
+    constexpr int T_BM = MW * WROWS;     // tile height: 256, or 512 (NWN = 2, NXF = 8)
+    constexpr int A_OP = T_BM * 128;     // bytes per activation slot
+    constexpr int AI = T_BM / 64;        // activation DMA instructions per wave and k-tile (8 rows each)
+    constexpr int A_SLOTS = (NWN == 1 || T_BM > 256) ? 2 : 3;
+    char* const smem_w = smem + A_SLOTS * A_OP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- XCD-aware tile assignment
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     if (CONV && ml >= ((m_tiles + 7) >> 3)) return;
     const int mt = CONV ? xcd * ((m_tiles + 7) >> 3) + ml : ml * 8 + xcd;
     if (mt >= m_tiles) return;
-    const int m0 = mt * L_BM, n0 = nt * T_BN;
+    const int m0 = mt * T_BM, n0 = nt * T_BN;
     const int wm = wave % MW, wn = wave / MW;
     // a wave whose 128 x 64 sub-tile lies wholly outside the matrix (N = 1408 is 5.5 tiles wide) still
     // stages its share of the operands and joins every barrier, but issues no LDS reads and no MFMAs:
@@ -369,9 +386,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
 
     // ---- LDS-DMA assignment: wave w stages rows [32w, 32w+32) of both operands, 4 instructions of
     // 8 rows each; lane l of an instruction fills slot (l & 7) of row r0 + (l >> 3)
-    const bf16_t* a_src[4];
+    const bf16_t* a_src[AI];
     const bf16_t* w_src[WI];
-    int a_row[4], a_yx[4];   // CONV: pixel index of the staged row and its (y << 16 | x)
+    int a_row[AI], a_yx[AI];   // CONV: pixel index of the staged row and its (y << 16 | x)
 #pragma unroll
     for (int i = 0; i < WI; i++) {
         const int row = wave * (8 * WI) + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
@@ -379,8 +396,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         w_src[i] = W + (int64_t)wr * p.ldw + c * 8;
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int row = wave * 32 + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
+    for (int i = 0; i < AI; i++) {
+        const int row = wave * (8 * AI) + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
         const int am = (m0 + row) < p.M ? (m0 + row) : p.M - 1;
         if constexpr (CONV) {
             const int hw = p.conv_H * p.conv_W, img = am / hw, rem = am - img * hw;
@@ -407,19 +424,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         const bf16_t* base = first ? A : reinterpret_cast<const bf16_t*>(p.A2);                         \
         const int64_t ld = first ? p.lda : p.lda2;                                                      \
         const int cc = first ? cv_c0 : cv_c0 - p.conv_split;                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                 \
+        _Pragma("unroll") for (int i = 0; i < AI; i++) {                                                \
             const int c8 = ((lane & 7) ^ ((i * 4 + (lane >> 4)) & 7)) * 8;                              \
             const int y = (a_yx[i] >> 16) * cst + dy, x = (a_yx[i] & 0xffff) * cst + dx;                \
             const bool ok = (unsigned)y < (unsigned)Hi && (unsigned)x < (unsigned)Wi;                   \
             const bf16_t* src = ok ? base + (int64_t)(a_row[i] + y * Wi + x) * ld + cc + c8             \
                                    : reinterpret_cast<const bf16_t*>(p.zero_page) + c8;                 \
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (slot) * L_OP_BYTES + (wave * 32 + i * 8) * 128), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (slot) * A_OP + (wave * (8 * AI) + i * 8) * 128), 16, 0, 0); \
         }                                                                                               \
         cv_tap++;                                                                                       \
         if (cv_tap == p.conv_KH * p.conv_KW) { cv_tap = 0; cv_c0 += L_BK; }                             \
     } else {                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; i++)                                                   \
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + (k0)), (lptr_t)(smem + (slot) * L_OP_BYTES + (wave * 32 + i * 8) * 128), 16, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < AI; i++)                                                  \
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + (k0)), (lptr_t)(smem + (slot) * A_OP + (wave * (8 * AI) + i * 8) * 128), 16, 0, 0); \
     }
 #define L_ISSUE_W(slot, k0)                                                                             \
     _Pragma("unroll") for (int i = 0; i < WI; i++)                                                      \
@@ -441,8 +458,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         L_ISSUE_W(1, L_BK)
     }
     if (A_SLOTS == 3 && nk > 2) L_ISSUE_A(2, 2 * L_BK)
-    if (A_SLOTS == 3 && nk > 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (8 + WI));        // vmcnt(8 + WI): A(0), W(0) landed
-    else if (nk >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (4 + WI));                  // vmcnt(4 + WI)
+    if (A_SLOTS == 3 && nk > 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * AI + WI));   // vmcnt(2 AI + WI): A(0), W(0) landed
+    else if (nk >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (AI + WI));                 // vmcnt(AI + WI)
     else __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
     __builtin_amdgcn_s_barrier();
 
@@ -493,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     L_READ(wf0, xf0, smem, smem_w, 0)
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): see the note at the bottom of the loop
     for (int kt = 0; kt + 1 < nk; kt++) {     // every iteration has a successor tile (no join before the MFMAs)
-        const char* as = smem + a_slot * L_OP_BYTES;
+        const char* as = smem + a_slot * A_OP;
         const char* ws = smem_w + (kt & 1) * W_OP;
         const int a_nxt = a_slot == A_SLOTS - 1 ? 0 : a_slot + 1;
         L_READ(wf1, xf1, as, ws, 1)
@@ -507,7 +524,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
             if (kt + 2 < nk) { L_ISSUE_W(kt & 1, (kt + 2) * L_BK) }
             if (kt + A_SLOTS < nk) { L_ISSUE_A(a_slot, (kt + A_SLOTS) * L_BK) }
         }
-        L_READ(wf0, xf0, smem + a_nxt * L_OP_BYTES, smem_w + ((kt + 1) & 1) * W_OP, 0)
+        L_READ(wf0, xf0, smem + a_nxt * A_OP, smem_w + ((kt + 1) & 1) * W_OP, 0)
         L_MFMA(wf1, xf1)
         // The half-0 fragments of the next tile were requested 32 MFMAs ago: this wait is free, and it
         // lets hipcc's waitcnt pass see (at the loop-header join) that set 0 is complete, so it does not
@@ -516,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         a_slot = a_nxt;
     }
     {   // last k-tile
-        const char* as = smem + a_slot * L_OP_BYTES;
+        const char* as = smem + a_slot * A_OP;
         const char* ws = smem_w + ((nk - 1) & 1) * W_OP;
         L_READ(wf1, xf1, as, ws, 1)
         L_MFMA(wf0, xf0)
@@ -563,22 +580,42 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                     *reinterpret_cast<bf16x4*>(cst + row * 128 + c16 * 16 + (fg & 1) * 8) = pk;
                 }
             bf16_t* const outp = reinterpret_cast<bf16_t*>(p.out);
+            // operands of the fused elementwise tails (r * h gate, ResidualBlock skip): all rows' loads in flight before the
+            // first store, not one HBM round trip per row
+            const bool gated = EPI == EPI_STORE && p.gate_from > 0, resd = EPI == EPI_STORE && !gated && p.resid_bf16 != nullptr;
+            const int ch0 = lane & 7, nn = n0 + wn * 64 + ch0 * 8;
+            bf16x8 opnd[WROWS / 8];
+            if (gated || resd) {
+#pragma unroll
+                for (int rr = 0; rr < WROWS / 8; rr++) {
+                    const int m = m0 + wm * WROWS + rr * 8 + (lane >> 3);
+                    opnd[rr] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (m < p.M && nn < p.N) {
+                        if (gated) {
+                            if (nn >= p.gate_from)
+                                opnd[rr] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)m * p.ldaux + (nn - p.gate_from));
+                        } else {
+                            opnd[rr] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.resid_bf16) + (int64_t)m * p.ldrb + nn);
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int rr = 0; rr < WROWS / 8; rr++) {
                 const int row = rr * 8 + (lane >> 3), ch = lane & 7;
                 const uint4 v = *reinterpret_cast<const uint4*>(cst + row * 128 + ((ch ^ (row & 7)) << 4));
                 const int m = m0 + wm * WROWS + row, n = n0 + wn * 64 + ch * 8;
                 if (m < p.M && n < p.N) {
-                    if (EPI == EPI_STORE && p.gate_from > 0 && n >= p.gate_from) {
+                    if (gated && n >= p.gate_from) {
                         const int ng = n - p.gate_from;
-                        const bf16x8 g = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)m * p.ldaux + ng);
+                        const bf16x8 g = opnd[rr];
                         const bf16x8 a = __builtin_bit_cast(bf16x8, v);
                         bf16x8 o;
 #pragma unroll
                         for (int e = 0; e < 8; e++) o[e] = (bf16_t)((float)a[e] * (float)g[e]);
                         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.out2) + (int64_t)m * p.ldo2 + ng) = o;
-                    } else if (EPI == EPI_STORE && p.resid_bf16) {
-                        const bf16x8 r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.resid_bf16) + (int64_t)m * p.ldrb + n);
+                    } else if (resd) {
+                        const bf16x8 r = opnd[rr];
                         const bf16x8 a = __builtin_bit_cast(bf16x8, v);
                         bf16x8 o;
 #pragma unroll
@@ -669,7 +706,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                             float* st = p.col_stats + ((int64_t)img_a * p.N + n) * 2;
                             unsafeAtomicAdd(st, t[0]);
                             unsafeAtomicAdd(st + 1, t[1]);
-                            if (m0 + L_BM > m_b && m_b < p.M) {
+                            if (m0 + T_BM > m_b && m_b < p.M) {
                                 unsafeAtomicAdd(st + 2 * p.N, t[2]);
                                 unsafeAtomicAdd(st + 2 * p.N + 1, t[3]);
                             }
@@ -683,14 +720,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     if constexpr (EPI == EPI_GRU) {
         if (gru_staged(p)) {
             // h' = (1 - z) h + z tanh(acc): the accumulators go through LDS as in the fp32 path so that h, z
-            // and both outputs are touched as whole row segments (16 B of fp32 / 8 B of bf16 per lane)
+            // and both outputs are touched as whole row segments (16 B of fp32 / 8 B of bf16 per lane).
+            // ALL of a pass's h / z loads are issued before the pass's LDS transpose and its first store (16 rows x 24 B per
+            // lane in flight): interleaved load -> tanh -> store made every row wait out a full HBM round trip plus the
+            // previous row's store acknowledgement (vmcnt counts stores), a serial chain as long as half the k-loop.
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();
             constexpr int PR = WROWS < 64 ? WROWS : 64;
             char* const cst = smem + wave * (PR * 256);
             const int rl = lane >> 4, cl = lane & 15;
+            const int n = n0 + wn * 64 + cl * 4;
+            const bool ncol = n < p.N;
 #pragma unroll
             for (int half = 0; half < WROWS / PR; half++) {
+                f32x4 hreg[PR / 4];
+                bf16x4 zreg[PR / 4];
+#pragma unroll
+                for (int rr = 0; rr < PR / 4; rr++) {
+                    const int m = m0 + wm * WROWS + half * PR + rr * 4 + rl;
+                    hreg[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    zreg[rr] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                    if (m < p.M && ncol) {
+                        hreg[rr] = *reinterpret_cast<const f32x4*>(p.resid + map_row(p.r_map, m) * p.ldr + n);
+                        zreg[rr] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)m * p.ldaux + n);
+                    }
+                }
 #pragma unroll
                 for (int jj = 0; jj < PR / 16; jj++)
 #pragma unroll
@@ -702,15 +756,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                 for (int rr = 0; rr < PR / 4; rr++) {
                     const int row = rr * 4 + rl;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(cst + row * 256 + ((cl ^ (row & 15)) << 4));
-                    const int m = m0 + wm * WROWS + half * PR + row, n = n0 + wn * 64 + cl * 4;
-                    if (m < p.M && n < p.N) {
-                        const f32x4 h = *reinterpret_cast<const f32x4*>(p.resid + map_row(p.r_map, m) * p.ldr + n);
-                        const bf16x4 zb = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)m * p.ldaux + n);
+                    const int m = m0 + wm * WROWS + half * PR + row;
+                    if (m < p.M && ncol) {
                         f32x4 hn;
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
-                            const float z = (float)zb[e];
-                            hn[e] = (1.0f - z) * h[e] + z * tanhf(v[e]);
+                            const float z = (float)zreg[rr][e];
+                            hn[e] = (1.0f - z) * hreg[rr][e] + z * tanh_fast(v[e]);
                         }
                         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + map_row(p.o_map, m) * p.ldo + n) = hn;
                         const bf16x4 pk = {(bf16_t)hn[0], (bf16_t)hn[1], (bf16_t)hn[2], (bf16_t)hn[3]};
@@ -780,12 +832,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc p) {
 }
 
 // tile-count threshold above which the 256x256 LDS-DMA kernel is used (tunable for experiments)
+// Experiment knobs.  The setters (and the timing-only ablation instantiations, whose results are WRONG by construction) exist
+// only in builds with -DVTGB_DEBUG_HOOKS (VTGB_DEBUG_HOOKS=1 python -m videotgb_amd.build; tools/gemm_ablate.py): the
+// production library exports none of them.
 static int g_large_min_tiles = 200;
 static int g_large_variant = 0;   // > 0 forces the m-tiles per XCD super-tile (G); 0 = heuristic
+static int g_ablate = 0;          // 1 no DMA, 2 one LDS stage, 4 no LDS reads, 8 no barrier (timing only)
+#ifdef VTGB_DEBUG_HOOKS
 extern "C" void vtgb_debug_set_gemm_large_min_tiles(int v) { g_large_min_tiles = v; }
 extern "C" void vtgb_debug_set_gemm_large_variant(int v) { g_large_variant = v; }
-static int g_ablate = 0;   // timing-only experiments (compile-time variants) (results are wrong when non-zero): 1 no DMA, 2 one LDS stage, 4 no LDS reads, 8 no barrier
 extern "C" void vtgb_debug_set_gemm_ablate(int v) { g_ablate = v; }
+#endif
 
 template <int EPI>
 static int launch_epi(const GemmDesc& d, hipStream_t s) {
@@ -797,6 +854,7 @@ static int launch_epi(const GemmDesc& d, hipStream_t s) {
             const int mx = (m_tiles + 7) / 8, groups = (mx + G - 1) / G;
             const dim3 grid(8 * groups * G * n_tiles);
             ProfScope prof(VTGB_PROF_GEMM, 2.0 * d.M * d.N * d.K, s);
+#ifdef VTGB_DEBUG_HOOKS
             if (g_ablate && (EPI == EPI_STORE || EPI == EPI_RESID_F32)) {
 #define ABL_CASE(v)                                                                                              \
     case v:                                                                                                       \
@@ -806,13 +864,11 @@ static int launch_epi(const GemmDesc& d, hipStream_t s) {
         break;
                 switch (g_ablate) { ABL_CASE(1) ABL_CASE(8) ABL_CASE(16) ABL_CASE(17) ABL_CASE(25) ABL_CASE(32) default: break; }
 #undef ABL_CASE
-            } else {
-                static bool attr0 = false;
-                if (!attr0) {
-                    VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_large_kernel<EPI, 0>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS));
-                    attr0 = true;
-                }
+            } else
+#endif
+            {
+                static DeviceOnce attr0;
+                VTGB_FUNC_LDS_ONCE(attr0, (gemm_bf16_large_kernel<EPI, 0>), L_LDS);
                 hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, 0>), grid, dim3(512), L_LDS, s, d, m_tiles, n_tiles, G);
             }
             VTGB_HIP(hipGetLastError());
@@ -820,12 +876,8 @@ static int launch_epi(const GemmDesc& d, hipStream_t s) {
         }
         dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM);
         const size_t lds = 4 * TILE_BYTES;
-        static bool attr_set = false;
-        if (!attr_set) {
-            VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        static DeviceOnce attr_set;
+        VTGB_FUNC_LDS_ONCE(attr_set, gemm_bf16_kernel<EPI>, lds);
         ProfScope prof(VTGB_PROF_GEMM, 2.0 * d.M * d.N * d.K, s);
         hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(256), lds, s, d);
     } else {
@@ -838,32 +890,40 @@ static int launch_epi(const GemmDesc& d, hipStream_t s) {
 
 // Implicit-GEMM convolution (and plain GEMMs that need the activation / GRU epilogues) on the large
 // kernel.  d.conv_KH == 0: plain GEMM through the same kernel (RAFT's 1x1 convolutions).
-template <int EPI, bool CONV, int NWN>
+template <int EPI, bool CONV, int NWN, int NXF = 2 * NWN>
 static int launch_large_nwn(const GemmDesc& d, hipStream_t s) {
-    constexpr int T_BN = 64 * NWN, LDS = (NWN == 1 ? 2 : 3) * L_OP_BYTES + L_W_SLOTS * T_BN * 128;
-    const int m_tiles = (d.M + L_BM - 1) / L_BM, n_tiles = (d.N + T_BN - 1) / T_BN;
+    constexpr int T_BM = (8 / NWN) * 16 * NXF, T_BN = 64 * NWN;
+    constexpr int LDS = ((NWN == 1 || T_BM > 256) ? 2 : 3) * T_BM * 128 + L_W_SLOTS * T_BN * 128;
+    const int m_tiles = (d.M + T_BM - 1) / T_BM, n_tiles = (d.N + T_BN - 1) / T_BN;
     const int G = n_tiles <= 8 ? 2 : 8;
     const int mx = (m_tiles + 7) / 8, groups = (mx + G - 1) / G;
-    static bool attr = false;
-    if (!attr) {
-        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_large_kernel<EPI, 0, CONV, NWN>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
-    }
+    static DeviceOnce attr;
+    VTGB_FUNC_LDS_ONCE(attr, (gemm_bf16_large_kernel<EPI, 0, CONV, NWN, NXF>), LDS);
     ProfScope prof(CONV ? VTGB_PROF_CONV : VTGB_PROF_GEMM, 2.0 * d.M * d.N * d.K, s);
-    hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, 0, CONV, NWN>), dim3(8 * groups * G * n_tiles), dim3(512), LDS, s, d, m_tiles, n_tiles, G);
+    hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, 0, CONV, NWN, NXF>), dim3(8 * groups * G * n_tiles), dim3(512), LDS, s, d, m_tiles, n_tiles, G);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }
 
-static int g_conv_nwn = 0;   // > 0 forces the tile width (experiments); 0 = by output width
+static int g_conv_nwn = 0;   // > 0 forces the tile (experiments: 1, 2, 4 = waves along N; 5 = the 512 x 128 tile for 128-wide outputs); 0 = by shape
+#ifdef VTGB_DEBUG_HOOKS
 extern "C" void vtgb_debug_set_conv_nwn(int v) { g_conv_nwn = v; }
+#endif
 
 template <int EPI, bool CONV>
 static int launch_large_forced(const GemmDesc& d, hipStream_t s) {
-    const int nwn = g_conv_nwn > 0 ? g_conv_nwn : (d.N <= 64 ? 1 : d.N <= 128 ? 2 : 4);
+    const int nwn = (g_conv_nwn > 0 && g_conv_nwn != 5) ? g_conv_nwn : (d.N <= 64 ? 1 : d.N <= 128 ? 2 : 4);
     if (nwn == 1) return launch_large_nwn<EPI, CONV, 1>(d, s);
-    if (nwn == 2) return launch_large_nwn<EPI, CONV, 2>(d, s);
+    if (nwn == 2) {
+        // The 512 x 128 tile (same wave tile as 256 x 256) measured NO faster than 256 x 128 on RAFT's 128-channel
+        // convolutions (GRU q: 1.69 vs 1.71 ms before the epilogue change, 1.76 vs 1.61 ms after it; round 2): every tile
+        // shape sits at the same ~30 GB/s per CU of operand fill, which is what bounds them, not the fragment-read ratio.
+        // It stays selectable for experiments only.
+#ifdef VTGB_DEBUG_HOOKS
+        if (g_conv_nwn == 5 && d.M >= 512 * 1024 && (!d.col_stats || d.stats_rows >= 512)) return launch_large_nwn<EPI, CONV, 2, 8>(d, s);
+#endif
+        return launch_large_nwn<EPI, CONV, 2>(d, s);
+    }
     return launch_large_nwn<EPI, CONV, 4>(d, s);
 }
 
