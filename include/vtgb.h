@@ -336,8 +336,14 @@ int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream);
  *   [14] gru.convz2|convr2.weight [256, 5,1,384] [15] bias [256]  [16] gru.convq2.weight [128, 5,1,384] [17] .bias
  *   [18] flow_head.conv1.weight [256, 3,3,128] [19] .bias  [20] flow_head.conv2.weight [32, 256], row tap*2+o (18 rows zero-padded) [21] .bias
  *   [22] mask.0.weight [256, 3,3,128] [23] .bias           [24] mask.2.weight [576, 256] [25] .bias
+ *   [26..29] optional, VTGB_BF16 only (all four or none; NULL = the plain form above): the `inp` split of the GRU
+ *       convolutions.  `inp` (input channels 128..255) does not change over the refinement iterations, so its contribution
+ *       is computed once per call and the 80 GRU launches contract over the other 256 channels only.  With the split,
+ *       [10] / [12] / [14] / [16] hold the [h(128) | motion(126) | flow(2)] channels: [256 or 128, taps, 256], and
+ *       [26] gru.convz1|convr1 inp part [256, 1,5,128]   [27] gru.convq1 inp part [128, 1,5,128]
+ *       [28] gru.convz2|convr2 inp part [256, 5,1,128]   [29] gru.convq2 inp part [128, 5,1,128]
  * Biases fp32.  GRU input channels are [h(128) | inp(128) | motion(126) | flow(2)] as in the reference. */
-#define VTGB_RAFT_NW 26
+#define VTGB_RAFT_NW 30
 typedef struct {
     int32_t dtype, n_pairs, H8, W8, iters;
     const float* net;           /* [n_pairs, 128, H8, W8] tanh(cnet[:, :128])   (xraft.py:126-127) */

@@ -147,6 +147,11 @@ struct GemmDesc {
     const void* resid_bf16;
     int64_t ldrb;
     int post_relu;
+    // bf16 large kernel: the accumulators start at init_bf16[m][n] (bf16, row stride ldinit, 4-aligned) in addition to the
+    // bias -- a per-(row, column) constant folded out of the k-loop (RAFT: the loop-invariant `inp` third of the GRU
+    // convolutions, computed once per pair instead of once per refinement iteration)
+    const void* init_bf16;
+    int64_t ldinit;
 };
 #define VTGB_EPI_GRU 4
 int launch_gemm(const GemmDesc& d, hipStream_t s);

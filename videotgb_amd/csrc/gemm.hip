@@ -228,6 +228,10 @@ __device__ __forceinline__ f32x4 acc_init4(const GemmDesc& p, int m, int n0) {
             for (int i = 0; i < 4; i++) if (n0 + i < p.N) v[i] += r[i];
         }
     }
+    if (p.init_bf16 && full) {   // (launch_conv_gemm requires N % 4 == 0 and ldinit % 4 == 0 with init_bf16)
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.init_bf16) + (int64_t)m * p.ldinit + n0);
+        v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3];
+    }
     return v;
 }
 
@@ -946,6 +950,8 @@ int launch_conv_gemm(const GemmDesc& d, hipStream_t s) {
     if (d.resid_bf16)
         VTGB_REQUIRE(d.epi == EPI_STORE && d.gate_from == 0 && (d.N % 8) == 0 && (d.ldo % 8) == 0 && (d.ldrb % 8) == 0, VTGB_EINVAL,
                      "conv gemm: bf16 residual needs 8-aligned bf16 rows");
+    if (d.init_bf16)
+        VTGB_REQUIRE(d.dtype == VTGB_BF16 && (d.N % 4) == 0 && (d.ldinit % 4) == 0, VTGB_EINVAL, "conv gemm: accumulator start map needs 4-aligned bf16 rows");
     if (d.col_stats)
         VTGB_REQUIRE(d.epi == EPI_STORE_F32 && d.stats_rows >= L_BM && (d.N % 4) == 0 && (d.ldo % 4) == 0 && d.act == 0 && d.out_scale == 0.f,
                      VTGB_EINVAL, "conv gemm: column statistics need fp32 whole-row stores and images of >= 256 rows");

@@ -443,12 +443,16 @@ def conv_k_order(w: Tensor) -> Tensor:
 class RaftWeights(_WeightTable):
     """of_extractor.update_block.* -> the packed table of vtgb_raft_update ([C_out, KH, KW, C_in] in the compute dtype)."""
 
-    def __init__(self, sd: Dict[str, Tensor], prefix: str = "update_block.", code: int = BF16):
+    def __init__(self, sd: Dict[str, Tensor], prefix: str = "update_block.", code: int = BF16, hoist_inp: Optional[bool] = None):
         super().__init__(code)
         p = prefix
+        # bf16 mode: split the loop-invariant `inp` channels (128..255) out of the GRU convolutions (include/vtgb.h [26..29])
+        self.hoist_inp = (code == BF16) if hoist_inp is None else (hoist_inp and code == BF16)
 
-        def conv(name, cin_pad=None):
+        def conv(name, cin_pad=None, channels=None):
             w = sd[p + name + ".weight"].float()
+            if channels is not None:
+                w = w[:, channels]
             co, ci, kh, kw = w.shape
             w = w.permute(0, 2, 3, 1)                       # [co, kh, kw, ci]
             if cin_pad and cin_pad != ci:
@@ -472,10 +476,12 @@ class RaftWeights(_WeightTable):
         self.add(sd[p + "encoder.convf1.bias"])
         add_conv("encoder.convf2")
         add_conv("encoder.conv")
+        dyn = (list(range(0, 128)) + list(range(256, 384))) if self.hoist_inp else None     # [h | motion + flow]
         for sfx in ("1", "2"):
-            self.add(torch.cat([conv("gru.convz" + sfx), conv("gru.convr" + sfx)], 0), True)
+            self.add(torch.cat([conv("gru.convz" + sfx, channels=dyn), conv("gru.convr" + sfx, channels=dyn)], 0), True)
             self.add(torch.cat([sd[p + "gru.convz" + sfx + ".bias"], sd[p + "gru.convr" + sfx + ".bias"]], 0))
-            add_conv("gru.convq" + sfx)
+            self.add(conv("gru.convq" + sfx, channels=dyn), True)
+            self.add(sd[p + "gru.convq" + sfx + ".bias"])
         add_conv("flow_head.conv1")
         # flow_head.conv2 as a GEMM with the taps on the output side: row tap*2 + o = w[o, :, ky, kx]; 18 rows padded to 32
         w2 = sd[p + "flow_head.conv2.weight"].float().permute(2, 3, 0, 1).reshape(18, 256)
@@ -483,6 +489,13 @@ class RaftWeights(_WeightTable):
         self.add(sd[p + "flow_head.conv2.bias"])
         add_conv("mask.0")
         add_conv("mask.2")
+        inp = list(range(128, 256))
+        for sfx in ("1", "2"):
+            if self.hoist_inp:
+                self.add(torch.cat([conv("gru.convz" + sfx, channels=inp), conv("gru.convr" + sfx, channels=inp)], 0), True)
+                self.add(conv("gru.convq" + sfx, channels=inp), True)
+            else:
+                self.add(None); self.add(None)
         self.finish()
 
 
