@@ -146,8 +146,8 @@ class QFormer(_Stage):
         text_mask = None
         if input_ids is not None and attention_mask is not None:
             text_mask = attention_mask[:, nq:]
-        if isinstance(encoder_attention_mask, Tensor) and bool((encoder_attention_mask != 0).all()):
-            encoder_attention_mask = None      # all-ones: nothing to mask (every caller on the path)
+        # (a given encoder_attention_mask goes to the kernel as is -- no host-side "is it all ones" read; the path's own
+        # callers pass None for the all-ones case)
         q = ops.qformer_forward(self.table(), query_embeds[0], encoder_hidden_states, input_ids, text_mask,
                                 encoder_attention_mask)
         return ModelOutput(q, q[:, 0])

@@ -44,16 +44,18 @@ def act_dtype(code: int) -> torch.dtype:
 
 
 class _Workspace:
-    """Per-device scratch buffer handed to the library (grown on demand, never shrunk)."""
+    """Scratch buffer handed to the library, one per (device, stream) -- calls on different streams never share scratch, so
+    the wrappers are as re-entrant across streams as the C ABI underneath (grown on demand, never shrunk)."""
 
     def __init__(self):
-        self.bufs: Dict[int, Tensor] = {}
+        self.bufs: Dict[Tuple[int, int], Tensor] = {}
 
     def get(self, nbytes: int, device) -> Tensor:
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        b = self.bufs.get(idx)
+        key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+        b = self.bufs.get(key)
         if b is None or b.numel() < nbytes:
-            self.bufs[idx] = b = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            self.bufs[key] = b = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         return b
 
 
