@@ -89,6 +89,8 @@ def parse():
     ap.add_argument("--no-prof", action="store_true", help="skip the (untimed) roofline pass that records per-launch HIP events")
     ap.add_argument("--prof-steps", type=int, default=2, help="steps of the untimed roofline pass")
     ap.add_argument("--stage-times", action="store_true", help="print a per-stage breakdown to stderr")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl = RCCL) even with one rank: exercises the "
+                                                              "barrier / MAX-over-ranks path of the multi-GPU launch on a 1-GPU box")
     return ap.parse_args()
 
 
@@ -230,7 +232,7 @@ def timed_steps(fn, steps, barrier, dev, world):
         fn(i)
     barrier()
     t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -285,9 +287,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the hot path has no CPU implementation)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -312,7 +316,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -431,7 +435,7 @@ def main():
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(cfg, T, nframe, sd, inline_raft=(args.flow == "raft"))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
