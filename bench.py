@@ -361,9 +361,16 @@ def main():
             if not n or ms <= 0:
                 return None
             ach = fl / (ms * 1e-3) / 1e12
-            return {"kernel": name, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                    "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "ms_per_step": round(ms / args.prof_steps, 3),
-                    "gflop_per_step": round(fl / args.prof_steps / 1e9, 1)}
+            out = {"kernel": name, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                   "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "ms_per_step": round(ms / args.prof_steps, 3),
+                   "gflop_per_step": round(fl / args.prof_steps / 1e9, 1)}
+            ex = _lib.prof_executed_flops(kind)
+            if abs(ex - fl) > 1e-6 * fl:   # loop-invariant work hoisted out of the launches: algorithmic (the reference's form) vs executed
+                out["executed_tflops"] = round(ex / (ms * 1e-3) / 1e12, 2)
+                out["flops_note"] = ("achieved = ALGORITHMIC FLOPs (the convolutions as the reference computes them: 118.56 GFLOP per frame pair) / launch "
+                                     "time; executed_tflops counts only what the launches execute (the GRU convolutions' loop-invariant `inp` third is "
+                                     "computed once per pair, not once per iteration)")
+            return out
         gemm = fam(0, "gemm_bf16_large_kernel<EPI,0,false> / gemm_bf16_kernel: plain bf16 MFMA GEMMs (ViT-g, Q-Former, TGB, projection)")
         conv = fam(2, "gemm_bf16_large_kernel<EPI,0,true>: the same MFMA kernel as implicit-GEMM convolution (RAFT encoders + update block)")
         attn = fam(1, "attn_bf16_kernel")

@@ -425,14 +425,17 @@ int vtgb_llm_silu_mul(int dtype, const void* gu, void* act, int64_t rows, int32_
  * While enabled, every GEMM / attention launch of the bf16 path is bracketed by a pair of HIP
  * events recorded on the launch stream (no synchronisation at record time).  vtgb_prof_summary
  * synchronises on the recorded events and returns launch count, summed kernel time and summed
- * algorithmic FLOPs (2*M*N*K per GEMM, 4*B*H*Sq*Skv*hd per attention) of one kind since the
- * last vtgb_prof_reset. */
+ * algorithmic FLOPs (2*M*N*K per GEMM / convolution of the reference's form, 4*B*H*Sq*Skv*hd per attention) of one kind
+ * since the last vtgb_prof_reset. */
 #define VTGB_PROF_GEMM 0   /* plain GEMM launches (ViT / Q-Former / TGB / projections)             */
 #define VTGB_PROF_ATTN 1
 #define VTGB_PROF_CONV 2   /* implicit-GEMM convolution launches of the same kernel (RAFT)          */
 void vtgb_prof_enable(int on);
 void vtgb_prof_reset(void);
 int vtgb_prof_summary(int kind, int64_t* launches, double* ms, double* flops);
+/* FLOPs the recorded launches of `kind` actually EXECUTED: smaller than the algorithmic figure of vtgb_prof_summary where
+ * loop-invariant work has been hoisted out of a launch (RAFT's GRU convolutions: the `inp` third, see vtgb_raft_update). */
+int vtgb_prof_executed_flops(int kind, double* flops);
 
 #ifdef __cplusplus
 }

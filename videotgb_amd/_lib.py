@@ -25,7 +25,7 @@ EXPORTS = [
     "vtgb_gather_frames", "vtgb_vit_patch_kpad", "vtgb_vit_workspace_bytes", "vtgb_vit_forward",
     "vtgb_qformer_workspace_bytes", "vtgb_qformer_forward", "vtgb_pool_project_workspace_bytes",
     "vtgb_pool_project", "vtgb_tgb_workspace_bytes", "vtgb_tgb_forward", "vtgb_gemm", "vtgb_attention",
-    "vtgb_layernorm", "vtgb_prof_enable", "vtgb_prof_reset", "vtgb_prof_summary",
+    "vtgb_layernorm", "vtgb_prof_enable", "vtgb_prof_reset", "vtgb_prof_summary", "vtgb_prof_executed_flops",
     "vtgb_llm_rmsnorm", "vtgb_llm_rope_cache", "vtgb_llm_decode_attention", "vtgb_llm_silu_mul",
     "vtgb_raft_update_workspace_bytes", "vtgb_raft_update", "vtgb_raft_encoder_workspace_bytes", "vtgb_raft_encoder",
     "vtgb_raft_corr_workspace_bytes", "vtgb_raft_corr", "vtgb_preprocess_frames", "vtgb_concat_text_io", "vtgb_shifted_ce_forward", "vtgb_shifted_ce_backward",
@@ -177,6 +177,8 @@ def lib() -> C.CDLL:
     L.vtgb_prof_reset.restype = None
     L.vtgb_prof_summary.argtypes = [C.c_int, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.vtgb_prof_summary.restype = C.c_int
+    L.vtgb_prof_executed_flops.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    L.vtgb_prof_executed_flops.restype = C.c_int
     _lib = L
     return L
 
@@ -186,6 +188,12 @@ def prof_summary(kind: int):
     n, ms, fl = i64(0), C.c_double(0), C.c_double(0)
     check(lib().vtgb_prof_summary(kind, C.byref(n), C.byref(ms), C.byref(fl)))
     return n.value, ms.value, fl.value
+
+
+def prof_executed_flops(kind: int) -> float:
+    f = C.c_double(0)
+    check(lib().vtgb_prof_executed_flops(kind, C.byref(f)))
+    return f.value
 
 
 _ERR = {-1: ValueError, -2: VtgbError, -3: VtgbError, -4: NotImplementedError}

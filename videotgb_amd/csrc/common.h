@@ -152,6 +152,11 @@ struct GemmDesc {
     // convolutions, computed once per pair instead of once per refinement iteration)
     const void* init_bf16;
     int64_t ldinit;
+    // launch timing (vtgb_prof_*): ALGORITHMIC FLOPs of this launch when they differ from the executed 2 M N K -- the GRU
+    // convolutions with the hoisted `inp` third are credited with the full 384-channel convolution the reference computes in
+    // every iteration; the once-per-call start-map convolutions that carry the hoisted part are credited with 0 (< 0 here).
+    // 0 = executed.  The executed FLOPs are accumulated separately (vtgb_prof_executed_flops).
+    double algo_flops;
 };
 #define VTGB_EPI_GRU 4
 int launch_gemm(const GemmDesc& d, hipStream_t s);
@@ -207,6 +212,6 @@ int launch_mrc_head(const float* x, const float* w, const float* b, float* logit
 struct ProfScope {
     int slot;
     hipStream_t s;
-    ProfScope(int kind, double flops, hipStream_t stream);
+    ProfScope(int kind, double flops, hipStream_t stream, double executed_flops = -1.0);
     ~ProfScope();
 };

@@ -31,14 +31,14 @@ extern "C" int vtgb_pack_bf16(const float* src, void* dst, int64_t rows, int64_t
 // ---------------------------------------------------------------------------------------
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+struct ProfRec { hipEvent_t a, b; int kind; double flops, executed; };
 struct Prof {
     bool on = false;
     std::vector<ProfRec> recs;   // pool: events are created once and reused after reset
     size_t used = 0;
 } g_prof;
 }  // namespace
-ProfScope::ProfScope(int kind, double flops, hipStream_t stream) : slot(-1), s(stream) {
+ProfScope::ProfScope(int kind, double flops, hipStream_t stream, double executed_flops) : slot(-1), s(stream) {
     if (!g_prof.on) return;
     if (g_prof.used == g_prof.recs.size()) {
         ProfRec r;
@@ -48,6 +48,7 @@ ProfScope::ProfScope(int kind, double flops, hipStream_t stream) : slot(-1), s(s
     slot = (int)g_prof.used++;
     g_prof.recs[slot].kind = kind;
     g_prof.recs[slot].flops = flops;
+    g_prof.recs[slot].executed = executed_flops < 0 ? flops : executed_flops;
     (void)hipEventRecord(g_prof.recs[slot].a, s);
 }
 ProfScope::~ProfScope() {
@@ -68,6 +69,14 @@ extern "C" int vtgb_prof_summary(int kind, int64_t* launches, double* ms, double
     }
     if (launches) *launches = n;
     if (ms) *ms = t;
+    if (flops) *flops = f;
+    return VTGB_OK;
+}
+
+extern "C" int vtgb_prof_executed_flops(int kind, double* flops) {
+    double f = 0;
+    for (size_t i = 0; i < g_prof.used; i++)
+        if (g_prof.recs[i].kind == kind) f += g_prof.recs[i].executed;
     if (flops) *flops = f;
     return VTGB_OK;
 }

@@ -903,7 +903,8 @@ static int launch_large_nwn(const GemmDesc& d, hipStream_t s) {
     const int mx = (m_tiles + 7) / 8, groups = (mx + G - 1) / G;
     static DeviceOnce attr;
     VTGB_FUNC_LDS_ONCE(attr, (gemm_bf16_large_kernel<EPI, 0, CONV, NWN, NXF>), LDS);
-    ProfScope prof(CONV ? VTGB_PROF_CONV : VTGB_PROF_GEMM, 2.0 * d.M * d.N * d.K, s);
+    const double exec_flops = 2.0 * d.M * d.N * d.K;
+    ProfScope prof(CONV ? VTGB_PROF_CONV : VTGB_PROF_GEMM, d.algo_flops > 0 ? d.algo_flops : d.algo_flops < 0 ? 0.0 : exec_flops, s, exec_flops);
     hipLaunchKernelGGL((gemm_bf16_large_kernel<EPI, 0, CONV, NWN, NXF>), dim3(8 * groups * G * n_tiles), dim3(512), LDS, s, d, m_tiles, n_tiles, G);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;

@@ -353,10 +353,13 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
         // start maps = bias + conv(inp): X[:, 0:128] holds relu(cnet[:, 128:]) (raft_init_kernel); same taps as the GRU halves
         for (int half = 0; half < 2; half++) {
             const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1, wi = 10 + 4 * half;
-            VTGB_TRY(launch_conv_gemm(conv_desc(dt, Mi, 256, H8, W8, kh, kw, 128, 128, X, 256, nullptr, 0, w[26 + 2 * half], F(w[wi + 1]), VTGB_EPI_STORE, 0,
-                                                inp_zr[half], 256, zero), s));
-            VTGB_TRY(launch_conv_gemm(conv_desc(dt, Mi, 128, H8, W8, kh, kw, 128, 128, X, 256, nullptr, 0, w[27 + 2 * half], F(w[wi + 3]), VTGB_EPI_STORE, 0,
-                                                inp_q[half], 128, zero), s));
+            GemmDesc mz = conv_desc(dt, Mi, 256, H8, W8, kh, kw, 128, 128, X, 256, nullptr, 0, w[26 + 2 * half], F(w[wi + 1]), VTGB_EPI_STORE, 0,
+                                    inp_zr[half], 256, zero);
+            GemmDesc mq = conv_desc(dt, Mi, 128, H8, W8, kh, kw, 128, 128, X, 256, nullptr, 0, w[27 + 2 * half], F(w[wi + 3]), VTGB_EPI_STORE, 0,
+                                    inp_q[half], 128, zero);
+            mz.algo_flops = mq.algo_flops = -1.0;   // their work is credited to the 20 per-iteration launches (the reference's form)
+            VTGB_TRY(launch_conv_gemm(mz, s));
+            VTGB_TRY(launch_conv_gemm(mq, s));
         }
     }
     for (int it = 0; it < a->iters; it++) {
@@ -387,12 +390,12 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
             // second operand starts at column 128 of X, bias and the inp term come from the start map
             GemmDesc zr = hoist ? conv_desc(dt, Mi, 256, H8, W8, kh, kw, 256, 128, hb, 128, E(X, 128), 256, w[wi], nullptr, VTGB_EPI_STORE, 2, ZR, 256, zero)
                                 : conv_desc(dt, Mi, 256, H8, W8, kh, kw, 384, 128, hb, 128, X, 256, w[wi], F(w[wi + 1]), VTGB_EPI_STORE, 2, ZR, 256, zero);
-            if (hoist) { zr.init_bf16 = inp_zr[half]; zr.ldinit = 256; }
+            if (hoist) { zr.init_bf16 = inp_zr[half]; zr.ldinit = 256; zr.algo_flops = 2.0 * Mi * 256.0 * (5 * 384); }
             zr.gate_from = 128; zr.aux = hb; zr.ldaux = 128; zr.out2 = RH; zr.ldo2 = 128;
             VTGB_TRY(launch_conv_gemm(zr, s));
             GemmDesc q = hoist ? conv_desc(dt, Mi, 128, H8, W8, kh, kw, 256, 128, RH, 128, E(X, 128), 256, w[wi + 2], nullptr, VTGB_EPI_GRU, 0, h32, 128, zero)
                                : conv_desc(dt, Mi, 128, H8, W8, kh, kw, 384, 128, RH, 128, X, 256, w[wi + 2], F(w[wi + 3]), VTGB_EPI_GRU, 0, h32, 128, zero);
-            if (hoist) { q.init_bf16 = inp_q[half]; q.ldinit = 128; }
+            if (hoist) { q.init_bf16 = inp_q[half]; q.ldinit = 128; q.algo_flops = 2.0 * Mi * 128.0 * (5 * 384); }
             q.resid = h32; q.ldr = 128; q.aux = ZR; q.ldaux = 256; q.out2 = hb; q.ldo2 = 128;
             VTGB_TRY(launch_conv_gemm(q, s));
         }
