@@ -135,3 +135,35 @@ def test_lightning_module_twin_eval_forward(dev, tmp_path, tag):
     loss, logits = m.forward(batch, noise=(g[f"{tag}_noise"].to(dev) if uses_of and f"{tag}_noise" in g else None))
     loss.backward()
     assert torch.isfinite(loss) and m.model.query_tokens.grad is not None and m.model.query_tokens.grad.abs().max() > 0
+
+
+def test_sf_module_self_refinement_forward(dev, tmp_path):
+    """LSTPSFModule.forward with the pseudo-label loop on (src/models/LSTP_SF_module.py:147-298): per-frame answers through the
+    twin's own prefix / decoder, ROUGE vs the text answers, monotone-stack span, MRC loss added to the LM loss."""
+    from videotgb_amd import models, modules, refine
+    from videotgb_amd.synth import tiny_cfg
+    cfg = tiny_cfg("instructblip")
+    base = write_hf_config(str(tmp_path / "instructblip-tiny"), "instructblip", cfg, "llama")
+    sd = full_state_dict(cfg, models.build_language_model(models.load_hf_config(base, "instructblip")))
+    raft_pth = str(tmp_path / "raft.pth")
+    torch.save({"module." + k[len("of_extractor."):]: v for k, v in sd.items() if k.startswith("of_extractor.")}, raft_pth)
+    words = ["w%d" % i for i in range(120)]
+    proc = BE(tokenizer=BE(pad_token_id=0), batch_decode=lambda ids, skip_special_tokens=True: [" ".join(words[t] for t in r if t > 2) for r in ids.tolist()])
+    m = modules.LSTPSFModule(model_name_or_path=base, sampler_name_or_path=str(tmp_path / "x"), of_extractor_name_or_path=raft_pth, temperature=1.0,
+                             optimizer=functools.partial(torch.optim.AdamW, lr=1e-4), scheduler=None, scheduler_params={},
+                             generate_configs=dict(do_sample=False, max_new_tokens=4), compute_dtype="f32", processor=proc, tgb_cfg=cfg.tgb)
+    m.load_state_dict(sd, strict=True)
+    m.to(dev)
+    g = load_golden("tiny_modules")
+    B = 2
+    batch = dict(frames=(up4(g["frames_q8"]) / 48).to(dev), nframe=int(g["nframe"]), of_lengths=g["of_lengths"].tolist(),
+                 of=(up4(g["of_q8"]) / 127).to(dev), of_mask=g["of_mask"].to(dev),
+                 sampler_question=g["sf_sampler_ids"].to(dev), sampler_question_attention_mask=g["sf_sampler_mask"].to(dev),
+                 qformer_text=g["sf_qformer_ids"].to(dev), qformer_text_attention_mask=g["sf_qformer_mask"].to(dev),
+                 question=g["sf_question"].to(dev), question_attention_mask=g["sf_question_mask"].to(dev),
+                 answer=torch.tensor([[1, 21, 45, 70], [1, 16, 96, 15]], device=dev), answer_attention_mask=torch.ones(B, 4, dtype=torch.long, device=dev),
+                 text_answer=["w21 w45 w70", "w16 w96 w15"])
+    scores, st, en = refine.self_refine_targets(m, batch, lambda ids: proc.batch_decode(ids), num_frames=8, max_length=32 + 5 + 6)
+    assert scores.shape == (B, 8) and st.shape == en.shape == (B,) and bool((st <= en).all())
+    loss, logits = m.forward(batch, noise=g["sf_noise"].to(dev))
+    assert torch.isfinite(loss) and logits.shape[0] == B

@@ -197,17 +197,16 @@ class _LSTPLightningBase(_Base):
             train.apply_lora(self.model.language_model, r=8, lora_alpha=32, lora_dropout=0.1)
         self.freeze_weights()
 
-    # ---- plumbing shared with the eval twins
-    def _stages(self) -> models._LSTPBase:
-        """The eval-side object over the SAME sub-modules (select_frames / prefix live there)."""
-        st = getattr(self, "_st", None)
-        if st is None:
-            st = object.__new__(models.LSTP if self.ARCH == "instructblip" else models.LSTP_blip2)
-            nn.Module.__init__(st)
-            st.cfg, st.model, st.temporal_encoder, st.of_extractor = None, self.model, self.temporal_encoder, self.of_extractor
-            st.TGB_MODE, st.MAP = self.TGB_MODE, self.MAP
-            object.__setattr__(self, "_st", st)          # not a registered child: parameters are owned once, by self
-        return st
+    # ---- the eval twin's ``prefix`` signature, so refine.frame_answers can drive a LightningModule twin as well
+    @torch.no_grad()
+    def prefix(self, sampled: torch.Tensor, batch_size: int, nframe: int, text_encoding=None, pool: str = "mean") -> torch.Tensor:
+        """models._LSTPBase.prefix: ViT -> Q-Former -> pooling + projection for ``batch_size`` clips of ``nframe`` frames each;
+        ``text_encoding["qformer_input_ids"]`` holds one instruction per clip (InstructBLIP)."""
+        img = self.model.vision_model(pixel_values=sampled, return_dict=True, act_output=True).last_hidden_state
+        batch = {}
+        if self.ARCH == "instructblip":
+            batch = {"qformer_text": text_encoding["qformer_input_ids"], "qformer_text_attention_mask": text_encoding["qformer_attention_mask"]}
+        return self._prefix_nograd(batch, img, [nframe] * batch_size, pool)
 
     @torch.no_grad()
     def _flow_of_candidates(self, pixel_values: torch.Tensor) -> torch.Tensor:
@@ -348,7 +347,7 @@ class _LSTPLightningBase(_Base):
             out = lm(inputs_embeds=emb, attention_mask=attention_mask, labels=labels)
             loss, logits = out[0], out[1]
         if self.SELF_REFINE:
-            scores, st, en = refine.self_refine_targets(self._stages(), batch, lambda ids: self.processor.batch_decode(ids, skip_special_tokens=True),
+            scores, st, en = refine.self_refine_targets(self, batch, lambda ids: self.processor.batch_decode(ids, skip_special_tokens=True),
                                                         num_frames=batch["frames"].shape[0] // batch["answer"].shape[0])
             loss = loss + refine.mrc_loss(of_logits, st, en)
         return loss, logits
