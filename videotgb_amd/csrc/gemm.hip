@@ -323,6 +323,10 @@ constexpr int L_LDS = (L_A_SLOTS + L_W_SLOTS) * L_OP_BYTES;   // 160 KiB
 // workgroups), so that tools/gemm_ablate.py can report the clock the chip actually holds under each variant
 __device__ unsigned long long g_clk[2];
 #ifdef VTGB_DEBUG_HOOKS
+__device__ int g_exp_dev = 0;   // experiment selector read by the large kernel (debug-hook builds only)
+extern "C" void vtgb_debug_set_exp(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_exp_dev), &v, sizeof(v)); }
+#endif
+#ifdef VTGB_DEBUG_HOOKS
 extern "C" void vtgb_debug_read_clk(unsigned long long* out, int reset) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(g_clk));
     if (reset) {
@@ -488,6 +492,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     //   read half 1 of tile t | MFMAs of half 0 | counted wait + barrier (tile t fully read by everyone;
     //   A(t+1), W(t+1) visible) | re-arm the freed slots with W(t+2), A(t+3) | read half 0 of tile t+1 |
     //   MFMAs of half 1
+#ifdef VTGB_DEBUG_HOOKS
+    if (g_exp_dev == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (g_exp_dev == 2 && wave < 4) __builtin_amdgcn_s_setprio(1);
+    if (g_exp_dev == 3 && (wave & 1)) __builtin_amdgcn_s_setprio(1);
+#endif
     int a_slot = 0;   // A(t) lives in slot t % 3, W(t) in slot t % 2
     if (!wave_active) {
         // same DMA issues, waits and barriers as the active waves, nothing else
