@@ -105,26 +105,52 @@ __global__ __launch_bounds__(256) void raft_corr_kernel(const vtgb_raft_corr_arg
 #pragma unroll
         for (int ks = 0; ks < CORR_D / 32; ks++) bfrag[ks] = *reinterpret_cast<const half8*>(f1l + fr * CORR_F1H_LD + ks * 32 + fg * 8);
         const int n_qt = (HW + 15) >> 4;
-        for (int qt = wave; qt < n_qt; qt += 4) {
+        // image-2 fragments come straight from L2: the loads of q-tile t+1 are in flight while tile t's MFMAs run (without the
+        // prefetch every q-tile waited out a full L2 round trip: the kernel was latency-bound at 0.6 TB/s of output)
+        half8 afrag[2][CORR_D / 32];
+        auto load_a = [&](int qt, half8 (&dst)[CORR_D / 32]) {
             const int q = min(qt * 16 + fr, HW - 1);
             const half_t* row = f2 + (int64_t)q * CORR_D + fg * 8;
-            half8 afrag[CORR_D / 32];
 #pragma unroll
-            for (int ks = 0; ks < CORR_D / 32; ks++) afrag[ks] = *reinterpret_cast<const half8*>(row + ks * 32);
+            for (int ks = 0; ks < CORR_D / 32; ks++) dst[ks] = *reinterpret_cast<const half8*>(row + ks * 32);
+        };
+        auto compute = [&](int qt, const half8 (&src)[CORR_D / 32]) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < CORR_D / 32; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[ks], bfrag[ks], acc, 0, 0, 0);
+            for (int ks = 0; ks < CORR_D / 32; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(src[ks], bfrag[ks], acc, 0, 0, 0);
             // D: rows fg * 4 + r = q within the tile, column fr = p
             *reinterpret_cast<f32x4*>(S + fr * ldS + qt * 16 + fg * 4) = acc * a.scale;
+        };
+        int qt = wave;
+        if (qt < n_qt) load_a(qt, afrag[0]);
+        for (; qt < n_qt; qt += 8) {
+            if (qt + 4 < n_qt) load_a(qt + 4, afrag[1]);
+            compute(qt, afrag[0]);
+            if (qt + 4 < n_qt) {
+                if (qt + 8 < n_qt) load_a(qt + 8, afrag[0]);
+                compute(qt + 4, afrag[1]);
+            }
         }
     }
     __syncthreads();
     // ---- the four levels.  Row p of level l is [n * HW + p0 + p][n_l]: the tile's outputs are one contiguous span.
     const int rows = min(16, HW - p0);
     OT* const o0 = reinterpret_cast<OT*>(a.levels[0]) + (n * HW + p0) * (int64_t)HW;
-    for (int i = tid; i < rows * HW; i += 256) {
-        const int p = i / HW, q = i - p * HW;
-        o0[i] = (OT)S[p * ldS + q];
+    if ((HW & 7) == 0) {
+        // 8 consecutive q per lane: 16-byte (half) / 2 x 16-byte (fp32) stores -- element-wise 2-byte stores made this
+        // write-out (3/4 of the kernel's bytes) the longest phase of the kernel
+        typedef OT OT8 __attribute__((ext_vector_type(8)));
+        for (int i = tid * 8; i < rows * HW; i += 256 * 8) {
+            const int p = i / HW, q = i - p * HW;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(S + p * ldS + q), hi = *reinterpret_cast<const f32x4*>(S + p * ldS + q + 4);
+            const OT8 v = {(OT)lo[0], (OT)lo[1], (OT)lo[2], (OT)lo[3], (OT)hi[0], (OT)hi[1], (OT)hi[2], (OT)hi[3]};
+            *reinterpret_cast<OT8*>(o0 + i) = v;
+        }
+    } else {
+        for (int i = tid; i < rows * HW; i += 256) {
+            const int p = i / HW, q = i - p * HW;
+            o0[i] = (OT)S[p * ldS + q];
+        }
     }
     const int w1 = W / 2, w2 = W / 4, w3 = W / 8, n3 = (H / 8) * w3;
     OT* const o1 = reinterpret_cast<OT*>(a.levels[1]) + (n * HW + p0) * (int64_t)n1;
