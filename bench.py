@@ -293,6 +293,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local), rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the hot path has no CPU implementation)"
+    if world > 1:   # N ranks share the host: keep the (untimed) CPU-side weight synthesis from oversubscribing the cores N-fold
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from videotgb_amd import _lib, llm, models, synth
