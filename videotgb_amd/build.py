@@ -10,8 +10,17 @@ LIB = os.path.join(HERE, "libvtgb.so")
 SOURCES = ["gemm.hip", "conv_f32.hip", "attn.hip", "elementwise.hip", "select.hip", "forward.hip", "llm.hip", "raft.hip", "raft_corr.hip", "raft_enc.hip", "train.hip"]
 
 
+FLAGS_STAMP = os.path.join(HERE, "build", "flags")
+
+
+def _flags():
+    return "debug-hooks" if os.environ.get("VTGB_DEBUG_HOOKS") == "1" else "production"
+
+
 def _stale():
     if not os.path.exists(LIB):
+        return True
+    if not os.path.exists(FLAGS_STAMP) or open(FLAGS_STAMP).read() != _flags():   # a debug-hook build is never mistaken for the product
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(REPO, "include", "vtgb.h")]
@@ -45,6 +54,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if failed:
         raise RuntimeError("hipcc failed building libvtgb.so")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(_flags())
     return LIB
 
 

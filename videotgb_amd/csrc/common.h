@@ -56,7 +56,8 @@ static inline RowMap rowmap(int seg_rows, int64_t seg_stride, int64_t seg_off) {
 }
 __host__ __device__ static inline int64_t map_row(const RowMap& m, int64_t r) {
     if (m.seg_rows == 0) return r;
-    return (r / m.seg_rows) * m.seg_stride + m.seg_off + (r % m.seg_rows);
+    const int32_t r32 = (int32_t)r, seg = r32 / m.seg_rows;   // GemmDesc::M is an int32: 32-bit division
+    return (int64_t)seg * m.seg_stride + m.seg_off + (r32 - seg * m.seg_rows);
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -19,18 +19,18 @@ enum { EPI_STORE = VTGB_EPI_STORE, EPI_GELU = VTGB_EPI_GELU, EPI_RESID_F32 = VTG
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// GELU for bf16 outputs: erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below the bf16
-// rounding of the result) -- 1 rcp + 1 exp + 8 FMA instead of libm erff's ~40 instructions, which
-// otherwise makes the fc1 epilogue as long as its whole k-loop.
+// GELU for bf16 outputs: x * Phi(x) with Phi(x) ~ sigmoid(x (a + b x^2 + c x^4)), a minimax fit on [-8, 8] (the argument is
+// clamped there; Phi is 0 / 1 to 1e-12 outside): |error| <= 2.6e-5 absolute and <= 7e-4 of the result for |x| < 2.5, i.e. below
+// the bf16 rounding of every result larger than 0.013 -- at 7 plain VALU instructions + v_exp + v_rcp (44 issue cycles per
+// value).  The erf form it replaces (Abramowitz-Stegun 7.1.26: 15 plain + 2 transcendental, 76 cycles) made the fc1 epilogue
+// 15 % of a tile's life: 128 values per lane, two waves per SIMD, nothing to hide under.  libm's erff is ~40 instructions.
+// The fp32 exactness mode keeps the exact erf (gelu_erf).
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float e = 1.0f - poly * t * __expf(-z * z);      // erf(|x| / sqrt 2)
-    return 0.5f * x * (1.0f + copysignf(e, x));
+    const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+    const float x2 = xc * xc;
+    float q = fmaf(1.0145391570e-3f, x2, -1.0677742213e-1f);      // -(a + b x^2 + c x^4) log2(e), Horner in x^2
+    q = fmaf(q, x2, -2.3011195660f);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xc * q));
 }
 
 // Store 4 consecutive n (n0..n0+3) of logical row m.  TAct is the activation type of
@@ -496,6 +496,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     if (g_exp_dev == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     if (g_exp_dev == 2 && wave < 4) __builtin_amdgcn_s_setprio(1);
     if (g_exp_dev == 3 && (wave & 1)) __builtin_amdgcn_s_setprio(1);
+    if ((g_exp_dev & 0xff) == 4 && bid < 256) {   // phase-stagger the first wave of workgroups: CU slot c of 32 waits c/32 of (g_exp_dev >> 8) us
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), ticks = (unsigned long long)((bid >> 3) & 31) * (g_exp_dev >> 8) * 100 / 32;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    }
 #endif
     int a_slot = 0;   // A(t) lives in slot t % 3, W(t) in slot t % 2
     if (!wave_active) {
@@ -593,6 +597,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                     *reinterpret_cast<bf16x4*>(cst + row * 128 + c16 * 16 + (fg & 1) * 8) = pk;
                 }
             bf16_t* const outp = reinterpret_cast<bf16_t*>(p.out);
+#ifdef VTGB_DEBUG_HOOKS
+            const bool skip_store = (g_exp_dev & 0xff) == 5;   // timing only: the whole epilogue but the global stores
+#else
+            constexpr bool skip_store = false;
+#endif
             // operands of the fused elementwise tails (r * h gate, ResidualBlock skip): all rows' loads in flight before the
             // first store, not one HBM round trip per row
             const bool gated = EPI == EPI_STORE && p.gate_from > 0, resd = EPI == EPI_STORE && !gated && p.resid_bf16 != nullptr;
@@ -613,35 +622,66 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                     }
                 }
             }
+#ifdef VTGB_DEBUG_HOOKS
+            unsigned long long ts0 = 0;
+            if ((g_exp_dev & 0xff) == 6) ts0 = __builtin_amdgcn_s_memrealtime();
+#endif
+            // Every LDS read of the wave's tile is issued before its first global store, and the common case (identity row
+            // map, no fused tail) runs a branch-free store loop: stores then leave back to back.  (Interleaved
+            // read -> address -> store through the general path cost 8.2 us per wave for 16 stores -- 15 GB/s per CU against
+            // the 95 GB/s the same store shape reaches in isolation, tools/exp/store_rate.hip: a 64-bit division per row for
+            // the row map, ~10 uniform branches per row, and vmcnt(0) waits the compiler places in front of LDS reads that
+            // follow a store.)
+            uint4 vv[WROWS / 8];
 #pragma unroll
             for (int rr = 0; rr < WROWS / 8; rr++) {
-                const int row = rr * 8 + (lane >> 3), ch = lane & 7;
-                const uint4 v = *reinterpret_cast<const uint4*>(cst + row * 128 + ((ch ^ (row & 7)) << 4));
-                const int m = m0 + wm * WROWS + row, n = n0 + wn * 64 + ch * 8;
-                if (m < p.M && n < p.N) {
-                    if (gated && n >= p.gate_from) {
-                        const int ng = n - p.gate_from;
-                        const bf16x8 g = opnd[rr];
-                        const bf16x8 a = __builtin_bit_cast(bf16x8, v);
-                        bf16x8 o;
+                const int row = rr * 8 + (lane >> 3);
+                vv[rr] = *reinterpret_cast<const uint4*>(cst + row * 128 + ((ch0 ^ (row & 7)) << 4));
+            }
+            // fused tails, in place, for every row before the first store (a conditional load-use + store per row makes hipcc's
+            // waitcnt pass fall back to vmcnt(0) in front of each row: every row then waits for the previous row's store)
+            const bool to_out2 = gated && nn >= p.gate_from;   // per lane: this lane's 8 columns are r (-> r * h, out2) or z (-> out)
+            if (gated || resd) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // the operand loads, once and outside the per-row conditionals (see the GRU path)
+#pragma unroll
+                for (int rr = 0; rr < WROWS / 8; rr++) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, vv[rr]);
+                    const bf16x8 g = opnd[rr];
+                    bf16x8 o = a;
+                    if (to_out2) {
 #pragma unroll
                         for (int e = 0; e < 8; e++) o[e] = (bf16_t)((float)a[e] * (float)g[e]);
-                        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.out2) + (int64_t)m * p.ldo2 + ng) = o;
                     } else if (resd) {
-                        const bf16x8 r = opnd[rr];
-                        const bf16x8 a = __builtin_bit_cast(bf16x8, v);
-                        bf16x8 o;
 #pragma unroll
                         for (int e = 0; e < 8; e++) {
-                            const float t = (float)a[e] + (float)r[e];
+                            const float t = (float)a[e] + (float)g[e];
                             o[e] = (bf16_t)(p.post_relu ? fmaxf(t, 0.f) : t);
                         }
-                        *reinterpret_cast<bf16x8*>(outp + map_row(p.o_map, m) * p.ldo + n) = o;
-                    } else {
-                        *reinterpret_cast<uint4*>(outp + map_row(p.o_map, m) * p.ldo + n) = v;
                     }
+                    vv[rr] = __builtin_bit_cast(uint4, o);
                 }
             }
+            const int mrow = m0 + wm * WROWS + (lane >> 3);
+            const bool nok = nn < p.N && !skip_store;
+            if (to_out2 || p.o_map.seg_rows == 0) {
+                bf16_t* const o = to_out2 ? reinterpret_cast<bf16_t*>(p.out2) + (int64_t)mrow * p.ldo2 + (nn - p.gate_from) : outp + (int64_t)mrow * p.ldo + nn;
+                const int64_t step = (int64_t)8 * (to_out2 ? p.ldo2 : p.ldo);
+#pragma unroll
+                for (int rr = 0; rr < WROWS / 8; rr++)
+                    if (nok && mrow + rr * 8 < p.M) *reinterpret_cast<uint4*>(o + rr * step) = vv[rr];
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < WROWS / 8; rr++)
+                    if (nok && mrow + rr * 8 < p.M) *reinterpret_cast<uint4*>(outp + map_row(p.o_map, mrow + rr * 8) * p.ldo + nn) = vv[rr];
+            }
+#ifdef VTGB_DEBUG_HOOKS
+            if ((g_exp_dev & 0xff) == 6) {   // per wave: 10 ns ticks from the first store's issue to the last one's, and to their completion
+                const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
+                if (lane == 0) { atomicAdd(&g_clk[0], ts1 - ts0); atomicAdd(&g_clk[1], ts2 - ts0); }
+            }
+#endif
             return;
         }
     }
@@ -672,13 +712,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                         const int row = jj * 16 + fr, chunk = i * 4 + fg;
                         *reinterpret_cast<f32x4*>(cst + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][half * (PR / 16) + jj];
                     }
+                // all of the pass's LDS reads before its first store (see the bf16 path)
+                f32x4 vv[PR / 4];
 #pragma unroll
                 for (int rr = 0; rr < PR / 4; rr++) {
                     const int row = rr * 4 + rl;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(cst + row * 256 + ((cl ^ (row & 15)) << 4));
-                    const int m = m0 + wm * WROWS + half * PR + row, n = n0 + wn * 64 + cl * 4;
+                    vv[rr] = *reinterpret_cast<const f32x4*>(cst + row * 256 + ((cl ^ (row & 15)) << 4));
+                }
+                const int n = n0 + wn * 64 + cl * 4;
+                const bool ident = p.o_map.seg_rows == 0;
+#pragma unroll
+                for (int rr = 0; rr < PR / 4; rr++) {
+                    const int row = rr * 4 + rl;
+                    const f32x4 v = vv[rr];
+                    const int m = m0 + wm * WROWS + half * PR + row;
                     if (m < p.M && n < p.N) {
-                        *reinterpret_cast<f32x4*>(outp + map_row(p.o_map, m) * p.ldo + n) = v;
+                        *reinterpret_cast<f32x4*>(outp + (ident ? (int64_t)m : map_row(p.o_map, m)) * p.ldo + n) = v;
                         if constexpr (EPI == EPI_STORE_F32) {
                             if (do_stats) {
                                 if (m < m_b) { sa += v; qa += v * v; }
@@ -754,7 +803,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                     hreg[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
                     zreg[rr] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
                     if (m < p.M && ncol) {
-                        hreg[rr] = *reinterpret_cast<const f32x4*>(p.resid + map_row(p.r_map, m) * p.ldr + n);
+                        hreg[rr] = *reinterpret_cast<const f32x4*>(p.resid + (p.r_map.seg_rows == 0 ? (int64_t)m : map_row(p.r_map, m)) * p.ldr + n);
                         zreg[rr] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)m * p.ldaux + n);
                     }
                 }
@@ -765,21 +814,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                         const int row = jj * 16 + fr, chunk = i * 4 + fg;
                         *reinterpret_cast<f32x4*>(cst + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][half * (PR / 16) + jj];
                     }
+                // ONE explicit vmcnt(0) here, outside every conditional: the h / z loads above sit in per-row conditionals, so
+                // hipcc's waitcnt pass cannot count them and, left alone, puts `s_waitcnt vmcnt(0)` in front of every row's
+                // first use -- which also waits for the PREVIOUS row's stores to be acknowledged (vmcnt counts stores): a
+                // memory round trip per row, 16 rows per pass.  After this wait no later row needs one.
+                __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
                 for (int rr = 0; rr < PR / 4; rr++) {
                     const int row = rr * 4 + rl;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(cst + row * 256 + ((cl ^ (row & 15)) << 4));
-                    const int m = m0 + wm * WROWS + half * PR + row;
-                    if (m < p.M && ncol) {
-                        f32x4 hn;
+                    f32x4 hn;
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const float z = (float)zreg[rr][e];
-                            hn[e] = (1.0f - z) * hreg[rr][e] + z * tanh_fast(v[e]);
-                        }
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + map_row(p.o_map, m) * p.ldo + n) = hn;
-                        const bf16x4 pk = {(bf16_t)hn[0], (bf16_t)hn[1], (bf16_t)hn[2], (bf16_t)hn[3]};
-                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out2) + (int64_t)m * p.ldo2 + n) = pk;
+                    for (int e = 0; e < 4; e++) {
+                        const float z = (float)zreg[rr][e];
+                        hn[e] = (1.0f - z) * hreg[rr][e] + z * tanh_fast(v[e]);
+                    }
+                    hreg[rr] = hn;
+                    zreg[rr] = bf16x4{(bf16_t)hn[0], (bf16_t)hn[1], (bf16_t)hn[2], (bf16_t)hn[3]};
+                }
+                const bool o_ident = p.o_map.seg_rows == 0;
+#pragma unroll
+                for (int rr = 0; rr < PR / 4; rr++) {
+                    const int m = m0 + wm * WROWS + half * PR + rr * 4 + rl;
+                    if (m < p.M && ncol) {
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (o_ident ? (int64_t)m : map_row(p.o_map, m)) * p.ldo + n) = hreg[rr];
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out2) + (int64_t)m * p.ldo2 + n) = zreg[rr];
                     }
                 }
             }
