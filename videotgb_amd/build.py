@@ -14,7 +14,7 @@ FLAGS_STAMP = os.path.join(HERE, "build", "flags")
 
 
 def _flags():
-    return "debug-hooks" if os.environ.get("VTGB_DEBUG_HOOKS") == "1" else "production"
+    return ("debug-hooks" if os.environ.get("VTGB_DEBUG_HOOKS") == "1" else "production") + os.environ.get("VTGB_CFLAGS", "")
 
 
 def _stale():
@@ -42,6 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                "-I", os.path.join(REPO, "include"), "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        cmd[1:1] = os.environ.get("VTGB_CFLAGS", "").split()      # experiments: e.g. VTGB_CFLAGS=-DVTGB_SPREAD=0
         if os.environ.get("VTGB_DEBUG_HOOKS") == "1":      # experiment knobs + timing-only ablation kernels (tools/gemm_ablate.py)
             cmd.insert(1, "-DVTGB_DEBUG_HOOKS")
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -353,8 +353,18 @@ struct ClkScope {
 // 128 x 64, the SAME wave tile (and LDS-read : MFMA ratio, 12 fragment reads per 32 MFMAs) as the 256 x 256 tile, for
 // 128-channel outputs with many rows (RAFT's GRU q convolution, the 126-channel motion-encoder output, the stage 2 / 3
 // encoder convolutions); its activation slot is 64 KiB, so the ring is 2 activation + 2 weight slots = 160 KiB.
+#ifndef VTGB_BUFDMA
+#define VTGB_BUFDMA 1   // 0: global_load_lds with 64-bit per-lane addresses and a zero page (rounds 1-2a)
+#endif
+#ifndef VTGB_NOSCHED
+#define VTGB_NOSCHED 0
+#endif
+#ifndef VTGB_SPREAD
+#define VTGB_SPREAD 1   // 0: the round-1 k-loop (all eight LDS-DMA pieces issued in one burst behind the barrier)
+#endif
 template <int EPI, int ABL = 0, bool CONV = false, int NWN = 4, int NXF = 2 * NWN>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass needs only the launch stub (and cannot type the buffer-descriptor builtins)
     ClkScope clk(ABL != 0);
     constexpr int NX = NXF;              // activation fragments per wave: wave tile = (16 NX) x 64
     constexpr int WROWS = 16 * NX;       // rows of the wave tile
@@ -392,6 +402,76 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
 
+#if VTGB_BUFDMA
+    // ---- LDS-DMA assignment: wave w stages rows [32w, 32w+32) of both operands, 4 instructions of 8 rows each; lane l of an
+    // instruction fills slot (l & 7) of row r0 + (l >> 3).  Addressing is `buffer_load_dwordx4 ... lds`: a descriptor on the
+    // TILE's first row (wave-uniform: SGPRs), a loop-invariant 32-bit byte offset per lane and piece, and the k offset in the
+    // scalar offset -- no per-piece 64-bit VALU arithmetic in the k-loop (plain GEMM: none at all).  Convolution: the per-lane
+    // offset is (centre pixel + tap shift) * row pitch, and a tap that falls outside the image gets an offset beyond the
+    // descriptor's range: the hardware range check then writes ZEROS to LDS for that lane (measured, tools/exp/buf_lds_oob.hip),
+    // which is the padding -- no zero page, no pointer select.
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr unsigned OOB = 0x80000000u;   // + the scalar offset (< 2^31) it neither wraps nor re-enters the range
+    constexpr int RANGE = 0x7FFFFF00;
+    unsigned w_voff[WI], a_voff[AI];
+    int a_bits[AI];   // CONV: bit ky = tap row ky lands inside the image, bit 8 + kx = tap column kx does
+    const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W + (int64_t)n0 * p.ldw), 0, RANGE, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < WI; i++) {
+        const int row = wave * (8 * WI) + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
+        const int wr = (n0 + row) < p.N ? row : p.N - 1 - n0;
+        w_voff[i] = (unsigned)(wr * (int)p.ldw + c * 8) * 2u;
+    }
+    const int cv_hw = CONV ? p.conv_H * p.conv_W : 1, cv_Hi = CONV ? (p.conv_Hi ? p.conv_Hi : p.conv_H) : 1,
+              cv_Wi = CONV ? (p.conv_Wi ? p.conv_Wi : p.conv_W) : 1, cv_st = CONV ? (p.conv_stride ? p.conv_stride : 1) : 1;
+    const int cv_img0 = CONV ? m0 / cv_hw : 0;
+    const int64_t a_row0 = CONV ? (int64_t)cv_img0 * (cv_Hi * cv_Wi) : map_row(p.a_map, m0);   // first source row of the tile
+    const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + a_row0 * p.lda), 0, RANGE, 0x00020000);
+    const auto a2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(CONV && p.A2 ? p.A2 : p.A) + a_row0 * (CONV && p.A2 ? p.lda2 : p.lda)), 0, RANGE, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < AI; i++) {
+        const int row = wave * (8 * AI) + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
+        const int am = (m0 + row) < p.M ? (m0 + row) : p.M - 1;
+        if constexpr (CONV) {
+            const int img = am / cv_hw, rem = am - img * cv_hw, y = (rem / p.conv_W) * cv_st, x = (rem % p.conv_W) * cv_st;
+            a_voff[i] = (unsigned)((img - cv_img0) * (cv_Hi * cv_Wi) + y * cv_Wi + x) | ((unsigned)c << 28);   // pixel (24 bits) | chunk
+            int bits = 0;
+            for (int k = 0; k < p.conv_KH; k++) bits |= ((unsigned)(y + k - (p.conv_KH >> 1)) < (unsigned)cv_Hi) << k;
+            for (int k = 0; k < p.conv_KW; k++) bits |= ((unsigned)(x + k - (p.conv_KW >> 1)) < (unsigned)cv_Wi) << (8 + k);
+            a_bits[i] = bits;
+        } else {
+            a_voff[i] = (unsigned)((int)(map_row(p.a_map, am) - a_row0) * (int)p.lda + c * 8) * 2u;
+            a_bits[i] = 0;
+        }
+    }
+    // CONV: running (channel chunk, tap) of the next A k-tile to stage; A tiles are issued in k order, and K runs
+    // chunk-major / tap-minor: the KH*KW shifted reads of one 64-channel slab follow each other directly
+    // (32 KiB per workgroup, L2 / L1 hits), instead of sweeping the whole tile footprint once per tap (which
+    // overflowed the XCD's 4 MiB L2 and sent every tap's re-read to the fabric: 5.4 TB/s of FETCH on the GRU convs)
+    int cv_ky = 0, cv_kx = 0, cv_c0 = 0;
+#define L_ISSUE_A(slot, k0)                                                                             \
+    if constexpr (CONV) {                                                                               \
+        const bool first = cv_c0 < p.conv_split;                                                        \
+        const unsigned ldb = (unsigned)(first ? p.lda : p.lda2) * 2u;                                   \
+        const int cc2 = (first ? cv_c0 : cv_c0 - p.conv_split) * 2;                                     \
+        const int dpix = (cv_ky - (p.conv_KH >> 1)) * cv_Wi + (cv_kx - (p.conv_KW >> 1));               \
+        const int need = (1 << cv_ky) | (256 << cv_kx);                                                 \
+        _Pragma("unroll") for (int i = 0; i < AI; i++) {                                                \
+            const unsigned pix = (a_voff[i] & 0x00FFFFFFu) + (unsigned)dpix;                            \
+            const unsigned v = ((a_bits[i] & need) == need) ? pix * ldb + (a_voff[i] >> 28) * 16u : OOB; \
+            if (first) { __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(smem + (slot) * A_OP + (wave * (8 * AI) + i * 8) * 128), 16, v, cc2, 0, 0); } \
+            else { __builtin_amdgcn_raw_ptr_buffer_load_lds(a2_rsrc, (lptr_t)(smem + (slot) * A_OP + (wave * (8 * AI) + i * 8) * 128), 16, v, cc2, 0, 0); } \
+        }                                                                                               \
+        if (++cv_kx == p.conv_KW) { cv_kx = 0; if (++cv_ky == p.conv_KH) { cv_ky = 0; cv_c0 += L_BK; } } \
+    } else {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < AI; i++)                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(smem + (slot) * A_OP + (wave * (8 * AI) + i * 8) * 128), 16, a_voff[i], (k0) * 2, 0, 0); \
+    }
+#define L_ISSUE_W(slot, k0)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < WI; i++)                                                      \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(smem_w + (slot) * W_OP + (wave * (8 * WI) + i * 8) * 128), 16, w_voff[i], (k0) * 2, 0, 0);
+#else
     // ---- LDS-DMA assignment: wave w stages rows [32w, 32w+32) of both operands, 4 instructions of
     // 8 rows each; lane l of an instruction fills slot (l & 7) of row r0 + (l >> 3)
     const bf16_t* a_src[AI];
@@ -449,6 +529,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
 #define L_ISSUE_W(slot, k0)                                                                             \
     _Pragma("unroll") for (int i = 0; i < WI; i++)                                                      \
         __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (k0)), (lptr_t)(smem_w + (slot) * W_OP + (wave * (8 * WI) + i * 8) * 128), 16, 0, 0);
+#endif
     const int nk = p.K / L_BK;
     const int fr = lane & 15, fg = lane >> 4;
     // accumulators start at bias (+ residual): these loads are OLDER than every DMA below, so the
@@ -502,6 +583,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     }
 #endif
     int a_slot = 0;   // A(t) lives in slot t % 3, W(t) in slot t % 2
+#ifdef VTGB_DEBUG_HOOKS
+    const bool late_a = ((g_exp_dev & 0xff) == 7) || ((g_exp_dev & 0xff) == 8 && wave >= 4) || ((g_exp_dev & 0xff) == 9 && (wave & 1));
+#else
+    constexpr bool late_a = false;
+#endif
     if (!wave_active) {
         // same DMA issues, waits and barriers as the active waves, nothing else
         for (int kt = 0; kt + 1 < nk; kt++) {
@@ -526,6 +612,57 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     }
     L_READ(wf0, xf0, smem, smem_w, 0)
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): see the note at the bottom of the loop
+#if VTGB_SPREAD
+    // One k-loop iteration.  The eight LDS-DMA pieces of an iteration are not issued as one burst behind the barrier (a piece
+    // costs its wave 100-185 issue cycles inside a burst, ~60 between MFMAs; both waves of a SIMD burst at the same moment):
+    // the W pieces go between the MFMA groups of the second half, and -- with three activation slots -- the A pieces of the
+    // tile three ahead are DEFERRED into the first half of the next iteration (they have two k-tiles of slack; program order
+    // stays W(t+2), A(t+3), next counted wait, so the vmcnt bookkeeping is unchanged).  DEFER / WCOND / ACOND are literal
+    // `true` in the steady-state loop, which keeps each half one basic block for the sched_group_barrier pipeline below.
+#define L_SCHED_IL(PIECES)                                                                             \
+    if constexpr (!VTGB_NOSCHED && (PIECES) > 0 && (4 * NX) % (PIECES) == 0) {                         \
+        _Pragma("unroll") for (int g_ = 0; g_ < (PIECES); g_++) {                                      \
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);               /* one LDS-DMA piece */   \
+            __builtin_amdgcn_sched_group_barrier(0x008, (4 * NX) / (PIECES), 0);   /* its share of the half's MFMAs */ \
+        }                                                                                              \
+    }
+#define L_ITER(DEFER, WCOND, ACOND, WAIT4)                                                             \
+    {                                                                                                  \
+        const char* as = smem + a_slot * A_OP;                                                         \
+        const char* ws = smem_w + (kt & 1) * W_OP;                                                     \
+        const int a_nxt = a_slot == A_SLOTS - 1 ? 0 : a_slot + 1;                                      \
+        const int a_prv = a_slot == 0 ? A_SLOTS - 1 : a_slot - 1;                                      \
+        if constexpr (!(ABL & 1)) { if (DEFER) { L_ISSUE_A(a_prv, (kt - 1 + A_SLOTS) * L_BK) } }       \
+        L_READ(wf1, xf1, as, ws, 1)                                                                    \
+        L_MFMA(wf0, xf0)                                                                               \
+        if constexpr (!(ABL & 1) && A_SLOTS == 3) { L_SCHED_IL(AI) }                                   \
+        if constexpr (!(ABL & 8)) {                                                                    \
+            if (WAIT4) __builtin_amdgcn_s_waitcnt(0x0074);   /* vmcnt(4) lgkmcnt(0): all but A(t+2) landed */ \
+            else __builtin_amdgcn_s_waitcnt(0x0070);         /* vmcnt(0) lgkmcnt(0) */                 \
+            __builtin_amdgcn_s_barrier();                                                              \
+        }                                                                                              \
+        if constexpr (!(ABL & 1)) {                                                                    \
+            if (WCOND) { L_ISSUE_W(kt & 1, (kt + 2) * L_BK) }                                          \
+            if (ACOND) { L_ISSUE_A(a_slot, (kt + A_SLOTS) * L_BK) }                                    \
+        }                                                                                              \
+        L_READ(wf0, xf0, smem + a_nxt * A_OP, smem_w + ((kt + 1) & 1) * W_OP, 0)                       \
+        L_MFMA(wf1, xf1)                                                                               \
+        if constexpr (!(ABL & 1)) { L_SCHED_IL(A_SLOTS == 3 ? WI : WI + AI) }                          \
+        /* the half-0 fragments of the next tile were requested 32 MFMAs ago: this wait is free, and it lets hipcc's      \
+           waitcnt pass see (at the loop-header join) that set 0 is complete */                        \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                            \
+        a_slot = a_nxt;                                                                                \
+    }
+    {
+        constexpr bool A3 = A_SLOTS == 3, A2 = A_SLOTS != 3;
+        int kt = 0;
+        if (nk > 1) { L_ITER(false, kt + 2 < nk, A2 && kt + 2 < nk, A3 && kt + 2 < nk) kt = 1; }
+        for (; kt + 2 < nk; kt++) L_ITER(A3, true, A2, A3)                      // steady state: no conditions
+        for (; kt + 1 < nk; kt++) L_ITER(A3 && kt + 2 < nk, kt + 2 < nk, A2 && kt + 2 < nk, A3 && kt + 2 < nk)
+    }
+#undef L_ITER
+#undef L_SCHED_IL
+#else
     for (int kt = 0; kt + 1 < nk; kt++) {     // every iteration has a successor tile (no join before the MFMAs)
         const char* as = smem + a_slot * A_OP;
         const char* ws = smem_w + (kt & 1) * W_OP;
@@ -539,16 +676,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         }
         if constexpr (!(ABL & 1)) {
             if (kt + 2 < nk) { L_ISSUE_W(kt & 1, (kt + 2) * L_BK) }
-            if (kt + A_SLOTS < nk) { L_ISSUE_A(a_slot, (kt + A_SLOTS) * L_BK) }
+            if (!late_a && kt + A_SLOTS < nk) { L_ISSUE_A(a_slot, (kt + A_SLOTS) * L_BK) }
         }
         L_READ(wf0, xf0, smem + a_nxt * A_OP, smem_w + ((kt + 1) & 1) * W_OP, 0)
         L_MFMA(wf1, xf1)
+        if constexpr (!(ABL & 1)) {
+            // the activation tile three k-tiles ahead has two k-tiles of slack: issued here, behind this half's MFMAs, by the
+            // waves of `late_a` -- same program order (W, then A, all before the next counted wait), so the vmcnt bookkeeping
+            // above is unchanged
+            if (late_a && kt + A_SLOTS < nk) { L_ISSUE_A(a_slot, (kt + A_SLOTS) * L_BK) }
+        }
         // The half-0 fragments of the next tile were requested 32 MFMAs ago: this wait is free, and it
         // lets hipcc's waitcnt pass see (at the loop-header join) that set 0 is complete, so it does not
         // put an lgkmcnt(0) between the next iteration's set-1 reads and its set-0 MFMAs.
         __builtin_amdgcn_s_waitcnt(0xC07F);
         a_slot = a_nxt;
     }
+#endif
     {   // last k-tile
         const char* as = smem + a_slot * A_OP;
         const char* ws = smem_w + ((nk - 1) & 1) * W_OP;
@@ -854,6 +998,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
             store4<EPI>(p, m, n, acc[i][j]);
         }
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

@@ -14,14 +14,15 @@
 // Space-to-depth: the image is repacked (bf16 NHWC at half resolution) so that pixel (Y, X) carries the 4 x 2 x 2 x 3
 // raw values img[c][2Y + py][2(X + dX - 2) + px], dX = 0..3 -- 48 channels padded to 64 -- and the stride-2 7x7
 // stencil becomes a 4 x 1 stride-1 convolution (vertical taps dY = -2..1; K = 4 * 64 = 256, 147 of them non-zero).
-// Raw 0..255 integers are exact in bf16; the normalisation lives in the packed weights (w * 2/255) and bias
-// (b - 127.5 * sum w'), and out-of-image taps hold 127.5 (= normalised 0): horizontally in the packed tensor,
-// vertically through the convolution's padding page.
+// The packed values are raw - 127.5: (2 r - 255) / 2 has 8 significant bits for every integer r in 0..255, so it is exact in
+// bf16; the normalisation's scale lives in the packed weights (w * 2/255), the bias is untouched, and an out-of-image tap is
+// 0 (= normalised 0) -- horizontally in the packed tensor, vertically through the convolution's zero padding (which the
+// implicit-GEMM kernel gets from the buffer descriptor's range check, not from a page).
 template <typename T>
 __global__ __launch_bounds__(256) void raft_stem_pack_kernel(const float* __restrict__ img, T* __restrict__ out, T* __restrict__ pad_page,
                                                              int64_t n_px, int H, int W) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 64) pad_page[i] = (T)(i < 48 ? 127.5f : 0.f);
+    if (i < 64) pad_page[i] = (T)0.f;   // (the fp32 exactness kernel still reads its padding from a page)
     if (i >= n_px * 4) return;
     const int64_t px_i = i >> 2;
     const int dX = (int)(i & 3), W2 = W >> 1, H2 = H >> 1;
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void raft_stem_pack_kernel(const float* __rest
             const int col = 2 * (X + dX - 2) + pxx, row = 2 * Y + py;
             const bool ok = (unsigned)col < (unsigned)W;
 #pragma unroll
-            for (int c = 0; c < 3; c++) v[py * 6 + pxx * 3 + c] = (T)(ok ? img[((n * 3 + c) * H + row) * W + col] : 127.5f);
+            for (int c = 0; c < 3; c++) v[py * 6 + pxx * 3 + c] = (T)(ok ? img[((n * 3 + c) * H + row) * W + col] - 127.5f : 0.f);
         }
     typedef T T4 __attribute__((ext_vector_type(4)));
     T* o = out + px_i * 64 + dX * 12;
@@ -155,7 +156,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     float* stats = (float*)ws.take((int64_t)n * 128 * 2 * 4);
     float* stats2 = (float*)ws.take((int64_t)n * 128 * 2 * 4);   // the downsample branch's moments
     void* zero = ws.take(256);
-    void* pad_page = ws.take(256);   // the stem's out-of-image value (raw 127.5)
+    void* pad_page = ws.take(256);   // the stem's out-of-image value (0 = normalised 0 in the raw - 127.5 encoding)
     if (ws.dry) return VTGB_OK;
     VTGB_REQUIRE(ws.ok(), VTGB_EWORKSPACE, "raft_encoder: workspace %zu < %zu bytes", ws.size, ws.used);
     VTGB_REQUIRE(a->images && a->weights && a->out, VTGB_EINVAL, "raft_encoder: NULL operand");
