@@ -353,15 +353,7 @@ struct ClkScope {
 // 128 x 64, the SAME wave tile (and LDS-read : MFMA ratio, 12 fragment reads per 32 MFMAs) as the 256 x 256 tile, for
 // 128-channel outputs with many rows (RAFT's GRU q convolution, the 126-channel motion-encoder output, the stage 2 / 3
 // encoder convolutions); its activation slot is 64 KiB, so the ring is 2 activation + 2 weight slots = 160 KiB.
-#ifndef VTGB_BUFDMA
-#define VTGB_BUFDMA 1   // 0: global_load_lds with 64-bit per-lane addresses and a zero page (rounds 1-2a)
-#endif
-#ifndef VTGB_NOSCHED
-#define VTGB_NOSCHED 0
-#endif
-#ifndef VTGB_SPREAD
-#define VTGB_SPREAD 1   // 0: the round-1 k-loop (all eight LDS-DMA pieces issued in one burst behind the barrier)
-#endif
+
 template <int EPI, int ABL = 0, bool CONV = false, int NWN = 4, int NXF = 2 * NWN>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass needs only the launch stub (and cannot type the buffer-descriptor builtins)
@@ -402,7 +394,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
 
-#if VTGB_BUFDMA
     // ---- LDS-DMA assignment: wave w stages rows [32w, 32w+32) of both operands, 4 instructions of 8 rows each; lane l of an
     // instruction fills slot (l & 7) of row r0 + (l >> 3).  Addressing is `buffer_load_dwordx4 ... lds`: a descriptor on the
     // TILE's first row (wave-uniform: SGPRs), a loop-invariant 32-bit byte offset per lane and piece, and the k offset in the
@@ -471,65 +462,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
 #define L_ISSUE_W(slot, k0)                                                                             \
     _Pragma("unroll") for (int i = 0; i < WI; i++)                                                      \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(smem_w + (slot) * W_OP + (wave * (8 * WI) + i * 8) * 128), 16, w_voff[i], (k0) * 2, 0, 0);
-#else
-    // ---- LDS-DMA assignment: wave w stages rows [32w, 32w+32) of both operands, 4 instructions of
-    // 8 rows each; lane l of an instruction fills slot (l & 7) of row r0 + (l >> 3)
-    const bf16_t* a_src[AI];
-    const bf16_t* w_src[WI];
-    int a_row[AI], a_yx[AI];   // CONV: pixel index of the staged row and its (y << 16 | x)
-#pragma unroll
-    for (int i = 0; i < WI; i++) {
-        const int row = wave * (8 * WI) + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
-        const int wr = (n0 + row) < p.N ? (n0 + row) : p.N - 1;
-        w_src[i] = W + (int64_t)wr * p.ldw + c * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < AI; i++) {
-        const int row = wave * (8 * AI) + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
-        const int am = (m0 + row) < p.M ? (m0 + row) : p.M - 1;
-        if constexpr (CONV) {
-            const int hw = p.conv_H * p.conv_W, img = am / hw, rem = am - img * hw;
-            a_row[i] = img * (p.conv_Hi ? p.conv_Hi * p.conv_Wi : hw);      // first input pixel of this row's image
-            a_yx[i] = ((rem / p.conv_W) << 16) | (rem % p.conv_W);          // output (y, x)
-            a_src[i] = nullptr;
-        } else {
-            a_src[i] = A + map_row(p.a_map, am) * p.lda + c * 8;
-        }
-    }
-    // CONV: running (channel chunk, tap) of the next A k-tile to stage; A tiles are issued in k order, and K runs
-    // chunk-major / tap-minor: the KH*KW shifted reads of one 64-channel slab follow each other directly
-    // (32 KiB per workgroup, L2 / L1 hits), instead of sweeping the whole tile footprint once per tap (which
-    // overflowed the XCD's 4 MiB L2 and sent every tap's re-read to the fabric: 5.4 TB/s of FETCH on the GRU convs)
-    int cv_tap = 0, cv_c0 = 0;
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-#define L_ISSUE_A(slot, k0)                                                                             \
-    if constexpr (CONV) {                                                                               \
-        const int dy = cv_tap / p.conv_KW - (p.conv_KH >> 1), dx = cv_tap % p.conv_KW - (p.conv_KW >> 1); \
-        const int cst = p.conv_stride ? p.conv_stride : 1;                                              \
-        const int Hi = p.conv_Hi ? p.conv_Hi : p.conv_H, Wi = p.conv_Wi ? p.conv_Wi : p.conv_W;         \
-        const bool first = cv_c0 < p.conv_split;                                                        \
-        const bf16_t* base = first ? A : reinterpret_cast<const bf16_t*>(p.A2);                         \
-        const int64_t ld = first ? p.lda : p.lda2;                                                      \
-        const int cc = first ? cv_c0 : cv_c0 - p.conv_split;                                            \
-        _Pragma("unroll") for (int i = 0; i < AI; i++) {                                                \
-            const int c8 = ((lane & 7) ^ ((i * 4 + (lane >> 4)) & 7)) * 8;                              \
-            const int y = (a_yx[i] >> 16) * cst + dy, x = (a_yx[i] & 0xffff) * cst + dx;                \
-            const bool ok = (unsigned)y < (unsigned)Hi && (unsigned)x < (unsigned)Wi;                   \
-            const bf16_t* src = ok ? base + (int64_t)(a_row[i] + y * Wi + x) * ld + cc + c8             \
-                                   : reinterpret_cast<const bf16_t*>(p.zero_page) + c8;                 \
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (slot) * A_OP + (wave * (8 * AI) + i * 8) * 128), 16, 0, 0); \
-        }                                                                                               \
-        cv_tap++;                                                                                       \
-        if (cv_tap == p.conv_KH * p.conv_KW) { cv_tap = 0; cv_c0 += L_BK; }                             \
-    } else {                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < AI; i++)                                                  \
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + (k0)), (lptr_t)(smem + (slot) * A_OP + (wave * (8 * AI) + i * 8) * 128), 16, 0, 0); \
-    }
-#define L_ISSUE_W(slot, k0)                                                                             \
-    _Pragma("unroll") for (int i = 0; i < WI; i++)                                                      \
-        __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + (k0)), (lptr_t)(smem_w + (slot) * W_OP + (wave * (8 * WI) + i * 8) * 128), 16, 0, 0);
-#endif
     const int nk = p.K / L_BK;
     const int fr = lane & 15, fg = lane >> 4;
     // accumulators start at bias (+ residual): these loads are OLDER than every DMA below, so the
@@ -583,11 +515,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     }
 #endif
     int a_slot = 0;   // A(t) lives in slot t % 3, W(t) in slot t % 2
-#ifdef VTGB_DEBUG_HOOKS
-    const bool late_a = ((g_exp_dev & 0xff) == 7) || ((g_exp_dev & 0xff) == 8 && wave >= 4) || ((g_exp_dev & 0xff) == 9 && (wave & 1));
-#else
-    constexpr bool late_a = false;
-#endif
     if (!wave_active) {
         // same DMA issues, waits and barriers as the active waves, nothing else
         for (int kt = 0; kt + 1 < nk; kt++) {
@@ -612,7 +539,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     }
     L_READ(wf0, xf0, smem, smem_w, 0)
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): see the note at the bottom of the loop
-#if VTGB_SPREAD
     // One k-loop iteration.  The eight LDS-DMA pieces of an iteration are not issued as one burst behind the barrier (a piece
     // costs its wave 100-185 issue cycles inside a burst, ~60 between MFMAs; both waves of a SIMD burst at the same moment):
     // the W pieces go between the MFMA groups of the second half, and -- with three activation slots -- the A pieces of the
@@ -620,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     // stays W(t+2), A(t+3), next counted wait, so the vmcnt bookkeeping is unchanged).  DEFER / WCOND / ACOND are literal
     // `true` in the steady-state loop, which keeps each half one basic block for the sched_group_barrier pipeline below.
 #define L_SCHED_IL(PIECES)                                                                             \
-    if constexpr (!VTGB_NOSCHED && (PIECES) > 0 && (4 * NX) % (PIECES) == 0) {                         \
+    if constexpr ((PIECES) > 0 && (4 * NX) % (PIECES) == 0) {                         \
         _Pragma("unroll") for (int g_ = 0; g_ < (PIECES); g_++) {                                      \
             __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);               /* one LDS-DMA piece */   \
             __builtin_amdgcn_sched_group_barrier(0x008, (4 * NX) / (PIECES), 0);   /* its share of the half's MFMAs */ \
@@ -662,37 +588,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     }
 #undef L_ITER
 #undef L_SCHED_IL
-#else
-    for (int kt = 0; kt + 1 < nk; kt++) {     // every iteration has a successor tile (no join before the MFMAs)
-        const char* as = smem + a_slot * A_OP;
-        const char* ws = smem_w + (kt & 1) * W_OP;
-        const int a_nxt = a_slot == A_SLOTS - 1 ? 0 : a_slot + 1;
-        L_READ(wf1, xf1, as, ws, 1)
-        L_MFMA(wf0, xf0)
-        if constexpr (!(ABL & 8)) {
-            if (A_SLOTS == 3 && kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4) lgkmcnt(0): all but A(t+2) landed
-            else __builtin_amdgcn_s_waitcnt(0x0070);                               // vmcnt(0) lgkmcnt(0)
-            __builtin_amdgcn_s_barrier();
-        }
-        if constexpr (!(ABL & 1)) {
-            if (kt + 2 < nk) { L_ISSUE_W(kt & 1, (kt + 2) * L_BK) }
-            if (!late_a && kt + A_SLOTS < nk) { L_ISSUE_A(a_slot, (kt + A_SLOTS) * L_BK) }
-        }
-        L_READ(wf0, xf0, smem + a_nxt * A_OP, smem_w + ((kt + 1) & 1) * W_OP, 0)
-        L_MFMA(wf1, xf1)
-        if constexpr (!(ABL & 1)) {
-            // the activation tile three k-tiles ahead has two k-tiles of slack: issued here, behind this half's MFMAs, by the
-            // waves of `late_a` -- same program order (W, then A, all before the next counted wait), so the vmcnt bookkeeping
-            // above is unchanged
-            if (late_a && kt + A_SLOTS < nk) { L_ISSUE_A(a_slot, (kt + A_SLOTS) * L_BK) }
-        }
-        // The half-0 fragments of the next tile were requested 32 MFMAs ago: this wait is free, and it
-        // lets hipcc's waitcnt pass see (at the loop-header join) that set 0 is complete, so it does not
-        // put an lgkmcnt(0) between the next iteration's set-1 reads and its set-0 MFMAs.
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        a_slot = a_nxt;
-    }
-#endif
     {   // last k-tile
         const char* as = smem + a_slot * A_OP;
         const char* ws = smem_w + ((nk - 1) & 1) * W_OP;
@@ -1061,11 +956,29 @@ extern "C" void vtgb_debug_set_gemm_large_variant(int v) { g_large_variant = v; 
 extern "C" void vtgb_debug_set_gemm_ablate(int v) { g_ablate = v; }
 #endif
 
+// The large kernel addresses its operands as (tile base descriptor) + 32-bit byte offset: true when every offset inside one
+// tile fits (row maps must be monotone: a 256-row tile then spans 256 rows plus the gaps of the segments it crosses).
+static bool large_kernel_addressable(const GemmDesc& d) {
+    int64_t span = 512;                                        // rows of the widest tile
+    if (d.a_map.seg_rows != 0) {
+        if (d.a_map.seg_stride < d.a_map.seg_rows) return false;
+        span += (512 / d.a_map.seg_rows + 2) * (d.a_map.seg_stride - d.a_map.seg_rows);
+    }
+    if (d.conv_KH > 0) {
+        if (d.conv_KH > 7 || d.conv_KW > 7) return false;      // tap-validity bits: 7 + 7 per staged row
+        const int64_t hw = (int64_t)d.conv_H * d.conv_W, hiwi = (int64_t)(d.conv_Hi ? d.conv_Hi : d.conv_H) * (d.conv_Wi ? d.conv_Wi : d.conv_W);
+        span = (512 / hw + 2) * hiwi;                          // input pixels of the images one tile touches
+        if (span >= (1 << 24)) return false;                   // pixel index field of the per-lane offset word
+    }
+    const int64_t ld = d.lda > d.lda2 ? d.lda : d.lda2;
+    return span * ld * 2 < 0x7FFFFF00ll && (int64_t)256 * d.ldw * 2 < 0x7FFFFF00ll;
+}
+
 template <int EPI>
 static int launch_epi(const GemmDesc& d, hipStream_t s) {
     if (d.dtype == VTGB_BF16) {
         const int m_tiles = (d.M + L_BM - 1) / L_BM, n_tiles = (d.N + L_BN - 1) / L_BN;
-        if ((d.K % L_BK) == 0 && (int64_t)m_tiles * n_tiles >= g_large_min_tiles) {
+        if ((d.K % L_BK) == 0 && (int64_t)m_tiles * n_tiles >= g_large_min_tiles && large_kernel_addressable(d)) {
             // m-tiles per XCD super-tile: measured best 2 for narrow outputs (<= 8 n-tiles), 8 for wide ones
             const int G = g_large_variant > 0 ? g_large_variant : (n_tiles <= 8 ? 2 : 8);
             const int mx = (m_tiles + 7) / 8, groups = (mx + G - 1) / G;
@@ -1157,6 +1070,7 @@ int launch_conv_gemm(const GemmDesc& d, hipStream_t s) {
     }
     if (d.dtype == VTGB_F32) return launch_conv_f32(d, s);
     VTGB_REQUIRE((d.K % L_BK) == 0 && (d.lda % 8) == 0 && (d.ldw % 8) == 0, VTGB_EUNSUPPORTED, "conv gemm: K=%d must be a multiple of 64", d.K);
+    VTGB_REQUIRE(large_kernel_addressable(d), VTGB_EUNSUPPORTED, "conv gemm: tile footprint beyond the 32-bit offsets of the LDS-DMA descriptors (%dx%d taps)", d.conv_KH, d.conv_KW);
     if (d.gate_from > 0)
         VTGB_REQUIRE(d.epi == EPI_STORE && (d.gate_from % 8) == 0 && (d.N % 8) == 0 && (d.ldo % 8) == 0 && d.aux && d.out2 && (d.ldaux % 8) == 0 &&
                          (d.ldo2 % 8) == 0,
