@@ -54,13 +54,19 @@ __global__ void raft_init_kernel(const float* __restrict__ net, const float* __r
 struct CorrPyr { const void* lvl[4]; int h[4], w[4]; };
 
 constexpr int CL_PIX = 8;   // pixels per wave (the per-lane tap tables are built once and reused)
+// Software-pipelined over the wave's pixels: the 8 window loads of pixel i + 1 (unconditional, clamped addresses: hipcc can
+// then count them) are in flight while pixel i is interpolated out of LDS; the flow of all CL_PIX pixels is fetched by one load
+// up front; the 384 outputs of a pixel leave through an LDS staging row as ONE 16-byte store per lane (48 lanes; was six 2-byte
+// stores per lane -- the store path is per-instruction bound).
 template <typename CT, typename OT>
 __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr, const float* __restrict__ flow, OT* __restrict__ out,
                                                                int64_t M, int H8, int W8) {
     __shared__ float win[4][4][104];   // [wave][level][10 x 10 window | wx | wy | pad]
+    __shared__ __attribute__((aligned(16))) OT stage[4][2][384];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wy0 = lane / 10, wx0 = lane - wy0 * 10;                 // window element `lane`
-    const int wy1 = (lane + 64) / 10, wx1 = lane + 64 - wy1 * 10;     // window element `lane + 64` (< 100 for lane < 36)
+    const int e1 = lane < 36 ? lane + 64 : 99;                        // window element `lane + 64` (lanes >= 36 repeat the last one)
+    const int wy1 = e1 / 10, wx1 = e1 - wy1 * 10;
     // output k = kk * 64 + lane = level * 81 + i * 9 + j  (i: x offset, j: y offset): LDS offsets, fixed per lane
     int tap_off[6], frac_off[6];
 #pragma unroll
@@ -68,35 +74,63 @@ __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr
         const int k = kk * 64 + lane;
         const int l = k / 81, t = k - l * 81, i = t / 9, j = t - i * 9;
         tap_off[kk] = k < 324 ? l * 104 + j * 10 + i : -1;
-        frac_off[kk] = l * 104 + 100;
+        frac_off[kk] = (k < 324 ? l : 0) * 104 + 100;
     }
-    const float* wv = &win[wave][0][0];
+    float* const wv = &win[wave][0][0];
     const int HW = H8 * W8;
     const int64_t m_first = ((int64_t)blockIdx.x * 4 + wave) * CL_PIX;
-    for (int pi = 0; pi < CL_PIX; pi++) {
-        const int64_t m = m_first + pi;
-        if (m >= M) break;                                            // wave-uniform
-        const int p = (int)(m % HW);
-        const float2 fl = *reinterpret_cast<const float2*>(flow + m * 2);
-        const float cx = (float)(p % W8) + fl.x, cy = (float)(p / W8) + fl.y;
-#pragma unroll
-        for (int l = 0; l < 4; l++) {
-            const int hl = pyr.h[l], wl = pyr.w[l];
-            const CT* img = reinterpret_cast<const CT*>(pyr.lvl[l]) + m * (int64_t)(hl * wl);
-            const float sc = 1.0f / (float)(1 << l);
-            const float xs = cx * sc, ys = cy * sc, x0f = floorf(xs), y0f = floorf(ys);
-            const int x0 = (int)x0f - 4, y0 = (int)y0f - 4;
-            {
-                const int y = y0 + wy0, x = x0 + wx0;
-                win[wave][l][lane] = ((unsigned)y < (unsigned)hl && (unsigned)x < (unsigned)wl) ? (float)img[y * wl + x] : 0.f;
-            }
-            if (lane < 36) {
-                const int y = y0 + wy1, x = x0 + wx1;
-                win[wave][l][lane + 64] = ((unsigned)y < (unsigned)hl && (unsigned)x < (unsigned)wl) ? (float)img[y * wl + x] : 0.f;
-            }
-            if (lane == 63) { win[wave][l][100] = xs - x0f; win[wave][l][101] = ys - y0f; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the windows are private to this wave
+    if (m_first >= M) return;                                         // wave-uniform
+    const int npx = (int)(M - m_first < CL_PIX ? M - m_first : CL_PIX);
+    const int p_first = (int)(m_first % HW);                          // one 64-bit division per wave, not per pixel
+    // flows of the wave's pixels: lane i holds pixel i's
+    const float2 flv = *reinterpret_cast<const float2*>(flow + (m_first + (lane < npx ? lane : 0)) * 2);
+    CT cur[8], nxt[8];
+    float fx[4], fy[4], nfx[4], nfy[4];
+    int cur_ok, nxt_ok;
+    // the window of pixel pi: 2 loads per level into r[2 l], r[2 l + 1]; fractions into qx / qy
+#define CL_FETCH(pi, r, qx, qy)                                                                         \
+    {                                                                                                   \
+        r##_ok = 0;                                                                                     \
+        const int64_t m = m_first + (pi);                                                               \
+        int p = p_first + (pi);                          /* pixel inside its image (CL_PIX <= HW) */    \
+        p = p >= HW ? p - HW : p;                                                                       \
+        const float cx = (float)(p % W8) + __shfl(flv.x, (pi)), cy = (float)(p / W8) + __shfl(flv.y, (pi)); \
+        _Pragma("unroll") for (int l = 0; l < 4; l++) {                                                 \
+            const int hl = pyr.h[l], wl = pyr.w[l];                                                     \
+            const CT* img = reinterpret_cast<const CT*>(pyr.lvl[l]) + m * (int64_t)(hl * wl);           \
+            const float sc = 1.0f / (float)(1 << l);                                                    \
+            const float xs = cx * sc, ys = cy * sc, x0f = floorf(xs), y0f = floorf(ys);                 \
+            const int x0 = (int)x0f - 4, y0 = (int)y0f - 4;                                             \
+            const int ya = y0 + wy0, xa = x0 + wx0, yb = y0 + wy1, xb = x0 + wx1;                       \
+            const bool oka = (unsigned)ya < (unsigned)hl && (unsigned)xa < (unsigned)wl;                \
+            const bool okb = (unsigned)yb < (unsigned)hl && (unsigned)xb < (unsigned)wl;                \
+            r[2 * l] = img[oka ? ya * wl + xa : 0];          /* raw: the out-of-window select waits until the deposit */ \
+            r[2 * l + 1] = img[okb ? yb * wl + xb : 0];                                                 \
+            r##_ok |= ((int)oka << (2 * l)) | ((int)okb << (2 * l + 1));                                \
+            qx[l] = xs - x0f; qy[l] = ys - y0f;                                                         \
+        }                                                                                               \
+    }
+#define CL_DEPOSIT(r, qx, qy)                                                                           \
+    _Pragma("unroll") for (int l = 0; l < 4; l++) {                                                     \
+        wv[l * 104 + lane] = (r##_ok >> (2 * l)) & 1 ? (float)r[2 * l] : 0.f;                           \
+        if (lane < 36) wv[l * 104 + lane + 64] = (r##_ok >> (2 * l + 1)) & 1 ? (float)r[2 * l + 1] : 0.f; \
+        if (lane == 63) { wv[l * 104 + 100] = qx[l]; wv[l * 104 + 101] = qy[l]; }                       \
+    }
+    constexpr int CHUNKS = 384 * (int)sizeof(OT) / 16;
+#define CL_STORE(pi)                                                                                    \
+    _Pragma("unroll") for (int c = lane; c < CHUNKS; c += 64)                                           \
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out + (m_first + (pi)) * 384) + c * 16) =     \
+            *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(&stage[wave][(pi) & 1][0]) + c * 16);
+    CL_FETCH(0, cur, fx, fy)
+    CL_DEPOSIT(cur, fx, fy)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // the windows are private to this wave
+    // iteration pi: store pixel pi - 1 (staged last time) | issue the window loads of pixel pi + 1 | interpolate pixel pi out of
+    // LDS into the other staging row | wait for the loads (the only vmcnt wait of the iteration: the store in front of them
+    // has had the whole interpolation to complete) and deposit them
+    for (int pi = 0; pi < npx; pi++) {
+        if (pi > 0) { CL_STORE(pi - 1) }
+        const int pn = pi + 1 < npx ? pi + 1 : pi;                    // (the last iteration re-fetches its own pixel: no tail branch)
+        CL_FETCH(pn, nxt, nfx, nfy)
 #pragma unroll
         for (int kk = 0; kk < 6; kk++) {
             float v = 0.f;
@@ -105,10 +139,16 @@ __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr
                 const float* q = wv + tap_off[kk];
                 v = (1.f - wy) * ((1.f - wx) * q[0] + wx * q[1]) + wy * ((1.f - wx) * q[10] + wx * q[11]);
             }
-            out[m * 384 + kk * 64 + lane] = (OT)v;
+            stage[wave][pi & 1][kk * 64 + lane] = (OT)v;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // before the next pixel overwrites the windows
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // window reads done, staging row written
+        CL_DEPOSIT(nxt, nfx, nfy)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    CL_STORE(npx - 1)
+#undef CL_STORE
+#undef CL_FETCH
+#undef CL_DEPOSIT
 }
 
 // ---------------------------------------------------------------------------------------
