@@ -421,6 +421,30 @@ int vtgb_llm_decode_attention(int dtype, const void* q, const void* kc, const vo
                               int32_t nq, int32_t nkv, int32_t hd, int32_t tmax, float scale, vtgb_stream_t stream);
 int vtgb_llm_silu_mul(int dtype, const void* gu, void* act, int64_t rows, int32_t I, vtgb_stream_t stream);
 
+/* Skinny GEMM of the decode step: out[M, N] = x[M, K] . w[N, K]^T, bf16 operands, M <= 128 (one token per
+ * clip), K a multiple of 64 -- what `F.linear(h, weight)` (hipBLASLt) computes under `language_model.generate`
+ * (eval/utils/model.py:223-233; transformers LlamaDecoderLayer's q/k/v/o/gate/up/down projections and lm_head).  The weights
+ * stream from HBM once: one workgroup per (128-row weight tile, K split) -- `n_splits` splits (0 = chosen by the library) where
+ * the tiles alone would leave CUs without a stream; every workgroup leaves an fp32 fragment in `workspace` (n_tiles * n_splits
+ * * M * 128 * 4 bytes) and a second launch adds a tile's fragments in a fixed order and rounds once to `out_dtype`
+ * (deterministic: no atomics). */
+typedef struct {
+    int32_t M, N, K, n_splits;
+    const void* x; int64_t ldx;          /* bf16 [M, K] */
+    const void* w; int64_t ldw;          /* bf16 [N, K] (nn.Linear.weight) */
+    void* out; int64_t ldo;              /* [M, N] */
+    int32_t out_dtype;                   /* VTGB_BF16 | VTGB_F32 */
+    int32_t w_tiled;                     /* 1: `w` was prepared by vtgb_pack_skinny_weight (ldw ignored): every (128-row tile, 64-deep
+                                            k-tile) is one contiguous 16 KiB block in the kernel's LDS order -- 1 KiB reads instead of
+                                            eight 128-byte row segments a DRAM page apart */
+    void* workspace;
+    size_t workspace_bytes;
+} vtgb_gemm_skinny_args;
+size_t vtgb_pack_skinny_weight_bytes(int32_t N, int32_t K);
+int vtgb_pack_skinny_weight(const void* w, int64_t ldw, int32_t N, int32_t K, void* dst, vtgb_stream_t stream);
+size_t vtgb_gemm_skinny_workspace_bytes(const vtgb_gemm_skinny_args* a);
+int vtgb_gemm_skinny(const vtgb_gemm_skinny_args* a, vtgb_stream_t stream);
+
 /* ---- in-library launch timing (used by bench.py for the roofline figure) -------------------
  * While enabled, every GEMM / attention launch of the bf16 path is bracketed by a pair of HIP
  * events recorded on the launch stream (no synchronisation at record time).  vtgb_prof_summary

@@ -69,3 +69,28 @@ def test_greedy_decoder_hipgraph_matches_hf_generate_gpu():
     _check("cuda:0", True, fused=False)
     _check_eos("cuda:0", True)
     _check_eos("cuda:0", False)
+
+
+@pytest.mark.gpu
+def test_small_batch_decode_runs_on_the_skinny_gemm_and_matches_hipblaslt():
+    """Batches <= GreedyDecoder.SKINNY_MAX_BATCH take every projection (q|k|v, o, gate|up, down, lm_head) through
+    vtgb_gemm_skinny; the ids must be the ones the hipBLASLt path (F.linear) emits, under graph replay and eagerly."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from videotgb_amd import llm
+    from videotgb_amd.decode import GreedyDecoder
+    dev = "cuda:0"
+    lm = llm.build_llama("tiny", torch.bfloat16, dev, seed=5, hidden_size=128, intermediate_size=256, num_attention_heads=4, num_key_value_heads=4,
+                         num_hidden_layers=3, vocab_size=320)
+    g = torch.Generator(device=dev).manual_seed(2)
+    emb = (torch.randn(2, 5, 128, generator=g, device=dev) * 0.5).bfloat16()
+    own, lib = GreedyDecoder(lm), GreedyDecoder(lm)
+    lib.SKINNY_MAX_BATCH = 0
+    for use_graph in (True, False):
+        a = own.generate(emb, 6, use_graph=use_graph)
+        b = lib.generate(emb, 6, use_graph=use_graph)
+        assert a.tolist() == b.tolist()
+    assert all("sk_ws" in st for st in own.graphs.values()) and not any("sk_ws" in st for st in lib.graphs.values())
+    ref = lm.generate(inputs_embeds=emb, attention_mask=torch.ones(2, 5, dtype=torch.long, device=dev), do_sample=False, max_new_tokens=6,
+                      min_new_tokens=6, use_cache=True)
+    assert own.generate(emb, 6, use_graph=True, min_new_tokens=0).tolist() == ref.tolist()

@@ -27,6 +27,7 @@ EXPORTS = [
     "vtgb_pool_project", "vtgb_tgb_workspace_bytes", "vtgb_tgb_forward", "vtgb_gemm", "vtgb_attention",
     "vtgb_layernorm", "vtgb_prof_enable", "vtgb_prof_reset", "vtgb_prof_summary", "vtgb_prof_executed_flops",
     "vtgb_llm_rmsnorm", "vtgb_llm_rope_cache", "vtgb_llm_decode_attention", "vtgb_llm_silu_mul",
+    "vtgb_gemm_skinny_workspace_bytes", "vtgb_gemm_skinny", "vtgb_pack_skinny_weight_bytes", "vtgb_pack_skinny_weight",
     "vtgb_raft_update_workspace_bytes", "vtgb_raft_update", "vtgb_raft_encoder_workspace_bytes", "vtgb_raft_encoder",
     "vtgb_raft_corr_workspace_bytes", "vtgb_raft_corr", "vtgb_preprocess_frames", "vtgb_concat_text_io", "vtgb_shifted_ce_forward", "vtgb_shifted_ce_backward",
 ]
@@ -111,6 +112,11 @@ class RaftEncoderArgs(C.Structure):
                 ("workspace", vp), ("workspace_bytes", sz)]
 
 
+class GemmSkinnyArgs(C.Structure):
+    _fields_ = [("M", i32), ("N", i32), ("K", i32), ("n_splits", i32), ("x", vp), ("ldx", i64), ("w", vp), ("ldw", i64), ("out", vp), ("ldo", i64),
+                ("out_dtype", i32), ("w_tiled", i32), ("workspace", vp), ("workspace_bytes", sz)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [("dtype", i32), ("M", i32), ("N", i32), ("K", i32), ("epilogue", i32), ("A", vp), ("lda", i64),
                 ("W", vp), ("ldw", i64), ("bias", vp), ("resid", vp), ("out", vp), ("ldo", i64)]
@@ -172,6 +178,14 @@ def lib() -> C.CDLL:
     L.vtgb_llm_rope_cache.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.vtgb_llm_decode_attention.argtypes = [C.c_int, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]
     L.vtgb_llm_silu_mul.argtypes = [C.c_int, vp, vp, i64, i32, vp]
+    L.vtgb_gemm_skinny.argtypes = [C.POINTER(GemmSkinnyArgs), vp]
+    L.vtgb_gemm_skinny.restype = C.c_int
+    L.vtgb_gemm_skinny_workspace_bytes.argtypes = [C.POINTER(GemmSkinnyArgs)]
+    L.vtgb_gemm_skinny_workspace_bytes.restype = sz
+    L.vtgb_pack_skinny_weight_bytes.argtypes = [i32, i32]
+    L.vtgb_pack_skinny_weight_bytes.restype = sz
+    L.vtgb_pack_skinny_weight.argtypes = [vp, i64, i32, i32, vp, vp]
+    L.vtgb_pack_skinny_weight.restype = C.c_int
     L.vtgb_prof_enable.argtypes = [C.c_int]
     L.vtgb_prof_enable.restype = None
     L.vtgb_prof_reset.restype = None

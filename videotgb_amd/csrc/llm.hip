@@ -197,3 +197,214 @@ extern "C" int vtgb_llm_silu_mul(int dtype, const void* gu, void* act, int64_t r
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// Skinny GEMM for the decode step: out[M, N] = x[M, K] . w[N, K]^T with M <= 128 rows (one token per clip) -- the weight
+// matrix is read exactly once, so the kernel is an HBM stream of W with the matrix cores idling behind it.
+//   work      one workgroup per (128-row weight tile, K split): K is split where N / 128 tiles alone would leave most of the 256
+//             CUs without a stream (N = 4096: 32 tiles).  Every workgroup leaves an fp32 fragment of its tile; a second tiny
+//             launch adds a tile's fragments in a FIXED order and rounds once (deterministic: no atomics).  (Equal runs of steps
+//             per CU across tile boundaries -- "stream-K" -- were built and measured slower: two 63 KiB fragments per
+//             workgroup at M = 124 cost more than the balance gains; round 2.)
+//   tile      128 (all of M) x 128 weight rows, 4 waves of 64 x 64, v_mfma_f32_16x16x32_bf16
+//   staging   buffer_load ... lds (LDS-DMA) into TWO rings: 7 weight slots (6 k-tiles = 96 KiB of weights in flight) and 3
+//             activation slots (L2-resident, two ahead) = 160 KiB.  vmcnt completes in order PER WAVE, so a wave that mixed the
+//             deep weight stream with the shallow activation stream would drain the weights every k-tile: waves 0-1 load only
+//             weights, waves 2-3 only activations (each with its own counted wait); all four multiply.  One barrier per step.
+// x rows beyond M are clamped duplicates (never stored); weight rows beyond N read as zeros (descriptor range / packed zeros).
+// ---------------------------------------------------------------------------------------
+constexpr int SK_BN = 128, SK_BK = 64, SK_WSLOTS = 7, SK_XSLOTS = 3, SK_TILE = 128 * 128;   // bytes of one operand tile (128 rows x 64 bf16)
+typedef __attribute__((address_space(3))) void* sk_lptr_t;
+
+__device__ __forceinline__ int sk_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// s_waitcnt vmcnt(8 n), n = 0..5 (vmcnt is 6 bits: [3:0] and [15:14]); the other counters are left alone
+__device__ __forceinline__ void sk_wait_stages(int n) {
+    if (n >= 5) __builtin_amdgcn_s_waitcnt(0x8F78);
+    else if (n == 4) __builtin_amdgcn_s_waitcnt(0x8F70);
+    else if (n == 3) __builtin_amdgcn_s_waitcnt(0x4F78);
+    else if (n == 2) __builtin_amdgcn_s_waitcnt(0x4F70);
+    else if (n == 1) __builtin_amdgcn_s_waitcnt(0x0F78);
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
+// part: [gridDim.x tiles][gridDim.y splits][M][128] fp32
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ x, int M, int ldx, const bf16_t* __restrict__ w, int N, int ldw,
+                                                          int nk, float* __restrict__ part, int w_tiled) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    char* const w_ring = sk_smem;                              // SK_WSLOTS tiles
+    char* const x_ring = sk_smem + SK_WSLOTS * SK_TILE;        // SK_XSLOTS tiles
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const bool w_loader = wave < 2;
+    const int lw = wave & 1;                                   // which half (64 rows) of its operand tile this wave stages
+    const int b = blockIdx.x, S = gridDim.y, sp = blockIdx.y;
+    const int s0 = b * nk + (int)((int64_t)nk * sp / S), s1 = b * nk + (int)((int64_t)nk * (sp + 1) / S), ns = s1 - s0;   // steps = global k-tile index
+    if (ns <= 0) return;
+    // one descriptor per wave (its operand's base); per-lane byte offsets are loop invariant, everything else is scalar.
+    // Row-major weights: range = the matrix, so the rows of the last tile beyond N read as zeros.
+    const bool tiled = w_loader && w_tiled;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(w_loader ? w : x), 0,
+                                                        w_loader && !w_tiled ? (int)(((int64_t)(N - 1) * ldw + nk * SK_BK) * 2) : 0x7FFFFF00, 0x00020000);
+    unsigned voff[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int row = lw * 64 + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
+        const int r = w_loader ? row : (row < M ? row : M - 1);
+        voff[i] = tiled ? (unsigned)((lw * 64 + i * 8) * 128 + lane * 16) : (unsigned)(r * (w_loader ? ldw : ldx) + c * 8) * 2u;
+    }
+    char* const ring = w_loader ? w_ring : x_ring;
+    // scalar byte offset of step st: tiled weights -- the st-th 16 KiB block; row-major weights -- (tile * 128 rows, kt * 64);
+    // activations -- kt * 64
+#define SK_ISSUE(slot, st)                                                                                   \
+    {                                                                                                        \
+        const int b_ = (st) / nk, kt_ = (st) - b_ * nk;                                                      \
+        const int so_ = tiled ? (st) * SK_TILE : w_loader ? (b_ * SK_BN * ldw + kt_ * SK_BK) * 2 : kt_ * (SK_BK * 2); \
+        _Pragma("unroll") for (int i = 0; i < 8; i++)                                                        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (sk_lptr_t)(ring + (slot) * SK_TILE + (lw * 64 + i * 8) * 128), 16, voff[i], so_, 0, 0); \
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int depth = w_loader ? SK_WSLOTS - 1 : SK_XSLOTS - 1, slots = w_loader ? SK_WSLOTS : SK_XSLOTS;   // steps ahead; ring size
+    for (int t = 0; t < depth && t < ns; t++) { SK_ISSUE(t, s0 + t) }
+    const int fr = lane & 15, fg = lane >> 4;
+    int slot_w = 0, slot_x = 0, slot_in = depth % slots;       // slot_in: where this wave's next step goes
+    for (int t = 0; t < ns; t++) {
+        // my pieces of step t have landed when only the younger steps' (8 pieces each) are outstanding
+        const int younger = ns - 1 - t < depth - 1 ? ns - 1 - t : depth - 1;
+        sk_wait_stages(younger);
+        __builtin_amdgcn_s_barrier();                          // both operands of step t are in LDS; everyone is done with step t - 1
+        if (t + depth < ns) { SK_ISSUE(slot_in, s0 + t + depth) }
+        slot_in = slot_in + 1 == slots ? 0 : slot_in + 1;
+        const char* ws = w_ring + slot_w * SK_TILE;
+        const char* xs = x_ring + slot_x * SK_TILE;
+        slot_w = slot_w + 1 == SK_WSLOTS ? 0 : slot_w + 1;
+        slot_x = slot_x + 1 == SK_XSLOTS ? 0 : slot_x + 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 wf[4], xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                wf[i] = *reinterpret_cast<const bf16x8*>(ws + sk_swz(wn * 64 + i * 16 + fr, ks * 4 + fg));
+                xf[i] = *reinterpret_cast<const bf16x8*>(xs + sk_swz(wm * 64 + i * 16 + fr, ks * 4 + fg));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // this workgroup's fragment.  D layout: column (lane & 15) <- x row (m), rows (lane >> 4) * 4 + reg <- w row (n)
+    float* const ps = part + (int64_t)(b * S + sp) * M * SK_BN;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int m = wm * 64 + j * 16 + fr;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (m < M) *reinterpret_cast<f32x4*>(ps + m * SK_BN + wn * 64 + i * 16 + fg * 4) = acc[i][j];
+    }
+#undef SK_ISSUE
+#endif
+}
+
+// One-time weight preparation for the tiled layout: dst[tile b][k-tile kt][row r][16-byte slot q] = src[b * 128 + r][kt * 64 + 8 (q ^ ((r >> 1) & 7)) ...],
+// rows beyond N zero.  One thread per 16-byte chunk.
+__global__ __launch_bounds__(256) void skinny_pack_kernel(const bf16_t* __restrict__ src, int64_t ld, int N, int nk, bf16_t* __restrict__ dst, int64_t chunks) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= chunks) return;
+    const int q = (int)(i & 7), r = (int)((i >> 3) & 127);
+    const int64_t blk = i >> 10, b = blk / nk, kt = blk - b * nk;
+    const int64_t n = b * 128 + r;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (n < N) v = *reinterpret_cast<const uint4*>(src + n * ld + kt * 64 + 8 * (q ^ ((r >> 1) & 7)));
+    *reinterpret_cast<uint4*>(dst + i * 8) = v;
+}
+
+extern "C" size_t vtgb_pack_skinny_weight_bytes(int32_t N, int32_t K) {
+    if (N <= 0 || K <= 0 || (K % SK_BK) != 0) return 0;
+    return (size_t)((N + SK_BN - 1) / SK_BN) * (K / SK_BK) * SK_TILE;
+}
+
+extern "C" int vtgb_pack_skinny_weight(const void* w, int64_t ldw, int32_t N, int32_t K, void* dst, vtgb_stream_t s) {
+    VTGB_REQUIRE(w && dst && N > 0 && K > 0 && (K % SK_BK) == 0 && (ldw % 8) == 0 && ldw >= K, VTGB_EINVAL, "pack_skinny_weight: N=%d K=%d ldw=%lld", N, K,
+                 (long long)ldw);
+    const int64_t chunks = (int64_t)vtgb_pack_skinny_weight_bytes(N, K) / 16;
+    hipLaunchKernelGGL(skinny_pack_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, (const bf16_t*)w, ldw, N, K / SK_BK, (bf16_t*)dst, chunks);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+// out[m][b * 128 + c] = sum over the splits, in split order, of tile b's fragments
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_skinny_reduce_kernel(const float* __restrict__ part, int M, int N, int S, T* __restrict__ out, int64_t ldo) {
+    const int b = blockIdx.x, c4 = (threadIdx.x & 31) * 4, n = b * SK_BN + c4;
+    if (n >= N) return;
+    for (int m = blockIdx.y * 8 + (threadIdx.x >> 5); m < M; m += gridDim.y * 8) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < S; sp++) v += *reinterpret_cast<const f32x4*>(part + ((int64_t)(b * S + sp) * M + m) * SK_BN + c4);
+        T* o = out + m * ldo + n;
+        if (n + 3 < N) {
+            if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x4*>(o) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            else *reinterpret_cast<f32x4*>(o) = v;
+        } else {
+            for (int e = 0; e < 4 && n + e < N; e++) o[e] = (T)v[e];
+        }
+    }
+}
+
+// splits: every CU should hold a stream, but a split costs an fp32 fragment (M x 128 x 4 bytes written and read back) and a
+// shorter pipeline: the smallest count in 1..8 that reaches 192 workgroups, never below 8 k-tiles per split
+static int skinny_splits(const vtgb_gemm_skinny_args* a) {
+    const int nk = a->K / SK_BK, n_tiles = (a->N + SK_BN - 1) / SK_BN;
+    if (a->n_splits > 0) return a->n_splits < nk ? a->n_splits : nk;
+    int S = 1;
+    while (S < 8 && n_tiles * S < 192 && nk / (S + 1) >= 8) S++;
+    return S;
+}
+
+static int skinny_check(const vtgb_gemm_skinny_args* a) {
+    VTGB_REQUIRE(a, VTGB_EINVAL, "gemm_skinny: NULL args");
+    VTGB_REQUIRE(a->M > 0 && a->M <= 128 && a->N > 0 && a->K > 0 && (a->K % SK_BK) == 0, VTGB_EUNSUPPORTED,
+                 "gemm_skinny: M=%d (<= 128), N=%d, K=%d (multiple of 64)", a->M, a->N, a->K);
+    VTGB_REQUIRE((a->ldx % 8) == 0 && a->ldx >= a->K && a->ldo >= a->N && (int64_t)128 * a->ldx * 2 < 0x7FFFFF00ll &&
+                     (a->w_tiled ? (int64_t)((a->N + 127) / 128) * 128 * a->K * 2 < 0x7FFFFF00ll
+                                 : ((a->ldw % 8) == 0 && a->ldw >= a->K && (int64_t)((a->N + 127) / 128) * 128 * a->ldw * 2 < 0x7FFFFF00ll)),
+                 VTGB_EINVAL, "gemm_skinny: row pitches ldx=%lld ldw=%lld ldo=%lld (operands must stay below 2 GiB)", (long long)a->ldx, (long long)a->ldw,
+                 (long long)a->ldo);
+    VTGB_REQUIRE(a->out_dtype == VTGB_BF16 || a->out_dtype == VTGB_F32, VTGB_EINVAL, "gemm_skinny: bad out_dtype %d", a->out_dtype);
+    VTGB_REQUIRE(a->n_splits >= 0 && a->n_splits <= 64, VTGB_EINVAL, "gemm_skinny: n_splits=%d", a->n_splits);
+    return VTGB_OK;
+}
+
+extern "C" size_t vtgb_gemm_skinny_workspace_bytes(const vtgb_gemm_skinny_args* a) {
+    if (skinny_check(a) != VTGB_OK) return 0;
+    return (size_t)((a->N + SK_BN - 1) / SK_BN) * skinny_splits(a) * a->M * SK_BN * sizeof(float);
+}
+
+extern "C" int vtgb_gemm_skinny(const vtgb_gemm_skinny_args* a, vtgb_stream_t s) {
+    VTGB_TRY(skinny_check(a));
+    VTGB_REQUIRE(a->x && a->w && a->out && a->workspace, VTGB_EINVAL, "gemm_skinny: NULL operand");
+    const int nk = a->K / SK_BK, n_tiles = (a->N + SK_BN - 1) / SK_BN, S = skinny_splits(a);
+    const size_t need = (size_t)n_tiles * S * a->M * SK_BN * sizeof(float);
+    VTGB_REQUIRE(a->workspace_bytes >= need, VTGB_EWORKSPACE, "gemm_skinny: workspace %zu < %zu bytes", a->workspace_bytes, need);
+    constexpr int LDS = (SK_WSLOTS + SK_XSLOTS) * SK_TILE;
+    static DeviceOnce attr;
+    VTGB_FUNC_LDS_ONCE(attr, gemm_skinny_kernel, LDS);
+    {
+        ProfScope prof(VTGB_PROF_GEMM, 2.0 * a->M * a->N * a->K, s);
+        hipLaunchKernelGGL(gemm_skinny_kernel, dim3(n_tiles, S), dim3(256), LDS, s, (const bf16_t*)a->x, a->M, (int)a->ldx, (const bf16_t*)a->w, a->N,
+                           (int)a->ldw, nk, (float*)a->workspace, a->w_tiled);
+    }
+    const dim3 rgrid(n_tiles, (a->M + 7) / 8 < 4 ? (a->M + 7) / 8 : 4);
+    if (a->out_dtype == VTGB_BF16)
+        hipLaunchKernelGGL(gemm_skinny_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, s, (const float*)a->workspace, a->M, a->N, S, (bf16_t*)a->out, a->ldo);
+    else
+        hipLaunchKernelGGL(gemm_skinny_reduce_kernel<float>, rgrid, dim3(256), 0, s, (const float*)a->workspace, a->M, a->N, S, (float*)a->out, a->ldo);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}

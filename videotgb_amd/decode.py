@@ -65,6 +65,24 @@ class GreedyDecoder:
         self.inter = cfg.intermediate_size
         self.fused = fused
         self.graphs: Dict[Tuple[int, int, int], dict] = {}
+        self._skinny = None            # per layer (wqkv, wo, wgu, wd) + lm_head in vtgb_gemm_skinny's tiled layout, built on first use
+
+    # Projections of the decode step through libvtgb.so's own weight-streaming GEMM (vtgb_gemm_skinny, tiled weights).  Measured
+    # on Vicuna-7B shapes (tools/exp/skinny_bench.py): 3.89 vs 4.30 ms per token at batch 1, 4.06 vs 3.66 at 32, 5.34 vs 4.50 at
+    # 124 (its fp32 fragments grow with the batch) -- so it serves small batches (the one-clip latency path) and hipBLASLt
+    # (F.linear) keeps the clip-batched throughput path.
+    SKINNY_MAX_BATCH = 8
+
+    def _skinny_weights(self):
+        if self._skinny is None:
+            from . import ops
+            self._skinny = [tuple(ops.SkinnyWeight(w) for w in (wqkv, wo, wgu, wd)) for (_, wqkv, wo, _, wgu, wd) in self.layers]
+            self._skinny.append(ops.SkinnyWeight(self.lm.lm_head.weight))
+        return self._skinny
+
+    def _use_skinny(self, B: int, dtype) -> bool:
+        H, I = self.cfg.hidden_size, self.inter
+        return self.fused and dtype == torch.bfloat16 and B <= self.SKINNY_MAX_BATCH and H % 64 == 0 and I % 64 == 0 and (self.nh * self.hd) % 64 == 0
 
     def _rope(self, tmax: int, device, dtype):
         inv = 1.0 / (self.theta ** (torch.arange(0, self.hd, 2, device=device, dtype=torch.float32) / self.hd))
@@ -115,6 +133,16 @@ class GreedyDecoder:
                       q=torch.zeros(B, self.nh * self.hd, device=device, dtype=dtype),
                       a=torch.zeros(B, self.nh * self.hd, device=device, dtype=dtype),
                       act=torch.zeros(B, self.inter, device=device, dtype=dtype))
+            if device.type == "cuda" and self._use_skinny(B, dtype):
+                from . import ops
+                Hq, V = (self.nh + 2 * self.nkv) * self.hd, self.lm.lm_head.weight.shape[0]
+                shapes = ((Hq, self.cfg.hidden_size), (self.cfg.hidden_size, self.nh * self.hd), (2 * self.inter, self.cfg.hidden_size),
+                          (self.cfg.hidden_size, self.inter), (V, self.cfg.hidden_size))
+                st.update(sk_qkv=torch.zeros(B, Hq, device=device, dtype=dtype), sk_o=torch.zeros(B, self.cfg.hidden_size, device=device, dtype=dtype),
+                          sk_gu=torch.zeros(B, 2 * self.inter, device=device, dtype=dtype),
+                          sk_d=torch.zeros(B, self.cfg.hidden_size, device=device, dtype=dtype), sk_logits=torch.zeros(B, V, device=device, dtype=dtype),
+                          sk_ws=torch.zeros(max(ops.gemm_skinny_workspace_bytes(B, n, k) for n, k in shapes), dtype=torch.uint8, device=device))
+                self._skinny_weights()
             self.graphs[key] = st
         return st
 
@@ -134,22 +162,35 @@ class GreedyDecoder:
         pos = st["pos"]
         h, q, a, act = st["h"], st["q"], st["a"], st["act"]
         delta = None
+        skinny = "sk_ws" in st
+        if skinny:
+            from . import ops
+            sw, ws = self._skinny_weights(), st["sk_ws"]
+
+            def lin(xin, li, which, buf):      # which: 0 qkv, 1 o, 2 gate|up, 3 down
+                return ops.gemm_skinny(xin, sw[li][which], out=st[buf], workspace=ws)
+        else:
+            def lin(xin, li, which, buf):
+                return F.linear(xin, self.layers[li][(1, 2, 4, 5)[which]])
         for li, (ln1, wqkv, wo, ln2, wgu, wd) in enumerate(self.layers):
             L.check(lib.vtgb_llm_rmsnorm(code, x.data_ptr(), None if delta is None else delta.data_ptr(), ln1.data_ptr(), h.data_ptr(),
                                          B, H, self.eps, stream))
-            qkv = F.linear(h, wqkv)
+            qkv = lin(h, li, 0, "sk_qkv")
             L.check(lib.vtgb_llm_rope_cache(code, qkv.data_ptr(), q.data_ptr(), st["kc"][li].data_ptr(), st["vc"][li].data_ptr(),
                                             st["cos"].data_ptr(), st["sin"].data_ptr(), pos.data_ptr(), B, nq, nkv, hd, tmax, stream))
             L.check(lib.vtgb_llm_decode_attention(code, q.data_ptr(), st["kc"][li].data_ptr(), st["vc"][li].data_ptr(), a.data_ptr(),
                                                   pos.data_ptr(), B, nq, nkv, hd, tmax, float(hd) ** -0.5, stream))
-            o = F.linear(a, wo)
+            o = lin(a, li, 1, "sk_o")
             L.check(lib.vtgb_llm_rmsnorm(code, x.data_ptr(), o.data_ptr(), ln2.data_ptr(), h.data_ptr(), B, H, self.eps, stream))
-            gu = F.linear(h, wgu)
+            gu = lin(h, li, 2, "sk_gu")
             L.check(lib.vtgb_llm_silu_mul(code, gu.data_ptr(), act.data_ptr(), B, self.inter, stream))
-            delta = F.linear(act, wd)
+            delta = lin(act, li, 3, "sk_d")
         L.check(lib.vtgb_llm_rmsnorm(code, x.data_ptr(), delta.data_ptr(), self.lm.model.norm.weight.data_ptr(), h.data_ptr(), B, H,
                                      self.eps, stream))
-        self._emit(st, F.linear(h, self.lm.lm_head.weight))
+        if skinny:
+            self._emit(st, ops.gemm_skinny(h, sw[-1], out=st["sk_logits"], workspace=ws))
+        else:
+            self._emit(st, F.linear(h, self.lm.lm_head.weight))
 
     def _pick(self, st, logits: Tensor, step) -> Tensor:
         """Greedy token of every row with HF's EOS semantics (device-side, capturable): EOS masked while step < min_new_tokens,

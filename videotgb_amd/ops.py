@@ -159,6 +159,50 @@ def gemm(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, epilogue: int = L.
     return out
 
 
+class SkinnyWeight:
+    """nn.Linear.weight [N, K] (bf16) re-laid for vtgb_gemm_skinny's weight stream (vtgb_pack_skinny_weight; one-time)."""
+
+    def __init__(self, w: Tensor):
+        _need_cuda(w)
+        w = w.detach()
+        assert w.dtype == torch.bfloat16 and w.dim() == 2 and w.stride(1) == 1
+        self.N, self.K = w.shape
+        nbytes = L.lib().vtgb_pack_skinny_weight_bytes(self.N, self.K)
+        if nbytes == 0:
+            raise NotImplementedError(f"SkinnyWeight: K={self.K} must be a multiple of 64")
+        self.data = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        L.check(L.lib().vtgb_pack_skinny_weight(w.data_ptr(), w.stride(0), self.N, self.K, self.data.data_ptr(), _stream()))
+
+
+def gemm_skinny_workspace_bytes(M: int, N: int, K: int, n_splits: int = 0) -> int:
+    a = L.GemmSkinnyArgs(M, N, K, n_splits, None, K, None, K, None, N, BF16, 0, None, 0)
+    return int(L.lib().vtgb_gemm_skinny_workspace_bytes(C.byref(a)))
+
+
+def gemm_skinny(x: Tensor, w: Tensor, out: Optional[Tensor] = None, n_splits: int = 0, out_dtype: Optional[torch.dtype] = None,
+                workspace: Optional[Tensor] = None) -> Tensor:
+    """x [M <= 128, K] bf16, w [N, K] bf16 (nn.Linear.weight, or its SkinnyWeight) -> x @ w.T [M, N]: the decode step's projections (vtgb_gemm_skinny:
+    the weights stream once, K split over workgroups, fp32 partials added in a fixed order).  ``out`` may be a preallocated
+    [M, N] tensor and ``workspace`` a preallocated uint8 scratch (hipGraph capture: fixed addresses, no allocation)."""
+    tiled = isinstance(w, SkinnyWeight)
+    _need_cuda(x, w.data if tiled else w)
+    assert x.dtype == torch.bfloat16 and x.stride(1) == 1 and (tiled or (w.dtype == torch.bfloat16 and w.stride(1) == 1))
+    M, K = x.shape
+    N = w.N if tiled else w.shape[0]
+    assert not tiled or w.K == K
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype or x.dtype, device=x.device)
+    a = L.GemmSkinnyArgs(M, N, K, n_splits, x.data_ptr(), x.stride(0), w.data.data_ptr() if tiled else w.data_ptr(), K if tiled else w.stride(0),
+                         out.data_ptr(), out.stride(0), dtype_code(out.dtype), 1 if tiled else 0, None, 0)
+    need = L.lib().vtgb_gemm_skinny_workspace_bytes(C.byref(a))
+    if need == 0:
+        L.check(L.lib().vtgb_gemm_skinny(C.byref(a), _stream()))      # reports the argument error
+    ws = workspace if workspace is not None else _ws.get(need, x.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.check(L.lib().vtgb_gemm_skinny(C.byref(a), _stream()))
+    return out
+
+
 def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, key_mask: Optional[Tensor] = None,
               rope_q: Optional[Tensor] = None, rope_k: Optional[Tensor] = None) -> Tensor:
     """q [B, Sq, H*hd], k/v [B, Skv, H*hd] (any token/batch strides, unit channel stride) -> [B, Sq, H*hd]."""
