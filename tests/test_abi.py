@@ -85,6 +85,19 @@ def test_argument_validation_of_the_wider_rows(lib):
     assert L.vtgb_raft_corr_workspace_bytes(C.byref(cp)) == 0 and b"pair -> image map" in L.vtgb_last_error()
     cp.n_images, cp.dim = 96, 128
     assert L.vtgb_raft_corr(C.byref(cp), None) == EINVAL and b"bad dims" in L.vtgb_last_error()
+    # decode-step GEMM: M <= 128, K a multiple of 64; one fp32 fragment per (128-column tile, split)
+    sk = lib.GemmSkinnyArgs(124, 4096, 4096, 0, None, 4096, None, 4096, None, 4096, lib.BF16, 0, None, 0)
+    need = L.vtgb_gemm_skinny_workspace_bytes(C.byref(sk))
+    assert need % (32 * 124 * 128 * 4) == 0 and 1 <= need // (32 * 124 * 128 * 4) <= 8                  # 32 tiles x 1..8 splits
+    assert L.vtgb_gemm_skinny(C.byref(sk), None) == EINVAL and b"NULL" in L.vtgb_last_error()
+    sk.n_splits = 3
+    assert L.vtgb_gemm_skinny_workspace_bytes(C.byref(sk)) == 3 * 32 * 124 * 128 * 4
+    sk.M = 129
+    assert L.vtgb_gemm_skinny_workspace_bytes(C.byref(sk)) == 0 and b"M=129" in L.vtgb_last_error()
+    sk.M, sk.K = 1, 100
+    assert L.vtgb_gemm_skinny_workspace_bytes(C.byref(sk)) == 0 and b"K=100" in L.vtgb_last_error()
+    assert L.vtgb_pack_skinny_weight_bytes(32000, 4096) == 250 * 64 * 16384 and L.vtgb_pack_skinny_weight_bytes(100, 100) == 0
+    assert L.vtgb_pack_skinny_weight(None, 4096, 4096, 4096, None, None) == EINVAL
 
 
 def test_product_path_has_no_cpu_fallback(lib):
