@@ -158,6 +158,13 @@ struct GemmDesc {
     // every iteration; the once-per-call start-map convolutions that carry the hoisted part are credited with 0 (< 0 here).
     // 0 = executed.  The executed FLOPs are accumulated separately (vtgb_prof_executed_flops).
     double algo_flops;
+    // EPI_STORE, 256-wide tile, N == 256 (one n-tile), bf16 staged store: instead of storing the activated tile, multiply it
+    // by tail_w [32][256] (bf16, a following 1x1 convolution with <= 32 outputs, no bias) while it sits in LDS and store
+    // tail_out[m][0..32) (fp32, row stride ldtail) -- RAFT's FlowHead: relu(conv1) never leaves the CU, only the 18 per-tap
+    // partial products of conv2 do.  `out` is not written.
+    const void* tail_w;
+    float* tail_out;
+    int64_t ldtail;
 };
 #define VTGB_EPI_GRU 4
 int launch_gemm(const GemmDesc& d, hipStream_t s);

@@ -527,6 +527,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         }
         if constexpr (EPI == EPI_STORE || EPI == EPI_GELU) {
             if (staged_store) __builtin_amdgcn_s_barrier();   // the barrier in front of the LDS-staged stores
+            if constexpr (EPI == EPI_STORE && NWN == 4 && NXF == 8) {
+                if (staged_store && p.tail_w) __builtin_amdgcn_s_barrier();   // ... and the one in front of the fused 1x1 tail
+            }
         } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
             if (((p.N & 3) == 0) && ((p.ldo & 3) == 0) && p.act == 0 && p.out_scale == 0.f) {
                 __builtin_amdgcn_s_barrier();
@@ -635,6 +638,41 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                     const int row = j * 16 + fr, c16 = (i * 2 + (fg >> 1)) ^ (row & 7);
                     *reinterpret_cast<bf16x4*>(cst + row * 128 + c16 * 16 + (fg & 1) * 8) = pk;
                 }
+            if constexpr (EPI == EPI_STORE && NWN == 4 && NXF == 8) {
+                if (p.tail_w) {
+                    // Fused 1x1 tail: T[256 px][32] = tile[256 px][256 ch] . tail_w[32][256]^T.  The activated bf16 tile is in LDS
+                    // (wave (wm, wn) owns rows wm * 128 .., columns wn * 64 .. as 128-byte rows, 16-byte chunks XOR row & 7); the
+                    // four waves of a row half split its 8 pixel blocks, two each: 2 blocks x 2 output blocks x 8 k-steps = 32 MFMAs.
+                    // tail_w fragments come straight from global (16 KiB, L2 resident) into registers the accumulators no longer need.
+                    const bf16_t* const tw = reinterpret_cast<const bf16_t*>(p.tail_w);
+                    bf16x8 twf[2][8];
+#pragma unroll
+                    for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+                        for (int ks = 0; ks < 8; ks++) twf[nb][ks] = *reinterpret_cast<const bf16x8*>(tw + (nb * 16 + fr) * 256 + ks * 32 + fg * 8);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);   // my staging writes
+                    __builtin_amdgcn_s_barrier();         // everyone's: the tile is complete
+#pragma unroll
+                    for (int pb = 0; pb < 2; pb++) {
+                        const int blk = wn * 2 + pb, row = blk * 16 + fr;          // pixel block inside this wave's row half
+                        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+#pragma unroll
+                        for (int ks = 0; ks < 8; ks++) {
+                            const int k = ks * 32 + fg * 8, reg = k >> 6, c16 = (k & 63) >> 3;   // column k lives in wave (wm, k / 64)'s region
+                            const bf16x8 xfr = *reinterpret_cast<const bf16x8*>(smem + (wm + MW * reg) * (WROWS * 128) + row * 128 + ((c16 ^ (row & 7)) << 4));
+                            t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twf[0][ks], xfr, t0, 0, 0, 0);
+                            t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twf[1][ks], xfr, t1, 0, 0, 0);
+                        }
+                        const int m = m0 + wm * WROWS + row;                       // D: column (lane & 15) <- pixel, rows 4 fg + r <- output
+                        if (m < p.M) {
+                            float* o = p.tail_out + (int64_t)m * p.ldtail + fg * 4;
+                            *reinterpret_cast<f32x4*>(o) = t0;
+                            *reinterpret_cast<f32x4*>(o + 16) = t1;
+                        }
+                    }
+                    return;
+                }
+            }
             bf16_t* const outp = reinterpret_cast<bf16_t*>(p.out);
 #ifdef VTGB_DEBUG_HOOKS
             const bool skip_store = (g_exp_dev & 0xff) == 5;   // timing only: the whole epilogue but the global stores
@@ -1080,6 +1118,10 @@ int launch_conv_gemm(const GemmDesc& d, hipStream_t s) {
                      "conv gemm: bf16 residual needs 8-aligned bf16 rows");
     if (d.init_bf16)
         VTGB_REQUIRE(d.dtype == VTGB_BF16 && (d.N % 4) == 0 && (d.ldinit % 4) == 0, VTGB_EINVAL, "conv gemm: accumulator start map needs 4-aligned bf16 rows");
+    if (d.tail_w)
+        VTGB_REQUIRE(d.dtype == VTGB_BF16 && d.epi == EPI_STORE && d.N == 256 && d.gate_from == 0 && !d.resid_bf16 && d.tail_out && (d.ldtail % 4) == 0 &&
+                         d.ldtail >= 32 && (d.ldo % 8) == 0,
+                     VTGB_EINVAL, "conv gemm: the fused 1x1 tail needs a 256-channel bf16 EPI_STORE convolution and a 4-aligned fp32 output of >= 32 columns");
     if (d.col_stats)
         VTGB_REQUIRE(d.epi == EPI_STORE_F32 && d.stats_rows >= L_BM && (d.N % 4) == 0 && (d.ldo % 4) == 0 && d.act == 0 && d.out_scale == 0.f,
                      VTGB_EINVAL, "conv gemm: column statistics need fp32 whole-row stores and images of >= 256 rows");

@@ -440,10 +440,17 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
             VTGB_TRY(launch_conv_gemm(q, s));
         }
         // ---- FlowHead (update.py:10-18) and coords1 += delta_flow (xraft.py:145)
-        VTGB_TRY(launch_conv_gemm(conv_desc(dt, Mi, 256, H8, W8, 3, 3, 128, 128, hb, 128, nullptr, 0, w[18], F(w[19]), VTGB_EPI_STORE, 1, FH, 256, zero), s));
-        {
+        if (f32) {
+            VTGB_TRY(launch_conv_gemm(conv_desc(dt, Mi, 256, H8, W8, 3, 3, 128, 128, hb, 128, nullptr, 0, w[18], F(w[19]), VTGB_EPI_STORE, 1, FH, 256, zero), s));
             GemmDesc d = conv_desc(dt, Mi, 32, H8, W8, 0, 0, 0, 0, FH, 256, nullptr, 0, w[20], nullptr, VTGB_EPI_STORE_F32, 0, P2, 32, zero);
             d.K = 256; d.ldw = 256;
+            VTGB_TRY(launch_conv_gemm(d, s));
+        } else {
+            // relu(conv1) never leaves the CU: conv2's 18 per-tap partial products (32 padded columns, weights [32][256]) are
+            // formed from the tile while it sits in LDS (GemmDesc::tail_w) -- one launch and a 2 x 1.2 GB round trip less
+            GemmDesc d = conv_desc(dt, Mi, 256, H8, W8, 3, 3, 128, 128, hb, 128, nullptr, 0, w[18], F(w[19]), VTGB_EPI_STORE, 1, FH, 256, zero);
+            d.tail_w = w[20]; d.tail_out = P2; d.ldtail = 32;
+            d.algo_flops = 2.0 * Mi * 256.0 * (9 * 128) + 2.0 * Mi * 32.0 * 256.0;
             VTGB_TRY(launch_conv_gemm(d, s));
         }
         hipLaunchKernelGGL(raft_flow_head2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, P2, F(w[21]), flow, M, H8, W8);
