@@ -13,6 +13,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnDesc p) {
     const int nchunk = p.D >> 2;
     // grid-stride over rows: a bounded grid of resident workgroups walks the rows (one workgroup per 4 rows exits after
     // ~2 us and the dispatcher, not HBM, then sets the pace: 2.9 TB/s on the ViT's 255 k x 1408 rows)
+    // gamma / beta stay in registers across the rows a wave walks (they were re-read -- as many bytes as the row itself -- per row)
+    float4 gm[8], bt[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int ch = c * 64 + lane;
+        gm[c] = bt[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ch < nchunk) {
+            gm[c] = *reinterpret_cast<const float4*>(p.gamma + ch * 4);
+            bt[c] = *reinterpret_cast<const float4*>(p.beta + ch * 4);
+        }
+    }
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < p.M; row += (int64_t)gridDim.x * 4) {
     const float* x = p.x + map_row(p.x_map, row) * p.ldx;
     float4 v[8];
@@ -44,8 +55,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnDesc p) {
     for (int c = 0; c < 8; c++) {
         const int ch = c * 64 + lane;
         if (ch < nchunk) {
-            const float4 g = *reinterpret_cast<const float4*>(p.gamma + ch * 4);
-            const float4 b = *reinterpret_cast<const float4*>(p.beta + ch * 4);
+            const float4 g = gm[c], b = bt[c];
             float4 y;
             y.x = (v[c].x - mean) * rstd * g.x + b.x;
             y.y = (v[c].y - mean) * rstd * g.y + b.y;
