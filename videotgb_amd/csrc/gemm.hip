@@ -206,20 +206,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // is store-only.  (Measured: with the residual read in the tail, load -> add -> store chains at
 // ~250 live VGPRs ran at ~6 B/clk/CU and the epilogue of the K=1408 projection took longer than its
 // whole k-loop.)
+// resid_late: the fp32 residual is added by the whole-row epilogue instead (large kernel, staged fp32 store)
 template <int EPI>
-__device__ __forceinline__ f32x4 acc_init4(const GemmDesc& p, int m, int n0) {
+__device__ __forceinline__ f32x4 acc_init4(const GemmDesc& p, int m, int n0, bool resid_late = false) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (m >= p.M || n0 >= p.N) return v;
     const bool full = (n0 + 3 < p.N);
-    if (p.bias) {
-        if (full) {
-            v = *reinterpret_cast<const f32x4*>(p.bias + n0);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) if (n0 + i < p.N) v[i] = p.bias[n0 + i];
-        }
-    }
-    if constexpr (EPI == EPI_RESID_F32) {
+    if (EPI == EPI_RESID_F32 && !resid_late) {
         const float* r = p.resid + map_row(p.r_map, m) * p.ldr + n0;
         if (full && ((p.ldr & 3) == 0)) {
             v += *reinterpret_cast<const f32x4*>(r);
@@ -322,6 +315,14 @@ constexpr int L_LDS = (L_A_SLOTS + L_W_SLOTS) * L_OP_BYTES;   // 160 KiB
 // debug: shader-clock cycles and 100 MHz reference ticks spent inside the large kernel (summed over
 // workgroups), so that tools/gemm_ablate.py can report the clock the chip actually holds under each variant
 __device__ unsigned long long g_clk[2];
+__device__ unsigned long long g_stamp[8];   // exp 10: prologue phase sums (10 ns ticks) + tile count
+extern "C" void vtgb_debug_read_stamps(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(g_stamp));
+    if (reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z));
+    }
+}
 #ifdef VTGB_DEBUG_HOOKS
 __device__ int g_exp_dev = 0;   // experiment selector read by the large kernel (debug-hook builds only)
 extern "C" void vtgb_debug_set_exp(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_exp_dev), &v, sizeof(v)); }
@@ -358,6 +359,9 @@ template <int EPI, int ABL = 0, bool CONV = false, int NWN = 4, int NXF = 2 * NW
 __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass needs only the launch stub (and cannot type the buffer-descriptor builtins)
     ClkScope clk(ABL != 0);
+#ifdef VTGB_DEBUG_HOOKS
+    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int NX = NXF;              // activation fragments per wave: wave tile = (16 NX) x 64
     constexpr int WROWS = 16 * NX;       // rows of the wave tile
     constexpr int MW = 8 / NWN;          // waves along M
@@ -464,16 +468,46 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(smem_w + (slot) * W_OP + (wave * (8 * WI) + i * 8) * 128), 16, w_voff[i], (k0) * 2, 0, 0);
     const int nk = p.K / L_BK;
     const int fr = lane & 15, fg = lane >> 4;
-    // accumulators start at bias (+ residual): these loads are OLDER than every DMA below, so the
-    // counted vmcnt waits of the k-loop also cover them
-    f32x4 acc[4][NX];
-#pragma unroll
-    for (int j = 0; j < NX; j++)
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            acc[i][j] = acc_init4<EPI>(p, m0 + wm * WROWS + j * 16 + fr, n0 + wn * 64 + i * 16 + fg * 4);
+#ifdef VTGB_DEBUG_HOOKS
+    const unsigned long long t_setup = __builtin_amdgcn_s_memrealtime();
+#endif
+    // The first k-tile's DMAs go out FIRST; the accumulator start values (bias: one 16-byte load per weight-fragment column group,
+    // not one per accumulator block; + fp32 residual / bf16 start map) are requested behind them, so the two latencies overlap.
+    // (In-kernel stamps, tools/exp/prologue_probe.py: with the start values loaded first -- and the adds that consume them
+    // waiting for every one -- that phase alone was 4.2 us of a 46 us qkv tile and 20 us of a 60 us projection tile.)
+#ifdef VTGB_DEBUG_HOOKS
+    const unsigned long long t_init = __builtin_amdgcn_s_memrealtime();
+#endif
     L_ISSUE_A(0, 0)
     L_ISSUE_W(0, 0)
+#ifdef VTGB_DEBUG_HOOKS
+    const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
+#endif
+    // EPI_RESID_F32 through the staged fp32 store: the residual tile (256 KB) is NOT preloaded into the accumulators (16 rows x
+    // 64 B per load instruction, all of it waited for before the first MFMA: 20 us of a 60 us projection tile) but added in the
+    // epilogue from whole 256-byte row segments requested one pass ahead
+    const bool resid_late = EPI == EPI_RESID_F32 && ((p.N & 3) == 0) && ((p.ldo & 3) == 0) && ((p.ldr & 3) == 0) && p.act == 0 && p.out_scale == 0.f;
+    f32x4 acc[4][NX];
+    {
+        f32x4 b4[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int n = n0 + wn * 64 + i * 16 + fg * 4;
+            b4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) {
+                if (n + 3 < p.N) b4[i] = *reinterpret_cast<const f32x4*>(p.bias + n);
+                else
+                    for (int e = 0; e < 4; e++) if (n + e < p.N) b4[i][e] = p.bias[n + e];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NX; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                acc[i][j] = b4[i] + acc_init4<EPI>(p, m0 + wm * WROWS + j * 16 + fr, n0 + wn * 64 + i * 16 + fg * 4, resid_late);
+    }
+    // the later k-tiles queue behind EVERY wave's first one (and behind the start values): the first barrier waits for the
+    // slowest wave's A(0) / W(0), which must not sit behind another wave's A(2)
     if (nk > 1) {
         L_ISSUE_A(1, L_BK)
         L_ISSUE_W(1, L_BK)
@@ -482,7 +516,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     if (A_SLOTS == 3 && nk > 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * AI + WI));   // vmcnt(2 AI + WI): A(0), W(0) landed
     else if (nk >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (AI + WI));                 // vmcnt(AI + WI)
     else __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+#ifdef VTGB_DEBUG_HOOKS
+    const unsigned long long t_landed = __builtin_amdgcn_s_memrealtime();
+#endif
     __builtin_amdgcn_s_barrier();
+#ifdef VTGB_DEBUG_HOOKS
+    if ((g_exp_dev & 0xff) == 10 && tid == 0) {   // prologue phases of wave 0 (10 ns ticks): setup | acc init issue | DMA issue | wait | barrier; tile count
+        const unsigned long long t_bar = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&g_stamp[0], t_setup - t_entry); atomicAdd(&g_stamp[1], t_init - t_setup); atomicAdd(&g_stamp[2], t_issued - t_init);
+        atomicAdd(&g_stamp[3], t_landed - t_issued); atomicAdd(&g_stamp[4], t_bar - t_landed); atomicAdd(&g_stamp[5], 1ull);
+        atomicAdd(&g_clk[0], t_bar - t_entry); atomicAdd(&g_clk[1], 1ull);
+    }
+#endif
 
     // fragment byte offsets inside an operand tile for the two 32-deep halves of a k-tile
     int w_off[2][4], x_off[2][NX];
@@ -770,7 +815,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
             // measured 1.6 TB/s against 6.5 TB/s for whole-line stores.)
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();
-            constexpr int PR = WROWS < 64 ? WROWS : 64;   // rows per pass
+            constexpr int PR = EPI == EPI_RESID_F32 ? 32 : (WROWS < 64 ? WROWS : 64);   // rows per pass (the residual rows ride along: half the registers)
             char* const cst = smem + wave * (PR * 256);
             float* const outp = reinterpret_cast<float*>(p.out);
             const int rl = lane >> 4, cl = lane & 15;
@@ -780,6 +825,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
             const int img_a = do_stats ? m0 / p.stats_rows : 0;
             const int m_b = do_stats ? (img_a + 1) * p.stats_rows : 0x7fffffff;   // first row of image b
             f32x4 sa = {0.f, 0.f, 0.f, 0.f}, qa = sa, sb = sa, qb = sa;
+            const int n = n0 + wn * 64 + cl * 4;
+            // late residual: the rows of pass `h` in the store layout (4 rows x 256 B per instruction)
+            f32x4 rq[PR / 4];
+#define L_RESID_LOAD(dst, h)                                                                                        \
+    _Pragma("unroll") for (int rr = 0; rr < PR / 4; rr++) {                                                          \
+        const int m_ = m0 + wm * WROWS + (h) * PR + rr * 4 + rl;                                                    \
+        dst[rr] = f32x4{0.f, 0.f, 0.f, 0.f};                                                                        \
+        if (m_ < p.M && n < p.N) dst[rr] = *reinterpret_cast<const f32x4*>(p.resid + (p.r_map.seg_rows == 0 ? (int64_t)m_ : map_row(p.r_map, m_)) * p.ldr + n); \
+    }
 #pragma unroll
             for (int half = 0; half < WROWS / PR; half++) {
 #pragma unroll
@@ -789,14 +843,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                         const int row = jj * 16 + fr, chunk = i * 4 + fg;
                         *reinterpret_cast<f32x4*>(cst + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][half * (PR / 16) + jj];
                     }
+                if constexpr (EPI == EPI_RESID_F32) {
+                    if (half == 0) { L_RESID_LOAD(rq, 0) }   // (behind the first LDS write: that half of the accumulators is dead, the registers are there)
+                    __builtin_amdgcn_s_waitcnt(0x0F70);      // this pass's residual rows (one wait, outside the per-row conditionals)
+                }
                 // all of the pass's LDS reads before its first store (see the bf16 path)
                 f32x4 vv[PR / 4];
 #pragma unroll
                 for (int rr = 0; rr < PR / 4; rr++) {
                     const int row = rr * 4 + rl;
                     vv[rr] = *reinterpret_cast<const f32x4*>(cst + row * 256 + ((cl ^ (row & 15)) << 4));
+                    if constexpr (EPI == EPI_RESID_F32) vv[rr] += rq[rr];
                 }
-                const int n = n0 + wn * 64 + cl * 4;
+                if constexpr (EPI == EPI_RESID_F32) {
+                    if (half + 1 < WROWS / PR) { L_RESID_LOAD(rq, half + 1) }   // the next pass's rows, requested before this pass's stores
+                }
                 const bool ident = p.o_map.seg_rows == 0;
 #pragma unroll
                 for (int rr = 0; rr < PR / 4; rr++) {
@@ -814,6 +875,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                     }
                 }
             }
+#undef L_RESID_LOAD
             if constexpr (EPI == EPI_STORE_F32) {
                 if (do_stats) {
                     // lanes with equal cl hold the same four columns: fold the four row groups, park the
