@@ -153,6 +153,13 @@ struct GemmDesc {
     // convolutions, computed once per pair instead of once per refinement iteration)
     const void* init_bf16;
     int64_t ldinit;
+    // fragment order (bf16 large kernel, EPI_STORE without tails / start maps): instead of rows, a tile's accumulators are kept
+    // as the MFMA leaves them -- element ((((tile * 8 + wave) * NX + j) * 4 + i) * 64 + lane) is that lane's 4 values (8 bytes)
+    // of accumulator block (i, j) -- so one wave instruction moves 512 contiguous bytes.  frag_out: `out` is written in this
+    // order (activated, bf16; size m_tiles * n_tiles * 256 * tile width * 2 bytes).  init_frag: init_bf16 is read in this order
+    // (it must come from a frag_out launch with the same M, N and tile shape).  RAFT's loop-invariant start maps: the row-major
+    // form cost 32 loads of 16 rows x 32 bytes per lane in front of every GRU tile's first MFMA.
+    int frag_out, init_frag;
     // launch timing (vtgb_prof_*): ALGORITHMIC FLOPs of this launch when they differ from the executed 2 M N K -- the GRU
     // convolutions with the hoisted `inp` third are credited with the full 384-channel convolution the reference computes in
     // every iteration; the once-per-call start-map convolutions that carry the hoisted part are credited with 0 (< 0 here).

@@ -221,7 +221,7 @@ __device__ __forceinline__ f32x4 acc_init4(const GemmDesc& p, int m, int n0, boo
             for (int i = 0; i < 4; i++) if (n0 + i < p.N) v[i] += r[i];
         }
     }
-    if (p.init_bf16 && full) {   // (launch_conv_gemm requires N % 4 == 0 and ldinit % 4 == 0 with init_bf16)
+    if (p.init_bf16 && !p.init_frag && full) {   // (launch_conv_gemm requires N % 4 == 0 and ldinit % 4 == 0 with init_bf16)
         const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.init_bf16) + (int64_t)m * p.ldinit + n0);
         v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3];
     }
@@ -500,11 +500,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                     for (int e = 0; e < 4; e++) if (n + e < p.N) b4[i][e] = p.bias[n + e];
             }
         }
+        if (p.init_frag) {
+            const bf16x4* fsrc = reinterpret_cast<const bf16x4*>(p.init_bf16) + ((int64_t)(mt * n_tiles + nt) * 8 + wave) * (NX * 4 * 64) + lane;
+#pragma unroll
+            for (int j = 0; j < NX; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const bf16x4 t = fsrc[(j * 4 + i) * 64];
+                    acc[i][j] = b4[i] + f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+                }
+        } else {
 #pragma unroll
         for (int j = 0; j < NX; j++)
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 acc[i][j] = b4[i] + acc_init4<EPI>(p, m0 + wm * WROWS + j * 16 + fr, n0 + wn * 64 + i * 16 + fg * 4, resid_late);
+        }
     }
     // the later k-tiles queue behind EVERY wave's first one (and behind the start values): the first barrier waits for the
     // slowest wave's A(0) / W(0), which must not sit behind another wave's A(2)
@@ -571,6 +582,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
             a_slot = a_slot == A_SLOTS - 1 ? 0 : a_slot + 1;
         }
         if constexpr (EPI == EPI_STORE || EPI == EPI_GELU) {
+            if (EPI == EPI_STORE && p.frag_out) return;        // fragment-order stores use no LDS: no barrier to join
             if (staged_store) __builtin_amdgcn_s_barrier();   // the barrier in front of the LDS-staged stores
             if constexpr (EPI == EPI_STORE && NWN == 4 && NXF == 8) {
                 if (staged_store && p.tail_w) __builtin_amdgcn_s_barrier();   // ... and the one in front of the fused 1x1 tail
@@ -657,6 +669,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
             for (int i = 0; i < 4; i++) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
         if (t == 123.456f) reinterpret_cast<float*>(p.out)[0] = t;
         return;
+    }
+    if constexpr (EPI == EPI_STORE) {
+        if (p.frag_out) {   // fragment order: straight from the accumulators, 512 contiguous bytes per wave instruction, no LDS
+            bf16x4* fdst = reinterpret_cast<bf16x4*>(p.out) + ((int64_t)(mt * n_tiles + nt) * 8 + wave) * (NX * 4 * 64) + lane;
+#pragma unroll
+            for (int j = 0; j < NX; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    f32x4 v = acc[i][j];
+                    if (p.act) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act);
+                    }
+                    fdst[(j * 4 + i) * 64] = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                }
+            return;
+        }
     }
     if constexpr (EPI == EPI_STORE || EPI == EPI_GELU) {
         if (staged_store) {
@@ -1180,6 +1209,10 @@ int launch_conv_gemm(const GemmDesc& d, hipStream_t s) {
                      "conv gemm: bf16 residual needs 8-aligned bf16 rows");
     if (d.init_bf16)
         VTGB_REQUIRE(d.dtype == VTGB_BF16 && (d.N % 4) == 0 && (d.ldinit % 4) == 0, VTGB_EINVAL, "conv gemm: accumulator start map needs 4-aligned bf16 rows");
+    if (d.frag_out)
+        VTGB_REQUIRE(d.dtype == VTGB_BF16 && d.epi == EPI_STORE && d.gate_from == 0 && !d.resid_bf16 && !d.tail_w && d.out_scale == 0.f, VTGB_EINVAL,
+                     "conv gemm: fragment-order output needs a plain bf16 EPI_STORE launch");
+    if (d.init_frag) VTGB_REQUIRE(d.dtype == VTGB_BF16 && d.init_bf16, VTGB_EINVAL, "conv gemm: init_frag without a start map");
     if (d.tail_w)
         VTGB_REQUIRE(d.dtype == VTGB_BF16 && d.epi == EPI_STORE && d.N == 256 && d.gate_from == 0 && !d.resid_bf16 && d.tail_out && (d.ldtail % 4) == 0 &&
                          d.ldtail >= 32 && (d.ldo % 8) == 0,

@@ -353,8 +353,9 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     bf16_t* inp_q[2] = {nullptr, nullptr};
     if (!f32) {
         for (int half = 0; half < 2; half++) {
-            inp_zr[half] = (bf16_t*)ws.take(M * 256 * 2);
-            inp_q[half] = (bf16_t*)ws.take(M * 128 * 2);
+            const int64_t Mt = (M + 255) / 256 * 256;   // fragment order: whole 256-row tiles
+            inp_zr[half] = (bf16_t*)ws.take(Mt * 256 * 2);
+            inp_q[half] = (bf16_t*)ws.take(Mt * 128 * 2);
         }
     }
     float* mask = (float*)ws.take(M * 576 * 4);
@@ -398,6 +399,7 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
             GemmDesc mq = conv_desc(dt, Mi, 128, H8, W8, kh, kw, 128, 128, X, 256, nullptr, 0, w[27 + 2 * half], F(w[wi + 3]), VTGB_EPI_STORE, 0,
                                     inp_q[half], 128, zero);
             mz.algo_flops = mq.algo_flops = -1.0;   // their work is credited to the 20 per-iteration launches (the reference's form)
+            mz.frag_out = mq.frag_out = 1;          // kept as the MFMA leaves them: the GRU launches read them back the same way
             VTGB_TRY(launch_conv_gemm(mz, s));
             VTGB_TRY(launch_conv_gemm(mq, s));
         }
@@ -430,12 +432,12 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
             // second operand starts at column 128 of X, bias and the inp term come from the start map
             GemmDesc zr = hoist ? conv_desc(dt, Mi, 256, H8, W8, kh, kw, 256, 128, hb, 128, E(X, 128), 256, w[wi], nullptr, VTGB_EPI_STORE, 2, ZR, 256, zero)
                                 : conv_desc(dt, Mi, 256, H8, W8, kh, kw, 384, 128, hb, 128, X, 256, w[wi], F(w[wi + 1]), VTGB_EPI_STORE, 2, ZR, 256, zero);
-            if (hoist) { zr.init_bf16 = inp_zr[half]; zr.ldinit = 256; zr.algo_flops = 2.0 * Mi * 256.0 * (5 * 384); }
+            if (hoist) { zr.init_bf16 = inp_zr[half]; zr.ldinit = 256; zr.init_frag = 1; zr.algo_flops = 2.0 * Mi * 256.0 * (5 * 384); }
             zr.gate_from = 128; zr.aux = hb; zr.ldaux = 128; zr.out2 = RH; zr.ldo2 = 128;
             VTGB_TRY(launch_conv_gemm(zr, s));
             GemmDesc q = hoist ? conv_desc(dt, Mi, 128, H8, W8, kh, kw, 256, 128, RH, 128, E(X, 128), 256, w[wi + 2], nullptr, VTGB_EPI_GRU, 0, h32, 128, zero)
                                : conv_desc(dt, Mi, 128, H8, W8, kh, kw, 384, 128, RH, 128, X, 256, w[wi + 2], F(w[wi + 3]), VTGB_EPI_GRU, 0, h32, 128, zero);
-            if (hoist) { q.init_bf16 = inp_q[half]; q.ldinit = 128; q.algo_flops = 2.0 * Mi * 128.0 * (5 * 384); }
+            if (hoist) { q.init_bf16 = inp_q[half]; q.ldinit = 128; q.init_frag = 1; q.algo_flops = 2.0 * Mi * 128.0 * (5 * 384); }
             q.resid = h32; q.ldr = 128; q.aux = ZR; q.ldaux = 256; q.out2 = hb; q.ldo2 = 128;
             VTGB_TRY(launch_conv_gemm(q, s));
         }
