@@ -40,4 +40,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "raft":
     lib.vtgb_debug_read_clk(clk, 1); lib.vtgb_debug_set_exp(0)
     st = (C.c_ulonglong * 8)(); lib.vtgb_debug_read_stamps(st, 1)
     print("  phases (ns): setup %.0f | acc-init issue %.0f | DMA issue %.0f | wait %.0f | barrier %.0f" % tuple(st[i] / max(st[5], 1) * 10 for i in range(5)))
+    lib.vtgb_debug_set_exp(11); r.forward_clips(frames); torch.cuda.synchronize(); lib.vtgb_debug_set_exp(0)
+    lib.vtgb_debug_read_stamps(st, 1)
+    print("  per-wave entry -> own first operands landed (ns):", [round(st[i] / clk[1] * 10) for i in range(8)])
     print(f"RAFT pass {ms:.0f} ms: {clk[1]} tiles, mean prologue {clk[0] / clk[1] * 10:.0f} ns; sum of prologues / 256 CUs = {clk[0] * 10 / 256 / 1e6:.1f} ms")

@@ -160,6 +160,9 @@ struct GemmDesc {
     // (it must come from a frag_out launch with the same M, N and tile shape).  RAFT's loop-invariant start maps: the row-major
     // form cost 32 loads of 16 rows x 32 bytes per lane in front of every GRU tile's first MFMA.
     int frag_out, init_frag;
+    // filled by launch_conv_gemm: round-up magic numbers for n / (conv_H * conv_W) and n / conv_W, n < 2^31 (the per-lane
+    // pixel decomposition of every tile's prologue: q = (umulhi(n, mul) + n) >> sh)
+    uint32_t div_hw_mul, div_hw_sh, div_w_mul, div_w_sh;
     // launch timing (vtgb_prof_*): ALGORITHMIC FLOPs of this launch when they differ from the executed 2 M N K -- the GRU
     // convolutions with the hoisted `inp` third are credited with the full 384-channel convolution the reference computes in
     // every iteration; the once-per-call start-map convolutions that carry the hoisted part are credited with 0 (< 0 here).
