@@ -443,6 +443,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(cfg, T, nframe, sd, inline_raft=(args.flow == "raft"))
+        # RCCL prints its version banner through C stdio, which (on a pipe) is flushed at exit -- AFTER Python's line: flush the
+        # C buffers first so that the JSON line is the LAST line of stdout under multi-rank launches too
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
