@@ -198,3 +198,19 @@ def test_corr_large_features_do_not_overflow(dev):
     fm = torch.full((2, 64, 256), 20.0)                     # raw dot product 256 * 400 = 102400 > 65504; scaled 6400
     got = ops.raft_corr(fm.to(dev), 1, 8, 8, 1, 2, 0, 1, ops.BF16)
     assert torch.isfinite(got[0].float()).all() and abs(got[0].float().mean().item() - 6400.0) < 4.0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_raft_partial_last_tile(dev, tiny_sd, dtype):
+    """2 frame pairs of 144 x 144: 2 x 324 = 648 coarse pixels, so the tiles of every update-block launch straddle the two images
+    and the third one is partial -- fragment-order start maps, the fused flow-head tail, the gated and GRU epilogues and the
+    correlation lookup all meet rows beyond M.  (Coarse grids below 16 x 16 are not valid RAFT inputs: the 1 x 1 top pyramid level
+    divides by zero in the reference's own sampler.)"""
+    from oracle import vtgb_oracle as O
+    sd = tiny_sd["instructblip"][1]
+    fr = torch.randn(3, 3, 144, 144, generator=torch.Generator().manual_seed(21))
+    ref = O.raft_forward(sd, "of_extractor.", fr[:-1], fr[1:], iters=4)
+    got = make(dev, tiny_sd, dtype)(fr[:-1].to(dev), fr[1:].to(dev), iters=4).cpu()
+    e = rel_rms(got, ref)
+    print(f"[raft 144x144 x 2 pairs {dtype}] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
+    assert torch.isfinite(got).all() and e <= (1e-4 if dtype == "f32" else 2e-2)
