@@ -283,15 +283,17 @@ __device__ __forceinline__ void store4(const GemmDesc& p, int m, int n0, f32x4 v
 // ---------------------------------------------------------------------------------------
 // bf16 MFMA kernel, large-problem variant: 256x256x64 tile, 512 threads = 8 waves in
 // 2(M) x 4(N), each wave 128(m) x 64(n) = 8 x 4 v_mfma_f32_16x16x32_bf16 tiles (128 accumulator
-// VGPRs).  Operands are staged by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no
-// ds_write).  The whole 160 KiB of LDS is the staging ring: THREE 32 KiB slots for the
+// VGPRs).  Operands are staged by LDS-DMA (buffer_load_dwordx4 ... lds through per-tile descriptors:
+// no VGPR round trip, no ds_write, no 64-bit per-lane address arithmetic in the k-loop; round 1 used
+// global_load_lds_dwordx4).  The whole 160 KiB of LDS is the staging ring: THREE 32 KiB slots for the
 // activation tile (streamed from HBM: two k-tiles of lookahead) and TWO for the weight tile
 // (L2 / Infinity-Cache resident: one k-tile of lookahead).  The k-loop is rotated so that a
 // wave's LDS fragment reads (two 48-register sets) always run under its own MFMAs; once per
 // k-tile there is a COUNTED s_waitcnt vmcnt(4) -- everything but the four youngest DMAs has
-// landed -- and one barrier, after which the freed slots are re-armed.  (Ablations on MI355X,
-// tools/gemm_ablate.py: MFMAs alone ~1.37 PFLOP/s at the clock the chip holds under load; the
-// exposed DMA wait and the exposed LDS reads each cost ~20 % in the un-rotated loop.)
+// landed -- and one barrier, after which the freed slots are re-armed, the DMA pieces spread between
+// the MFMA groups.  The prologue issues the first k-tile's DMAs before anything else is loaded
+// (start values, later k-tiles); every epilogue finishes its LDS reads and operand loads before its
+// first store.  (Evidence for each of these choices: DESIGN.md section 4.)
 // The LDS image is lane-linear per DMA instruction (8 rows x 128 B per wave-instruction), so
 // the bank swizzle is applied to the per-lane SOURCE chunk and to the fragment reads (same
 // involution: slot = chunk ^ ((row >> 1) & 7); SQ_LDS_BANK_CONFLICT = 0 measured).
