@@ -317,7 +317,8 @@ constexpr int L_LDS = (L_A_SLOTS + L_W_SLOTS) * L_OP_BYTES;   // 160 KiB
 // debug: shader-clock cycles and 100 MHz reference ticks spent inside the large kernel (summed over
 // workgroups), so that tools/gemm_ablate.py can report the clock the chip actually holds under each variant
 __device__ unsigned long long g_clk[2];
-__device__ unsigned long long g_stamp[8];   // exp 10: prologue phase sums (10 ns ticks) + tile count
+#ifdef VTGB_DEBUG_HOOKS
+__device__ unsigned long long g_stamp[8];   // exp 10 / 11: prologue phase sums (10 ns ticks) + tile count; per-wave landing times
 extern "C" void vtgb_debug_read_stamps(unsigned long long* out, int reset) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(g_stamp));
     if (reset) {
@@ -325,7 +326,6 @@ extern "C" void vtgb_debug_read_stamps(unsigned long long* out, int reset) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z));
     }
 }
-#ifdef VTGB_DEBUG_HOOKS
 __device__ int g_exp_dev = 0;   // experiment selector read by the large kernel (debug-hook builds only)
 extern "C" void vtgb_debug_set_exp(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_exp_dev), &v, sizeof(v)); }
 #endif
