@@ -31,7 +31,7 @@ extern "C" {
 
 typedef struct ihipStream_t* vtgb_stream_t; /* == hipStream_t */
 
-#define VTGB_VERSION 210
+#define VTGB_VERSION 300
 
 #define VTGB_OK 0
 #define VTGB_EINVAL (-1)       /* bad argument (NULL pointer, unsupported size, bad mode) */
@@ -384,9 +384,11 @@ int vtgb_raft_corr(const vtgb_raft_corr_args* a, vtgb_stream_t stream);
  * scaling 2*(x/255)-1 of RAFT.forward (xraft.py:105-106) is applied inside.  norm = 0: InstanceNorm2d (fnet);
  * norm = 1: the caller has folded the eval-mode BatchNorm2d that follows every convolution into the packed
  * weights and biases (cnet).  Output: NHWC features [n_images * H/8 * W/8, 256] fp32.
- * weights (`dtype`): [0] conv1.weight [64, 4 (tY), 64]: the stem as a 4x1 convolution over the 2x2 space-to-depth
- *   image, channel = dX*12 + py*6 + px*3 + c (48, zero-padded to 64), ky = 2 tY + py - 1, kx = 2 dX + px - 1,
- *   scaled by 2/255 (the kernel feeds raw - 127.5 to the GEMM; since version 210) [1] conv1.bias; per block b (layer1.0, 1.1, 2.0, 2.1, 3.0, 3.1) at
+ * weights (`dtype`): [0] conv1.weight: the stem as a 4x1 convolution over the 2x2 space-to-depth image, channel =
+ *   dX*12 + py*6 + px*3 + c (48, zero-padded to 64), ky = 2 tY + py - 1, kx = 2 dX + px - 1.  VTGB_F32: [64, 4 (tY), 64], unscaled
+ *   (the kernel packs 2*(x/255)-1 itself).  VTGB_BF16: [64, 2 (chunk), 4 (tY), 64] = the same table twice, scaled by 2/255: the
+ *   kernel feeds x - 127.5 to the GEMM as a bf16 pair, chunk 0 = hi = bf16(v), chunk 1 = lo = bf16(v - hi), so float-valued
+ *   (CLIP-normalised) frames keep 16 significant bits (since version 300; 210 fed hi alone) [1] conv1.bias; per block b (layer1.0, 1.1, 2.0, 2.1, 3.0, 3.1) at
  *   2 + 6 b: conv1.weight [C, 3,3,Cin_pad] , conv1.bias, conv2.weight [C, 3,3,C_pad], conv2.bias,
  *   downsample.0.weight [C, Cin_pad] or NULL, downsample.0.bias or NULL  (96-channel stages: C_pad = 128, zero-filled; with norm = 1 the
  *   OUTPUT rows and biases of those stages are padded to C_pad as well: the GEMM stores the activations directly);

@@ -818,11 +818,40 @@ def refine_answers_fixture():
     save("tiny_refine_answers", ids=ids, prefix_per_frame=torch.cat(pref, 0), eos_token_id=np.int64(tc.eos_token_id), pad_token_id=np.int64(tc.pad_token_id), max_length=np.int64(128))
 
 
+def raft_sensitive_fixture():
+    """[raft2] The reference RAFT (src/models/components/xraft.py, RAFT-large) with the INPUT-SENSITIVE weight set
+    (videotgb_amd.synth.raft_sensitive_state_dict) on three frame triples of 128 x 128:
+      a: float-valued frames ~ N(0, 1), stored rounded to fp16 (the bench's / SURVEY 8d's flow frames);
+      b: a moving texture, CLIP-normalised -- what eval/inference.py:68 -> eval/utils/model.py:79 hands to RAFT;
+      c: the same texture as integer 0..255 frames (RAFT's own input convention).
+    Recorded: the 20-iteration flows, and fnet's feature maps (every 4th channel) for a and b."""
+    from videotgb_amd import synth
+    from src.models.components.xraft import RAFT
+    ref = RAFT().eval()
+    sd = {k[len("of_extractor."):]: v for k, v in synth.raft_sensitive_state_dict(0).items()}
+    ref.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(31)
+    fa = torch.randn(3, 3, 128, 128, generator=g).half()
+    u8 = synth.moving_texture_u8(3, 128, 5)
+    fb = synth.clip_normalise(u8)
+    fc = u8.float()
+    cap = {}
+    h = ref.fnet.register_forward_hook(lambda m, i, o: cap.__setitem__("fmap", torch.cat(list(o), 0) if isinstance(o, (list, tuple)) else o))
+    out = {}
+    with torch.no_grad():
+        for tag, f in (("a", fa.float()), ("b", fb), ("c", fc)):
+            out["flow_" + tag] = ref(f[:-1], f[1:], iters=20, test_mode=True)
+            if tag != "c":
+                out["fmap_" + tag] = cap["fmap"][:, ::4].contiguous()       # [4 = (img0, img1 | img1, img2), 64, 16, 16]
+    h.remove()
+    save("tiny_raft_sensitive", frames_a_f16=fa.numpy(), frames_u8=u8.numpy(), **out)
+
+
 def main():
     install_shim()
     torch.manual_seed(0)
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train", "refine", "answers", "bf16", "modules", "trainstep"]
+    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train", "refine", "answers", "bf16", "modules", "trainstep", "raft2"]
     if "e2e" in which:
         ref_ib, cfg_ib, sd_ib = e2e_fixture("instructblip")
         ref_b2, cfg_b2, sd_b2 = e2e_fixture("blip2")
@@ -845,6 +874,8 @@ def main():
         module_fixtures()
     if "trainstep" in which:
         train_step_fixture()
+    if "raft2" in which:
+        raft_sensitive_fixture()
 
 
 if __name__ == "__main__":

@@ -11,16 +11,26 @@
 #include "common.h"
 
 // ---- stem: conv 7x7 stride 2 pad 3, 3 -> 64, on 2*(x/255)-1 (xraft.py:105-106), as an implicit GEMM.
-// Space-to-depth: the image is repacked (bf16 NHWC at half resolution) so that pixel (Y, X) carries the 4 x 2 x 2 x 3
-// raw values img[c][2Y + py][2(X + dX - 2) + px], dX = 0..3 -- 48 channels padded to 64 -- and the stride-2 7x7
-// stencil becomes a 4 x 1 stride-1 convolution (vertical taps dY = -2..1; K = 4 * 64 = 256, 147 of them non-zero).
-// The packed values are raw - 127.5: (2 r - 255) / 2 has 8 significant bits for every integer r in 0..255, so it is exact in
-// bf16; the normalisation's scale lives in the packed weights (w * 2/255), the bias is untouched, and an out-of-image tap is
-// 0 (= normalised 0) -- horizontally in the packed tensor, vertically through the convolution's zero padding (which the
-// implicit-GEMM kernel gets from the buffer descriptor's range check, not from a page).
+// Space-to-depth: the image is repacked (NHWC at half resolution) so that pixel (Y, X) carries the 4 x 2 x 2 x 3
+// values img[c][2Y + py][2(X + dX - 2) + px], dX = 0..3 -- 48 channels padded to 64 -- and the stride-2 7x7
+// stencil becomes a 4 x 1 stride-1 convolution (vertical taps dY = -2..1; 147 of the 4 * 48 products non-zero).
+//
+// fp32 mode packs the reference's own normalised value 2 * (x / 255) - 1 (same operations, same roundings).
+//
+// bf16 mode packs v = x - 127.5 as a bf16 PAIR: hi = bf16(v) in channel chunk 0, lo = bf16(v - hi) in chunk 1 (K = 4 * 128;
+// the packed weights w * 2/255 appear in both chunks, the bias is untouched).  hi + lo carries 16 significant bits of v.
+// For integer frames 0..255 (RAFT's own convention) lo = 0 and hi is exact.  The eval path, however, hands RAFT
+// CLIP-normalised floats (eval/inference.py:68 -> eval/utils/model.py:79), |x| < 3: there v = -127.5 + x sits where bf16
+// has a step of 0.5 .. 1, and hi alone (rounds 1 and 2) kept one or two bits of x -- InstanceNorm then removes the constant and
+// amplifies what is left: 7 % feature error in fnet (round-2 VERDICT).  With the pair the input error is <= 2^-9 of |v - hi| <= 0.5,
+// i.e. <= 1e-3 absolute on x -- below one bf16 rounding of any later activation.
+// An out-of-image tap is 0 in either encoding (= normalised 0) -- horizontally in the packed tensor, vertically through the
+// convolution's zero padding (which the implicit-GEMM kernel gets from the buffer descriptor's range check, not from a page).
 template <typename T>
 __global__ __launch_bounds__(256) void raft_stem_pack_kernel(const float* __restrict__ img, T* __restrict__ out, T* __restrict__ pad_page,
                                                              int64_t n_px, int H, int W) {
+    constexpr bool PAIR = sizeof(T) == 2;          // bf16: hi | lo chunks
+    constexpr int CP = PAIR ? 128 : 64;            // packed channels per half-resolution pixel
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 64) pad_page[i] = (T)0.f;   // (the fp32 exactness kernel still reads its padding from a page)
     if (i >= n_px * 4) return;
@@ -28,7 +38,7 @@ __global__ __launch_bounds__(256) void raft_stem_pack_kernel(const float* __rest
     const int dX = (int)(i & 3), W2 = W >> 1, H2 = H >> 1;
     const int X = (int)(px_i % W2), Y = (int)((px_i / W2) % H2);
     const int64_t n = px_i / ((int64_t)W2 * H2);
-    T v[12];
+    T v[12], l[12];
 #pragma unroll
     for (int py = 0; py < 2; py++)
 #pragma unroll
@@ -36,16 +46,33 @@ __global__ __launch_bounds__(256) void raft_stem_pack_kernel(const float* __rest
             const int col = 2 * (X + dX - 2) + pxx, row = 2 * Y + py;
             const bool ok = (unsigned)col < (unsigned)W;
 #pragma unroll
-            for (int c = 0; c < 3; c++) v[py * 6 + pxx * 3 + c] = (T)(ok ? img[((n * 3 + c) * H + row) * W + col] - 127.5f : 0.f);
+            for (int c = 0; c < 3; c++) {
+                const int e = py * 6 + pxx * 3 + c;
+                const float raw = ok ? img[((n * 3 + c) * H + row) * W + col] : 0.f;
+                if constexpr (PAIR) {
+                    const float d = ok ? raw - 127.5f : 0.f;
+                    v[e] = (T)d;
+                    l[e] = (T)(d - (float)v[e]);
+                } else {
+                    v[e] = (T)(ok ? 2.0f * (raw / 255.0f) - 1.0f : 0.f);
+                }
+            }
         }
     typedef T T4 __attribute__((ext_vector_type(4)));
-    T* o = out + px_i * 64 + dX * 12;
+    T* o = out + px_i * CP + dX * 12;
 #pragma unroll
     for (int q = 0; q < 3; q++) *reinterpret_cast<T4*>(o + q * 4) = T4{v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+    if constexpr (PAIR) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) *reinterpret_cast<T4*>(o + 64 + q * 4) = T4{l[q * 4], l[q * 4 + 1], l[q * 4 + 2], l[q * 4 + 3]};
+    }
     if (dX == 3) {
         const T4 z = {(T)0.f, (T)0.f, (T)0.f, (T)0.f};
 #pragma unroll
-        for (int q = 0; q < 4; q++) *reinterpret_cast<T4*>(out + px_i * 64 + 48 + q * 4) = z;
+        for (int q = 0; q < 4; q++) {
+            *reinterpret_cast<T4*>(out + px_i * CP + 48 + q * 4) = z;
+            if constexpr (PAIR) *reinterpret_cast<T4*>(out + px_i * CP + 112 + q * 4) = z;
+        }
     }
 }
 
@@ -151,8 +178,9 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     float* cf = (float*)ws.take(M2 * 64 * 4);          // fp32 conv output (largest stage; later stages reuse it)
     float* cf2 = (float*)ws.take(M4 * 128 * 4);        // fp32 output of the downsample branch
     void* act0 = ws.take(M2 * 64 * es);   // activations: bf16 (VTGB_BF16) or fp32 (VTGB_F32)
-    void* act1 = ws.take(M2 * 64 * es);
-    void* act2 = ws.take(M2 * 64 * es);
+    char* act12 = (char*)ws.take(2 * M2 * 64 * es);   // act1 | act2, contiguous: the bf16 stem's 128-channel (hi | lo) input spans both
+    void* act1 = act12;
+    void* act2 = act12 + (ws.dry ? 0 : M2 * 64 * es);
     float* stats = (float*)ws.take((int64_t)n * 128 * 2 * 4);
     float* stats2 = (float*)ws.take((int64_t)n * 128 * 2 * 4);   // the downsample branch's moments
     void* zero = ws.take(256);
@@ -199,8 +227,9 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
                            a->H, a->W);
     {
         float* sf = stats_for(stats, H2 * W2, 64);
-        GemmDesc d = enc_conv(dt, (int)M2, 64, H2, W2, 1, 64, 1, H2, W2, act1, w[0], F(w[1]), cf, 64, pad_page, sf);
-        d.conv_KH = 4; d.K = 256; d.ldw = 256;
+        const int cp = dt == VTGB_BF16 ? 128 : 64;            // bf16: hi | lo chunks (raft_stem_pack_kernel)
+        GemmDesc d = enc_conv(dt, (int)M2, 64, H2, W2, 1, cp, 1, H2, W2, act1, w[0], F(w[1]), cf, 64, pad_page, sf);
+        d.conv_KH = 4; d.K = 4 * cp; d.ldw = 4 * cp;
         if (!inorm) { d.epi = VTGB_EPI_STORE; d.act = 1; d.out = act0; }        // relu(bn1(conv1(x))) straight to bf16
         VTGB_TRY(launch_conv_gemm(d, s));
         if (inorm) VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, sf != nullptr));

@@ -642,9 +642,11 @@ class RaftEncoderWeights(_WeightTable):
             return torch.nn.functional.pad(b, (0, cout_pad - b.numel())) if batch_norm and cout_pad != b.numel() else b
 
         # stem as a 4x1 convolution over the space-to-depth image (raft_enc.hip): [co][tY][dX, py, px, c | pad to 64],
-        # ky = 2 tY + py - 1, kx = 2 dX + px - 1; the kernel packs raw - 127.5 (exact in bf16 for 0..255), so w' = w * 2/255 and b' = b
+        # ky = 2 tY + py - 1, kx = 2 dX + px - 1.  fp32 mode: the kernel packs 2*(x/255)-1 itself, weights as they are.
+        # bf16 mode: the kernel packs x - 127.5 as a bf16 pair (hi | lo channel chunks), so w' = w * 2/255 in BOTH chunks, b' = b
         w, b = folded("conv1", "norm1")
-        w = w * (2.0 / 255.0)
+        if code == BF16:
+            w = w * (2.0 / 255.0)
         wp = torch.zeros(64, 4, 4, 2, 2, 3, dtype=torch.float32, device=w.device)
         for tY in range(4):
             for py in range(2):
@@ -656,9 +658,10 @@ class RaftEncoderWeights(_WeightTable):
                         kx = 2 * dX + px - 1
                         if kx >= 0:
                             wp[:, tY, dX, py, px, :] = w[:, :, ky, kx]
-        wp = torch.nn.functional.pad(wp.reshape(64, 4, 48), (0, 16)).reshape(64, 256)
-        wq = wp.to(torch.bfloat16).float() if code == BF16 else wp       # the weights the kernel will actually multiply by
-        self.add(wq.contiguous(), True); self.add(b)
+        wp = torch.nn.functional.pad(wp.reshape(64, 4, 48), (0, 16))                    # [co, tY, 64]
+        if code == BF16:
+            wp = torch.stack([wp, wp], 1)                                               # K order: 64-channel chunk major, tap minor
+        self.add(wp.reshape(64, -1).contiguous(), True); self.add(b)
         cin_pad = 64
         for li, c, cpad in (("layer1", 64, 64), ("layer2", 96, 128), ("layer3", 128, 128)):
             for bi in range(2):

@@ -306,6 +306,53 @@ def path_state_dict(c: PathCfg, seed: int = 0, with_raft: bool = True) -> Dict[s
     return sd
 
 
+def raft_sensitive_state_dict(seed: int = 0, p: str = "of_extractor.") -> Dict[str, torch.Tensor]:
+    """A second, INPUT-SENSITIVE RAFT weight set for parity tests.  With the default N(0, 0.02) weights the activations shrink
+    layer by layer and the refinement loop's flow hardly depends on the images: a 7 % error in fnet's feature maps moved the
+    6-iteration flow by 3e-3 (round-2 VERDICT), so flow-level tests could not see encoder-level errors.  Here every convolution
+    weight is N(0, gain^2 / fan_in): gain sqrt(2) (He) keeps activations O(1) through both encoders and the update block;
+    the correlation branch's first layer (convc1) gets gain 4 so the motion features are driven by the correlation lookups, and
+    the flow head's last layer gain 0.03 so 20 iterations move the flow by a few pixels (lookups stay inside the image and the
+    recurrence stays contractive: on the oracle a 1e-3 feature perturbation moves the flow by 2.4e-4, a 7e-2 one by 1.8e-2).
+    Biases, BatchNorm parameters and running statistics are the default set's."""
+    shapes = raft_shapes(p)
+    sd = synth_state_dict(shapes, seed)
+    for k, shp in shapes.items():
+        if not (k.endswith(".weight") and len(shp) == 4):
+            continue
+        gain = 2.0 ** 0.5
+        if k.endswith("encoder.convc1.weight"):
+            gain = 4.0
+        elif k.endswith("flow_head.conv2.weight"):
+            gain = 0.03
+        g = torch.Generator().manual_seed((zlib.crc32(k.encode()) + 1000003 * seed + 77) & 0x7FFFFFFF)
+        sd[k] = torch.randn(shp, generator=g, dtype=torch.float32) * (gain / float(shp[1] * shp[2] * shp[3]) ** 0.5)
+    for k in list(sd):
+        if ".downsample.1." in k:
+            sd[k] = sd[k.replace(".downsample.1.", ".norm3.")]
+    return sd
+
+
+def moving_texture_u8(n_frames: int, size: int, seed: int, step=(2, 3)) -> torch.Tensor:
+    """[n_frames, 3, size, size] uint8: a smooth random texture translated by `step` pixels per frame (real motion for RAFT tests)."""
+    g = torch.Generator().manual_seed(seed)
+    big = size + n_frames * max(abs(step[0]), abs(step[1])) + 8
+    base = torch.nn.functional.interpolate(torch.randn(1, 3, big // 6 + 2, big // 6 + 2, generator=g), size=(big, big), mode="bicubic", align_corners=False)[0]
+    base = ((base - base.min()) / (base.max() - base.min()) * 255.0).round().clamp(0, 255)
+    out = torch.empty(n_frames, 3, size, size)
+    for t in range(n_frames):
+        oy, ox = 4 + t * abs(step[0]), 4 + t * abs(step[1])
+        out[t] = base[:, oy:oy + size, ox:ox + size]
+    return out.to(torch.uint8)
+
+
+def clip_normalise(u8: torch.Tensor) -> torch.Tensor:
+    """uint8 frames -> /255 -> CLIP mean / std (get_frames, eval/utils/builder_utils.py:121-128): what the eval path hands to RAFT."""
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(1, 3, 1, 1)
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(1, 3, 1, 1)
+    return (u8.float() / 255.0 - mean) / std
+
+
 # ----------------------------------------------------------------------------
 # synthetic clips (SURVEY.md 8d)
 # ----------------------------------------------------------------------------
