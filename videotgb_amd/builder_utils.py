@@ -6,7 +6,7 @@
 * ``get_frames`` (:117-144): the reference decodes the file with PyAV and transforms on the CPU; here the transform chain
   and the 32-frame pick run on the device (videotgb_amd.video / vtgb_preprocess_frames).  A path is decoded with PyAV when
   it is installed (it is not part of this package); a uint8 tensor [T, H, W, 3] of decoded frames is taken as is.
-* ``KeywordsStoppingCriteria`` (:320-346).
+* ``KeywordsStoppingCriteria`` (:320-346): the same contract, written for this package (token test, then text test).
 """
 from __future__ import annotations
 
@@ -67,27 +67,44 @@ def get_frames(video_path, target_size=224, keyframe=False, start_ratio=0.0, end
 
 
 class KeywordsStoppingCriteria:
-    """eval/utils/builder_utils.py:320-346 (a transformers StoppingCriteria: callable on (output_ids, scores))."""
+    """Stop generation when the answer ends with, or its recent text contains, one of ``keywords`` -- the contract of the class
+    the eval driver imports under this name (eval/utils/builder_utils.py:320-346; batch size 1, callable as
+    ``criteria(output_ids, scores) -> bool``).  Two tests per call, cheapest first:
+      1. token test: the last ``len(ids_k)`` generated ids equal keyword k's token ids (a leading BOS id is not part of a keyword);
+      2. text test: the decoded window of the last ``min(n_generated, longest keyword)`` ids contains a keyword as a substring."""
 
     def __init__(self, keywords, tokenizer, input_ids):
-        self.keywords = keywords
-        self.keyword_ids = []
-        self.max_keyword_len = 0
-        for keyword in keywords:
-            cur = tokenizer(keyword).input_ids
-            if len(cur) > 1 and cur[0] == tokenizer.bos_token_id:
-                cur = cur[1:]
-            self.max_keyword_len = max(self.max_keyword_len, len(cur))
-            self.keyword_ids.append(torch.tensor(cur))
+        self.keywords = list(keywords)
         self.tokenizer = tokenizer
-        self.start_len = input_ids.shape[1]
+        self.start_len = int(input_ids.shape[1])
+        self._id_tails = [self._keyword_ids(tokenizer, kw) for kw in self.keywords]
+        self.max_keyword_len = max((t.numel() for t in self._id_tails), default=0)
 
-    def __call__(self, output_ids: torch.LongTensor, scores: torch.FloatTensor, **kwargs) -> bool:
-        assert output_ids.shape[0] == 1, "Only support batch size 1 (yet)"
-        offset = min(output_ids.shape[1] - self.start_len, self.max_keyword_len)
-        self.keyword_ids = [k.to(output_ids.device) for k in self.keyword_ids]
-        for k in self.keyword_ids:
-            if (output_ids[0, -k.shape[0]:] == k).all():
+    @staticmethod
+    def _keyword_ids(tokenizer, keyword) -> torch.Tensor:
+        ids = list(tokenizer(keyword).input_ids)
+        if len(ids) > 1 and ids[0] == tokenizer.bos_token_id:
+            ids = ids[1:]
+        return torch.tensor(ids, dtype=torch.long)
+
+    @property
+    def keyword_ids(self):                                     # the reference's attribute name
+        return self._id_tails
+
+    def _token_hit(self, row: torch.Tensor) -> bool:
+        for n, tail in enumerate(self._id_tails):
+            if tail.device != row.device:
+                self._id_tails[n] = tail = tail.to(row.device)
+            if torch.equal(row[-tail.numel():], tail):
                 return True
-        outputs = self.tokenizer.batch_decode(output_ids[:, -offset:], skip_special_tokens=True)[0]
-        return any(keyword in outputs for keyword in self.keywords)
+        return False
+
+    def _text_hit(self, output_ids: torch.Tensor) -> bool:
+        window = min(output_ids.shape[1] - self.start_len, self.max_keyword_len)
+        text = self.tokenizer.batch_decode(output_ids[:, -window:], skip_special_tokens=True)[0]    # window 0 -> the whole row, as `[-0:]` is
+        return any(kw in text for kw in self.keywords)
+
+    def __call__(self, output_ids: torch.LongTensor, scores: torch.FloatTensor = None, **kwargs) -> bool:
+        if output_ids.shape[0] != 1:
+            raise AssertionError("Only support batch size 1 (yet)")
+        return self._token_hit(output_ids[0]) or self._text_hit(output_ids)

@@ -357,6 +357,32 @@ struct ClkScope {
 // 128-channel outputs with many rows (RAFT's GRU q convolution, the 126-channel motion-encoder output, the stage 2 / 3
 // encoder convolutions); its activation slot is 64 KiB, so the ring is 2 activation + 2 weight slots = 160 KiB.
 
+// Column-statistics fold (EPI_STORE_F32 + col_stats): 64 NWN threads add up the MW waves' partial sums of a column (parked in the
+// waves' staging regions) and issue one atomic per (image, column, moment).  Run by waves 0 .. NWN-1 WHETHER OR NOT their own
+// sub-tile holds valid rows: with a last tile of <= WROWS valid rows those waves are row-inactive, and (rounds 1-2) returned
+// before the fold -- the last image's moments then missed that tile for the columns they should have folded (found in round 3:
+// fnet 3-10 % off on the last image whenever n_images * H/8 * W/8 mod 256 <= 64).
+#define L_STATS_FOLD(PR_)                                                                                           \
+    if (tid < 64 * NWN) {                                                                                           \
+        const int wn_ = tid >> 6, c = tid & 63, n = n0 + wn_ * 64 + c;                                              \
+        if (n < p.N) {                                                                                              \
+            const int img_a_ = m0 / p.stats_rows, m_b_ = (img_a_ + 1) * p.stats_rows;                               \
+            float t[4] = {0.f, 0.f, 0.f, 0.f};                                                                      \
+            for (int wm_ = 0; wm_ < MW; wm_++) {                                                                    \
+                if (m0 + wm_ * WROWS >= p.M) break;                                                                 \
+                const float* pr = reinterpret_cast<const float*>(smem + (wn_ * MW + wm_) * ((PR_) * 256));          \
+                _Pragma("unroll") for (int e = 0; e < 4; e++) t[e] += pr[e * 64 + c];                               \
+            }                                                                                                       \
+            float* st = p.col_stats + ((int64_t)img_a_ * p.N + n) * 2;                                              \
+            unsafeAtomicAdd(st, t[0]);                                                                              \
+            unsafeAtomicAdd(st + 1, t[1]);                                                                          \
+            if (m0 + T_BM > m_b_ && m_b_ < p.M) {                                                                   \
+                unsafeAtomicAdd(st + 2 * p.N, t[2]);                                                                \
+                unsafeAtomicAdd(st + 2 * p.N + 1, t[3]);                                                            \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
+
 template <int EPI, int ABL = 0, bool CONV = false, int NWN = 4, int NXF = 2 * NWN>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass needs only the launch stub (and cannot type the buffer-descriptor builtins)
@@ -596,7 +622,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
             if (((p.N & 3) == 0) && ((p.ldo & 3) == 0) && p.act == 0 && p.out_scale == 0.f) {
                 __builtin_amdgcn_s_barrier();
-                if (EPI == EPI_STORE_F32 && p.col_stats) __builtin_amdgcn_s_barrier();   // the partial-sum exchange
+                if constexpr (EPI == EPI_STORE_F32) {
+                    if (p.col_stats) {
+                        __builtin_amdgcn_s_barrier();   // the partial-sum exchange
+                        constexpr int PR_I = WROWS < 64 ? WROWS : 64;
+                        L_STATS_FOLD(PR_I)              // a row-inactive wave still folds its share of the columns
+                    }
+                }
             }
         } else if constexpr (EPI == EPI_GRU) {
             if (gru_staged(p)) __builtin_amdgcn_s_barrier();
@@ -929,25 +961,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                     }
                     __builtin_amdgcn_s_waitcnt(0xC07F);
                     __builtin_amdgcn_s_barrier();
-                    if (tid < 64 * NWN) {
-                        const int wn_ = tid >> 6, c = tid & 63, n = n0 + wn_ * 64 + c;
-                        if (n < p.N) {
-                            float t[4] = {0.f, 0.f, 0.f, 0.f};
-                            for (int wm_ = 0; wm_ < MW; wm_++) {
-                                if (m0 + wm_ * WROWS >= p.M) break;
-                                const float* pr = reinterpret_cast<const float*>(smem + (wn_ * MW + wm_) * (PR * 256));
-#pragma unroll
-                                for (int e = 0; e < 4; e++) t[e] += pr[e * 64 + c];
-                            }
-                            float* st = p.col_stats + ((int64_t)img_a * p.N + n) * 2;
-                            unsafeAtomicAdd(st, t[0]);
-                            unsafeAtomicAdd(st + 1, t[1]);
-                            if (m0 + T_BM > m_b && m_b < p.M) {
-                                unsafeAtomicAdd(st + 2 * p.N, t[2]);
-                                unsafeAtomicAdd(st + 2 * p.N + 1, t[3]);
-                            }
-                        }
-                    }
+                    L_STATS_FOLD(PR)
                 }
             }
             return;
