@@ -9,7 +9,8 @@ import torch  # noqa: F401  -- FIRST: libvtgb.so must bind to the HIP runtime Py
 #                             one device context per process); loading it before torch gives it a second one
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvtgb.so")
+# VTGB_LIB: another build of the same library (same-box A/B runs: tools/ab_*.sh) -- the product path never sets it
+LIB_PATH = os.environ.get("VTGB_LIB") or os.path.join(HERE, "libvtgb.so")
 
 F32, BF16 = 0, 1
 MAP_A, MAP_B = 0, 1

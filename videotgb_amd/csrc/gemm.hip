@@ -12,26 +12,10 @@
 // rows of a fragment read hit 16 distinct 16-byte slots of the 256-byte bank row.
 //
 // fp32 path (exactness mode): plain 64x64x16 register-tiled FMA kernel, k summed in order.
+#include <stdlib.h>
+
 #include "common.h"
-
-enum { EPI_STORE = VTGB_EPI_STORE, EPI_GELU = VTGB_EPI_GELU, EPI_RESID_F32 = VTGB_EPI_RESID_F32,
-       EPI_STORE_F32 = VTGB_EPI_STORE_F32, EPI_GRU = VTGB_EPI_GRU };
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-// GELU for bf16 outputs: x * Phi(x) with Phi(x) ~ sigmoid(x (a + b x^2 + c x^4)), a minimax fit on [-8, 8] (the argument is
-// clamped there; Phi is 0 / 1 to 1e-12 outside): |error| <= 2.6e-5 absolute and <= 7e-4 of the result for |x| < 2.5, i.e. below
-// the bf16 rounding of every result larger than 0.013 -- at 7 plain VALU instructions + v_exp + v_rcp (44 issue cycles per
-// value).  The erf form it replaces (Abramowitz-Stegun 7.1.26: 15 plain + 2 transcendental, 76 cycles) made the fc1 epilogue
-// 15 % of a tile's life: 128 values per lane, two waves per SIMD, nothing to hide under.  libm's erff is ~40 instructions.
-// The fp32 exactness mode keeps the exact erf (gelu_erf).
-__device__ __forceinline__ float gelu_erf_fast(float x) {
-    const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
-    const float x2 = xc * xc;
-    float q = fmaf(1.0145391570e-3f, x2, -1.0677742213e-1f);      // -(a + b x^2 + c x^4) log2(e), Horner in x^2
-    q = fmaf(q, x2, -2.3011195660f);
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xc * q));
-}
+#include "gemm_dev.h"
 
 // Store 4 consecutive n (n0..n0+3) of logical row m.  TAct is the activation type of
 // EPI_STORE / EPI_GELU outputs.
@@ -94,7 +78,6 @@ __device__ __forceinline__ void epilogue4(const GemmDesc& p, int m, int n0, floa
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per buffer
 
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmDesc p) {
@@ -182,100 +165,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmDesc p) {
         for (int i = 0; i < 4; i++) {
             const int n = n0 + wn * 64 + i * 16 + fg * 4;
             epilogue4<EPI, bf16_t, true>(p, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        }
-    }
-}
-
-// tanh for the GRU candidate (bf16 mode): 1 - 2 / (exp(2x) + 1) with the hardware exp / rcp (~1e-6 relative, far below
-// the bf16 rounding of the inputs) instead of libm tanhf's ~90 instructions per element, which made the GRU epilogue a
-// VALU-bound tail as long as a third of the k-loop.  The exactness mode (conv_f32.hip) keeps tanhf.
-__device__ __forceinline__ float tanh_fast(float x) {
-    const float e = __expf(2.0f * x);                 // inf for large x -> 1 - 0 = 1; 0 for very negative x -> -1
-    return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
-}
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == 1) return fmaxf(v, 0.f);
-    if (act == 2) return 1.0f / (1.0f + __expf(-v));
-    return v;
-}
-
-// Large-kernel epilogue split: bias (and the fp32 residual) are loaded INTO the accumulators before
-// the k-loop -- 32 independent 16-byte loads per lane in flight while the first LDS-DMA tiles
-// land, with the accumulator registers themselves as destination -- so that the tail of the tile
-// is store-only.  (Measured: with the residual read in the tail, load -> add -> store chains at
-// ~250 live VGPRs ran at ~6 B/clk/CU and the epilogue of the K=1408 projection took longer than its
-// whole k-loop.)
-// resid_late: the fp32 residual is added by the whole-row epilogue instead (large kernel, staged fp32 store)
-template <int EPI>
-__device__ __forceinline__ f32x4 acc_init4(const GemmDesc& p, int m, int n0, bool resid_late = false) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (m >= p.M || n0 >= p.N) return v;
-    const bool full = (n0 + 3 < p.N);
-    if (EPI == EPI_RESID_F32 && !resid_late) {
-        const float* r = p.resid + map_row(p.r_map, m) * p.ldr + n0;
-        if (full && ((p.ldr & 3) == 0)) {
-            v += *reinterpret_cast<const f32x4*>(r);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) if (n0 + i < p.N) v[i] += r[i];
-        }
-    }
-    if (p.init_bf16 && !p.init_frag && full) {   // (launch_conv_gemm requires N % 4 == 0 and ldinit % 4 == 0 with init_bf16)
-        const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.init_bf16) + (int64_t)m * p.ldinit + n0);
-        v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3];
-    }
-    return v;
-}
-
-template <int EPI>
-__device__ __forceinline__ void store4(const GemmDesc& p, int m, int n0, f32x4 v) {
-    if (m >= p.M || n0 >= p.N) return;
-    const bool full = (n0 + 3 < p.N) && ((p.ldo & 3) == 0);
-    const int64_t orow = map_row(p.o_map, m);
-    if constexpr (EPI == EPI_STORE || EPI == EPI_STORE_F32) {
-        if (p.act | (p.out_scale != 0.f)) {
-            const float sc = p.out_scale != 0.f ? p.out_scale : 1.0f;
-#pragma unroll
-            for (int i = 0; i < 4; i++) v[i] = apply_act(v[i], p.act) * sc;
-        }
-    }
-    if constexpr (EPI == EPI_GRU) {
-        // h' = (1 - z) h + z tanh(acc + bias)
-        const float* hp = p.resid + map_row(p.r_map, m) * p.ldr + n0;
-        const bf16_t* zp = reinterpret_cast<const bf16_t*>(p.aux) + (int64_t)m * p.ldaux + n0;
-        float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + n0;
-        bf16_t* o2 = reinterpret_cast<bf16_t*>(p.out2) + (int64_t)m * p.ldo2 + n0;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (n0 + i < p.N) {
-                const float z = (float)zp[i], h = hp[i], q = tanh_fast(v[i]);
-                const float hn = (1.0f - z) * h + z * q;
-                o[i] = hn;
-                o2[i] = (bf16_t)hn;
-            }
-        return;
-    }
-    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
-        float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + n0;
-        if (full) {
-            *reinterpret_cast<f32x4*>(o) = v;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) if (n0 + i < p.N) o[i] = v[i];
-        }
-    } else {
-        if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) v[i] = gelu_erf_fast(v[i]);
-        }
-        bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + orow * p.ldo + n0;
-        if (full) {
-            const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-            *reinterpret_cast<bf16x4*>(o) = pk;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) if (n0 + i < p.N) o[i] = (bf16_t)v[i];
         }
     }
 }
@@ -1092,6 +981,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc p) {
         epilogue4<EPI, float>(p, m0 + ty * 4 + i, n0 + tx * 4, acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
 }
 
+// round 3: the persistent ping-pong form of the large kernel (gemm_pp.hip); VTGB_GEMM_OLD=1 keeps the one-tile-per-workgroup kernel
+template <int EPI, bool CONV, int NWN>
+int launch_large_pp(const GemmDesc& d, hipStream_t s);
+bool pp_supported(const GemmDesc& d);
+static bool use_old_large() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VTGB_GEMM_OLD"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+// bisecting aid: VTGB_PP_MASK = bit set of launch classes that may use the persistent kernel (default: all)
+//   1 plain GEMM   2 conv 256-wide bf16 store   4 conv + fused 1x1 tail   8 conv 128-wide bf16 store   16 GRU   32 conv fp32 store
+static bool pp_class_enabled(int epi, bool conv, int nwn, bool tail) {
+    static int mask = -1;
+    if (mask < 0) { const char* e = getenv("VTGB_PP_MASK"); mask = e ? atoi(e) : 63; }
+    int c;
+    if (!conv) c = 1;
+    else if (epi == EPI_GRU) c = 16;
+    else if (epi == EPI_STORE_F32) c = 32;
+    else if (tail) c = 4;
+    else c = nwn == 4 ? 2 : 8;
+    return (mask & c) != 0;
+}
+
 // tile-count threshold above which the 256x256 LDS-DMA kernel is used (tunable for experiments)
 // Experiment knobs.  The setters (and the timing-only ablation instantiations, whose results are WRONG by construction) exist
 // only in builds with -DVTGB_DEBUG_HOOKS (VTGB_DEBUG_HOOKS=1 python -m videotgb_amd.build; tools/gemm_ablate.py): the
@@ -1132,6 +1044,7 @@ static int launch_epi(const GemmDesc& d, hipStream_t s) {
             const int G = g_large_variant > 0 ? g_large_variant : (n_tiles <= 8 ? 2 : 8);
             const int mx = (m_tiles + 7) / 8, groups = (mx + G - 1) / G;
             const dim3 grid(8 * groups * G * n_tiles);
+            if (!use_old_large() && !g_ablate && pp_supported(d) && pp_class_enabled(EPI, false, 4, false)) return launch_large_pp<EPI, false, 4>(d, s);
             ProfScope prof(VTGB_PROF_GEMM, 2.0 * d.M * d.N * d.K, s);
 #ifdef VTGB_DEBUG_HOOKS
             if (g_ablate && (EPI == EPI_STORE || EPI == EPI_RESID_F32)) {
@@ -1176,6 +1089,11 @@ static int launch_large_nwn(const GemmDesc& d, hipStream_t s) {
     const int m_tiles = (d.M + T_BM - 1) / T_BM, n_tiles = (d.N + T_BN - 1) / T_BN;
     const int G = n_tiles <= 8 ? 2 : 8;
     const int mx = (m_tiles + 7) / 8, groups = (mx + G - 1) / G;
+    if constexpr (NXF == 2 * NWN) {
+        if constexpr (!(EPI == EPI_GRU && NWN == 4) && NWN != 1) {      // (64-wide tiles: two workgroups per CU already overlap prologues)
+            if (!use_old_large() && pp_supported(d) && pp_class_enabled(EPI, CONV, NWN, d.tail_w != nullptr)) return launch_large_pp<EPI, CONV, NWN>(d, s);
+        }
+    }
     static DeviceOnce attr;
     VTGB_FUNC_LDS_ONCE(attr, (gemm_bf16_large_kernel<EPI, 0, CONV, NWN, NXF>), LDS);
     const double exec_flops = 2.0 * d.M * d.N * d.K;

@@ -1,0 +1,872 @@
+// gemm_pp.hip -- the round-3 form of the large bf16 MFMA kernel (plain GEMM and implicit-GEMM convolution): PERSISTENT workgroups
+// with a PING-PONG k-loop.  Same tile (256 rows x 64 NWN columns x 64 deep), same LDS image (LDS-DMA staging, XOR-swizzled 128-byte
+// rows), same accumulator layout and the same epilogue arithmetic as gemm_bf16_large_kernel in gemm.hip (which stays for A/B runs and
+// for the timing ablations: VTGB_GEMM_OLD=1); what changed is the structure around them:
+//
+//  * Ping-pong k-loop.  The rounds-1/2 loop ran both waves of a SIMD in lockstep (one barrier per k-tile, two fragment sets): both
+//    issued LDS-DMA pieces, both waited on LDS reads, both multiplied at the same moments.  Here waves 4-7 run ONE BARRIER BEHIND
+//    waves 0-3 and every wave alternates a COMPUTE segment (the 4 NX MFMAs of one 32-deep half, nothing else) with a LOAD segment
+//    (the next half's 4 + NX ds_read_b128 and this wave's share of the LDS-DMA pieces), so that on every SIMD one wave's MFMAs run
+//    beside its partner's LDS / DMA traffic.  One fragment set (48 VGPRs fewer at NWN = 4), four barriers per k-tile.
+//    A(t+2) is issued in the segment after half 0 of tile t (its slot held tile t-1), W(t+2) in the segment after half 1 (the slot of
+//    tile t); one counted wait per k-tile (all but the youngest activation pieces), placed where BOTH groups pass it before the first
+//    read of tile t+1.  Standalone (tools/exp/pp_gemm.hip, same box, random data): +3 ... +6.5 % over the lockstep loop.
+//  * Persistent workgroups.  Rounds 1-2 launched one workgroup per tile: every tile paid its own prologue -- first operands' HBM
+//    latency plus the skew until the slowest wave's pieces land: 5-7 us of a 43-54 us ViT tile, 15 us of the average 27 us RAFT
+//    convolution tile (profiles/r02_exp_prologue_probe_after.log) -- with the matrix pipe idle.  Here a workgroup walks the tile list
+//    (stride = grid size, all its tiles on one XCD) and issues the NEXT tile's first k-tile (A'(0), W'(0)) at the start of the current
+//    tile's epilogue -- behind the epilogue's operand loads, in front of its stores; every epilogue's first wait is a counted one that
+//    leaves exactly those pieces in flight -- so they land while the accumulators are stored.  The epilogues stage through A slots
+//    1.. only (8 KiB per wave, more passes) so that slot 0 of both rings is free for them.
+//
+// Requires K % 64 == 0 and descriptor-addressable operands (launch_* in gemm.hip check).
+#include "common.h"
+#include "gemm_dev.h"
+
+constexpr int P_BK = 64;
+constexpr int P_AOP = 256 * P_BK * 2;   // 32 KiB activation slot (256 rows)
+
+
+// Buffer STORES keep the row offset in the per-lane offset register, not in the scalar offset: with a scalar-register soffset hipcc
+// (ROCm 7.2) places NO wait state between a > 8-byte store and the next instruction that overwrites its data registers (its hazard
+// table exempts MUBUF stores with an SGPR soffset), and on gfx950 that exemption does not hold: single components of the 16-byte
+// h' stores of the GRU epilogue came out as the NEXT value written to the register (0.0), different elements on every run
+// (tools/exp/conv_unit.hip; round 3).  Loads are unaffected (their registers are scoreboarded).
+#define P_STORE128(data, rs, lane_off, soff) __builtin_amdgcn_raw_buffer_store_b128(data, rs, (lane_off) + (unsigned)(soff), 0, 0)
+#define P_STORE64(data, rs, lane_off, soff) __builtin_amdgcn_raw_buffer_store_b64(data, rs, (lane_off) + (unsigned)(soff), 0, 0)
+
+template <int EPI, bool CONV, int NWN, bool TAIL = false, bool PING = !CONV>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G, const int total_blocks) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NX = 2 * NWN;          // activation fragments per wave: wave tile = (16 NX) x 64
+    constexpr int WROWS = 16 * NX;
+    constexpr int MW = 8 / NWN;          // waves along M
+    constexpr int T_BM = 256, T_BN = 64 * NWN;
+    constexpr int A_OP = P_AOP, W_OP = T_BN * 128;
+    constexpr int AI = 4, WI = NWN;      // LDS-DMA instructions per wave and k-tile
+    constexpr int A_SLOTS = 3;
+    constexpr bool WHOLE = PING && NWN < 4;   // ping-pong on narrow tiles: one compute segment per k-tile (both halves), three weight slots
+    constexpr int W_SLOTS = WHOLE ? 3 : 2;
+    constexpr int SB = (A_SLOTS - 1) * A_OP / 8;   // epilogue staging bytes per wave (A slots 1, 2): 8 KiB
+    constexpr int NPRE = AI + WI;        // pieces of the next tile's first k-tile, in flight under the epilogue
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const smem_w = smem + A_SLOTS * A_OP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % MW, wn = wave / MW;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = p.K / P_BK;
+    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
+#ifdef PP_EXP_STAGE0
+    char* const stage = smem + wave * SB;
+#else
+    char* const stage = smem + A_OP + wave * SB;   // this wave's private epilogue staging region
+#endif
+
+    // ---- workgroup -> tile list (XCD-aware, as in gemm.hip): logical block b -> (mt, nt); this workgroup takes b, b + grid, ...
+    const int Gn = G * n_tiles, mx8 = (m_tiles + 7) >> 3;
+    auto decode = [&](int b, int& mt_, int& nt_) -> bool {
+        const int xcd = b & 7, idx = b >> 3;
+        const int group = idx / Gn, r = idx - group * Gn;
+        nt_ = r / G;
+        const int ml = group * G + (r - nt_ * G);
+        if (CONV) {                                   // each XCD takes a contiguous run of m-tiles (shared halo rows stay in ONE L2)
+            if (ml >= mx8) return false;
+            mt_ = xcd * mx8 + ml;
+        } else {
+            mt_ = ml * 8 + xcd;                       // plain GEMM: the XCDs take interleaved m-tiles
+        }
+        return mt_ < m_tiles;
+    };
+    auto next_valid = [&](int b, int& mt_, int& nt_) -> int {
+        for (; b < total_blocks; b += (int)gridDim.x)
+            if (decode(b, mt_, nt_)) return b;
+        return -1;
+    };
+
+    // ---- per-tile LDS-DMA state (see gemm.hip for the addressing scheme: tile descriptors + loop-invariant lane offsets)
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int RANGE = 0x7FFFFF00;
+    unsigned w_voff, a_voff[AI];
+    int a_bits[AI];
+    int m0 = 0, n0 = 0, mt = 0, nt = 0;
+    bool wave_active = false;
+    auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, RANGE, 0x00020000);
+    auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, RANGE, 0x00020000);
+    auto a2_rsrc = a_rsrc;
+    const int cv_hw = CONV ? p.conv_H * p.conv_W : 1, cv_Hi = CONV ? (p.conv_Hi ? p.conv_Hi : p.conv_H) : 1,
+              cv_Wi = CONV ? (p.conv_Wi ? p.conv_Wi : p.conv_W) : 1, cv_st = CONV ? (p.conv_stride ? p.conv_stride : 1) : 1;
+    int cv_ky = 0, cv_kx = 0, cv_c0 = 0;   // CONV: running (channel chunk, tap) of the next A k-tile to stage (K runs chunk-major, tap-minor)
+#define P_TILE_SETUP()                                                                                                       \
+    {                                                                                                                        \
+        m0 = mt * T_BM; n0 = nt * T_BN;                                                                                      \
+        wave_active = (n0 + wn * 64 < p.N) && (m0 + wm * WROWS < p.M);                                                       \
+        /* weight rows beyond N lie outside the descriptor's range: their LDS rows read as zeros (columns that are never stored) */ \
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W + (int64_t)n0 * p.ldw), 0, (int)(min(T_BN, p.N - n0) * p.ldw * 2), 0x00020000); \
+        {                                                                                                                    \
+            const int row = wave * (8 * WI) + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);   /* (piece i: row + 8 i, same swizzle term only if ... see P_ISSUE_W) */ \
+            w_voff = (unsigned)(row * (int)p.ldw + c * 8) * 2u;                                                              \
+        }                                                                                                                    \
+        const int cv_img0 = CONV ? m0 / cv_hw : 0;                                                                           \
+        const int64_t a_row0 = CONV ? (int64_t)cv_img0 * (cv_Hi * cv_Wi) : map_row(p.a_map, m0);                             \
+        a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + a_row0 * p.lda), 0, RANGE, 0x00020000);           \
+        a2_rsrc = __builtin_amdgcn_make_buffer_rsrc(                                                                         \
+            const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(CONV && p.A2 ? p.A2 : p.A) + a_row0 * (CONV && p.A2 ? p.lda2 : p.lda)), 0, RANGE, 0x00020000); \
+        _Pragma("unroll") for (int i = 0; i < AI; i++) {                                                                     \
+            const int row = wave * (8 * AI) + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);             \
+            const int am = (m0 + row) < p.M ? (m0 + row) : p.M - 1;                                                          \
+            if constexpr (CONV) {                                                                                            \
+                const int img = (int)((__umulhi((unsigned)am, p.div_hw_mul) + (unsigned)am) >> p.div_hw_sh), rem = am - img * cv_hw; \
+                const int oy = (int)((__umulhi((unsigned)rem, p.div_w_mul) + (unsigned)rem) >> p.div_w_sh), y = oy * cv_st, x = (rem - oy * p.conv_W) * cv_st; \
+                a_voff[i] = (unsigned)((img - cv_img0) * (cv_Hi * cv_Wi) + y * cv_Wi + x) | ((unsigned)c << 28);             \
+                const int py = p.conv_KH >> 1, px = p.conv_KW >> 1;                                                          \
+                const int ylo = max(0, py - y), yhi = min(p.conv_KH - 1, cv_Hi - 1 - y + py), xlo = max(0, px - x), xhi = min(p.conv_KW - 1, cv_Wi - 1 - x + px); \
+                const int yb = yhi >= ylo ? ((2 << yhi) - 1) & ~((1 << ylo) - 1) : 0, xb = xhi >= xlo ? ((2 << xhi) - 1) & ~((1 << xlo) - 1) : 0; \
+                a_bits[i] = yb | (xb << 8);                                                                                  \
+            } else {                                                                                                         \
+                a_voff[i] = (unsigned)((int)(map_row(p.a_map, am) - a_row0) * (int)p.lda + c * 8) * 2u;                      \
+                a_bits[i] = 0;                                                                                               \
+            }                                                                                                                \
+        }                                                                                                                    \
+        cv_ky = 0; cv_kx = 0; cv_c0 = 0;                                                                                     \
+    }
+#define P_ISSUE_A(slot, k0)                                                                             \
+    if constexpr (CONV) {                                                                               \
+        const bool first = cv_c0 < p.conv_split;                                                        \
+        const unsigned ldb = (unsigned)(first ? p.lda : p.lda2) * 2u;                                   \
+        const int cc2 = (first ? cv_c0 : cv_c0 - p.conv_split) * 2;                                     \
+        const int dpix = (cv_ky - (p.conv_KH >> 1)) * cv_Wi + (cv_kx - (p.conv_KW >> 1));               \
+        const int need = (1 << cv_ky) | (256 << cv_kx);                                                 \
+        _Pragma("unroll") for (int i = 0; i < AI; i++) {                                                \
+            const unsigned pix = (a_voff[i] & 0x00FFFFFFu) + (unsigned)dpix;                            \
+            const unsigned v = ((a_bits[i] & need) == need) ? pix * ldb + (a_voff[i] >> 28) * 16u : OOB; \
+            if (first) { __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(smem + (slot) * A_OP + (wave * (8 * AI) + i * 8) * 128), 16, v, cc2, 0, 0); } \
+            else { __builtin_amdgcn_raw_ptr_buffer_load_lds(a2_rsrc, (lptr_t)(smem + (slot) * A_OP + (wave * (8 * AI) + i * 8) * 128), 16, v, cc2, 0, 0); } \
+        }                                                                                               \
+        if (++cv_kx == p.conv_KW) { cv_kx = 0; if (++cv_ky == p.conv_KH) { cv_ky = 0; cv_c0 += P_BK; } } \
+    } else {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < AI; i++)                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(smem + (slot) * A_OP + (wave * (8 * AI) + i * 8) * 128), 16, a_voff[i], (k0) * 2, 0, 0); \
+    }
+/* piece i stages rows r + 8 i: (row >> 1) & 7 advances by 4 i, so its swizzled chunk is c ^ 4 for odd i: byte offset ^ 64 (16-byte chunks) */ \
+#define P_ISSUE_W(slot, k0)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < WI; i++)                                                      \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(smem_w + (slot) * W_OP + (wave * (8 * WI) + i * 8) * 128), 16, w_voff ^ ((i & 1) * 64), (k0) * 2 + i * 8 * (int)p.ldw * 2, 0, 0);
+
+    // fragment byte offsets inside an operand tile: fragment i / j of a wave sits 16 rows = 2048 bytes below fragment 0 with the SAME
+    // swizzle term ((row >> 1) & 7 does not see multiples of 16), and the second 32-deep half is chunk index ^ 4 = byte offset ^ 64:
+    // two registers per operand instead of 8 + 2 NX, the rest are ds_read immediates
+    constexpr int NH = (WHOLE || !PING) ? 2 : 1;   // fragment sets: one 32-deep half (ping-pong at NWN = 4), else two
+    bf16x8 wf[NH][4], xf[NH][NX];
+#define P_READ(H, as_, ws_, ks)                                                                          \
+    if (wave_active) {                                                                                   \
+        const char* const wp_ = (ws_) + (w_off0 ^ ((ks) * 64));                                          \
+        const char* const xp_ = (as_) + (x_off0 ^ ((ks) * 64));                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) wf[H][i] = *reinterpret_cast<const bf16x8*>(wp_ + i * 2048); \
+        _Pragma("unroll") for (int j = 0; j < NX; j++) xf[H][j] = *reinterpret_cast<const bf16x8*>(xp_ + j * 2048); \
+    }
+#define P_MFMAS(H)                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; i++)                                                    \
+            _Pragma("unroll") for (int j = 0; j < NX; j++)                                               \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[H][i], xf[H][j], acc[i][j], 0, 0, 0);
+#define P_COMPUTE()                                                                                      \
+    if (wave_active) {                                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                   \
+        P_MFMAS(0)                                                                                       \
+        if constexpr (WHOLE) { P_MFMAS(1) }                                                              \
+        __builtin_amdgcn_s_setprio(0);                                                                   \
+    }
+#define P_SEG_END() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+// phase barrier: hipcc may otherwise move LDS accesses across a bare s_barrier (it did: the epilogue's staging writes of a fast wave
+// landed in the slot a slower wave was still reading its last fragments from -- run-to-run different GRU outputs, found in round 3)
+#define P_PHASE_BARRIER() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+
+    int b = next_valid((int)blockIdx.x, mt, nt);
+    if (b < 0) return;
+    P_TILE_SETUP()
+    P_ISSUE_A(0, 0)
+    P_ISSUE_W(0, 0)
+    while (true) {
+        // (lane-derived constants are re-derived per phase from a laundered lane id: carried across the whole loop they -- not the
+        // accumulators -- were what hipcc pushed into scratch, and every reload is a serial memory round trip)
+        int lane_k = lane;
+        asm volatile("" : "+v"(lane_k));
+        const int w_off0 = swz(wn * 64 + (lane_k & 15), lane_k >> 4), x_off0 = swz(wm * WROWS + (lane_k & 15), lane_k >> 4);
+        // ================= accumulator start values, behind the first k-tile's DMAs (bias once per column group; start maps)
+        f32x4 acc[4][NX];
+        {
+            f32x4 b4[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int n = n0 + wn * 64 + i * 16 + fg * 4;
+                b4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias && n < p.N) b4[i] = *reinterpret_cast<const f32x4*>(p.bias + n);     // (N % 4 == 0: pp_supported)
+            }
+#ifdef PP_EXP_INIT_SIMPLE
+            if (p.init_frag) {
+                const bf16x4* fsrc = reinterpret_cast<const bf16x4*>(p.init_bf16) + ((int64_t)(mt * n_tiles + nt) * 8 + wave) * (NX * 4 * 64) + lane;
+#pragma unroll
+                for (int j = 0; j < NX; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const bf16x4 t = fsrc[(j * 4 + i) * 64];
+                        acc[i][j] = b4[i] + f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+                    }
+            } else
+#endif
+            if (p.init_frag) {
+                // all NX * 4 loads (512 contiguous bytes per wave instruction) in flight BEFORE the first add: left to itself hipcc
+                // consumed each load right behind its issue with `s_waitcnt vmcnt(0)` (a DMA is in flight: no counted waits), i.e.
+                // 32 serial memory round trips per tile -- 12 us of a 63 us GRU z|r tile
+                const bf16x4* fsrc = reinterpret_cast<const bf16x4*>(p.init_bf16) + ((int64_t)(mt * n_tiles + nt) * 8 + wave) * (NX * 4 * 64) + lane;
+                bf16x4 tq[NX * 4];
+#pragma unroll
+                for (int q = 0; q < NX * 4; q++) tq[q] = fsrc[q * 64];
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NX; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const bf16x4 t = tq[j * 4 + i];
+                        acc[i][j] = b4[i] + f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+                    }
+            } else {   // (row-major start maps and early residuals stay with the one-tile-per-workgroup kernel: pp_supported)
+#pragma unroll
+                for (int j = 0; j < NX; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[i][j] = b4[i];
+            }
+        }
+        if constexpr (!PING) {
+            // ---------- LOCKSTEP k-loop (the rounds-1/2 loop of gemm.hip inside the persistent frame; used for the convolutions): both
+            // waves of a SIMD multiply at the same time, one barrier per k-tile, two fragment sets; the LDS-DMA pieces sit BETWEEN the
+            // MFMAs (sched_group_barrier), where the partner wave's MFMAs cover their issue time.  The ping-pong loop below puts the
+            // pieces (plus, for a convolution, ~6 VALU per piece of tap arithmetic) into the load segment, which then outlasts the
+            // partner's compute segment: measured on RAFT's GRU convolutions +23 ... +28 % per launch, so they keep this loop.
+            if (nk > 1) { P_ISSUE_A(1, P_BK) P_ISSUE_W(1, P_BK) }
+            if (nk > 2) { P_ISSUE_A(2, 2 * P_BK) }
+            if (nk > 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * AI + WI));
+            else if (nk > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | NPRE);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            int a_slot = 0;
+            if (!wave_active) {
+                // same DMA issues, waits and barriers as the active waves, nothing else
+                for (int kt = 0; kt + 1 < nk; kt++) {
+                    if (kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | AI);
+                    else __builtin_amdgcn_s_waitcnt(0x0F70);
+                    __builtin_amdgcn_s_barrier();
+                    if (kt + 2 < nk) { P_ISSUE_W(kt & 1, (kt + 2) * P_BK) }
+                    if (kt + 3 < nk) { P_ISSUE_A(a_slot, (kt + 3) * P_BK) }
+                    a_slot = a_slot == 2 ? 0 : a_slot + 1;
+                }
+            } else {
+#define P_LREAD(H, as_, ws_, ks)                                                                         \
+    {                                                                                                    \
+        const char* const wp_ = (ws_) + (w_off0 ^ ((ks) * 64));                                          \
+        const char* const xp_ = (as_) + (x_off0 ^ ((ks) * 64));                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) wf[H][i] = *reinterpret_cast<const bf16x8*>(wp_ + i * 2048); \
+        _Pragma("unroll") for (int j = 0; j < NX; j++) xf[H][j] = *reinterpret_cast<const bf16x8*>(xp_ + j * 2048); \
+    }
+#define P_SCHED_IL(PIECES)                                                                               \
+    if constexpr ((PIECES) > 0 && (4 * NX) % (PIECES) == 0) {                                            \
+        _Pragma("unroll") for (int g_ = 0; g_ < (PIECES); g_++) {                                        \
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);               /* one LDS-DMA piece */     \
+            __builtin_amdgcn_sched_group_barrier(0x008, (4 * NX) / (PIECES), 0);   /* its share of the half's MFMAs */ \
+        }                                                                                                \
+    }
+#define P_LITER(DEFER, WCOND, WAIT4)                                                                     \
+    {                                                                                                    \
+        const char* as = smem + a_slot * A_OP;                                                           \
+        const char* ws = smem_w + (kt & 1) * W_OP;                                                       \
+        const int a_nxt = a_slot == 2 ? 0 : a_slot + 1;                                                  \
+        const int a_prv = a_slot == 0 ? 2 : a_slot - 1;                                                  \
+        if (DEFER) { P_ISSUE_A(a_prv, (kt + 2) * P_BK) }                                                 \
+        P_LREAD(1, as, ws, 1)                                                                            \
+        P_MFMAS(0)                                                                                       \
+        P_SCHED_IL(AI)                                                                                   \
+        if (WAIT4) __builtin_amdgcn_s_waitcnt(0x0070 | AI);   /* all but A(t+2) landed; lgkmcnt(0) */    \
+        else __builtin_amdgcn_s_waitcnt(0x0070);                                                         \
+        __builtin_amdgcn_s_barrier();                                                                    \
+        if (WCOND) { P_ISSUE_W(kt & 1, (kt + 2) * P_BK) }                                                \
+        P_LREAD(0, smem + a_nxt * A_OP, smem_w + ((kt + 1) & 1) * W_OP, 0)                               \
+        P_MFMAS(1)                                                                                       \
+        P_SCHED_IL(WI)                                                                                   \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                              \
+        a_slot = a_nxt;                                                                                  \
+    }
+                P_LREAD(0, smem, smem_w, 0)
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                int kt = 0;
+                if (nk > 1) { P_LITER(false, kt + 2 < nk, kt + 2 < nk) kt = 1; }
+                for (; kt + 2 < nk; kt++) P_LITER(true, true, true)                     // steady state: no conditions
+                for (; kt + 1 < nk; kt++) P_LITER(kt + 2 < nk, kt + 2 < nk, kt + 2 < nk)
+                {   // last k-tile
+                    const char* as = smem + a_slot * A_OP;
+                    const char* ws = smem_w + ((nk - 1) & 1) * W_OP;
+                    P_LREAD(1, as, ws, 1)
+                    P_MFMAS(0)
+                    P_MFMAS(1)
+                }
+#undef P_LITER
+#undef P_SCHED_IL
+#undef P_LREAD
+            }
+            P_PHASE_BARRIER()                      // every wave's LDS reads and DMAs of this tile are done: the ring is free
+        } else
+        if constexpr (!WHOLE) {
+            // ---------- 256-wide tile: half-k-tile segments.  A(g) in slot g % 3, W(g) in slot g % 2
+            if (nk > 1) {
+                P_ISSUE_A(1, P_BK)
+                P_ISSUE_W(1, P_BK)
+                __builtin_amdgcn_s_waitcnt(0x0F70 | NPRE);   // vmcnt(AI + WI): k-tile 0 (and everything older: the previous tile's stores) done
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            if (wave >= 4) __builtin_amdgcn_s_barrier();     // the second group runs one barrier behind the first
+            __builtin_amdgcn_sched_barrier(0);
+            P_READ(0, smem, smem_w, 0)
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            P_SEG_END()
+            int a_slot = 0;
+            for (int kt = 0; kt < nk; kt++) {
+                const char* as = smem + a_slot * A_OP;
+                const char* ws = smem_w + (kt & 1) * W_OP;
+                const int a_nxt = a_slot == A_SLOTS - 1 ? 0 : a_slot + 1;
+                const int a_prv = a_slot == 0 ? A_SLOTS - 1 : a_slot - 1;
+                // C(t, 0)
+                P_COMPUTE()
+                P_SEG_END()
+                // L_a(t): A(t+2) into the slot of tile t-1; fragments of half 1; counted wait: tile t+1 has landed
+                if (kt + 2 < nk) { P_ISSUE_A(a_prv, (kt + 2) * P_BK) }
+                P_READ(0, as, ws, 1)
+                if (kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0070 | AI);   // vmcnt(AI) lgkmcnt(0)
+                else __builtin_amdgcn_s_waitcnt(0x0070);                    // vmcnt(0) lgkmcnt(0)
+                P_SEG_END()
+                // C(t, 1)
+                P_COMPUTE()
+                P_SEG_END()
+                // L_b(t): W(t+2) into the slot of tile t; fragments of half 0 of tile t+1
+                if (kt + 2 < nk) { P_ISSUE_W(kt & 1, (kt + 2) * P_BK) }
+                if (kt + 1 < nk) { P_READ(0, smem + a_nxt * A_OP, smem_w + ((kt + 1) & 1) * W_OP, 0) }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                P_SEG_END()
+                a_slot = a_nxt;
+            }
+        } else {
+            // ---------- narrow tiles (16 MFMAs per half would leave the barriers as long as the segments): ONE compute segment per
+            // k-tile (both halves, two fragment sets) and one load segment that re-arms the slots of the tile just multiplied with
+            // tile t+3 and reads tile t+1.  A(g), W(g) in slot g % 3: three k-tiles of lookahead, two barriers per k-tile.
+            if (nk > 1) { P_ISSUE_A(1, P_BK) P_ISSUE_W(1, P_BK) }
+            if (nk > 2) { P_ISSUE_A(2, 2 * P_BK) P_ISSUE_W(2, 2 * P_BK) }
+            if (nk > 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NPRE));
+            else if (nk > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | NPRE);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            if (wave >= 4) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            P_READ(0, smem, smem_w, 0)
+            P_READ(1, smem, smem_w, 1)
+            if (nk > 2) __builtin_amdgcn_s_waitcnt(0x0070 | NPRE);   // k-tile 1 has landed (k-tile 2 may fly); lgkmcnt(0)
+            else __builtin_amdgcn_s_waitcnt(0x0070);
+            P_SEG_END()
+            int a_slot = 0;
+            for (int kt = 0; kt < nk; kt++) {
+                const int a_nxt = a_slot == 2 ? 0 : a_slot + 1;
+                P_COMPUTE()
+                P_SEG_END()
+                if (kt + 3 < nk) {
+                    P_ISSUE_A(a_slot, (kt + 3) * P_BK)
+                    P_ISSUE_W(a_slot, (kt + 3) * P_BK)
+                }
+                if (kt + 1 < nk) {
+                    P_READ(0, smem + a_nxt * A_OP, smem_w + a_nxt * W_OP, 0)
+                    P_READ(1, smem + a_nxt * A_OP, smem_w + a_nxt * W_OP, 1)
+                }
+                if (kt + 3 < nk) __builtin_amdgcn_s_waitcnt(0x0070 | NPRE);   // k-tile t+2 has landed (t+3 may fly); lgkmcnt(0)
+                else __builtin_amdgcn_s_waitcnt(0x0070);
+                P_SEG_END()
+                a_slot = a_nxt;
+            }
+        }
+        if constexpr (PING) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (wave < 4) __builtin_amdgcn_s_barrier();      // every wave's LDS reads and DMAs of this tile are done: the ring is free
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ================= the next tile: its setup replaces this tile's DMA state (dead), its first k-tile is issued by the epilogue
+        const int em0 = m0, en0 = n0, emt = mt, ent = nt;
+        const bool eactive = wave_active;
+        const int b2 = next_valid(b + (int)gridDim.x, mt, nt);
+        const bool has_next = b2 >= 0;
+        if (has_next) P_TILE_SETUP()
+        // NWN = 4 (128 accumulator registers): once the next tile's first k-tile is issued, its per-lane DMA state (AI offsets, AI tap
+        // masks, WI weight offsets) is parked in W slot 1 -- free during every epilogue -- and read back below: 12 registers the
+        // epilogue's staging arrays would otherwise push into scratch
+        constexpr bool PARK = NWN == 4;
+        uint4* const park = reinterpret_cast<uint4*>(smem_w + W_OP) + tid;
+        auto prefetch = [&]() {
+            if (has_next) {
+                P_ISSUE_A(0, 0)
+                P_ISSUE_W(0, 0)
+                if constexpr (PARK) {
+                    park[0] = make_uint4(a_voff[0], a_voff[1], a_voff[2], a_voff[3]);
+                    park[512] = make_uint4((unsigned)a_bits[0], (unsigned)a_bits[1], (unsigned)a_bits[2], (unsigned)a_bits[3]);
+                    park[1024] = make_uint4(w_voff, 0u, 0u, 0u);
+                }
+            }
+        };
+#define P_WAIT_OPERANDS()   /* the epilogue's first operand loads are done; the NPRE pieces issued behind them may still fly */ \
+    if (has_next) __builtin_amdgcn_s_waitcnt(0x0F70 | NPRE); else __builtin_amdgcn_s_waitcnt(0x0F70);
+
+        // ================= epilogue of tile (em0, en0)
+#ifdef PP_EXP_EPI_DRAIN
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        // Every global access of the epilogues goes through a buffer descriptor on the TILE's rows of the matrix (rows beyond M fall
+        // outside its range: loads return 0, stores are dropped by the hardware) with ONE per-lane_e byte offset per matrix (columns
+        // beyond N: an out-of-range offset) and the row inside the tile in the scalar offset: no per-row predicates, branches or 64-bit
+        // per-lane_e address arithmetic -- the round-2 pointer form of these loops kept ~2 address registers per row alive and, inside
+        // the persistent loop, spilled 100-350 registers per tile.  (launch_large_pp takes only identity output / residual row maps.)
+        const int rows_here = min(T_BM, p.M - em0);
+        auto tile_rsrc = [&](const void* base, int64_t ld, int es) {
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + (int64_t)em0 * ld * es, 0, (int)(rows_here * ld * es), 0x00020000);
+        };
+        typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+        typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2_t;
+        if constexpr (EPI == EPI_STORE && !TAIL) {
+            if (p.frag_out) {   // fragment order: straight from the accumulators, 512 contiguous bytes per wave instruction, no LDS
+                prefetch();
+                if (eactive) {
+                    bf16x4* fdst = reinterpret_cast<bf16x4*>(p.out) + ((int64_t)(emt * n_tiles + ent) * 8 + wave) * (NX * 4 * 64) + lane_e;
+#pragma unroll
+                    for (int j = 0; j < NX; j++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            f32x4 v = acc[i][j];
+                            if (p.act) {
+#pragma unroll
+                                for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act);
+                            }
+                            fdst[(j * 4 + i) * 64] = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        }
+                }
+                goto tile_done;
+            }
+        }
+        if constexpr (EPI == EPI_STORE && NWN == 4 && TAIL) {
+            {
+                // Fused 1x1 tail (RAFT's FlowHead): T[256 px][32] = relu(tile)[256 px][256 ch] . tail_w[32][256]^T.  The activated tile
+                // takes the whole ring (16 KiB per wave from offset 0), so the next tile's first k-tile is issued AFTER the tail's
+                // LDS reads (no overlap here; one launch of eleven per refinement iteration).
+                const bf16_t* const tw = reinterpret_cast<const bf16_t*>(p.tail_w);
+                char* const cst = smem + wave * (WROWS * 128);
+#pragma unroll
+                for (int j = 0; j < NX; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        f32x4 v = acc[i][j];
+                        if (p.act) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act);
+                        }
+                        const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        const int row = j * 16 + (lane_e & 15), c16 = (i * 2 + ((lane_e >> 4) >> 1)) ^ (row & 7);
+                        *reinterpret_cast<bf16x4*>(cst + row * 128 + c16 * 16 + ((lane_e >> 4) & 1) * 8) = pk;
+                    }
+                bf16x8 twf[2][8];
+#pragma unroll
+                for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+                    for (int ks = 0; ks < 8; ks++) twf[nb][ks] = *reinterpret_cast<const bf16x8*>(tw + (nb * 16 + (lane_e & 15)) * 256 + ks * 32 + (lane_e >> 4) * 8);
+                P_PHASE_BARRIER()
+                const auto t_rs = tile_rsrc(p.tail_out, p.ldtail, 4);
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++) {
+                    const int blk = wn * 2 + pb, row = blk * 16 + (lane_e & 15);
+                    f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ks++) {
+                        const int k = ks * 32 + (lane_e >> 4) * 8, reg = k >> 6, c16 = (k & 63) >> 3;
+                        const bf16x8 xfr = *reinterpret_cast<const bf16x8*>(smem + (wm + MW * reg) * (WROWS * 128) + row * 128 + ((c16 ^ (row & 7)) << 4));
+                        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twf[0][ks], xfr, t0, 0, 0, 0);
+                        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(twf[1][ks], xfr, t1, 0, 0, 0);
+                    }
+                    const unsigned vo = (unsigned)((wm * WROWS + row) * (int)p.ldtail + (lane_e >> 4) * 4) * 4u;      // (rows beyond M: out of range)
+                    P_STORE128(__builtin_bit_cast(u32x4_t, t0), t_rs, vo, 0);
+                    P_STORE128(__builtin_bit_cast(u32x4_t, t1), t_rs, vo + 64, 0);
+                }
+                P_PHASE_BARRIER()                      // every wave's reads of the staged tile are done: the ring is free again
+                prefetch();
+                goto tile_done;
+            }
+        }
+        if constexpr ((EPI == EPI_STORE || EPI == EPI_GELU) && !TAIL) {
+            // bf16 outputs through the wave's staging region in passes of RP rows (16-byte chunks XOR-swizzled by row & 7): 16 bytes
+            // per lane_e, 8 whole 128-byte row segments per store instruction.  The operands of the fused elementwise tails (r * h gate,
+            // ResidualBlock skip) of ALL passes are requested first, then the next tile's first k-tile; one counted wait.
+            constexpr int RP = SB / 128 < WROWS ? SB / 128 : WROWS, NP = WROWS / RP, JB = RP / 16;
+            const bool gated = EPI == EPI_STORE && p.gate_from > 0, resd = EPI == EPI_STORE && !gated && p.resid_bf16 != nullptr;
+            const int ch0 = lane_e & 7, nn = en0 + wn * 64 + ch0 * 8;
+            const bool to_out2 = gated && (en0 + wn * 64) >= p.gate_from;     // wave-uniform (gate_from % 64 == 0): this wave's columns are r -> r * h
+            const int col = to_out2 ? nn - p.gate_from : nn;
+            const int64_t ld_o = to_out2 ? p.ldo2 : p.ldo;
+            const auto o_rs = tile_rsrc(to_out2 ? p.out2 : p.out, ld_o, 2);
+            const unsigned o_lane = nn < p.N ? (unsigned)((wm * WROWS + (lane_e >> 3)) * (int)ld_o + col) * 2u : OOB;
+            u32x4_t opnd[RP / 8];
+            const int64_t ld_g = to_out2 ? p.ldaux : p.ldrb;
+            const bool has_opnd = to_out2 || resd;
+            const auto g_rs = tile_rsrc(to_out2 ? p.aux : (resd ? p.resid_bf16 : p.out), has_opnd ? ld_g : p.ldo, 2);
+            const unsigned g_lane = nn < p.N ? (unsigned)((wm * WROWS + (lane_e >> 3)) * (int)ld_g + col) * 2u : OOB;
+#define P_OPND_LOAD(h) _Pragma("unroll") for (int rr = 0; rr < RP / 8; rr++) opnd[rr] = __builtin_amdgcn_raw_buffer_load_b128(g_rs, g_lane, ((h) * RP + rr * 8) * (int)ld_g * 2, 0);
+            if (has_opnd) { P_OPND_LOAD(0) }
+            prefetch();
+#pragma unroll
+            for (int ps = 0; ps < NP; ps++) {
+#pragma unroll
+                for (int jj = 0; jj < JB; jj++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        f32x4 v = acc[i][ps * JB + jj];
+                        if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) v[e] = gelu_erf_fast(v[e]);
+                        } else if (p.act) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act);
+                        }
+                        const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        const int row = jj * 16 + (lane_e & 15), c16 = (i * 2 + ((lane_e >> 4) >> 1)) ^ (row & 7);
+                        *reinterpret_cast<bf16x4*>(stage + row * 128 + c16 * 16 + ((lane_e >> 4) & 1) * 8) = pk;
+                    }
+                if (gated || resd) {      // (wave-uniform per launch; waves of a gated launch that hold z columns wait for nothing they issued)
+                    if (ps == 0) { P_WAIT_OPERANDS() }
+                    else __builtin_amdgcn_s_waitcnt(0x0F70 | (RP / 8));      // this pass's operands; the previous pass's RP / 8 stores may still fly
+                }
+                u32x4_t vv[RP / 8];
+#pragma unroll
+                for (int rr = 0; rr < RP / 8; rr++) {
+                    const int row = rr * 8 + (lane_e >> 3);
+                    vv[rr] = *reinterpret_cast<const u32x4_t*>(stage + row * 128 + ((ch0 ^ (row & 7)) << 4));
+                }
+                if (has_opnd) {
+#pragma unroll
+                    for (int rr = 0; rr < RP / 8; rr++) {
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, vv[rr]);
+                        const bf16x8 g = __builtin_bit_cast(bf16x8, opnd[rr]);
+                        bf16x8 o;
+                        if (to_out2) {
+#pragma unroll
+                            for (int e = 0; e < 8; e++) o[e] = (bf16_t)((float)a[e] * (float)g[e]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; e++) {
+                                const float t = (float)a[e] + (float)g[e];
+                                o[e] = (bf16_t)(p.post_relu ? fmaxf(t, 0.f) : t);
+                            }
+                        }
+                        vv[rr] = __builtin_bit_cast(u32x4_t, o);
+                    }
+                    if (ps + 1 < NP) { P_OPND_LOAD(ps + 1) }     // the next pass's operands (same registers), requested before this pass's stores
+                }
+#pragma unroll
+                for (int rr = 0; rr < RP / 8; rr++) P_STORE128(vv[rr], o_rs, o_lane, (ps * RP + rr * 8) * (int)ld_o * 2);
+            }
+#undef P_OPND_LOAD
+        }
+        if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
+            // fp32 outputs: PR rows per pass through the staging region (256-byte rows, 16-byte chunks XOR-swizzled by row & 15), 4
+            // whole 256-byte row segments per store instruction.  The fp32 residual rows of pass h+1 are requested before pass h's
+            // stores; every wait is counted (the next tile's pieces / the previous pass's stores stay in flight).
+            constexpr int PR = SB / 256 < WROWS ? SB / 256 : WROWS, NP = WROWS / PR;
+            const int rl = lane_e >> 4, cl = lane_e & 15;
+            const bool do_stats = (EPI == EPI_STORE_F32) && p.col_stats != nullptr;
+            const int img_a = do_stats ? em0 / p.stats_rows : 0;
+            const int m_b = do_stats ? (img_a + 1) * p.stats_rows : 0x7fffffff;
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, qa = sa, sb = sa, qb = sa;
+            const int n = en0 + wn * 64 + cl * 4;
+            const auto o_rs = tile_rsrc(p.out, p.ldo, 4);
+            const unsigned o_lane = n < p.N ? (unsigned)((wm * WROWS + rl) * (int)p.ldo + n) * 4u : OOB;
+            const auto r_rs = tile_rsrc(EPI == EPI_RESID_F32 ? (const void*)p.resid : (const void*)p.out, EPI == EPI_RESID_F32 ? p.ldr : p.ldo, 4);
+            const unsigned r_lane = n < p.N ? (unsigned)((wm * WROWS + rl) * (int)(EPI == EPI_RESID_F32 ? p.ldr : p.ldo) + n) * 4u : OOB;
+            u32x4_t rq[PR / 4];
+#define P_RESID_LOAD(h)                                                                                             \
+    _Pragma("unroll") for (int rr = 0; rr < PR / 4; rr++) rq[rr] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, r_lane, ((h) * PR + rr * 4) * (int)p.ldr * 4, 0);
+            if constexpr (EPI == EPI_RESID_F32) { P_RESID_LOAD(0) }
+            prefetch();
+#pragma unroll
+            for (int ps = 0; ps < NP; ps++) {
+#pragma unroll
+                for (int jj = 0; jj < PR / 16; jj++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int row = jj * 16 + (lane_e & 15), chunk = i * 4 + (lane_e >> 4);
+                        *reinterpret_cast<f32x4*>(stage + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][ps * (PR / 16) + jj];
+                    }
+                if constexpr (EPI == EPI_RESID_F32) {
+                    if (ps == 0) { P_WAIT_OPERANDS() }
+                    else __builtin_amdgcn_s_waitcnt(0x0F70 | (PR / 4));   // this pass's rows; the previous pass's PR / 4 stores may still fly
+                }
+                f32x4 vv[PR / 4];
+#pragma unroll
+                for (int rr = 0; rr < PR / 4; rr++) {
+                    const int row = rr * 4 + rl;
+                    vv[rr] = *reinterpret_cast<const f32x4*>(stage + row * 256 + ((cl ^ (row & 15)) << 4));
+                    if constexpr (EPI == EPI_RESID_F32) vv[rr] += __builtin_bit_cast(f32x4, rq[rr]);
+                }
+                if constexpr (EPI == EPI_RESID_F32) {
+                    if (ps + 1 < NP) { P_RESID_LOAD(ps + 1) }   // the next pass's rows, requested before this pass's stores
+                }
+#pragma unroll
+                for (int rr = 0; rr < PR / 4; rr++) {
+                    P_STORE128(__builtin_bit_cast(u32x4_t, vv[rr]), o_rs, o_lane, (ps * PR + rr * 4) * (int)p.ldo * 4);
+                    if constexpr (EPI == EPI_STORE_F32) {
+                        if (do_stats) {
+                            const int m = em0 + wm * WROWS + ps * PR + rr * 4 + rl;
+                            if (m < p.M && n < p.N && eactive) {
+                                if (m < m_b) { sa += vv[rr]; qa += vv[rr] * vv[rr]; }
+                                else { sb += vv[rr]; qb += vv[rr] * vv[rr]; }
+                            }
+                        }
+                    }
+                }
+            }
+#undef P_RESID_LOAD
+            if constexpr (EPI == EPI_STORE_F32) {
+                if (do_stats) {
+                    // lanes with equal cl hold the same four columns: fold the four row groups, park the wave's partials in its staging
+                    // region, then 64 NWN threads fold the MW waves of a column and issue one atomic per (image, column, moment)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        sa[e] += __shfl_xor(sa[e], 16); sa[e] += __shfl_xor(sa[e], 32);
+                        qa[e] += __shfl_xor(qa[e], 16); qa[e] += __shfl_xor(qa[e], 32);
+                        sb[e] += __shfl_xor(sb[e], 16); sb[e] += __shfl_xor(sb[e], 32);
+                        qb[e] += __shfl_xor(qb[e], 16); qb[e] += __shfl_xor(qb[e], 32);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xC07F);      // (my staging reads are done before the region is reused)
+                    if (rl == 0) {
+                        f32x4* const pr = reinterpret_cast<f32x4*>(stage);
+                        pr[cl] = sa; pr[16 + cl] = qa; pr[32 + cl] = sb; pr[48 + cl] = qb;    // (a row-inactive wave parks zeros)
+                    }
+                    P_PHASE_BARRIER()
+                    if (tid < 64 * NWN) {                    // (threads of waves 0 .. NWN-1, whether or not their own rows are valid)
+                        const int wn_ = tid >> 6, c = tid & 63, nc = en0 + wn_ * 64 + c;
+                        if (nc < p.N) {
+                            float t[4] = {0.f, 0.f, 0.f, 0.f};
+                            for (int wm_ = 0; wm_ < MW; wm_++) {
+                                if (em0 + wm_ * WROWS >= p.M) break;
+                                const float* pr = reinterpret_cast<const float*>(smem + A_OP + (wn_ * MW + wm_) * SB);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) t[e] += pr[e * 64 + c];
+                            }
+                            float* st = p.col_stats + ((int64_t)img_a * p.N + nc) * 2;
+                            unsafeAtomicAdd(st, t[0]);
+                            unsafeAtomicAdd(st + 1, t[1]);
+                            if (em0 + T_BM > m_b && m_b < p.M) {
+                                unsafeAtomicAdd(st + 2 * p.N, t[2]);
+                                unsafeAtomicAdd(st + 2 * p.N + 1, t[3]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#ifdef PP_EXP_GRU_BUFNOLDS
+        if constexpr (EPI == EPI_GRU) {      // buffer ops, fragment-shaped, no LDS
+            prefetch();
+            const auto h_rs = tile_rsrc(p.resid, p.ldr, 4), z_rs = tile_rsrc(p.aux, p.ldaux, 2), o_rs = tile_rsrc(p.out, p.ldo, 4), o2_rs = tile_rsrc(p.out2, p.ldo2, 2);
+#pragma unroll
+            for (int j = 0; j < NX; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int row = wm * WROWS + j * 16 + (lane_e & 15), n = en0 + wn * 64 + i * 16 + (lane_e >> 4) * 4;
+                    const u32x4_t hq = __builtin_amdgcn_raw_buffer_load_b128(h_rs, (unsigned)(row * (int)p.ldr + n) * 4u, 0, 0);
+                    const u32x2_t zq = __builtin_amdgcn_raw_buffer_load_b64(z_rs, (unsigned)(row * (int)p.ldaux + n) * 2u, 0, 0);
+                    const f32x4 hv = __builtin_bit_cast(f32x4, hq);
+                    const bf16x4 zv = __builtin_bit_cast(bf16x4, zq);
+                    f32x4 hn;
+                    for (int e = 0; e < 4; e++) { const float z = (float)zv[e]; hn[e] = (1.0f - z) * hv[e] + z * tanh_fast(acc[i][j][e]); }
+                    const bf16x4 hb = {(bf16_t)hn[0], (bf16_t)hn[1], (bf16_t)hn[2], (bf16_t)hn[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, hn), o_rs, (unsigned)(row * (int)p.ldo + n) * 4u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, hb), o2_rs, (unsigned)(row * (int)p.ldo2 + n) * 2u, 0, 0);
+                }
+            goto tile_done;
+        }
+#endif
+#ifdef PP_EXP_GRU_GENERIC
+        if constexpr (EPI == EPI_GRU) {
+            prefetch();
+#pragma unroll
+            for (int j = 0; j < NX; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) store4<EPI>(p, em0 + wm * WROWS + j * 16 + (lane_e & 15), en0 + wn * 64 + i * 16 + (lane_e >> 4) * 4, acc[i][j]);
+            goto tile_done;
+        }
+#endif
+        if constexpr (EPI == EPI_GRU) {
+            // h' = (1 - z) h + z tanh(acc): the accumulators go through the staging region as in the fp32 path so that h, z and both
+            // outputs are touched as whole row segments.  h / z of pass h+1 are requested before pass h's stores (two register sets),
+            // every wait is counted.
+            constexpr int PR = SB / 256 < WROWS ? SB / 256 : WROWS, NP = WROWS / PR;
+            const int rl = lane_e >> 4, cl = lane_e & 15;
+            const int n = en0 + wn * 64 + cl * 4;
+            const auto h_rs = tile_rsrc(p.resid, p.ldr, 4), z_rs = tile_rsrc(p.aux, p.ldaux, 2), o_rs = tile_rsrc(p.out, p.ldo, 4), o2_rs = tile_rsrc(p.out2, p.ldo2, 2);
+            const int rowl = wm * WROWS + rl;
+            const unsigned h_lane = n < p.N ? (unsigned)(rowl * (int)p.ldr + n) * 4u : OOB, z_lane = n < p.N ? (unsigned)(rowl * (int)p.ldaux + n) * 2u : OOB;
+            const unsigned o_lane = n < p.N ? (unsigned)(rowl * (int)p.ldo + n) * 4u : OOB, o2_lane = n < p.N ? (unsigned)(rowl * (int)p.ldo2 + n) * 2u : OOB;
+            u32x4_t hreg[2][PR / 4];
+            u32x2_t zreg[2][PR / 4];
+#define P_GRU_LOAD(S, h)                                                                                            \
+    _Pragma("unroll") for (int rr = 0; rr < PR / 4; rr++) {                                                          \
+        hreg[S][rr] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, h_lane, ((h) * PR + rr * 4) * (int)p.ldr * 4, 0);   \
+        zreg[S][rr] = __builtin_amdgcn_raw_buffer_load_b64(z_rs, z_lane, ((h) * PR + rr * 4) * (int)p.ldaux * 2, 0);  \
+    }
+            P_GRU_LOAD(0, 0)
+            prefetch();
+#pragma unroll
+            for (int ps = 0; ps < NP; ps++) {
+#ifdef PP_EXP_GRU_NOAHEAD
+                if (ps > 0) { if (ps & 1) { P_GRU_LOAD(1, ps) } else { P_GRU_LOAD(0, ps) } }
+#endif
+#pragma unroll
+                for (int jj = 0; jj < PR / 16; jj++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int row = jj * 16 + (lane_e & 15), chunk = i * 4 + (lane_e >> 4);
+                        *reinterpret_cast<f32x4*>(stage + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][ps * (PR / 16) + jj];
+                    }
+#ifdef PP_EXP_GRU_SERIAL
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0x0070);
+                __builtin_amdgcn_sched_barrier(0);
+#else
+                if (ps == 0) { P_WAIT_OPERANDS() }
+                else __builtin_amdgcn_s_waitcnt(0x0F70 | ((PR / 2) & 15) | (((PR / 2) >> 4) << 14));      // the previous pass's 2 PR / 4 stores may still fly
+#endif
+#ifndef PP_EXP_GRU_NOAHEAD
+                if (ps + 1 < NP) {
+                    if ((ps & 1) == 0) { P_GRU_LOAD(1, ps + 1) } else { P_GRU_LOAD(0, ps + 1) }
+                }
+#endif
+#pragma unroll
+                for (int rr = 0; rr < PR / 4; rr++) {
+                    const int row = rr * 4 + rl;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 256 + ((cl ^ (row & 15)) << 4));
+                    const f32x4 hv = __builtin_bit_cast(f32x4, hreg[ps & 1][rr]);
+                    const bf16x4 zv = __builtin_bit_cast(bf16x4, zreg[ps & 1][rr]);
+                    f32x4 hn;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float z = (float)zv[e];
+                        hn[e] = (1.0f - z) * hv[e] + z * tanh_fast(v[e]);
+                    }
+                    const bf16x4 hb = {(bf16_t)hn[0], (bf16_t)hn[1], (bf16_t)hn[2], (bf16_t)hn[3]};
+                    P_STORE128(__builtin_bit_cast(u32x4_t, hn), o_rs, o_lane, (ps * PR + rr * 4) * (int)p.ldo * 4);
+                    P_STORE64(__builtin_bit_cast(u32x2_t, hb), o2_rs, o2_lane, (ps * PR + rr * 4) * (int)p.ldo2 * 2);
+                }
+            }
+#undef P_GRU_LOAD
+        }
+    tile_done:
+        if (!has_next) break;
+        b = b2;
+        if constexpr (PARK) {
+            const uint4 t0 = park[0], t1 = park[512], t2 = park[1024];
+            a_voff[0] = t0.x; a_voff[1] = t0.y; a_voff[2] = t0.z; a_voff[3] = t0.w;
+            a_bits[0] = (int)t1.x; a_bits[1] = (int)t1.y; a_bits[2] = (int)t1.z; a_bits[3] = (int)t1.w;
+            w_voff = t2.x;
+        }
+        P_PHASE_BARRIER()                 // every wave is done with its staging region (and its parked state): A'(1) / W'(1) may land
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------
+static int g_cu_count = 0;
+static int cu_count() {
+    if (g_cu_count == 0) {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_cu_count = n;
+    }
+    return g_cu_count;
+}
+
+// What the persistent kernel takes (everything else stays with gemm_bf16_large_kernel): identity output / residual row maps,
+// whole-vector rows for its staged epilogues, fragment-order start maps, wave-aligned gates.
+bool pp_supported(const GemmDesc& d) {
+    if (d.o_map.seg_rows != 0 || d.r_map.seg_rows != 0) return false;
+    if (d.init_bf16 && !d.init_frag) return false;
+    if ((d.N & 3) != 0 || (d.ldw & 63) != 0) return false;      // (the weight pieces' swizzle is applied as offset ^ 64: rows of whole 128 bytes)
+    switch (d.epi) {
+        case EPI_STORE:
+        case EPI_GELU:
+            if (d.frag_out) return true;
+            if ((d.N & 7) != 0 || (d.ldo & 7) != 0 || d.out_scale != 0.f) return false;
+            if (d.gate_from > 0 && ((d.gate_from & 63) != 0 || (d.ldaux & 7) != 0 || (d.ldo2 & 7) != 0)) return false;
+            if (d.resid_bf16 && (d.ldrb & 7) != 0) return false;
+            if (d.tail_w && (d.N != 256 || (d.ldtail & 3) != 0 || d.conv_KH == 0)) return false;
+            return true;
+        case EPI_RESID_F32:
+            return (d.ldo & 3) == 0 && (d.ldr & 3) == 0 && d.act == 0 && d.out_scale == 0.f && d.resid != nullptr;
+        case EPI_STORE_F32:
+            return (d.ldo & 3) == 0 && d.act == 0 && d.out_scale == 0.f;
+        case EPI_GRU:
+            return ((d.ldo | d.ldr | d.ldaux | d.ldo2) & 3) == 0 && d.N <= 128;      // (RAFT's q convolutions: 128 channels)
+    }
+    return false;
+}
+
+template <int EPI, bool CONV, int NWN>
+int launch_large_pp(const GemmDesc& d, hipStream_t s) {
+    constexpr int T_BM = 256, T_BN = 64 * NWN;
+    static_assert(NWN == 4 || NWN == 2, "the 64-wide tile (two workgroups per CU) stays with gemm_bf16_large_kernel");
+    constexpr bool PING = !CONV;
+    constexpr int LDS = 3 * P_AOP + ((PING && NWN < 4) ? 3 : 2) * T_BN * 128;
+    const int m_tiles = (d.M + T_BM - 1) / T_BM, n_tiles = (d.N + T_BN - 1) / T_BN;
+    const int G = n_tiles <= 8 ? 2 : 8;
+    const int mx = (m_tiles + 7) / 8, groups = (mx + G - 1) / G;
+    const int total = 8 * groups * G * n_tiles;
+    const int resident = cu_count();                                   // one workgroup per CU (LDS-limited)
+    const int grid = total < resident ? total : resident;
+    const double exec_flops = 2.0 * d.M * d.N * d.K;
+    ProfScope prof(CONV ? VTGB_PROF_CONV : VTGB_PROF_GEMM, d.algo_flops > 0 ? d.algo_flops : d.algo_flops < 0 ? 0.0 : exec_flops, s, exec_flops);
+    if constexpr (EPI == EPI_STORE && CONV && NWN == 4) {
+        if (d.tail_w) {      // the fused 1x1 tail is its own instantiation (its 64 weight-fragment registers are not every tile's problem)
+            static DeviceOnce attr_t;
+            VTGB_FUNC_LDS_ONCE(attr_t, (gemm_bf16_pp_kernel<EPI, CONV, NWN, true>), LDS);
+            hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, CONV, NWN, true>), dim3(grid), dim3(512), LDS, s, d, m_tiles, n_tiles, G, total);
+            VTGB_HIP(hipGetLastError());
+            return VTGB_OK;
+        }
+    }
+    static DeviceOnce attr;
+    VTGB_FUNC_LDS_ONCE(attr, (gemm_bf16_pp_kernel<EPI, CONV, NWN>), LDS);
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, CONV, NWN>), dim3(grid), dim3(512), LDS, s, d, m_tiles, n_tiles, G, total);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+// explicit entry points used by gemm.hip (one per instantiation it dispatches to)
+#define PP_INST(EPI, CONV, NWN) template int launch_large_pp<EPI, CONV, NWN>(const GemmDesc&, hipStream_t);
+PP_INST(EPI_STORE, false, 4) PP_INST(EPI_GELU, false, 4) PP_INST(EPI_RESID_F32, false, 4) PP_INST(EPI_STORE_F32, false, 4)
+PP_INST(EPI_STORE, false, 2) PP_INST(EPI_STORE_F32, false, 2)
+PP_INST(EPI_STORE, true, 4) PP_INST(EPI_STORE, true, 2)
+PP_INST(EPI_STORE_F32, true, 4) PP_INST(EPI_STORE_F32, true, 2)
+PP_INST(EPI_GRU, true, 2)
