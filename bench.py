@@ -89,6 +89,8 @@ def parse():
     ap.add_argument("--no-prof", action="store_true", help="skip the (untimed) roofline pass that records per-launch HIP events")
     ap.add_argument("--prof-steps", type=int, default=2, help="steps of the untimed roofline pass")
     ap.add_argument("--stage-times", action="store_true", help="print a per-stage breakdown to stderr")
+    ap.add_argument("--spawn", action="store_true", help="start the ranks through torch.distributed.run as a child process even for --gpus 1 "
+                    "(the launch path of --gpus N, testable on a 1-GPU box)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl = RCCL) even with one rank: exercises the "
                                                               "barrier / MAX-over-ranks path of the multi-GPU launch on a 1-GPU box")
     return ap.parse_args()
@@ -282,12 +284,12 @@ def host_resident_leg(m, rank, B, T, nframe, max_new_tokens, decoder, dev, steps
 
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.spawn) and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or args.force_dist
+    use_dist = world > 1 or args.force_dist or "TORCHELASTIC_RUN_ID" in os.environ      # under a launcher: always the RCCL path
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")

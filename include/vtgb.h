@@ -447,6 +447,22 @@ int vtgb_pack_skinny_weight(const void* w, int64_t ldw, int32_t N, int32_t K, vo
 size_t vtgb_gemm_skinny_workspace_bytes(const vtgb_gemm_skinny_args* a);
 int vtgb_gemm_skinny(const vtgb_gemm_skinny_args* a, vtgb_stream_t stream);
 
+/* ---- gradient exchange (config C5; the one collective of the path) ------------------------------------------------
+ * Thin wrapper over RCCL (SURVEY.md 8b "later: vtgb_allreduce_f32", 8e): replaces what Lightning's DDPStrategy does for the reference
+ * (configs/trainer/ddp.yaml:4, find_unused_parameters: the sum / mean all-reduce of the trainable gradients once per optimizer
+ * step).  One communicator per process (= per GPU); rank 0 creates the id with vtgb_comm_unique_id and the host side hands
+ * its VTGB_COMM_ID_BYTES bytes to every rank (any channel: torch.distributed's store, a file, MPI); vtgb_comm_init is
+ * collective.  vtgb_allreduce_f32 reduces `count` floats IN PLACE, asynchronously on `stream` (sum, or mean when `average`):
+ * the caller allocates its gradients as views of one flat buffer and reduces it in a few large pieces -- xGMI is
+ * point-to-point, ring collectives are per-link bound, large messages amortise the ring latency.  RCCL is bound with
+ * dlopen at the first call; processes that never call these functions never load it. */
+#define VTGB_COMM_ID_BYTES 128
+typedef struct vtgb_comm vtgb_comm;
+int vtgb_comm_unique_id(void* id_out /* host, VTGB_COMM_ID_BYTES */);
+int vtgb_comm_init(vtgb_comm** comm, const void* unique_id /* host */, int32_t rank, int32_t world);
+int vtgb_comm_destroy(vtgb_comm* comm);
+int vtgb_allreduce_f32(vtgb_comm* comm, float* buf, size_t count, int32_t average, vtgb_stream_t stream);
+
 /* ---- in-library launch timing (used by bench.py for the roofline figure) -------------------
  * While enabled, every GEMM / attention launch of the bf16 path is bracketed by a pair of HIP
  * events recorded on the launch stream (no synchronisation at record time).  vtgb_prof_summary

@@ -28,10 +28,28 @@ def _worker(rank, world, port, q):
     t = vd.max_over_ranks(1.0 + rank)
     torch.manual_seed(0)
     lin = torch.nn.Linear(4, 3)
-    lin.weight.grad = torch.full_like(lin.weight, float(rank + 1))
+    lin.weight.grad = torch.full_like(lin.weight, float(rank + 1))          # gradients that exist before the bucket: folded in
     lin.bias.grad = torch.full_like(lin.bias, 10.0 * (rank + 1))
     vd.FlatGradBucket(lin.parameters()).all_reduce(average=False)
-    q.put((rank, list(mine), merged, t, lin.weight.grad[0, 0].item(), lin.bias.grad[0].item()))
+    # the overlapped path: gradients are views of the flat buffer, segments go out from the backward hooks (last parameters first)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4))
+    bucket = vd.FlatGradBucket(net.parameters(), segment_bytes=256)         # several segments
+    views_ok = all(p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * o for p, o in zip(bucket.params, bucket.offsets))
+    x = torch.full((2, 8), float(rank + 1))
+    ref = [torch.zeros_like(p) for p in net.parameters()]
+    for r_ in range(world):                                                 # what the mean over ranks must be
+        net.zero_grad(set_to_none=False)
+        net(torch.full((2, 8), float(r_ + 1))).sum().backward()
+        for g, p in zip(ref, net.parameters()):
+            g += p.grad / world
+    bucket.zero_()
+    bucket.arm(average=True)
+    net(x).sum().backward()
+    launched_in_backward = sum(bucket._launched)
+    bucket.all_reduce(average=True)
+    overlap_ok = all(torch.allclose(p.grad, g, rtol=1e-6, atol=1e-6) for p, g in zip(net.parameters(), ref)) and views_ok \
+        and all(p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * o for p, o in zip(bucket.params, bucket.offsets))
+    q.put((rank, list(mine), merged, t, lin.weight.grad[0, 0].item(), lin.bias.grad[0].item(), overlap_ok, launched_in_backward, len(bucket.segments)))
     dist.destroy_process_group()
 
 
@@ -46,7 +64,9 @@ def test_two_rank_clip_sharding_and_grad_allreduce():
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    (r0, c0, m0, t0, w0, b0), (r1, c1, m1, t1, w1, b1) = out
+    (r0, c0, m0, t0, w0, b0, ok0, l0, ns0), (r1, c1, m1, t1, w1, b1, ok1, l1, ns1) = out
+    assert ok0 and ok1                                                   # views, mean over ranks, still views afterwards
+    assert ns0 > 1 and l0 == ns0 and l1 == ns1                           # every segment left from a backward hook, not from all_reduce()
     assert c0 == [0, 1, 2, 3, 4, 5] and c1 == [6, 7, 8, 9, 10]          # ceil(11/2) = 6 per chunk, contiguous
     assert m0 == m1 == [(c, c * c) for c in range(11)]                  # rank-order merge == `cat` of the shell driver
     assert t0 == t1 == 2.0                                              # slowest rank

@@ -31,7 +31,9 @@ EXPORTS = [
     "vtgb_gemm_skinny_workspace_bytes", "vtgb_gemm_skinny", "vtgb_pack_skinny_weight_bytes", "vtgb_pack_skinny_weight",
     "vtgb_raft_update_workspace_bytes", "vtgb_raft_update", "vtgb_raft_encoder_workspace_bytes", "vtgb_raft_encoder",
     "vtgb_raft_corr_workspace_bytes", "vtgb_raft_corr", "vtgb_preprocess_frames", "vtgb_concat_text_io", "vtgb_shifted_ce_forward", "vtgb_shifted_ce_backward",
+    "vtgb_comm_unique_id", "vtgb_comm_init", "vtgb_comm_destroy", "vtgb_allreduce_f32",
 ]
+COMM_ID_BYTES = 128
 
 i32, i64, f32, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -187,6 +189,12 @@ def lib() -> C.CDLL:
     L.vtgb_pack_skinny_weight_bytes.restype = sz
     L.vtgb_pack_skinny_weight.argtypes = [vp, i64, i32, i32, vp, vp]
     L.vtgb_pack_skinny_weight.restype = C.c_int
+    L.vtgb_comm_unique_id.argtypes = [vp]
+    L.vtgb_comm_init.argtypes = [C.POINTER(vp), vp, i32, i32]
+    L.vtgb_comm_destroy.argtypes = [vp]
+    L.vtgb_allreduce_f32.argtypes = [vp, vp, sz, i32, vp]
+    for fn in (L.vtgb_comm_unique_id, L.vtgb_comm_init, L.vtgb_comm_destroy, L.vtgb_allreduce_f32):
+        fn.restype = C.c_int
     L.vtgb_prof_enable.argtypes = [C.c_int]
     L.vtgb_prof_enable.restype = None
     L.vtgb_prof_reset.restype = None

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvtgb.so")
-SOURCES = ["gemm.hip", "gemm_pp.hip", "conv_f32.hip", "attn.hip", "elementwise.hip", "select.hip", "forward.hip", "llm.hip", "raft.hip", "raft_corr.hip", "raft_enc.hip", "train.hip"]
+SOURCES = ["gemm.hip", "gemm_pp.hip", "conv_f32.hip", "attn.hip", "elementwise.hip", "select.hip", "forward.hip", "llm.hip", "raft.hip", "raft_corr.hip", "raft_enc.hip", "train.hip", "comm.hip"]
 
 
 FLAGS_STAMP = os.path.join(HERE, "build", "flags")
@@ -54,7 +54,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         failed |= p.returncode != 0
     if failed:
         raise RuntimeError("hipcc failed building libvtgb.so")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     with open(FLAGS_STAMP, "w") as f:
         f.write(_flags())
     return LIB

@@ -303,7 +303,7 @@ class LoraTrainStep:
     accumulate_grad_batches=4).  ``train_prefix=False`` keeps the round-1 adapters-only step (not reference-equivalent)."""
 
     def __init__(self, lstp, pad_token_id: int, lr: float = 1e-4, weight_decay: float = 0.0, accumulate_grad_batches: int = 4,
-                 train_prefix: bool = True):
+                 train_prefix: bool = True, use_rccl: bool = True):
         from .dist import FlatGradBucket
         self.m = lstp
         self.lm = lstp.model.language_model
@@ -315,7 +315,11 @@ class LoraTrainStep:
             self.params = enable_prefix_training(lstp.model) + self.params
         cfg = configure_optimizers(self.params, lr=lr, weight_decay=weight_decay)
         self.optimizer, self.scheduler = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
-        self.bucket = FlatGradBucket(self.params)
+        # gradients are views of one flat buffer; with more than one rank the exchange runs over RCCL through the C ABI
+        # (vtgb_allreduce_f32), segment by segment under the last micro-batch's backward
+        from .dist import RcclComm, rank_world
+        comm = RcclComm(self.params[0].device) if (rank_world()[1] > 1 and self.params[0].is_cuda and use_rccl) else None
+        self.bucket = FlatGradBucket(self.params, comm=comm)
         self.accumulate = accumulate_grad_batches
         self.micro = 0
 
@@ -349,13 +353,16 @@ class LoraTrainStep:
         """One micro-batch from a prefix (``self.prefix(...)`` output: gradients flow into the Q-Former / projection when
         ``train_prefix``; a plain tensor is treated as a constant)."""
         loss = self.loss(language_model_inputs, question, question_mask, answer, answer_mask)
+        last = (self.micro + 1) % self.accumulate == 0
+        if last:
+            self.bucket.arm(average=True)            # this backward completes the window: segments go out as they become final
         (loss / self.accumulate).backward()
         self.micro += 1
         stepped = False
-        if self.micro % self.accumulate == 0:
-            self.bucket.all_reduce(average=True)     # DDP semantics: mean over ranks
+        if last:
+            self.bucket.all_reduce(average=True)     # DDP semantics: mean over ranks; waits for the segments in flight
             self.optimizer.step()
-            self.optimizer.zero_grad(set_to_none=False)
+            self.bucket.zero_()                      # (the gradients are views of the bucket: one memset)
             if self.train_prefix:                    # the packed (bf16) weight tables of the HIP stages are stale now
                 self.m.model.qformer._table = None
                 self.m.model.language_projection._packed = None
