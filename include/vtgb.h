@@ -447,6 +447,35 @@ int vtgb_pack_skinny_weight(const void* w, int64_t ldw, int32_t N, int32_t K, vo
 size_t vtgb_gemm_skinny_workspace_bytes(const vtgb_gemm_skinny_args* a);
 int vtgb_gemm_skinny(const vtgb_gemm_skinny_args* a, vtgb_stream_t stream);
 
+/* ---- attention for the TRAINABLE stages (config C5, SF flavours): forward + backward, fp32 ---------------------------
+ * Replaces, with its autograd, the matmul / softmax / dropout / matmul sequence of InstructBlipQFormerMultiHeadAttention.forward
+ * (xinstructblip.py:611-694; BLIP-2 twin xblip2.py) and RopeBertSelfAttention.forward (xropebert.py:243-332; the rotary
+ * embedding is applied by the caller): out = dropout(softmax(q k^T * scale + key_mask)) v per (batch, head).  `drop` is the
+ * multiplicative dropout mask on the probabilities (0 or 1 / (1 - p); NULL = no dropout): injectable, like the Gumbel noise.
+ * q / k / v / out and their gradients are token-major [batch, s, heads * head_dim] with element strides (channel stride 1);
+ * dq / dk / dv use the strides of q / k / v, dout those of out.  lse [batch, heads, s_q] is written by the forward and read by
+ * the backward; delta is backward scratch of the same size.  head_dim <= 128. */
+typedef struct {
+    int32_t batch, heads, head_dim, s_q, s_kv;
+    const float* q;
+    const float* k;
+    const float* v;
+    int64_t q_tok, kv_tok, q_batch, kv_batch;
+    const float* key_mask; /* additive fp32 [batch, s_kv] or NULL */
+    const float* drop;     /* [batch, heads, s_q, s_kv] or NULL   */
+    float scale;
+    float* out;
+    int64_t o_tok, o_batch;
+    float* lse;
+    const float* dout; /* backward only from here */
+    float* dq;
+    float* dk;
+    float* dv;
+    float* delta;
+} vtgb_attn_train_args;
+int vtgb_attn_train_forward(const vtgb_attn_train_args* a, vtgb_stream_t stream);
+int vtgb_attn_train_backward(const vtgb_attn_train_args* a, vtgb_stream_t stream);
+
 /* ---- gradient exchange (config C5; the one collective of the path) ------------------------------------------------
  * Thin wrapper over RCCL (SURVEY.md 8b "later: vtgb_allreduce_f32", 8e): replaces what Lightning's DDPStrategy does for the reference
  * (configs/trainer/ddp.yaml:4, find_unused_parameters: the sum / mean all-reduce of the trainable gradients once per optimizer

@@ -847,11 +847,63 @@ def raft_sensitive_fixture():
     save("tiny_raft_sensitive", frames_a_f16=fa.numpy(), frames_u8=u8.numpy(), **out)
 
 
+def sf_mrc_fixture():
+    """[sfmrc] "2) optimize temporal encoder" of LSTPSFModule.forward (src/models/LSTP_SF_module.py:275-296), sliced out of the live
+    function and executed on the tiny reference model (eval mode: dropout off): the TGB forward in fusion mode on batch["of"] with a
+    ragged of_mask, the MRC loss against given start / end targets (one of them beyond the sequence: clamped to the ignore index),
+    then ``mrc_loss.backward()``: the loss, the logits and the gradient of EVERY temporal_encoder parameter that receives one."""
+    train_stubs()
+    tm_mod = sys.modules["torchmetrics"]
+    if not hasattr(tm_mod, "Metric"):
+        tm_mod.Metric = type("Metric", (), {})
+    import src.models.LSTP_SF_module as sf
+    from torch.nn import CrossEntropyLoss
+    from videotgb_amd.synth import path_state_dict, tiny_cfg
+    cfg = tiny_cfg("instructblip")
+    ref, tc, _ = build_reference("instructblip", cfg, path_state_dict(cfg, seed=0))
+    lines = textwrap.dedent(inspect.getsource(sf.LSTPSFModule.forward)).split("\n")
+    lo = next(i for i, l in enumerate(lines) if l.strip().startswith("of_feat, of_logits = self.temporal_encoder("))
+    hi = next(i for i, l in enumerate(lines) if l.strip().startswith("mrc_loss = (start_loss + end_loss) / 2"))
+    code = compile(textwrap.dedent("\n".join(lines[lo:hi + 1])), "<reference MRC step>", "exec")
+    g = torch.Generator().manual_seed(71)
+    B, Lf = 2, 10
+    ofq = torch.randint(-127, 128, (B, Lf, 2, 56, 56), generator=g, dtype=torch.int32).to(torch.int8)
+    of = up4(ofq) / 127
+    of_mask = torch.ones(B, Lf + 2, dtype=torch.long)
+    of_mask[1, 7 + 2:] = 0
+    samp = torch.randint(3, cfg.tgb.vocab, (B, 7), generator=g)
+    smask = torch.ones_like(samp)
+    smask[1, 5:] = 0
+    start_targets = torch.tensor([2, 1], dtype=torch.long)
+    end_targets = torch.tensor([6, 12], dtype=torch.long)          # 12 > L: clamped to the ignore index
+    for p_ in ref.parameters():
+        p_.requires_grad_(True)
+    ref.zero_grad()
+    env = dict(self=ref, of=of, of_mask=of_mask, batch=dict(sampler_question=samp, sampler_question_attention_mask=smask), start_targets=start_targets,
+               end_targets=end_targets, CrossEntropyLoss=CrossEntropyLoss, torch=torch)
+    exec(code, env)
+    env["mrc_loss"].backward()
+    out = dict(of_q8=ofq, of_mask=of_mask, sampler_ids=samp, sampler_mask=smask, start_targets=start_targets, end_targets=end_targets,
+               mrc_loss=env["mrc_loss"].detach().reshape(1), of_logits=env["of_logits"].detach())
+    n_g = 0
+    for n, p_ in ref.temporal_encoder.named_parameters():
+        if p_.grad is not None and p_.grad.abs().max() > 0:
+            gq = p_.grad.detach()
+            if n.endswith("word_embeddings.weight"):           # the word-embedding table: only the rows that were looked up
+                rows = torch.unique(samp)
+                out["g_rows:" + n] = rows
+                gq = gq[rows]
+            out["g:" + n] = gq
+            n_g += 1
+    print(f"sf mrc step: loss {float(env['mrc_loss']):.6f}, {n_g} gradient tensors")
+    save("tiny_sf_mrc_step", **out)
+
+
 def main():
     install_shim()
     torch.manual_seed(0)
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train", "refine", "answers", "bf16", "modules", "trainstep", "raft2"]
+    which = sys.argv[1:] or ["e2e", "int", "full", "pre", "train", "refine", "answers", "bf16", "modules", "trainstep", "raft2", "sfmrc"]
     if "e2e" in which:
         ref_ib, cfg_ib, sd_ib = e2e_fixture("instructblip")
         ref_b2, cfg_b2, sd_b2 = e2e_fixture("blip2")
@@ -876,6 +928,8 @@ def main():
         train_step_fixture()
     if "raft2" in which:
         raft_sensitive_fixture()
+    if "sfmrc" in which:
+        sf_mrc_fixture()
 
 
 if __name__ == "__main__":

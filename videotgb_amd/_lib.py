@@ -32,10 +32,17 @@ EXPORTS = [
     "vtgb_raft_update_workspace_bytes", "vtgb_raft_update", "vtgb_raft_encoder_workspace_bytes", "vtgb_raft_encoder",
     "vtgb_raft_corr_workspace_bytes", "vtgb_raft_corr", "vtgb_preprocess_frames", "vtgb_concat_text_io", "vtgb_shifted_ce_forward", "vtgb_shifted_ce_backward",
     "vtgb_comm_unique_id", "vtgb_comm_init", "vtgb_comm_destroy", "vtgb_allreduce_f32",
+    "vtgb_attn_train_forward", "vtgb_attn_train_backward",
 ]
 COMM_ID_BYTES = 128
 
 i32, i64, f32, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+
+class AttnTrainArgs(C.Structure):
+    _fields_ = [("batch", i32), ("heads", i32), ("head_dim", i32), ("s_q", i32), ("s_kv", i32), ("q", vp), ("k", vp), ("v", vp),
+                ("q_tok", i64), ("kv_tok", i64), ("q_batch", i64), ("kv_batch", i64), ("key_mask", vp), ("drop", vp), ("scale", f32),
+                ("out", vp), ("o_tok", i64), ("o_batch", i64), ("lse", vp), ("dout", vp), ("dq", vp), ("dk", vp), ("dv", vp), ("delta", vp)]
 
 
 class VtgbError(RuntimeError):
@@ -189,6 +196,9 @@ def lib() -> C.CDLL:
     L.vtgb_pack_skinny_weight_bytes.restype = sz
     L.vtgb_pack_skinny_weight.argtypes = [vp, i64, i32, i32, vp, vp]
     L.vtgb_pack_skinny_weight.restype = C.c_int
+    for fn in (L.vtgb_attn_train_forward, L.vtgb_attn_train_backward):
+        fn.argtypes = [C.POINTER(AttnTrainArgs), vp]
+        fn.restype = C.c_int
     L.vtgb_comm_unique_id.argtypes = [vp]
     L.vtgb_comm_init.argtypes = [C.POINTER(vp), vp, i32, i32]
     L.vtgb_comm_destroy.argtypes = [vp]

@@ -79,7 +79,28 @@ class _Stage(nn.Module):
         for name, b in list(tree._buffers.items()):
             self.register_buffer(name, b)
         self.code = ops.dtype_code(compute_dtype)
-        self._table = None
+        self._table_cache = None
+        self._table_key = None
+
+    # The packed (bf16) weight table is a cache of the parameters: keyed on their in-place version counters, so an optimizer
+    # step (Lightning's or anyone's) invalidates it and nothing else does -- no per-forward repack, no stale table in
+    # validation_step after a training step (round-2 ADVICE).
+    def _versions(self):
+        return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+
+    @property
+    def _table(self):
+        if self._table_cache is not None and self._trainable() and self._versions() != self._table_key:
+            self._table_cache = None
+        return self._table_cache
+
+    @_table.setter
+    def _table(self, value):
+        self._table_cache = value
+        self._table_key = self._versions() if value is not None else None
+
+    def _trainable(self) -> bool:
+        return any(p.requires_grad for p in self.parameters())
 
     def _apply(self, fn, *a, **k):
         self._table = None
@@ -162,14 +183,17 @@ class LanguageProjection(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_features), requires_grad=False)
         self.code = ops.dtype_code(compute_dtype)
         self._packed = None
+        self._packed_key = None
 
     def _apply(self, fn, *a, **k):
         self._packed = None
         return super()._apply(fn, *a, **k)
 
     def packed(self) -> Tensor:
-        if self._packed is None:
+        key = (self.weight._version, self.weight.data_ptr(), self.code)     # repacked when (and only when) the weight changed
+        if self._packed is None or self._packed_key != key:
             self._packed = ops.pack_weight(self.weight.data, self.code)
+            self._packed_key = key
         return self._packed
 
     @torch.no_grad()

@@ -255,9 +255,18 @@ class _LSTPLightningBase(_Base):
                 rep = torch.as_tensor(widths, device=img.device)
                 qi = torch.repeat_interleave(batch["qformer_text"], rep, 0)
                 qm = torch.repeat_interleave(batch["qformer_text_attention_mask"], rep, 0)
-            return train.prefix_with_grad(self.model, img, qi, qm, widths, pool)
+            return train.prefix_with_grad(self.model, img, qi, qm, widths, pool, dropout=self._dropout())
         with torch.no_grad():
             return self._prefix_nograd(batch, img, widths, pool)
+
+    DROPOUT_P = 0.1             # hidden_dropout_prob / attention_probs_dropout_prob of the Q-Former and BERT configs the reference builds
+
+    def _dropout(self) -> Optional["train.Dropout"]:
+        """Training mode (``self.training``): the reference's dropout sites draw fresh masks (seedable through ``dropout_generator``);
+        eval mode -- what every parity fixture is recorded in -- has none."""
+        if not self.training:
+            return None
+        return train.Dropout(self.DROPOUT_P, generator=getattr(self, "dropout_generator", None))
 
     def _prefix_nograd(self, batch, img, widths, pool):
         query_tokens = self.model.query_tokens.expand(img.shape[0], -1, -1)
@@ -349,6 +358,11 @@ class _LSTPLightningBase(_Base):
         if self.SELF_REFINE:
             scores, st, en = refine.self_refine_targets(self, batch, lambda ids: self.processor.batch_decode(ids, skip_special_tokens=True),
                                                         num_frames=batch["frames"].shape[0] // batch["answer"].shape[0])
+            # "2) optimize temporal encoder" (LSTP_SF_module.py:275-296): the TGB runs again WITH autograd -- the MRC loss on its
+            # span logits is what trains the sampler (train.tgb_with_grad: own GEMM / attention kernels forward and backward)
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.temporal_encoder.parameters()):
+                _, of_logits = train.tgb_with_grad(self.temporal_encoder, batch["of"], batch["of_mask"], batch["sampler_question"],
+                                                   batch["sampler_question_attention_mask"], self.TGB_MODE, dropout=self._dropout())
             loss = loss + refine.mrc_loss(of_logits, st, en)
         return loss, logits
 
@@ -404,12 +418,15 @@ class _LSTPLightningBase(_Base):
             p.requires_grad = False
         for p in self.model.vision_model.parameters():
             p.requires_grad = False
-        # (the TGB's parameters are registered frozen: no backward is built for it -- in LSTP_module it receives no gradient
-        # anyway (selection is an argmax), the SF flavours' MRC loss on its logits is computed but does not train it here)
+        # the TGB: trainable wherever the reference leaves it so (LSTP_module.py / LSTP_SF_module.py:747-751 freeze only the vision
+        # tower and the language model).  In LSTP_module it receives no gradient (selection is an argmax); in the SF flavours the
+        # MRC loss reaches it through train.tgb_with_grad.  The sinusoid tables are buffers-by-convention (requires_grad False).
         if self.WIDTHS:
             for p in self.temporal_encoder.parameters():
                 p.requires_grad = False
         else:
+            for n, p in self.temporal_encoder.named_parameters():
+                p.requires_grad = "embed_positions" not in n
             for p in self.model.language_model.parameters():
                 p.requires_grad = False
 

@@ -9,13 +9,12 @@
 * ``freeze_weights`` (:682-690), AdamW + the cosine schedule as the reference configures it (:634-679)
 * gradient exchange: one flat bucket, one all-reduce per optimizer step (``dist.FlatGradBucket``; RCCL on the GPU box)
 * the trainable set is the reference's (``freeze_weights`` :682-690 freezes RAFT, the vision tower and the TGB only): the
-  Q-Former, ``query_tokens`` and ``language_projection`` train together with the adapters.  ``prefix_with_grad`` makes the
-  prefix differentiable: FORWARD = the HIP Q-Former + pooling + projection (libvtgb.so, what the loss is computed from);
-  BACKWARD = the same graph recomputed with PyTorch ops in fp32 on the same parameters and differentiated by autograd
-  (activation recomputation; 0.35 TFLOP per 8-frame clip against ~4.5 TFLOP of LLM forward + backward per sequence).  HIP
-  backward kernels for the Q-Former are not built; this is the documented torch-autograd path over the same weights.
-  Dropout (Q-Former hidden / attention dropout 0.1, LoRA dropout 0.1 inside ``LoraLinear``) : the HIP Q-Former forward has
-  no dropout, so Q-Former training here is the dropout-free variant of the reference's step.
+  Q-Former, ``query_tokens`` and ``language_projection`` train together with the adapters.  ``prefix_with_grad`` (and, for the
+  SF flavours, ``tgb_with_grad``) build the TRAINING forward as an autograd graph whose linear layers run forward, dgrad and
+  wgrad on the library's own GEMM kernel (``_HipLinear``) and whose attentions run on ``train_attn.hip`` forward and backward
+  (``_HipAttention``); LayerNorm / GELU / adds are elementwise torch ops.  The fused inference stages (vtgb_qformer_forward,
+  vtgb_tgb_forward) keep no activations and have no dropout: they serve eval.  Dropout (Q-Former / TGB hidden and
+  attention-probability dropout 0.1; LoRA dropout inside ``LoraLinear``) enters as injectable masks (``Dropout``).
 
 The language model itself, autograd through it and AdamW stay PyTorch, as they are third-party in the reference.
 """
@@ -87,101 +86,177 @@ def shifted_cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
     return _ShiftedCE.apply(logits, labels)
 
 
+# ----------------------------------------------------------------------------- own-kernel autograd building blocks
+def _gemm_nt(a: Tensor, w: Tensor, bias: Optional[Tensor], code: int) -> Tensor:
+    """a [M, K] . w [N, K]^T (+ bias) -> fp32 [M, N] on the library's GEMM kernels (vtgb_gemm): fp32 FMA kernel (exactness mode)
+    or bf16 MFMA with fp32 accumulation.  bf16 operands need a contraction length that is a multiple of 8: zero padded here."""
+    from . import ops
+    a, w = a.contiguous(), w.contiguous()
+    if code == L.F32:
+        return ops.gemm(a.float(), w.float(), None if bias is None else bias.float().contiguous(), L.EPI_STORE_F32)
+    k = a.shape[1]
+    if k % 8:
+        pad = 8 - k % 8
+        a, w = nn.functional.pad(a, (0, pad)), nn.functional.pad(w, (0, pad))
+    return ops.gemm(a.to(torch.bfloat16), w.to(torch.bfloat16), None if bias is None else bias.float().contiguous(), L.EPI_STORE_F32)
+
+
+class _HipLinear(torch.autograd.Function):
+    """y = x W^T + b with forward, dgrad and wgrad on the library's own GEMM kernel (no torch.matmul):
+    dX [M, K] = dY [M, N] . (W^T) [K, N]^T;  dW [N, K] = dY^T [N, M] . (X^T) [K, M]^T;  db = column sums of dY."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor], code: int):
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, w)
+        ctx.code, ctx.has_bias, ctx.shape = code, b is not None, x.shape
+        return _gemm_nt(x2, w, b, code).reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x2, w = ctx.saved_tensors
+        g2 = gy.reshape(-1, gy.shape[-1]).float().contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _gemm_nt(g2, w.t(), None, ctx.code).reshape(ctx.shape)
+        if ctx.needs_input_grad[1]:
+            gw = _gemm_nt(g2.t(), x2.t(), None, ctx.code)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gw, gb, None
+
+
+class _HipAttention(torch.autograd.Function):
+    """dropout(softmax(q k^T * scale + key_mask)) v per head on vtgb_attn_train_forward / _backward (train_attn.hip).
+    q [B, Sq, D], k / v [B, Skv, D] fp32; key_mask additive [B, Skv] or None; drop [B, H, Sq, Skv] multiplicative mask or None."""
+
+    @staticmethod
+    def _args(q, k, v, heads, scale, key_mask, drop, out, lse):
+        B, Sq, D = q.shape
+        return L.AttnTrainArgs(B, heads, D // heads, Sq, k.shape[1], q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1), k.stride(1), q.stride(0),
+                               k.stride(0), None if key_mask is None else key_mask.data_ptr(), None if drop is None else drop.data_ptr(), float(scale),
+                               out.data_ptr(), out.stride(1), out.stride(0), lse.data_ptr(), None, None, None, None, None)
+
+    @staticmethod
+    def forward(ctx, q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, key_mask: Optional[Tensor], drop: Optional[Tensor]):
+        _need_cuda(q, k, v)
+        q, k, v = q.float().contiguous(), k.float().contiguous(), v.float().contiguous()
+        key_mask = None if key_mask is None else key_mask.float().contiguous()
+        drop = None if drop is None else drop.float().contiguous()
+        out = torch.empty_like(q)
+        lse = torch.empty(q.shape[0], heads, q.shape[1], dtype=torch.float32, device=q.device)
+        a = _HipAttention._args(q, k, v, heads, scale, key_mask, drop, out, lse)
+        L.check(L.lib().vtgb_attn_train_forward(C.byref(a), _stream()))
+        ctx.save_for_backward(q, k, v, out, lse, key_mask, drop)
+        ctx.heads, ctx.scale = heads, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, go: Tensor):
+        q, k, v, out, lse, key_mask, drop = ctx.saved_tensors
+        go = go.float().contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse)
+        a = _HipAttention._args(q, k, v, ctx.heads, ctx.scale, key_mask, drop, out, lse)
+        a.dout, a.dq, a.dk, a.dv, a.delta = go.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
+        L.check(L.lib().vtgb_attn_train_backward(C.byref(a), _stream()))
+        return dq, dk, dv, None, None, None, None
+
+
+class Dropout:
+    """The reference's dropout sites as injectable masks (like the Gumbel noise of the sampler): ``masks[name]`` (multiplicative:
+    0 or 1 / (1 - p)) when given, else a fresh Bernoulli mask from ``generator`` when ``p > 0``, else the identity.  ``drawn``
+    records every mask by site name, so a step can be replayed (and a test can hand the same masks to a torch reference)."""
+
+    def __init__(self, p: float = 0.0, masks: Optional[Dict[str, Tensor]] = None, generator: Optional[torch.Generator] = None):
+        self.p, self.masks, self.generator, self.drawn = float(p), masks, generator, {}
+
+    def mask(self, name: str, shape, device) -> Optional[Tensor]:
+        if self.masks is not None:
+            m = self.masks.get(name)
+            if m is not None:
+                self.drawn[name] = m
+            return m
+        if self.p <= 0.0:
+            return None
+        m = (torch.rand(tuple(shape), device=device, generator=self.generator) >= self.p).float() / (1.0 - self.p)
+        self.drawn[name] = m
+        return m
+
+    def __call__(self, name: str, x: Tensor) -> Tensor:
+        m = self.mask(name, x.shape, x.device)
+        return x if m is None else x * m
+
+
+_NO_DROPOUT = Dropout(0.0)
+
+
 # ----------------------------------------------------------------------------- differentiable prefix (Q-Former + pooling + projection)
 def _qformer_graph(sd: Dict[str, Tensor], query_tokens: Tensor, image_embeds: Tensor, heads: int, input_ids: Optional[Tensor], text_mask: Optional[Tensor],
-                   cross_freq: int, eps: float) -> Tensor:
-    """The Q-Former as PyTorch ops (autograd) over the state_dict tensors ``sd`` (names relative to ``model.qformer.``):
+                   cross_freq: int, eps: float, code: int = L.F32, drop: Dropout = _NO_DROPOUT) -> Tensor:
+    """The Q-Former as an autograd graph over the LIVE parameters ``sd`` (names relative to ``model.qformer.``):
     InstructBlipQFormerModel.forward xinstructblip.py:1122-1242 (``input_ids`` given: embeddings :1018-1046, text FFN branch)
-    / Blip2QFormerModel.forward xblip2.py:1063-1174.  Used ONLY as the backward of ``prefix_with_grad``.  -> [n, n_query, hidden]."""
+    / Blip2QFormerModel.forward xblip2.py:1063-1174.  Every linear layer runs forward, dgrad and wgrad on the library's GEMM
+    kernel (_HipLinear), every attention on train_attn.hip (_HipAttention); LayerNorm / GELU / residual adds are elementwise
+    torch ops.  Dropout sites: embeddings (:1045), attention probabilities (:679), attention output (:707), FFN output (:788).
+    -> [n, n_query, hidden]."""
     F = nn.functional
     n = image_embeds.shape[0]
     q = query_tokens.expand(n, -1, -1)
     nq = q.shape[1]
 
     def lin(name, x):
-        return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
+        return _HipLinear.apply(x, sd[name + ".weight"], sd[name + ".bias"], code)
 
     def ln(name, x):
         return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], eps)
 
-    def split(x):
-        b, t, d = x.shape
-        return x.view(b, t, heads, d // heads).permute(0, 2, 1, 3)
+    def attn(ap, site, hidden, kv, key_mask):
+        qq, kk, vv = lin(ap + "attention.query", hidden), lin(ap + "attention.key", kv), lin(ap + "attention.value", kv)
+        dm = drop.mask(site + ".probs", (hidden.shape[0], heads, hidden.shape[1], kv.shape[1]), hidden.device)
+        ctx = _HipAttention.apply(qq, kk, vv, heads, 1.0 / math.sqrt(qq.shape[-1] // heads), key_mask, dm)
+        return ln(ap + "output.LayerNorm", drop(site + ".out", lin(ap + "output.dense", ctx)) + hidden)
 
-    def attn(ap, hidden, kv, mask):
-        qq, kk, vv = split(lin(ap + "attention.query", hidden)), split(lin(ap + "attention.key", kv)), split(lin(ap + "attention.value", kv))
-        sc = torch.matmul(qq, kk.transpose(-1, -2)) / math.sqrt(qq.shape[-1])
-        if mask is not None:
-            sc = sc + mask
-        ctx = torch.matmul(torch.softmax(sc, dim=-1), vv).permute(0, 2, 1, 3).reshape(hidden.shape)
-        return ln(ap + "output.LayerNorm", lin(ap + "output.dense", ctx) + hidden)
-
-    def ffn(lp, inter, outp, x):
-        h = lin(lp + outp + ".dense", F.gelu(lin(lp + inter + ".dense", x)))
+    def ffn(lp, site, inter, outp, x):
+        h = drop(site, lin(lp + outp + ".dense", F.gelu(lin(lp + inter + ".dense", x))))
         return ln(lp + outp + ".LayerNorm", h + x)
 
     if input_ids is not None:
         lt = input_ids.shape[1]
         emb = sd["embeddings.word_embeddings.weight"][input_ids] + sd["embeddings.position_embeddings.weight"][:lt][None]
-        x = ln("embeddings.layernorm", torch.cat([q, emb], dim=1))
+        x = drop("embeddings", ln("embeddings.layernorm", torch.cat([q, emb], dim=1)))
         m = torch.cat([torch.ones(n, nq, device=q.device), (text_mask if text_mask is not None else torch.ones(n, lt, device=q.device)).float()], 1)
-        self_mask = (1.0 - m)[:, None, None, :] * -10000.0
+        self_mask = (1.0 - m) * -10000.0                      # additive, per key (xinstructblip.py:1119)
     else:
-        x = ln("layernorm", q)
+        x = drop("embeddings", ln("layernorm", q))
         self_mask = None
+    image_embeds = image_embeds.float()
     i = 0
     while f"encoder.layer.{i}.attention.attention.query.weight" in sd:
         lp = f"encoder.layer.{i}."
-        att = attn(lp + "attention.", x, x, self_mask)
+        att = attn(lp + "attention.", f"layer.{i}.attention", x, x, self_mask)
         qa = att[:, :nq]
         if i % cross_freq == 0:
-            qa = attn(lp + "crossattention.", qa, image_embeds, None)
-        out = ffn(lp, "intermediate_query", "output_query", qa)
+            qa = attn(lp + "crossattention.", f"layer.{i}.crossattention", qa, image_embeds, None)
+        out = ffn(lp, f"layer.{i}.ffn_query", "intermediate_query", "output_query", qa)
         if att.shape[1] > nq:
-            out = torch.cat([out, ffn(lp, "intermediate", "output", att[:, nq:])], dim=1)
+            out = torch.cat([out, ffn(lp, f"layer.{i}.ffn_text", "intermediate", "output", att[:, nq:])], dim=1)
         x = out
         i += 1
     return x[:, :nq]
 
 
-def _pool_project_graph(query_out: Tensor, widths: Sequence[int], w: Tensor, b: Tensor, mode: str) -> Tensor:
+def _pool_project_graph(query_out: Tensor, widths: Sequence[int], w: Tensor, b: Tensor, mode: str, code: int = L.F32) -> Tensor:
     """eval/utils/model.py:186-195 / LSTP_Vicuna_IVT_module.py:244-249 (mean over ragged widths; width 0 -> zero row) or
-    LSTP_module.py:477-481 (concat), as autograd ops."""
+    LSTP_module.py:477-481 (concat); the projection on the library's GEMM (forward and backward)."""
     if mode == "mean":
         rows, idx = [], 0
         for wd in widths:
             rows.append(query_out[idx:idx + wd].mean(0) if wd > 0 else torch.zeros_like(query_out[0]))
             idx += wd
-        return nn.functional.linear(torch.stack(rows), w, b)
-    y = nn.functional.linear(query_out, w, b)
+        return _HipLinear.apply(torch.stack(rows), w, b, code)
+    y = _HipLinear.apply(query_out, w, b, code)
     return y.reshape(len(widths), -1, y.shape[-1])
-
-
-class _PrefixFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, pm, image_embeds, input_ids, text_mask, widths, mode, names, *params):
-        from . import ops
-        qf = pm.qformer
-        qf._table = None                                   # the parameters may have been stepped since the last pack
-        pm.language_projection._packed = None
-        q = ops.qformer_forward(qf.table(), pm.query_tokens[0], image_embeds, input_ids, text_mask, None)
-        out = pm.language_projection.pool(q, widths, mode)
-        ctx.save_for_backward(image_embeds, *params)
-        ctx.meta = (qf.cfg.heads, qf.cfg.cross_freq, qf.cfg.eps, input_ids, text_mask, tuple(widths), mode, names)
-        return out
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        image_embeds, *params = ctx.saved_tensors
-        heads, cross_freq, eps, input_ids, text_mask, widths, mode, names = ctx.meta
-        with torch.enable_grad():
-            leaves = [p.detach().float().requires_grad_(True) for p in params]
-            sd = dict(zip(names, leaves))
-            q = _qformer_graph({k[len("qformer."):]: v for k, v in sd.items() if k.startswith("qformer.")}, sd["query_tokens"],
-                               image_embeds.detach().float(), heads, input_ids, text_mask, cross_freq, eps)
-            out = _pool_project_graph(q, widths, sd["language_projection.weight"], sd["language_projection.bias"], mode)
-            grads = torch.autograd.grad(out, leaves, grad_out.float(), allow_unused=True)
-        return (None,) * 7 + tuple(None if g is None else g.to(p.dtype) for g, p in zip(grads, params))
 
 
 def prefix_params(pm) -> Tuple[List[str], List[nn.Parameter]]:
@@ -191,12 +266,111 @@ def prefix_params(pm) -> Tuple[List[str], List[nn.Parameter]]:
     return names, params
 
 
-def prefix_with_grad(pm, image_embeds: Tensor, input_ids: Optional[Tensor], text_mask: Optional[Tensor], widths: Sequence[int], mode: str = "mean") -> Tensor:
-    """``language_model_inputs`` [n_clips, P, H] from the frozen vision tower's ``image_embeds`` [sum(widths), tokens, enc] with
-    gradients to the Q-Former, ``query_tokens`` and ``language_projection`` (see the module docstring): HIP forward, PyTorch
-    recompute backward.  ``pm`` is the ``self.model`` object (models.PathModel)."""
+def prefix_with_grad(pm, image_embeds: Tensor, input_ids: Optional[Tensor], text_mask: Optional[Tensor], widths: Sequence[int], mode: str = "mean",
+                     compute_dtype=None, dropout: Optional[Dropout] = None) -> Tensor:
+    """``language_model_inputs`` [n_clips, P, H] from the frozen vision tower's ``image_embeds`` [sum(widths), tokens, enc] WITH
+    gradients to the Q-Former, ``query_tokens`` and ``language_projection``: the training forward is the autograd graph above
+    (own GEMM / attention kernels forward and backward), not the fused inference stage -- which has no dropout and keeps no
+    activations.  ``compute_dtype``: "f32" (exactness mode; default = the model's) or "bf16" GEMM operands.  ``dropout``: the
+    reference trains with p = 0.1 at the Q-Former's dropout sites; pass ``Dropout(0.1, generator=...)`` (or recorded masks)."""
     names, params = prefix_params(pm)
-    return _PrefixFn.apply(pm, image_embeds, input_ids, text_mask, list(widths), mode, names, *params)
+    sd = dict(zip(names, params))
+    code = dtype_code(compute_dtype) if compute_dtype is not None else pm.qformer.code
+    qf = pm.qformer
+    q = _qformer_graph({k[len("qformer."):]: v for k, v in sd.items() if k.startswith("qformer.")}, sd["query_tokens"], image_embeds.detach(),
+                       qf.cfg.heads, input_ids, text_mask, qf.cfg.cross_freq, qf.cfg.eps, code, dropout or _NO_DROPOUT)
+    return _pool_project_graph(q, widths, sd["language_projection.weight"], sd["language_projection.bias"], mode, code)
+
+
+# ----------------------------------------------------------------------------- differentiable Temporal Grounding Bridge (SF flavours)
+def _rope(table_rows: Tensor, x: Tensor) -> Tensor:
+    """apply_rotary_position_embeddings xropebert.py:335-377 on [B, S, H, hd]: interleaved pairs, table = [sin half | cos half]."""
+    sin, cos = table_rows.chunk(2, dim=-1)
+    sin_pos = torch.stack([sin, sin], dim=-1).reshape(table_rows.shape)[None, :, None, :]
+    cos_pos = torch.stack([cos, cos], dim=-1).reshape(table_rows.shape)[None, :, None, :]
+    rot = torch.stack([-x[..., 1::2], x[..., ::2]], dim=-1).reshape(x.shape)
+    return x * cos_pos + rot * sin_pos
+
+
+def _tgb_graph(sd: Dict[str, Tensor], of: Tensor, of_mask: Tensor, text_ids: Tensor, text_mask: Tensor, mode: str, heads: int, fusion_layer: int,
+               eps: float, code: int = L.F32, drop: Dropout = _NO_DROPOUT) -> Tuple[Tensor, Tensor]:
+    """RopeBertModel.forward with ``encoder_embeds=of`` (xropebert.py:1048-1169) as an autograd graph over the live parameters
+    ``sd`` (names relative to ``temporal_encoder.``) -> (sequence_output [B, L+2, D], logits [B, L, 2]).
+    TemporalOFEmbedding (:103-129): the k16 / s16 patch convolution and the 196 -> 1 linear commute, so the patches are reduced
+    with the fc weights first (elementwise) and ONE GEMM follows -- the order the HIP forward uses."""
+    F = nn.functional
+    b, l, c, hh, ww = of.shape
+    te = "temporal_embeddings."
+    pw = sd[te + "projection.weight"]
+    ps = pw.shape[-1]
+    d = pw.shape[0]
+
+    def lin(name, x):
+        return _HipLinear.apply(x, sd[name + ".weight"], sd[name + ".bias"], code)
+
+    def ln(name, x, e=eps):
+        return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], e)
+
+    patches = of.float().reshape(b * l, c, hh // ps, ps, ww // ps, ps).permute(0, 2, 4, 1, 3, 5).reshape(b * l, -1, c * ps * ps)   # [BL, 196, 512]
+    fcw, fcb = sd[te + "fc.weight"].reshape(-1), sd[te + "fc.bias"].reshape(())
+    red = (patches * fcw[None, :, None]).sum(1)                                                                                   # [BL, 512]
+    x = _HipLinear.apply(red, pw.reshape(d, -1), None, code) + sd[te + "projection.bias"] * fcw.sum() + fcb
+    x = x.view(b, l, d)
+    x = torch.cat([sd[te + "bos"].expand(b, 1, -1), x, torch.zeros(b, 1, d, device=x.device)], dim=1)
+    ends = of_mask.sum(dim=1) - 1
+    onehot = F.one_hot(ends, x.shape[1]).to(x.dtype)[..., None]                                                                   # x[b, ends[b]] = eos
+    x = x * (1.0 - onehot) + sd[te + "eos"][None, None] * onehot
+    x = x + sd[te + "frame_pos_embed.weight"][: x.shape[1]][None]
+    x = drop("temporal_embeddings", ln(te + "ln", x, 1e-5))
+    t = sd["embeddings.word_embeddings.weight"][text_ids] + sd["embeddings.token_type_embeddings.weight"][0]
+    t = drop("embeddings", ln("embeddings.LayerNorm", t))
+    s_len = x.shape[1]
+    self_mask = (1.0 - of_mask.float()) * -10000.0                                       # :1044-1045
+    cross_mask = (1.0 - text_mask.float()) * torch.finfo(torch.float32).min              # :1127
+    pos = sd["encoder.embed_positions.weight"][:s_len]
+    cpos = sd["encoder.c_embed_positions.weight"][: t.shape[1]]
+
+    def attn(ap, site, hidden, kv, key_mask, qpos, kpos):
+        hd = hidden.shape[-1] // heads
+        qq = _rope(qpos, lin(ap + "self.query", hidden).view(*hidden.shape[:2], heads, hd)).reshape(hidden.shape)
+        kk = _rope(kpos, lin(ap + "self.key", kv).view(*kv.shape[:2], heads, hd)).reshape(kv.shape[0], kv.shape[1], -1)
+        vv = lin(ap + "self.value", kv)
+        dm = drop.mask(site + ".probs", (hidden.shape[0], heads, hidden.shape[1], kv.shape[1]), hidden.device)
+        ctx = _HipAttention.apply(qq, kk, vv, heads, 1.0 / math.sqrt(hd), key_mask, dm)
+        return ln(ap + "output.LayerNorm", drop(site + ".out", lin(ap + "output.dense", ctx)) + hidden)
+
+    n_layers = 0
+    while f"encoder.layer.{n_layers}.attention.self.query.weight" in sd:
+        n_layers += 1
+    if mode in ("vision", "text"):
+        lo, hi = 0, fusion_layer
+    elif mode == "fusion":
+        lo, hi = fusion_layer, n_layers
+    elif mode == "multi_modal":
+        lo, hi = 0, n_layers
+    else:
+        raise ValueError(f"INVALID MODE: {mode}")
+    for i in range(lo, hi):
+        lp = f"encoder.layer.{i}."
+        a = attn(lp + "attention.", f"layer.{i}.attention", x, x, self_mask, pos, pos)
+        if i >= fusion_layer:
+            a = attn(lp + "crossattention.", f"layer.{i}.crossattention", a, t, cross_mask, pos, cpos)
+        hmid = F.gelu(lin(lp + "intermediate.dense", a))
+        x = ln(lp + "output.LayerNorm", drop(f"layer.{i}.ffn", lin(lp + "output.dense", hmid)) + a)
+    logits = lin("mrc_head", x[:, 1:-1])
+    return x, logits
+
+
+def tgb_with_grad(temporal_encoder, of: Tensor, of_mask: Tensor, text_ids: Tensor, text_mask: Tensor, mode: str, compute_dtype=None,
+                  dropout: Optional[Dropout] = None) -> Tuple[Tensor, Tensor]:
+    """``self.temporal_encoder(encoder_embeds=of, ...)`` WITH gradients to the TGB's parameters -- what LSTP_SF_module.py:276-298
+    needs: the self-refinement MRC loss is a loss on the TGB's span logits and is what trains the sampler.  Same graph
+    construction as ``prefix_with_grad`` (own GEMM / attention kernels forward and backward)."""
+    sd = dict(temporal_encoder.named_parameters())
+    sd.update({k: v for k, v in temporal_encoder.named_buffers()})
+    code = dtype_code(compute_dtype) if compute_dtype is not None else temporal_encoder.code
+    cfg = temporal_encoder.cfg
+    return _tgb_graph(sd, of, of_mask, text_ids, text_mask, mode, cfg.heads, cfg.fusion_layer, cfg.eps, code, dropout or _NO_DROPOUT)
 
 
 def enable_prefix_training(pm) -> List[nn.Parameter]:
@@ -363,9 +537,6 @@ class LoraTrainStep:
             self.bucket.all_reduce(average=True)     # DDP semantics: mean over ranks; waits for the segments in flight
             self.optimizer.step()
             self.bucket.zero_()                      # (the gradients are views of the bucket: one memset)
-            if self.train_prefix:                    # the packed (bf16) weight tables of the HIP stages are stale now
-                self.m.model.qformer._table = None
-                self.m.model.language_projection._packed = None
             stepped = True
         return loss.detach(), stepped
 
