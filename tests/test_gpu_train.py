@@ -250,11 +250,14 @@ def test_sf_mrc_step_trains_the_temporal_encoder_vs_reference(dev, tiny_sd):
             got = got[g["g_rows:" + n]]
         want = g[key]
         err, scale = (got - want).abs().max().item(), want.abs().max().item()
-        worst = max(worst, err / max(scale, 1e-12))
+        if scale <= 1e-6:       # analytically zero gradients (fc.bias: one scalar added to every feature of a token, removed by the LayerNorm
+            assert got.abs().max().item() <= 1e-6, n      # behind it; key biases: softmax shift invariance): rounding noise on both sides
+            continue
+        worst = max(worst, err / scale)
         assert err <= 1e-4 * scale + 1e-10, (n, err, scale)
         n_checked += 1
     print(f"[sf mrc step] loss {loss.item():.6f}; {n_checked} gradient tensors, worst max|diff| / max|ref| = {worst:.2e}")
-    assert n_checked >= 40
+    assert n_checked >= 30
 
 
 def test_dropout_masks_are_injectable_and_replayable(dev, tiny_sd):
