@@ -167,3 +167,27 @@ def test_sf_module_self_refinement_forward(dev, tmp_path):
     assert scores.shape == (B, 8) and st.shape == en.shape == (B,) and bool((st <= en).all())
     loss, logits = m.forward(batch, noise=g["sf_noise"].to(dev))
     assert torch.isfinite(loss) and logits.shape[0] == B
+    # round 3: the MRC loss TRAINS the sampler (LSTP_SF_module.py:275-296; freeze_weights :747-751 leaves the TGB trainable): its
+    # parameters are in the optimizer, the loss reaches them, and a step changes the span logits the fused inference stage computes
+    loss.backward()
+    te = m.temporal_encoder
+    assert te.mrc_head.weight.requires_grad and te.mrc_head.weight.grad is not None and te.mrc_head.weight.grad.abs().max() > 0
+    reached = [n for n, p in te.named_parameters() if p.grad is not None and p.grad.abs().max() > 0]
+    assert len(reached) >= 30 and any("crossattention" in n for n in reached) and any("temporal_embeddings.projection" in n for n in reached)
+    assert all(p.grad is None for p in m.model.vision_model.parameters()) and all(p.grad is None for p in m.model.language_model.parameters())
+    opt_ids = {id(p) for grp in m.configure_optimizers()["optimizer"].param_groups for p in grp["params"]}
+    assert id(te.mrc_head.weight) in opt_ids
+    with torch.no_grad():
+        _, before = te(encoder_embeds=batch["of"], attention_mask=batch["of_mask"], encoder_hidden_states=batch["sampler_question"],
+                       encoder_attention_mask=batch["sampler_question_attention_mask"], mode="fusion")
+    torch.optim.SGD([p for p in te.parameters() if p.grad is not None], lr=0.5).step()
+    with torch.no_grad():                                    # the packed weight table follows the parameters' version counters
+        _, after = te(encoder_embeds=batch["of"], attention_mask=batch["of_mask"], encoder_hidden_states=batch["sampler_question"],
+                      encoder_attention_mask=batch["sampler_question_attention_mask"], mode="fusion")
+    assert (after - before).abs().max() > 1e-4
+    # training mode: dropout masks are drawn (seedable), the loss stays finite
+    m.train()
+    m.model.language_model.eval()
+    m.dropout_generator = torch.Generator(device=dev).manual_seed(11)
+    loss2, _ = m.forward(batch, noise=g["sf_noise"].to(dev))
+    assert torch.isfinite(loss2) and abs(loss2.item() - loss.item()) > 1e-6
