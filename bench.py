@@ -401,16 +401,19 @@ def main():
         del batches
         torch.cuda.empty_cache()
 
-        def leg(name, Bn, flow, steps, note, raft_dtype=None, tokens=None):
+        def leg(name, Bn, flow, steps, note, raft_dtype=None, tokens=None, T_leg=None, raft_clips=None):
             if raft_dtype:
                 m.of_extractor.set_compute_dtype(raft_dtype)
-            bs = [synth_batch(rank, 100 + i, Bn, T, flow, dev, cfg) for i in range(2)]
+            if raft_clips:
+                m.flow_clips_per_call = raft_clips
+            bs = [synth_batch(rank, 100 + i, Bn, T_leg or T, flow, dev, cfg) for i in range(2)]
             ntok = tokens or args.max_new_tokens
             for i in range(2):
                 run_step(m, bs[i % 2], Bn, nframe, ntok, None, decoder)
             el = timed_steps(lambda i: run_step(m, bs[i % 2], Bn, nframe, ntok, None, decoder), steps, barrier, dev, world)
             if raft_dtype:
                 m.of_extractor.set_compute_dtype(args.raft_dtype)
+            m.flow_clips_per_call = args.raft_clips
             legs[name] = {"what": note, "clips_per_gpu_per_step": Bn, "steps": steps, "value": round(Bn * steps * world / el, 3),
                           "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 2)}
             del bs
@@ -424,6 +427,9 @@ def main():
         if args.raft_dtype == "bf16":
             leg("raft_fp32_exactness", 8, "raft", 1, "the headline path with RAFT in the fp32 exactness mode (the reference's RAFT arithmetic; "
                                                      "tests/test_gpu_selection.py: the selected frames are identical for 64/64 clips at T=96)", raft_dtype="f32")
+        # BASELINE configs[3] (C4): the long-video shape, per GPU (the 8 GPUs shard clips with no collective)
+        leg("c4_t256", 24, "raft", 2, "BASELINE configs[3]: InstructBLIP-Vicuna-7B + TGB, ActivityNet long-video shape T=256->8, per GPU (clip-parallel, no "
+                                     "collective); RAFT on 255 frame pairs per clip, 12 clips per RAFT batch", T_leg=256, raft_clips=12)
         legs["host_resident_inputs"] = host_resident_leg(m, rank, 32, T, nframe, args.max_new_tokens, decoder, dev, 3, barrier, world)
     if rank == 0:
         out = {"metric": "clips/sec end-to-end VideoQA (96->8 frames)", "value": round(value, 3), "unit": "clips/s",

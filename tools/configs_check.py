@@ -65,23 +65,27 @@ def blip2_module(cls_name, tmp, dev):
     return m.to(dev).eval()
 
 
-def c1(dev, tmp):
+def c1(dev, tmp, B=32, reps=3):
     m = blip2_module("LSTPBlip2Module", tmp, dev)
-    B, nframe = 32, 4
+    nframe = 4
     g = torch.Generator(device=dev).manual_seed(1)
     batch = dict(frames=torch.randn(B * 32, 3, 224, 224, generator=g, device=dev), nframe=nframe, of_lengths=[32] * B,
                  answer=torch.zeros(B, 1, dtype=torch.long, device=dev), text_answer=[""] * B,
                  question=torch.randint(3, 32000, (B, 20), generator=g, device=dev), question_attention_mask=torch.ones(B, 20, dtype=torch.long, device=dev))
     out, st = m.eval_forward(batch, return_stages=True)
     assert st["frame_idx"][0].tolist() == [3, 11, 19, 27] and st["of_logits"] is None, st["frame_idx"][0].tolist()
-    dt = timed(lambda: m.eval_forward(batch))
-    print(f"C1 BLIP2-Flan-T5-xl, no sampler, 32 -> {nframe} frames (idx {st['frame_idx'][0].tolist()}), concat prefix {tuple(st['language_model_inputs'].shape)}, "
-          f"T5 greedy 16 tokens: {B / dt:.1f} clips/s at {B} clips per call (HF generate, eager)")
+    assert tuple(out.shape) == (B, 17) or tuple(out.shape) == (B, 16), tuple(out.shape)      # 16 greedy tokens (+ the decoder start token)
+    assert tuple(st["language_model_inputs"].shape) == (B, nframe * 32, 2048)
+    dt = timed(lambda: m.eval_forward(batch), n=reps)
+    line = (f"C1 BLIP2-Flan-T5-xl, no sampler, 32 -> {nframe} frames (idx {st['frame_idx'][0].tolist()}), concat prefix {tuple(st['language_model_inputs'].shape)}, "
+            f"T5 greedy 16 tokens: {B / dt:.1f} clips/s at {B} clips per call (HF generate, eager)")
+    print(line)
+    return dict(clips_per_s=B / dt, frame_idx=st["frame_idx"][0].tolist(), line=line)
 
 
-def c2(dev, tmp):
+def c2(dev, tmp, B=32, reps=3):
     m = blip2_module("LSTPSFBlip2Module", tmp, dev)
-    B, nframe, L = 32, 8, 32
+    nframe, L = 8, 32
     g = torch.Generator(device=dev).manual_seed(2)
     batch = dict(frames=torch.randn(B * 32, 3, 224, 224, generator=g, device=dev), nframe=nframe, of_lengths=[L] * B,
                  of=torch.rand(B, L, 2, 224, 224, generator=g, device=dev) * 2 - 1, of_mask=torch.ones(B, L + 2, dtype=torch.long, device=dev),
@@ -91,9 +95,13 @@ def c2(dev, tmp):
                  question=torch.randint(3, 32000, (B, 20), generator=g, device=dev), question_attention_mask=torch.ones(B, 20, dtype=torch.long, device=dev))
     out, st = m.eval_forward(batch, return_stages=True)
     assert st["of_logits"].shape == (B, L, 2)
-    dt = timed(lambda: m.eval_forward(batch))
-    print(f"C2 BLIP2-Flan-T5-xl + TGB (fusion, flow length {L}, map B), 32 -> {nframe} frames, concat prefix {tuple(st['language_model_inputs'].shape)}, "
-          f"T5 greedy 16 tokens: {B / dt:.1f} clips/s at {B} clips per call (HF generate, eager)")
+    assert tuple(st["language_model_inputs"].shape) == (B, nframe * 32, 2048) and tuple(st["frame_idx"].shape) == (B, nframe)
+    assert bool((st["frame_idx"][:, 1:] >= st["frame_idx"][:, :-1]).all()) and int(st["frame_idx"].max()) < 32      # sorted candidate indices
+    dt = timed(lambda: m.eval_forward(batch), n=reps)
+    line = (f"C2 BLIP2-Flan-T5-xl + TGB (fusion, flow length {L}, map B), 32 -> {nframe} frames, concat prefix {tuple(st['language_model_inputs'].shape)}, "
+            f"T5 greedy 16 tokens: {B / dt:.1f} clips/s at {B} clips per call (HF generate, eager)")
+    print(line)
+    return dict(clips_per_s=B / dt, line=line)
 
 
 def sub(cmd):
