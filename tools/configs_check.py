@@ -65,8 +65,8 @@ def blip2_module(cls_name, tmp, dev):
     return m.to(dev).eval()
 
 
-def c1(dev, tmp, B=32, reps=3):
-    m = blip2_module("LSTPBlip2Module", tmp, dev)
+def c1(dev, tmp, B=32, reps=3, module=None):
+    m = module if module is not None else blip2_module("LSTPBlip2Module", tmp, dev)
     nframe = 4
     g = torch.Generator(device=dev).manual_seed(1)
     batch = dict(frames=torch.randn(B * 32, 3, 224, 224, generator=g, device=dev), nframe=nframe, of_lengths=[32] * B,
@@ -83,8 +83,8 @@ def c1(dev, tmp, B=32, reps=3):
     return dict(clips_per_s=B / dt, frame_idx=st["frame_idx"][0].tolist(), line=line)
 
 
-def c2(dev, tmp, B=32, reps=3):
-    m = blip2_module("LSTPSFBlip2Module", tmp, dev)
+def c2(dev, tmp, B=32, reps=3, module=None):
+    m = module if module is not None else blip2_module("LSTPSFBlip2Module", tmp, dev)
     nframe, L = 8, 32
     g = torch.Generator(device=dev).manual_seed(2)
     batch = dict(frames=torch.randn(B * 32, 3, 224, 224, generator=g, device=dev), nframe=nframe, of_lengths=[L] * B,

@@ -1111,6 +1111,12 @@ extern "C" void vtgb_debug_set_conv_nwn(int v) { g_conv_nwn = v; }
 template <int EPI, bool CONV>
 static int launch_large_forced(const GemmDesc& d, hipStream_t s) {
     const int nwn = (g_conv_nwn > 0 && g_conv_nwn != 5) ? g_conv_nwn : (d.N <= 64 ? 1 : d.N <= 128 ? 2 : 4);
+    const int nwn_shape = d.N <= 64 ? 1 : d.N <= 128 ? 2 : 4;
+    // the fused 1x1 tail exists only in the 256-wide tile, and fragment-order maps are only meaningful between launches of ONE tile
+    // shape (the one the shape rule picks): a forced tile (debug hook) would otherwise succeed and leave the output unwritten / scrambled
+    VTGB_REQUIRE(!d.tail_w || nwn == 4, VTGB_EUNSUPPORTED, "conv gemm: the fused 1x1 tail needs the 256-wide tile (forced tile %d)", nwn);
+    VTGB_REQUIRE(!(d.frag_out || d.init_frag) || nwn == nwn_shape, VTGB_EUNSUPPORTED,
+                 "conv gemm: fragment-order start maps need the producer's and the consumer's tile shape to agree (forced tile %d, shape rule %d)", nwn, nwn_shape);
     if (nwn == 1) return launch_large_nwn<EPI, CONV, 1>(d, s);
     if (nwn == 2) {
         // The 512 x 128 tile (same wave tile as 256 x 256) measured NO faster than 256 x 128 on RAFT's 128-channel

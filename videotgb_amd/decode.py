@@ -44,6 +44,8 @@ def _rot_half(x: Tensor) -> Tensor:
 
 
 class GreedyDecoder:
+    MAX_STATES = 4
+
     def __init__(self, lm, fused: bool = True):
         cfg = lm.config
         if "llama" not in cfg.model_type:
@@ -116,10 +118,18 @@ class GreedyDecoder:
         return F.linear(_rms(x, self.lm.model.norm.weight, self.eps), self.lm.lm_head.weight)
 
     def _state(self, B: int, P: int, N: int, device, dtype, eos=None, pad=0, min_new=0):
-        key = (B, P, N, eos, pad, min_new)
-        st = self.graphs.get(key)
+        # The cache length is bucketed (multiples of 64) and the true prompt length is device data (`pos`): an eval loop over real
+        # questions with varying P reuses a handful of graphs instead of capturing one -- and allocating 2 x n_layers KV caches --
+        # per distinct P.  At most MAX_STATES states are kept (least recently used goes: graph and caches are freed).
+        tmax = -(-(P + N) // 64) * 64
+        key = (B, tmax, N, eos, pad, min_new)
+        st = self.graphs.pop(key, None)
+        if st is not None:
+            self.graphs[key] = st                      # most recently used last
         if st is None:
-            tmax = P + N
+            while len(self.graphs) >= self.MAX_STATES:
+                old = self.graphs.pop(next(iter(self.graphs)))
+                old.clear()
             cos, sin = self._rope(tmax, device, dtype)
             st = dict(cos=cos, sin=sin, tmax=tmax,
                       kc=[torch.zeros(B, self.nkv, tmax, self.hd, device=device, dtype=dtype) for _ in self.layers],

@@ -555,6 +555,8 @@ class _LSTPBase(nn.Module):
                                              eos_token_id=gen_kwargs.pop("eos_token_id", getattr(gc, "eos_token_id", None)),
                                              pad_token_id=gen_kwargs.pop("pad_token_id", getattr(gc, "pad_token_id", None)),
                                              min_new_tokens=gen_kwargs.pop("min_new_tokens", 0))
+            if gen_kwargs:      # (nothing is dropped silently: what the graph decoder does not implement must go through HF generate)
+                raise TypeError(f"generate(fast_decode=True) does not take {sorted(gen_kwargs)}; call with fast_decode=False")
         else:
             outputs = lm.generate(inputs_embeds=inputs_embeds, attention_mask=attention_mask, do_sample=do_sample,
                                   temperature=temperature, max_new_tokens=max_new_tokens, use_cache=use_cache,
