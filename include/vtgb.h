@@ -298,6 +298,7 @@ typedef struct {
     float scale;
     void* out;                           /* [batch, s_q, heads*head_dim] in `dtype`    */
     int64_t out_tok_stride, out_batch_stride;
+    int32_t causal;                      /* != 0: query q attends keys <= q + (s_kv - s_q) (the LLM's prefill) */
 } vtgb_attention_args;
 int vtgb_attention(const vtgb_attention_args* a, vtgb_stream_t stream);
 

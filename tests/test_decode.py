@@ -94,3 +94,42 @@ def test_small_batch_decode_runs_on_the_skinny_gemm_and_matches_hipblaslt():
     ref = lm.generate(inputs_embeds=emb, attention_mask=torch.ones(2, 5, dtype=torch.long, device=dev), do_sample=False, max_new_tokens=6,
                       min_new_tokens=6, use_cache=True)
     assert own.generate(emb, 6, use_graph=True, min_new_tokens=0).tolist() == ref.tolist()
+
+
+@pytest.mark.gpu
+def test_bf16_prefill_runs_on_libvtgb_and_matches_the_blas_path():
+    """f2: at bf16 the prefill's projections go through vtgb_gemm, its causal attention through vtgb_attention
+    (head_dim 128) and norms / SwiGLU through vtgb_llm_* -- no BLAS library call.  Checked against the F.linear / SDPA prefill
+    (the arithmetic HF generate runs): KV caches and last hidden state within bf16 rounding, greedy ids equal."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from videotgb_amd import llm
+    from videotgb_amd.decode import GreedyDecoder
+    dev = "cuda:0"
+    lm = llm.build_llama("tiny", torch.bfloat16, dev, seed=7, hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=4,
+                         num_hidden_layers=3, vocab_size=320)
+    g = torch.Generator(device=dev).manual_seed(4)
+    for B, P in ((3, 52), (2, 131)):
+        emb = (torch.randn(B, P, 512, generator=g, device=dev) * 0.5).bfloat16()
+        own, blas = GreedyDecoder(lm), GreedyDecoder(lm)
+        blas.PREFILL_MAX_TOKENS = 0
+        assert own._use_hip_prefill(emb, P) and not blas._use_hip_prefill(emb, P)
+        a = own.generate(emb, 8)
+        b = blas.generate(emb, 8)
+        sa, sb = next(iter(own.graphs.values())), next(iter(blas.graphs.values()))
+        for li in range(3):
+            for c in ("kc", "vc"):
+                x, y = sa[c][li][:, :, :P].float(), sb[c][li][:, :, :P].float()
+                assert (x - y).abs().max().item() <= 3e-2 * max(1.0, y.abs().max().item()), (c, li)
+        # last hidden state -> first-token logits of both prefills (two bf16 arithmetics: later greedy ids of a random-weight
+        # model can part at a near tie, the logits cannot differ by more than rounding)
+        with torch.no_grad():
+            last = own._prefill_hip(sa, emb, P)
+            x = emb
+            pidx = sb["ar"][:P]
+            causal = torch.where(sb["ar"][None, :] <= pidx[:, None], 0.0, torch.finfo(x.dtype).min).to(x.dtype)[None, None]
+            for li, w in enumerate(blas.layers):
+                x = blas._layer(x, w, sb["cos"][:P], sb["sin"][:P], sb["kc"][li], sb["vc"][li], pidx, causal)
+            la, lb = own._head(last).float(), blas._head(x[:, -1]).float()
+        assert (la - lb).abs().max().item() <= 3e-2 * max(1.0, lb.abs().max().item())
+        assert a[:, 0].tolist() == b[:, 0].tolist() == lb.argmax(-1).tolist()

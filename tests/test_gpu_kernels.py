@@ -185,6 +185,26 @@ def test_attention(dev, B, H, hd, Sq, Skv, use_mask, use_rope, dtype):
     assert err <= (3e-2 if dtype == "bf16" else 2e-5) * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("B,H,hd,Sq,Skv", [(3, 4, 128, 52, 52), (2, 4, 128, 130, 130), (2, 3, 128, 7, 40), (2, 12, 64, 98, 98), (1, 2, 96, 33, 64)])
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_attention_causal(dev, B, H, hd, Sq, Skv, dtype):
+    """The LLM prefill's attention (transformers LlamaAttention under language_model.generate, eval/utils/model.py:223-233):
+    head_dim 128, query q attends keys <= q + (Skv - Sq)."""
+    from videotgb_amd import ops
+    g = torch.Generator().manual_seed(Sq * 7 + Skv + hd)
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    D = H * hd
+    qkv = torch.randn(B, Skv, 3 * D, generator=g).to(dev).to(td)
+    q, k, v = qkv[:, :Sq, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+    out = ops.attention(q, k, v, H, hd ** -0.5, causal=True)
+    qh, kh, vh = (t.float().reshape(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))
+    allowed = torch.arange(Skv, device=dev)[None, :] <= torch.arange(Sq, device=dev)[:, None] + (Skv - Sq)
+    sc = (qh @ kh.transpose(-1, -2)) * hd ** -0.5
+    ref = (torch.softmax(sc.masked_fill(~allowed, float("-inf")), -1) @ vh).transpose(1, 2).reshape(B, Sq, D)
+    err = report(f"causal attn {dtype} hd{hd} {Sq}x{Skv}", out.float(), ref)
+    assert err <= (3e-2 if dtype == "bf16" else 2e-5) * max(1.0, ref.abs().max().item())
+
+
 def test_attention_bf16_finfo_min_mask(dev):
     """HF invert_attention_mask uses finfo.min for cross-attention pads (xropebert.py:1127)."""
     from videotgb_amd import ops

@@ -136,7 +136,7 @@ class AttentionArgs(C.Structure):
     _fields_ = [("dtype", i32), ("batch", i32), ("heads", i32), ("head_dim", i32), ("s_q", i32), ("s_kv", i32),
                 ("q", vp), ("k", vp), ("v", vp), ("q_tok_stride", i64), ("kv_tok_stride", i64), ("q_batch_stride", i64),
                 ("kv_batch_stride", i64), ("key_mask", vp), ("rope_q", vp), ("rope_k", vp), ("scale", f32), ("out", vp),
-                ("out_tok_stride", i64), ("out_batch_stride", i64)]
+                ("out_tok_stride", i64), ("out_batch_stride", i64), ("causal", i32)]
 
 
 class LayerNormArgs(C.Structure):

@@ -197,13 +197,15 @@ __global__ __launch_bounds__(NKP <= 9 ? 576 : 256) void attn_bf16_kernel(const A
         }
         // ---- softmax over keys: registers (t, r) x lane groups fg
         float mx = -INFINITY;
+        const int klim = p.causal ? q + (p.s_kv - p.s_q) : 0x7fffffff;      // causal: query q sees keys <= q + (s_kv - s_q)
 #pragma unroll
         for (int t = 0; t < 2 * NKP; t++) {
             const float4 mk = *reinterpret_cast<const float4*>(maskv + t * 16 + fg * 4);
-            s[t][0] = s[t][0] * p.scale + mk.x;
-            s[t][1] = s[t][1] * p.scale + mk.y;
-            s[t][2] = s[t][2] * p.scale + mk.z;
-            s[t][3] = s[t][3] * p.scale + mk.w;
+            const int k0 = t * 16 + fg * 4;
+            s[t][0] = k0 <= klim ? s[t][0] * p.scale + mk.x : -INFINITY;
+            s[t][1] = k0 + 1 <= klim ? s[t][1] * p.scale + mk.y : -INFINITY;
+            s[t][2] = k0 + 2 <= klim ? s[t][2] * p.scale + mk.z : -INFINITY;
+            s[t][3] = k0 + 3 <= klim ? s[t][3] * p.scale + mk.w : -INFINITY;
             mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnDesc p) {
         }
         float v = dot * p.scale;
         if (p.key_mask) v += p.key_mask[(int64_t)b * p.s_kv + key];
+        if (p.causal && key > q + (p.s_kv - p.s_q)) v = -INFINITY;
         sc[wave][key] = v;
         mx = fmaxf(mx, v);
     }
@@ -358,7 +361,7 @@ int launch_attention(const AttnDesc& d, hipStream_t s) {
         return VTGB_OK;
     }
     VTGB_REQUIRE(d.dtype == VTGB_BF16, VTGB_EINVAL, "attention: bad dtype %d", d.dtype);
-    VTGB_REQUIRE((d.head_dim % 8) == 0 && d.head_dim <= 96, VTGB_EUNSUPPORTED, "attention bf16: head_dim=%d must be a multiple of 8, <= 96", d.head_dim);
+    VTGB_REQUIRE((d.head_dim % 8) == 0 && d.head_dim <= 128, VTGB_EUNSUPPORTED, "attention bf16: head_dim=%d must be a multiple of 8, <= 128", d.head_dim);
     VTGB_REQUIRE((d.q_tok % 8) == 0 && (d.kv_tok % 8) == 0 && (d.o_tok % 4) == 0 && (d.q_batch % 8) == 0 &&
                      (d.kv_batch % 8) == 0 && (d.o_batch % 4) == 0,
                  VTGB_EUNSUPPORTED, "attention bf16: strides must keep 16-byte alignment");
@@ -368,10 +371,14 @@ int launch_attention(const AttnDesc& d, hipStream_t s) {
         if (kv <= 128) return launch_bf16<64, 4>(d, s);
         if (kv <= 288) return launch_bf16<64, 9>(d, s);
         if (kv <= 512) return launch_bf16<64, 16>(d, s);
-    } else {
+    } else if (d.head_dim <= 96) {
         if (kv <= 64) return launch_bf16<96, 2>(d, s);
         if (kv <= 128) return launch_bf16<96, 4>(d, s);
         if (kv <= 288) return launch_bf16<96, 9>(d, s);
+    } else {      // 128: the language model's prefill (Llama heads; prefix + prompt <= 288 tokens)
+        if (kv <= 64) return launch_bf16<128, 2>(d, s);
+        if (kv <= 128) return launch_bf16<128, 4>(d, s);
+        if (kv <= 288) return launch_bf16<128, 9>(d, s);
     }
     vtgb_set_error("attention bf16: s_kv=%d with head_dim=%d exceeds the single-pass LDS budget", kv, d.head_dim);
     return VTGB_EUNSUPPORTED;

@@ -190,6 +190,7 @@ struct AttnDesc {
     float scale;
     void* out;
     int64_t o_tok, o_batch;
+    int causal = 0;                            // query q sees keys <= q + (s_kv - s_q)
 };
 int launch_attention(const AttnDesc& d, hipStream_t s);
 

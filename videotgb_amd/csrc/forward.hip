@@ -476,7 +476,7 @@ extern "C" int vtgb_attention(const vtgb_attention_args* a, vtgb_stream_t stream
     d.dtype = a->dtype; d.batch = a->batch; d.heads = a->heads; d.head_dim = a->head_dim; d.s_q = a->s_q; d.s_kv = a->s_kv;
     d.q = a->q; d.k = a->k; d.v = a->v; d.q_tok = a->q_tok_stride; d.kv_tok = a->kv_tok_stride; d.q_batch = a->q_batch_stride;
     d.kv_batch = a->kv_batch_stride; d.key_mask = a->key_mask; d.rope_q = a->rope_q; d.rope_k = a->rope_k; d.scale = a->scale;
-    d.out = a->out; d.o_tok = a->out_tok_stride; d.o_batch = a->out_batch_stride;
+    d.out = a->out; d.o_tok = a->out_tok_stride; d.o_batch = a->out_batch_stride; d.causal = a->causal;
     return launch_attention(d, stream);
 }
 extern "C" int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream) {

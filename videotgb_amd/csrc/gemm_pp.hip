@@ -64,26 +64,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
     char* const stage = smem + A_OP + wave * SB;   // this wave's private epilogue staging region
 #endif
 
-    // ---- workgroup -> tile list (XCD-aware, as in gemm.hip): logical block b -> (mt, nt); this workgroup takes b, b + grid, ...
-    const int Gn = G * n_tiles, mx8 = (m_tiles + 7) >> 3;
-    auto decode = [&](int b, int& mt_, int& nt_) -> bool {
-        const int xcd = b & 7, idx = b >> 3;
-        const int group = idx / Gn, r = idx - group * Gn;
-        nt_ = r / G;
-        const int ml = group * G + (r - nt_ * G);
-        if (CONV) {                                   // each XCD takes a contiguous run of m-tiles (shared halo rows stay in ONE L2)
-            if (ml >= mx8) return false;
-            mt_ = xcd * mx8 + ml;
-        } else {
-            mt_ = ml * 8 + xcd;                       // plain GEMM: the XCDs take interleaved m-tiles
-        }
-        return mt_ < m_tiles;
+    // ---- workgroup -> tile list.  The tiles are numbered q = 0 .. m_tiles * n_tiles - 1 in grouped order (G consecutive m-tiles x all
+    // n-tiles, m fastest: neighbours in q share a weight tile and, for convolutions, halo rows).  With the grid a multiple of 8,
+    // workgroup w (hardware XCD w & 7) takes q = j * grid + (grid / 8) * (w & 7) + (w >> 3), j = 0, 1, ...: in every round an XCD works
+    // on grid / 8 CONSECUTIVE q's (8 m-tiles x 4 n-tiles at 256 workgroups: 12 operand tiles per 32 output tiles through its L2), and
+    // every workgroup gets the same number of tiles +- 1 whatever m_tiles is.  (Rounds 1-2 strided a sparse logical grid whose
+    // invalid slots fell on the same workgroups every time: at 26 m-tiles -- the LLM prefill -- 104 of the 256 workgroups did all
+    // the work, 12 tiles each instead of 5.)
+    const int Gn = G * n_tiles;
+    auto decode = [&](int q, int& mt_, int& nt_) {
+        const int g = q / Gn, r = q - g * Gn;
+        const int Gc = min(G, m_tiles - g * G);
+        nt_ = r / Gc;
+        mt_ = g * G + (r - nt_ * Gc);
     };
-    auto next_valid = [&](int b, int& mt_, int& nt_) -> int {
-        for (; b < total_blocks; b += (int)gridDim.x)
-            if (decode(b, mt_, nt_)) return b;
-        return -1;
+    auto next_valid = [&](int q, int& mt_, int& nt_) -> int {
+        if (q >= total_blocks) return -1;
+        decode(q, mt_, nt_);
+        return q;
     };
+    const int grid_ = (int)gridDim.x;
+    const int first_q = (grid_ & 7) == 0 ? (grid_ >> 3) * ((int)blockIdx.x & 7) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
 
     // ---- per-tile LDS-DMA state (see gemm.hip for the addressing scheme: tile descriptors + loop-invariant lane offsets)
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
 // landed in the slot a slower wave was still reading its last fragments from -- run-to-run different GRU outputs, found in round 3)
 #define P_PHASE_BARRIER() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
 
-    int b = next_valid((int)blockIdx.x, mt, nt);
+    int b = next_valid(first_q, mt, nt);
     if (b < 0) return;
     P_TILE_SETUP()
     P_ISSUE_A(0, 0)
@@ -840,9 +841,8 @@ int launch_large_pp(const GemmDesc& d, hipStream_t s) {
     constexpr bool PING = !CONV;
     constexpr int LDS = 3 * P_AOP + ((PING && NWN < 4) ? 3 : 2) * T_BN * 128;
     const int m_tiles = (d.M + T_BM - 1) / T_BM, n_tiles = (d.N + T_BN - 1) / T_BN;
-    const int G = n_tiles <= 8 ? 2 : 8;
-    const int mx = (m_tiles + 7) / 8, groups = (mx + G - 1) / G;
-    const int total = 8 * groups * G * n_tiles;
+    const int G = 8;                                                   // m-tiles per group of the tile order (see the kernel)
+    const int total = m_tiles * n_tiles;
     const int resident = cu_count();                                   // one workgroup per CU (LDS-limited)
     const int grid = total < resident ? total : resident;
     const double exec_flops = 2.0 * d.M * d.N * d.K;

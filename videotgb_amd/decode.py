@@ -114,6 +114,52 @@ class GreedyDecoder:
         gu = F.linear(h, wgu)
         return x + F.linear(F.silu(gu[..., : self.inter]) * gu[..., self.inter:], wd)
 
+    # Prefill on libvtgb.so (bf16): the four projections of a layer through the persistent MFMA GEMM (vtgb_gemm; M = B*P rows), the
+    # causal attention through vtgb_attention (head_dim 128, whole K/V of a head in LDS), RMSNorm(+residual) and SwiGLU through
+    # the vtgb_llm_* kernels of the decode step -- no BLAS library call is left on the f2 path at the throughput batch.  fp32
+    # (the mode whose ids are compared token-for-token with HF generate) keeps the reference's own BLAS/SDPA arithmetic.
+    PREFILL_MAX_TOKENS = 288
+
+    def _use_hip_prefill(self, x: Tensor, P: int) -> bool:
+        return (self.fused and x.is_cuda and x.dtype == torch.bfloat16 and self.nq_eq_nkv and P <= self.PREFILL_MAX_TOKENS
+                and self.hd % 8 == 0 and self.hd <= 128 and self.cfg.hidden_size % 64 == 0 and self.inter % 64 == 0)
+
+    @property
+    def nq_eq_nkv(self) -> bool:
+        return self.nh == self.nkv
+
+    def _prefill_hip(self, st, x: Tensor, P: int) -> Tensor:
+        """x [B, P, H] bf16 -> hidden state of the last position [B, H]; fills rows 0..P-1 of every layer's KV cache."""
+        import ctypes as C
+        from . import _lib as L, ops
+        lib = L.lib()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        B, _, H = x.shape
+        nh, hd, M = self.nh, self.hd, B * P
+        x = x.reshape(M, H).clone()
+        h = torch.empty_like(x)
+        act = torch.empty(M, self.inter, dtype=x.dtype, device=x.device)
+        cos, sin = st["cos"][:P, None, :], st["sin"][:P, None, :]
+        delta = None
+        for li, (ln1, wqkv, wo, ln2, wgu, wd) in enumerate(self.layers):
+            L.check(lib.vtgb_llm_rmsnorm(L.BF16, x.data_ptr(), None if delta is None else delta.data_ptr(), ln1.data_ptr(), h.data_ptr(),
+                                         M, H, self.eps, stream))
+            qkv = ops.gemm(h, wqkv).view(B, P, 3 * nh, hd)
+            qk = qkv[:, :, : 2 * nh]
+            qk.copy_(qk * cos + _rot_half(qk) * sin)                               # rotary on q and k together, in place
+            st["kc"][li][:, :, :P].copy_(qkv[:, :, nh: 2 * nh].transpose(1, 2))
+            st["vc"][li][:, :, :P].copy_(qkv[:, :, 2 * nh:].transpose(1, 2))
+            flat = qkv.view(B, P, 3 * nh * hd)
+            a = ops.attention(flat[:, :, : nh * hd], flat[:, :, nh * hd: 2 * nh * hd], flat[:, :, 2 * nh * hd:], nh, float(hd) ** -0.5,
+                              causal=True)
+            o = ops.gemm(a.view(M, nh * hd), wo)
+            L.check(lib.vtgb_llm_rmsnorm(L.BF16, x.data_ptr(), o.data_ptr(), ln2.data_ptr(), h.data_ptr(), M, H, self.eps, stream))
+            gu = ops.gemm(h, wgu)
+            L.check(lib.vtgb_llm_silu_mul(L.BF16, gu.data_ptr(), act.data_ptr(), M, self.inter, stream))
+            delta = ops.gemm(act, wd)
+        last = (x.view(B, P, H)[:, -1] + delta.view(B, P, H)[:, -1])
+        return last
+
     def _head(self, x):
         return F.linear(_rms(x, self.lm.model.norm.weight, self.eps), self.lm.lm_head.weight)
 
@@ -255,12 +301,16 @@ class GreedyDecoder:
         pidx = st["ar"][:P]
         causal = torch.where(st["ar"][None, :] <= pidx[:, None], 0.0, torch.finfo(dt).min).to(dt)[None, None]   # [1,1,P,Tmax]
         cos, sin = st["cos"][:P], st["sin"][:P]
-        for li, w in enumerate(self.layers):
-            x = self._layer(x, w, cos, sin, st["kc"][li], st["vc"][li], pidx, causal)
+        if self._use_hip_prefill(x, P):
+            last = self._prefill_hip(st, x, P)
+        else:
+            for li, w in enumerate(self.layers):
+                x = self._layer(x, w, cos, sin, st["kc"][li], st["vc"][li], pidx, causal)
+            last = x[:, -1]
         st["fin"].zero_()
         if eos_token_id is not None:
             st["out"].fill_(st["pad"])
-        first = self._pick(st, self._head(x[:, -1]), 0)
+        first = self._pick(st, self._head(last), 0)
         st["tok"].copy_(first)
         st["out"][:, 0] = first
         st["pos"].fill_(P)

@@ -204,8 +204,9 @@ def gemm_skinny(x: Tensor, w: Tensor, out: Optional[Tensor] = None, n_splits: in
 
 
 def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, key_mask: Optional[Tensor] = None,
-              rope_q: Optional[Tensor] = None, rope_k: Optional[Tensor] = None) -> Tensor:
-    """q [B, Sq, H*hd], k/v [B, Skv, H*hd] (any token/batch strides, unit channel stride) -> [B, Sq, H*hd]."""
+              rope_q: Optional[Tensor] = None, rope_k: Optional[Tensor] = None, causal: bool = False) -> Tensor:
+    """q [B, Sq, H*hd], k/v [B, Skv, H*hd] (any token/batch strides, unit channel stride) -> [B, Sq, H*hd].
+    ``causal``: query q attends keys <= q + (Skv - Sq)."""
     _need_cuda(q, k, v)
     code = dtype_code(q.dtype)
     B, Sq, D = q.shape
@@ -214,7 +215,7 @@ def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, key_mas
     out = torch.empty(B, Sq, D, dtype=q.dtype, device=q.device)
     a = L.AttentionArgs(code, B, heads, D // heads, Sq, Skv, q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1), k.stride(1),
                         q.stride(0), k.stride(0), _ptr(key_mask), _ptr(rope_q), _ptr(rope_k), float(scale), out.data_ptr(),
-                        out.stride(1), out.stride(0))
+                        out.stride(1), out.stride(0), int(causal))
     L.check(L.lib().vtgb_attention(C.byref(a), _stream()))
     return out
 
