@@ -428,9 +428,10 @@ int vtgb_llm_silu_mul(int dtype, const void* gu, void* act, int64_t rows, int32_
  * clip), K a multiple of 64 -- what `F.linear(h, weight)` (hipBLASLt) computes under `language_model.generate`
  * (eval/utils/model.py:223-233; transformers LlamaDecoderLayer's q/k/v/o/gate/up/down projections and lm_head).  The weights
  * stream from HBM once: one workgroup per (128-row weight tile, K split) -- `n_splits` splits (0 = chosen by the library) where
- * the tiles alone would leave CUs without a stream; every workgroup leaves an fp32 fragment in `workspace` (n_tiles * n_splits
- * * M * 128 * 4 bytes) and a second launch adds a tile's fragments in a fixed order and rounds once to `out_dtype`
- * (deterministic: no atomics). */
+ * the tiles alone would leave CUs without a stream.  Without a split the tile is rounded and stored straight to `out` (no
+ * workspace: vtgb_gemm_skinny_workspace_bytes returns 0).  With a split every workgroup leaves an fp32 fragment in `workspace`
+ * (n_tiles * n_splits * M * 128 * 4 bytes) and a second launch adds a tile's fragments in split order and rounds once to
+ * `out_dtype` (deterministic: no atomics). */
 typedef struct {
     int32_t M, N, K, n_splits;
     const void* x; int64_t ldx;          /* bf16 [M, K] */

@@ -88,10 +88,12 @@ def test_argument_validation_of_the_wider_rows(lib):
     # decode-step GEMM: M <= 128, K a multiple of 64; one fp32 fragment per (128-column tile, split)
     sk = lib.GemmSkinnyArgs(124, 4096, 4096, 0, None, 4096, None, 4096, None, 4096, lib.BF16, 0, None, 0)
     need = L.vtgb_gemm_skinny_workspace_bytes(C.byref(sk))
-    assert need % (32 * 124 * 128 * 4) == 0 and 1 <= need // (32 * 124 * 128 * 4) <= 8                  # 32 tiles x 1..8 splits
+    assert need % (32 * 124 * 128 * 4) == 0 and 2 <= need // (32 * 124 * 128 * 4) <= 8                  # 32 tiles x 2..8 splits
     assert L.vtgb_gemm_skinny(C.byref(sk), None) == EINVAL and b"NULL" in L.vtgb_last_error()
     sk.n_splits = 3
     assert L.vtgb_gemm_skinny_workspace_bytes(C.byref(sk)) == 3 * 32 * 124 * 128 * 4
+    sk.n_splits = 1                                                                                    # no split: stored straight to `out`
+    assert L.vtgb_gemm_skinny_workspace_bytes(C.byref(sk)) == 0
     sk.M = 129
     assert L.vtgb_gemm_skinny_workspace_bytes(C.byref(sk)) == 0 and b"M=129" in L.vtgb_last_error()
     sk.M, sk.K = 1, 100

@@ -46,3 +46,20 @@ def test_skinny_strided_operands_and_errors(dev):
         ops.gemm_skinny(torch.zeros(129, 64, dtype=torch.bfloat16, device=dev), w[:, :64].contiguous())     # M > 128
     with pytest.raises((ValueError, NotImplementedError, RuntimeError)):
         ops.gemm_skinny(x[:, :100].contiguous(), w[:, :100].contiguous())                                  # K not a multiple of 64
+
+
+def test_skinny_shared_workspace(dev):
+    """One workspace serves calls of different shapes back to back (the decode step's five projections); repeated results are
+    equal bit for bit."""
+    from videotgb_amd import ops
+    g = torch.Generator(device=dev).manual_seed(11)
+    shapes = [(124, 4096, 4096, 0), (124, 12288, 4096, 2), (124, 4096, 11008, 0), (7, 1000, 320, 3)]
+    ops_in = [(torch.randn(M, K, generator=g, device=dev).bfloat16(), (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).bfloat16(), S)
+              for M, N, K, S in shapes]
+    ws = torch.empty(max(1, max(ops.gemm_skinny_workspace_bytes(M, N, K, S) for M, N, K, S in shapes)), dtype=torch.uint8, device=dev)
+    first = [ops.gemm_skinny(x, w, n_splits=S, workspace=ws) for x, w, S in ops_in]
+    for _ in range(3):
+        for (x, w, S), ref in zip(ops_in, first):
+            assert torch.equal(ops.gemm_skinny(x, w, n_splits=S, workspace=ws), ref)
+    for (x, w, S), ref in zip(ops_in, first):
+        assert (ref.float() - x.float() @ w.float().t()).abs().max().item() <= 2 ** -7 * ref.float().abs().max().item()

@@ -200,27 +200,38 @@ extern "C" int vtgb_llm_silu_mul(int dtype, const void* gu, void* act, int64_t r
 
 // ---------------------------------------------------------------------------------------
 // Skinny GEMM for the decode step: out[M, N] = x[M, K] . w[N, K]^T with M <= 128 rows (one token per clip) -- the weight
-// matrix is read exactly once, so the kernel is an HBM stream of W with the matrix cores idling behind it.
+// matrix is read exactly once, so the kernel is an HBM stream of W with the matrix cores idling behind it, and what bounds it
+// is the number of weight bytes a CU keeps IN FLIGHT (rate = bytes in flight / memory latency).
 //   work      one workgroup per (128-row weight tile, K split): K is split where N / 128 tiles alone would leave most of the 256
-//             CUs without a stream (N = 4096: 32 tiles).  Every workgroup leaves an fp32 fragment of its tile; a second tiny
-//             launch adds a tile's fragments in a FIXED order and rounds once (deterministic: no atomics).  (Equal runs of steps
-//             per CU across tile boundaries -- "stream-K" -- were built and measured slower: two 63 KiB fragments per
-//             workgroup at M = 124 cost more than the balance gains; round 2.)
-//   tile      128 (all of M) x 128 weight rows, 4 waves of 64 x 64, v_mfma_f32_16x16x32_bf16
-//   staging   buffer_load ... lds (LDS-DMA) into TWO rings: 7 weight slots (6 k-tiles = 96 KiB of weights in flight) and 3
-//             activation slots (L2-resident, two ahead) = 160 KiB.  vmcnt completes in order PER WAVE, so a wave that mixed the
-//             deep weight stream with the shallow activation stream would drain the weights every k-tile: waves 0-1 load only
-//             weights, waves 2-3 only activations (each with its own counted wait); all four multiply.  One barrier per step.
+//             CUs without a stream (N = 4096: 32 tiles).  Unsplit tiles round and store straight to `out`; split tiles leave an
+//             fp32 fragment each and a second small launch adds a tile's fragments in split order and rounds once (deterministic:
+//             no atomics.  Adding them in the last-arriving workgroup of the same launch was built in round 3 and measured 2-5x
+//             SLOWER: the device-scope release / acquire fences it needs write back and invalidate the L2 under the stream).
+//   tile      128 (all of M) x 128 weight rows; 4 multiplying waves of 128 x 32 (acc[2][8] of v_mfma_f32_16x16x32_bf16) + 2
+//             loader waves.
+//   weights   straight from global memory into the multiplying waves' REGISTERS in MFMA fragment layout (a wave owns its 32
+//             weight rows, nobody else reads them: no LDS): SK_D k-tiles = SK_D x 4 KiB per wave ahead, 160 KiB per workgroup
+//             (rounds 1-2 staged them through a 7-slot LDS ring: 96 KiB in flight, and LDS had to hold the activations too).
+//             k-tiles past the end of the split are requested OUT OF RANGE of the descriptor (zeros, no memory traffic), so the
+//             counted wait is the same constant on every step.
+//   x         L2-resident; the two loader waves stage it with buffer_load ... lds (LDS-DMA) into a 9-slot ring, 7 k-tiles ahead.
+//             They have their own vmcnt: a wave that mixed this shallow stream with the deep weight stream would drain the
+//             weights every k-tile (vmcnt completes in order per wave).  One barrier per k-tile.
 // x rows beyond M are clamped duplicates (never stored); weight rows beyond N read as zeros (descriptor range / packed zeros).
 // ---------------------------------------------------------------------------------------
-constexpr int SK_BN = 128, SK_BK = 64, SK_WSLOTS = 7, SK_XSLOTS = 3, SK_TILE = 128 * 128;   // bytes of one operand tile (128 rows x 64 bf16)
+constexpr int SK_BN = 128, SK_BK = 64, SK_TILE = 128 * 128;   // SK_TILE: bytes of one operand tile (128 rows x 64 bf16)
+constexpr int SK_D = 8;                                        // weight k-tiles in flight per multiplying wave (registers)
+constexpr int SK_XSLOTS = 9, SK_XD = 8;                        // x ring (LDS) and how far ahead the loaders run
+constexpr int SK_THREADS = 384;
 typedef __attribute__((address_space(3))) void* sk_lptr_t;
+typedef __attribute__((ext_vector_type(4))) int sk_i32x4;
 
 __device__ __forceinline__ int sk_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// s_waitcnt vmcnt(8 n), n = 0..5 (vmcnt is 6 bits: [3:0] and [15:14]); the other counters are left alone
+// s_waitcnt vmcnt(8 n), n = 0..6 (vmcnt is 6 bits: [3:0] and [15:14]); the other counters are left alone
 __device__ __forceinline__ void sk_wait_stages(int n) {
-    if (n >= 5) __builtin_amdgcn_s_waitcnt(0x8F78);
+    if (n >= 6) __builtin_amdgcn_s_waitcnt(0xCF70);
+    else if (n == 5) __builtin_amdgcn_s_waitcnt(0x8F78);
     else if (n == 4) __builtin_amdgcn_s_waitcnt(0x8F70);
     else if (n == 3) __builtin_amdgcn_s_waitcnt(0x4F78);
     else if (n == 2) __builtin_amdgcn_s_waitcnt(0x4F70);
@@ -228,87 +239,154 @@ __device__ __forceinline__ void sk_wait_stages(int n) {
     else __builtin_amdgcn_s_waitcnt(0x0F70);
 }
 
-// part: [gridDim.x tiles][gridDim.y splits][M][128] fp32
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ x, int M, int ldx, const bf16_t* __restrict__ w, int N, int ldw,
-                                                          int nk, float* __restrict__ part, int w_tiled) {
+// part: [gridDim.x tiles][gridDim.y splits][M][128] fp32 (gridDim.y > 1 only)
+__global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const bf16_t* __restrict__ x, int M, int ldx, const bf16_t* __restrict__ w, int N, int ldw,
+                                                                 int nk, float* __restrict__ part, int w_tiled, void* __restrict__ out, int64_t ldo, int out_f32) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
-    char* const w_ring = sk_smem;                              // SK_WSLOTS tiles
-    char* const x_ring = sk_smem + SK_WSLOTS * SK_TILE;        // SK_XSLOTS tiles
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];      // the x ring: SK_XSLOTS tiles
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
-    const bool w_loader = wave < 2;
-    const int lw = wave & 1;                                   // which half (64 rows) of its operand tile this wave stages
     const int b = blockIdx.x, S = gridDim.y, sp = blockIdx.y;
-    const int s0 = b * nk + (int)((int64_t)nk * sp / S), s1 = b * nk + (int)((int64_t)nk * (sp + 1) / S), ns = s1 - s0;   // steps = global k-tile index
+    const int k0 = (int)((int64_t)nk * sp / S), k1 = (int)((int64_t)nk * (sp + 1) / S), ns = k1 - k0;   // this split's k-tiles
     if (ns <= 0) return;
-    // one descriptor per wave (its operand's base); per-lane byte offsets are loop invariant, everything else is scalar.
-    // Row-major weights: range = the matrix, so the rows of the last tile beyond N read as zeros.
-    const bool tiled = w_loader && w_tiled;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(w_loader ? w : x), 0,
-                                                        w_loader && !w_tiled ? (int)(((int64_t)(N - 1) * ldw + nk * SK_BK) * 2) : 0x7FFFFF00, 0x00020000);
-    unsigned voff[8];
+    if (wave >= 4) {
+        // ---------------- loader waves: each stages 64 of the 128 x rows of every k-tile (8 pieces of 8 rows x 128 bytes)
+        const int lw = wave - 4;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, 0x7FFFFF00, 0x00020000);
+        unsigned voff[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int row = lw * 64 + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
-        const int r = w_loader ? row : (row < M ? row : M - 1);
-        voff[i] = tiled ? (unsigned)((lw * 64 + i * 8) * 128 + lane * 16) : (unsigned)(r * (w_loader ? ldw : ldx) + c * 8) * 2u;
-    }
-    char* const ring = w_loader ? w_ring : x_ring;
-    // scalar byte offset of step st: tiled weights -- the st-th 16 KiB block; row-major weights -- (tile * 128 rows, kt * 64);
-    // activations -- kt * 64
-#define SK_ISSUE(slot, st)                                                                                   \
-    {                                                                                                        \
-        const int b_ = (st) / nk, kt_ = (st) - b_ * nk;                                                      \
-        const int so_ = tiled ? (st) * SK_TILE : w_loader ? (b_ * SK_BN * ldw + kt_ * SK_BK) * 2 : kt_ * (SK_BK * 2); \
+        for (int i = 0; i < 8; i++) {
+            const int row = lw * 64 + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
+            voff[i] = (unsigned)((row < M ? row : M - 1) * ldx + c * 8) * 2u;
+        }
+#define SK_ISSUE_X(slot, kt)                                                                                 \
         _Pragma("unroll") for (int i = 0; i < 8; i++)                                                        \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (sk_lptr_t)(ring + (slot) * SK_TILE + (lw * 64 + i * 8) * 128), 16, voff[i], so_, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (sk_lptr_t)(sk_smem + (slot) * SK_TILE + (lw * 64 + i * 8) * 128), 16, voff[i], (kt) * (SK_BK * 2), 0, 0);
+        for (int t = 0; t < SK_XD && t < ns; t++) { SK_ISSUE_X(t, k0 + t) }
+        int slot_in = SK_XD % SK_XSLOTS;
+        const int nsp = (ns + SK_D - 1) / SK_D * SK_D;        // the multiplying waves run whole groups of SK_D steps: same barrier count here
+        for (int t = 0; t < nsp; t++) {
+            // my pieces of k-tiles t AND t + 1 (the multiplying waves read one fragment group ahead, across the barrier) have landed
+            // when only the k-tiles younger than t + 1 (8 pieces each) are outstanding
+            const int younger = t >= ns - 2 ? 0 : ns - 2 - t < SK_XD - 2 ? ns - 2 - t : SK_XD - 2;
+            sk_wait_stages(younger);
+            __builtin_amdgcn_s_barrier();                      // x of k-tiles t, t + 1 is in LDS; everyone is done with k-tile t - 1
+            if (t + SK_XD < ns) { SK_ISSUE_X(slot_in, k0 + t + SK_XD) }      // (slot of k-tile t + XD - XSLOTS = t - 1: free)
+            slot_in = slot_in + 1 == SK_XSLOTS ? 0 : slot_in + 1;
+        }
+#undef SK_ISSUE_X
+        return;
     }
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int depth = w_loader ? SK_WSLOTS - 1 : SK_XSLOTS - 1, slots = w_loader ? SK_WSLOTS : SK_XSLOTS;   // steps ahead; ring size
-    for (int t = 0; t < depth && t < ns; t++) { SK_ISSUE(t, s0 + t) }
+    // ---------------- multiplying waves: 32 weight rows each, fragments straight from memory
     const int fr = lane & 15, fg = lane >> 4;
-    int slot_w = 0, slot_x = 0, slot_in = depth % slots;       // slot_in: where this wave's next step goes
-    for (int t = 0; t < ns; t++) {
-        // my pieces of step t have landed when only the younger steps' (8 pieces each) are outstanding
-        const int younger = ns - 1 - t < depth - 1 ? ns - 1 - t : depth - 1;
-        sk_wait_stages(younger);
-        __builtin_amdgcn_s_barrier();                          // both operands of step t are in LDS; everyone is done with step t - 1
-        if (t + depth < ns) { SK_ISSUE(slot_in, s0 + t + depth) }
-        slot_in = slot_in + 1 == slots ? 0 : slot_in + 1;
-        const char* ws = w_ring + slot_w * SK_TILE;
-        const char* xs = x_ring + slot_x * SK_TILE;
-        slot_w = slot_w + 1 == SK_WSLOTS ? 0 : slot_w + 1;
-        slot_x = slot_x + 1 == SK_XSLOTS ? 0 : slot_x + 1;
+    // one descriptor for the tile; per-lane byte offsets of the two 16-row fragments' two 32-deep halves; k-tile step in bytes.
+    // Row-major: range = the tile's rows inside the matrix (rows beyond N read as zeros).  Tiled (vtgb_pack_skinny_weight): the
+    // tile's nk blocks of 16 KiB, rows in the LDS swizzle of rounds 1-2 (chunk q of row r holds k-chunk q ^ ((r >> 1) & 7)).
+    const int rows_in = N - b * SK_BN < SK_BN ? N - b * SK_BN : SK_BN;
+    const int64_t wbase = w_tiled ? (int64_t)b * nk * (SK_TILE / 2) : (int64_t)b * SK_BN * ldw;
+    const unsigned wrange = w_tiled ? (unsigned)nk * SK_TILE : (unsigned)(((int64_t)(rows_in - 1) * ldw + nk * SK_BK) * 2);
+    // (descriptor words by hand: the loads below are inline asm -- see SK_ISSUE_W)
+    const uint64_t wptr = reinterpret_cast<uint64_t>(w + wbase);
+    const sk_i32x4 wrsrc = {__builtin_amdgcn_readfirstlane((int)(unsigned)wptr), __builtin_amdgcn_readfirstlane((int)((wptr >> 32) & 0xFFFFu)),
+                            __builtin_amdgcn_readfirstlane((int)wrange), 0x00020000};
+    const int kstep = w_tiled ? SK_TILE : SK_BK * 2;
+    unsigned wv[2][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            bf16x8 wf[4], xf[4];
+    for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                wf[i] = *reinterpret_cast<const bf16x8*>(ws + sk_swz(wn * 64 + i * 16 + fr, ks * 4 + fg));
-                xf[i] = *reinterpret_cast<const bf16x8*>(xs + sk_swz(wm * 64 + i * 16 + fr, ks * 4 + fg));
+        for (int h = 0; h < 2; h++) {
+            const int row = wave * 32 + i * 16 + fr, chunk = h * 4 + fg;
+            wv[i][h] = w_tiled ? (unsigned)sk_swz(row, chunk) : (unsigned)(row * ldw + chunk * 8) * 2u;
+        }
+    sk_i32x4 wreg[SK_D][2][2];
+    // The ring's loads are inline asm and its waits are written by hand: with the builtin, hipcc's own vmcnt bookkeeping drained
+    // the whole ring (vmcnt(0)) at the top of every group of SK_D steps -- it cannot see that a register loaded in one trip of the
+    // loop is consumed in the next -- which halves the bytes in flight.  SK_WAIT_W(u): everything but the SK_D - 1 younger k-tiles
+    // (4 loads each) has landed, i.e. ring entry u; the empty asm ties the registers' next use to that point.
+#define SK_ISSUE_W(u, t)                                                                                     \
+    {                                                                                                        \
+        const int so_ = __builtin_amdgcn_readfirstlane((t) < ns ? (k0 + (t)) * kstep : 0x7FFFFF00);   /* past the split: out of range, no traffic */ \
+        _Pragma("unroll") for (int i = 0; i < 2; i++)                                                        \
+            _Pragma("unroll") for (int h = 0; h < 2; h++)                                                    \
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(wreg[u][i][h]) : "v"(wv[i][h]), "s"(wrsrc), "s"(so_) : "memory"); \
+    }
+#define SK_WAIT_W(u)                                                                                         \
+    {                                                                                                        \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (SK_D - 1)) : "memory");                                \
+        _Pragma("unroll") for (int i = 0; i < 2; i++)                                                        \
+            _Pragma("unroll") for (int h = 0; h < 2; h++) asm volatile("" : "+v"(wreg[u][i][h]));            \
+    }
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < SK_D; u++) { SK_ISSUE_W(u, u) }
+    // x fragments: four at a time ("quad" q of a k-tile: 32-deep half q >> 1, x rows 64 (q & 1) ...), double buffered -- the next
+    // quad's LDS reads are issued before the current quad's 8 MFMAs (one wave per SIMD: nobody else hides the LDS latency), and quad
+    // 0 of the NEXT k-tile before the last quad of this one (the loaders guarantee k-tile t + 1 at barrier t).
+    bf16x8 xf[2][4];
+#define SK_READ_X(buf, xs_, q)                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 4; j++)                                                            \
+        xf[buf][j] = *reinterpret_cast<const bf16x8*>((xs_) + sk_swz((((q) & 1) * 4 + j) * 16 + fr, ((q) >> 1) * 4 + fg));
+    int slot_x = 0;
+    const char* xs = sk_smem;
+    bool primed = false;
+    for (int t0 = 0; t0 < ns; t0 += SK_D) {
+#pragma unroll
+        for (int u = 0; u < SK_D; u++) {
+            // Straight-line steps (a branch per step made hipcc drain the weight ring with vmcnt(0..3) at every join): the steps of
+            // the last group past the split multiply ZERO weight fragments (out-of-range loads) with the last real x tile.
+            const int t = t0 + u;
+            __builtin_amdgcn_s_barrier();                      // x of k-tiles t, t + 1 is in LDS
+            if (!primed) { SK_READ_X(0, xs, 0) primed = true; }
+            if (t < ns - 1) slot_x = slot_x + 1 == SK_XSLOTS ? 0 : slot_x + 1;
+            const char* const xs_next = sk_smem + slot_x * SK_TILE;
+            SK_WAIT_W(u)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (q < 3) { SK_READ_X((q + 1) & 1, xs, q + 1) } else { SK_READ_X(0, xs_next, 0) }
+                __builtin_amdgcn_sched_barrier(0);             // (left alone, hipcc sinks the reads to just before their MFMAs)
+                const bf16x8 wf0 = __builtin_bit_cast(bf16x8, wreg[u][0][q >> 1]), wf1 = __builtin_bit_cast(bf16x8, wreg[u][1][q >> 1]);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    acc[0][(q & 1) * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0, xf[q & 1][j], acc[0][(q & 1) * 4 + j], 0, 0, 0);
+                    acc[1][(q & 1) * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, xf[q & 1][j], acc[1][(q & 1) * 4 + j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            xs = xs_next;
+            SK_ISSUE_W(u, t + SK_D)
         }
     }
-    // this workgroup's fragment.  D layout: column (lane & 15) <- x row (m), rows (lane >> 4) * 4 + reg <- w row (n)
-    float* const ps = part + (int64_t)(b * S + sp) * M * SK_BN;
+#undef SK_READ_X
+#undef SK_ISSUE_W
+#undef SK_WAIT_W
+    // D layout: column (lane & 15) <- x row (m), rows (lane >> 4) * 4 + reg <- w row (n)
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int m = wm * 64 + j * 16 + fr;
+    for (int j = 0; j < 8; j++) {
+        const int m = j * 16 + fr;
+        if (m >= M) continue;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (m < M) *reinterpret_cast<f32x4*>(ps + m * SK_BN + wn * 64 + i * 16 + fg * 4) = acc[i][j];
+        for (int i = 0; i < 2; i++) {
+            const int c = wave * 32 + i * 16 + fg * 4, n = b * SK_BN + c;
+            const f32x4 v = acc[i][j];
+            if (S > 1) {
+                *reinterpret_cast<f32x4*>(part + ((int64_t)(b * S + sp) * M + m) * SK_BN + c) = v;
+            } else if (n < N) {                                // no K split: round once and store straight to `out`
+                if (out_f32) {
+                    float* o = reinterpret_cast<float*>(out) + m * ldo + n;
+                    if (n + 3 < N) *reinterpret_cast<f32x4*>(o) = v;
+                    else for (int e = 0; e < 4 && n + e < N; e++) o[e] = v[e];
+                } else {
+                    bf16_t* o = reinterpret_cast<bf16_t*>(out) + m * ldo + n;
+                    if (n + 3 < N) *reinterpret_cast<bf16x4*>(o) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    else for (int e = 0; e < 4 && n + e < N; e++) o[e] = (bf16_t)v[e];
+                }
+            }
+        }
     }
-#undef SK_ISSUE
 #endif
 }
 
@@ -357,13 +435,19 @@ __global__ __launch_bounds__(256) void gemm_skinny_reduce_kernel(const float* __
     }
 }
 
-// splits: every CU should hold a stream, but a split costs an fp32 fragment (M x 128 x 4 bytes written and read back) and a
-// shorter pipeline: the smallest count in 1..8 that reaches 192 workgroups, never below 8 k-tiles per split
+// splits.  Measured (tools/exp/skinny_bench.py, hipGraph replay, M = 124; profiles/r03_skinny_experiments.md): a workgroup streams
+// ~16 KiB of weights per 0.45 us whatever is in flight (ablations: without the x stream 0.47 us per k-tile, without the weight stream
+// 0.43 us -- both go through the CU's one L1/TA path, and x is re-read by every tile), so the stream count decides: >= 160 tiles run
+// unsplit (gate|up, lm_head); fewer tiles are split until ~128 workgroups stream, long K a little further (one split per 24
+// k-tiles), never more than 8 splits (each costs an M x 128 fp32 fragment written and read back) or fewer than 8 k-tiles per split.
 static int skinny_splits(const vtgb_gemm_skinny_args* a) {
     const int nk = a->K / SK_BK, n_tiles = (a->N + SK_BN - 1) / SK_BN;
     if (a->n_splits > 0) return a->n_splits < nk ? a->n_splits : nk;
-    int S = 1;
-    while (S < 8 && n_tiles * S < 192 && nk / (S + 1) >= 8) S++;
+    if (n_tiles >= 160) return 1;
+    int S = (128 + n_tiles - 1) / n_tiles;
+    if (S < nk / 24) S = nk / 24;
+    if (S > 8) S = 8;
+    while (S > 1 && nk / S < 8) S--;
     return S;
 }
 
@@ -383,28 +467,31 @@ static int skinny_check(const vtgb_gemm_skinny_args* a) {
 
 extern "C" size_t vtgb_gemm_skinny_workspace_bytes(const vtgb_gemm_skinny_args* a) {
     if (skinny_check(a) != VTGB_OK) return 0;
-    return (size_t)((a->N + SK_BN - 1) / SK_BN) * skinny_splits(a) * a->M * SK_BN * sizeof(float);
+    const int S = skinny_splits(a);
+    return S == 1 ? 0 : (size_t)((a->N + SK_BN - 1) / SK_BN) * S * a->M * SK_BN * sizeof(float);
 }
 
 extern "C" int vtgb_gemm_skinny(const vtgb_gemm_skinny_args* a, vtgb_stream_t s) {
     VTGB_TRY(skinny_check(a));
-    VTGB_REQUIRE(a->x && a->w && a->out && a->workspace, VTGB_EINVAL, "gemm_skinny: NULL operand");
+    VTGB_REQUIRE(a->x && a->w && a->out, VTGB_EINVAL, "gemm_skinny: NULL operand");
     const int nk = a->K / SK_BK, n_tiles = (a->N + SK_BN - 1) / SK_BN, S = skinny_splits(a);
-    const size_t need = (size_t)n_tiles * S * a->M * SK_BN * sizeof(float);
-    VTGB_REQUIRE(a->workspace_bytes >= need, VTGB_EWORKSPACE, "gemm_skinny: workspace %zu < %zu bytes", a->workspace_bytes, need);
-    constexpr int LDS = (SK_WSLOTS + SK_XSLOTS) * SK_TILE;
+    const size_t need = S == 1 ? 0 : (size_t)n_tiles * S * a->M * SK_BN * sizeof(float);
+    VTGB_REQUIRE(need == 0 || (a->workspace && a->workspace_bytes >= need), VTGB_EWORKSPACE, "gemm_skinny: workspace %zu < %zu bytes", a->workspace_bytes, need);
+    constexpr int LDS = SK_XSLOTS * SK_TILE;
     static DeviceOnce attr;
     VTGB_FUNC_LDS_ONCE(attr, gemm_skinny_kernel, LDS);
     {
         ProfScope prof(VTGB_PROF_GEMM, 2.0 * a->M * a->N * a->K, s);
-        hipLaunchKernelGGL(gemm_skinny_kernel, dim3(n_tiles, S), dim3(256), LDS, s, (const bf16_t*)a->x, a->M, (int)a->ldx, (const bf16_t*)a->w, a->N,
-                           (int)a->ldw, nk, (float*)a->workspace, a->w_tiled);
+        hipLaunchKernelGGL(gemm_skinny_kernel, dim3(n_tiles, S), dim3(SK_THREADS), LDS, s, (const bf16_t*)a->x, a->M, (int)a->ldx, (const bf16_t*)a->w, a->N,
+                           (int)a->ldw, nk, (float*)a->workspace, a->w_tiled, a->out, a->ldo, a->out_dtype == VTGB_F32 ? 1 : 0);
     }
-    const dim3 rgrid(n_tiles, (a->M + 7) / 8 < 4 ? (a->M + 7) / 8 : 4);
-    if (a->out_dtype == VTGB_BF16)
-        hipLaunchKernelGGL(gemm_skinny_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, s, (const float*)a->workspace, a->M, a->N, S, (bf16_t*)a->out, a->ldo);
-    else
-        hipLaunchKernelGGL(gemm_skinny_reduce_kernel<float>, rgrid, dim3(256), 0, s, (const float*)a->workspace, a->M, a->N, S, (float*)a->out, a->ldo);
+    if (S > 1) {
+        const dim3 rgrid(n_tiles, (a->M + 7) / 8 < 4 ? (a->M + 7) / 8 : 4);
+        if (a->out_dtype == VTGB_BF16)
+            hipLaunchKernelGGL(gemm_skinny_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, s, (const float*)a->workspace, a->M, a->N, S, (bf16_t*)a->out, a->ldo);
+        else
+            hipLaunchKernelGGL(gemm_skinny_reduce_kernel<float>, rgrid, dim3(256), 0, s, (const float*)a->workspace, a->M, a->N, S, (float*)a->out, a->ldo);
+    }
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }

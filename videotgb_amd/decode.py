@@ -69,11 +69,11 @@ class GreedyDecoder:
         self.graphs: Dict[Tuple[int, int, int], dict] = {}
         self._skinny = None            # per layer (wqkv, wo, wgu, wd) + lm_head in vtgb_gemm_skinny's tiled layout, built on first use
 
-    # Projections of the decode step through libvtgb.so's own weight-streaming GEMM (vtgb_gemm_skinny, tiled weights).  Measured
-    # on Vicuna-7B shapes (tools/exp/skinny_bench.py): 3.89 vs 4.30 ms per token at batch 1, 4.06 vs 3.66 at 32, 5.34 vs 4.50 at
-    # 124 (its fp32 fragments grow with the batch) -- so it serves small batches (the one-clip latency path) and hipBLASLt
-    # (F.linear) keeps the clip-batched throughput path.
-    SKINNY_MAX_BATCH = 8
+    # Projections of the decode step through libvtgb.so's own weight-streaming GEMM (vtgb_gemm_skinny, tiled weights), at every batch
+    # it takes (one token per clip, <= 128 rows): no BLAS library call on the f2 path.  Measured on the Vicuna-7B shapes under hipGraph
+    # replay (tools/exp/skinny_bench.py; profiles/r03_skinny_experiments.md): 4.7 vs 4.5 ms per token at batch 124, 4.0 vs 4.2 at batch 1
+    # (hipBLASLt = F.linear).  Larger batches fall back to F.linear.
+    SKINNY_MAX_BATCH = 128
 
     def _skinny_weights(self):
         if self._skinny is None:
@@ -161,7 +161,11 @@ class GreedyDecoder:
         return last
 
     def _head(self, x):
-        return F.linear(_rms(x, self.lm.model.norm.weight, self.eps), self.lm.lm_head.weight)
+        h = _rms(x, self.lm.model.norm.weight, self.eps)
+        if h.is_cuda and h.dim() == 2 and self._use_skinny(h.shape[0], h.dtype):
+            from . import ops
+            return ops.gemm_skinny(h.contiguous(), self._skinny_weights()[-1])      # the first token's logits: same kernel as the decode step's
+        return F.linear(h, self.lm.lm_head.weight)
 
     def _state(self, B: int, P: int, N: int, device, dtype, eos=None, pad=0, min_new=0):
         # The cache length is bucketed (multiples of 64) and the true prompt length is device data (`pos`): an eval loop over real

@@ -47,15 +47,16 @@ class _Workspace:
     """Scratch buffer handed to the library, one per (device, stream) -- calls on different streams never share scratch, so
     the wrappers are as re-entrant across streams as the C ABI underneath (grown on demand, never shrunk)."""
 
-    def __init__(self):
+    def __init__(self, zero: bool = False):
         self.bufs: Dict[Tuple[int, int], Tensor] = {}
+        self.zero = zero
 
     def get(self, nbytes: int, device) -> Tensor:
         idx = device.index if device.index is not None else torch.cuda.current_device()
         key = (idx, torch.cuda.current_stream(idx).cuda_stream)
         b = self.bufs.get(key)
         if b is None or b.numel() < nbytes:
-            self.bufs[key] = b = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            self.bufs[key] = b = (torch.zeros if self.zero else torch.empty)(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         return b
 
 
@@ -194,11 +195,10 @@ def gemm_skinny(x: Tensor, w: Tensor, out: Optional[Tensor] = None, n_splits: in
         out = torch.empty(M, N, dtype=out_dtype or x.dtype, device=x.device)
     a = L.GemmSkinnyArgs(M, N, K, n_splits, x.data_ptr(), x.stride(0), w.data.data_ptr() if tiled else w.data_ptr(), K if tiled else w.stride(0),
                          out.data_ptr(), out.stride(0), dtype_code(out.dtype), 1 if tiled else 0, None, 0)
-    need = L.lib().vtgb_gemm_skinny_workspace_bytes(C.byref(a))
-    if need == 0:
-        L.check(L.lib().vtgb_gemm_skinny(C.byref(a), _stream()))      # reports the argument error
-    ws = workspace if workspace is not None else _ws.get(need, x.device)
-    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    need = L.lib().vtgb_gemm_skinny_workspace_bytes(C.byref(a))      # 0: no K split (or bad arguments, which the call reports)
+    if need:
+        ws = workspace if workspace is not None else _ws.get(need, x.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     L.check(L.lib().vtgb_gemm_skinny(C.byref(a), _stream()))
     return out
 
