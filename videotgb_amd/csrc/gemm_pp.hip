@@ -58,11 +58,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
     const int nk = p.K / P_BK;
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
-#ifdef PP_EXP_STAGE0
-    char* const stage = smem + wave * SB;
-#else
     char* const stage = smem + A_OP + wave * SB;   // this wave's private epilogue staging region
-#endif
 
     // ---- workgroup -> tile list.  The tiles are numbered q = 0 .. m_tiles * n_tiles - 1 in grouped order (G consecutive m-tiles x all
     // n-tiles, m fastest: neighbours in q share a weight tile and, for convolutions, halo rows).  With the grid a multiple of 8,
@@ -203,20 +199,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
             for (int i = 0; i < 4; i++) {
                 const int n = n0 + wn * 64 + i * 16 + fg * 4;
                 b4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p.bias && n < p.N) b4[i] = *reinterpret_cast<const f32x4*>(p.bias + n);     // (N % 4 == 0: pp_supported)
+                if (p.bias && n + 3 < p.N) b4[i] = *reinterpret_cast<const f32x4*>(p.bias + n);
+                else if (p.bias && n < p.N) {                                                    // (N % 4 != 0: plain bf16 stores only, pp_supported)
+                    for (int e = 0; e < 4 && n + e < p.N; e++) b4[i][e] = p.bias[n + e];
+                }
             }
-#ifdef PP_EXP_INIT_SIMPLE
-            if (p.init_frag) {
-                const bf16x4* fsrc = reinterpret_cast<const bf16x4*>(p.init_bf16) + ((int64_t)(mt * n_tiles + nt) * 8 + wave) * (NX * 4 * 64) + lane;
-#pragma unroll
-                for (int j = 0; j < NX; j++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const bf16x4 t = fsrc[(j * 4 + i) * 64];
-                        acc[i][j] = b4[i] + f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
-                    }
-            } else
-#endif
             if (p.init_frag) {
                 // all NX * 4 loads (512 contiguous bytes per wave instruction) in flight BEFORE the first add: left to itself hipcc
                 // consumed each load right behind its issue with `s_waitcnt vmcnt(0)` (a DMA is in flight: no counted waits), i.e.
@@ -431,12 +418,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
     if (has_next) __builtin_amdgcn_s_waitcnt(0x0F70 | NPRE); else __builtin_amdgcn_s_waitcnt(0x0F70);
 
         // ================= epilogue of tile (em0, en0)
-#ifdef PP_EXP_EPI_DRAIN
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         // Every global access of the epilogues goes through a buffer descriptor on the TILE's rows of the matrix (rows beyond M fall
@@ -450,6 +431,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
         };
         typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
         typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2_t;
+        typedef __attribute__((__vector_size__(3 * sizeof(unsigned)))) unsigned u32x3_t;
         if constexpr (EPI == EPI_STORE && !TAIL) {
             if (p.frag_out) {   // fragment order: straight from the accumulators, 512 contiguous bytes per wave instruction, no LDS
                 prefetch();
@@ -528,7 +510,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
             const int col = to_out2 ? nn - p.gate_from : nn;
             const int64_t ld_o = to_out2 ? p.ldo2 : p.ldo;
             const auto o_rs = tile_rsrc(to_out2 ? p.out2 : p.out, ld_o, 2);
-            const unsigned o_lane = nn < p.N ? (unsigned)((wm * WROWS + (lane_e >> 3)) * (int)ld_o + col) * 2u : OOB;
+            // N % 8 != 0 (RAFT's 126-channel motion convolution, whose last two output columns hold the flow written by another kernel):
+            // the chunk that straddles N is stored as its N % 8 valid columns (1-3 dwords) by a second, wave-uniformly guarded store
+            const int ncut = p.N & 7;
+            const bool whole = nn + 8 <= p.N || (ncut == 0 && nn < p.N);
+            const unsigned o_lane = whole ? (unsigned)((wm * WROWS + (lane_e >> 3)) * (int)ld_o + col) * 2u : OOB;
+            const unsigned o_part = (ncut != 0 && nn < p.N && nn + 8 > p.N) ? (unsigned)((wm * WROWS + (lane_e >> 3)) * (int)ld_o + col) * 2u : OOB;
             u32x4_t opnd[RP / 8];
             const int64_t ld_g = to_out2 ? p.ldaux : p.ldrb;
             const bool has_opnd = to_out2 || resd;
@@ -587,6 +574,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
                 }
 #pragma unroll
                 for (int rr = 0; rr < RP / 8; rr++) P_STORE128(vv[rr], o_rs, o_lane, (ps * RP + rr * 8) * (int)ld_o * 2);
+                if (ncut != 0 && !has_opnd) {
+#pragma unroll
+                    for (int rr = 0; rr < RP / 8; rr++) {
+                        const unsigned off = o_part + (unsigned)((ps * RP + rr * 8) * (int)ld_o * 2);
+                        if (ncut == 6) __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{vv[rr][0], vv[rr][1], vv[rr][2]}, o_rs, off, 0, 0);
+                        else if (ncut == 4) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{vv[rr][0], vv[rr][1]}, o_rs, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b32(vv[rr][0], o_rs, off, 0, 0);
+                    }
+                }
             }
 #undef P_OPND_LOAD
         }
@@ -687,38 +683,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
                 }
             }
         }
-#ifdef PP_EXP_GRU_BUFNOLDS
-        if constexpr (EPI == EPI_GRU) {      // buffer ops, fragment-shaped, no LDS
-            prefetch();
-            const auto h_rs = tile_rsrc(p.resid, p.ldr, 4), z_rs = tile_rsrc(p.aux, p.ldaux, 2), o_rs = tile_rsrc(p.out, p.ldo, 4), o2_rs = tile_rsrc(p.out2, p.ldo2, 2);
-#pragma unroll
-            for (int j = 0; j < NX; j++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int row = wm * WROWS + j * 16 + (lane_e & 15), n = en0 + wn * 64 + i * 16 + (lane_e >> 4) * 4;
-                    const u32x4_t hq = __builtin_amdgcn_raw_buffer_load_b128(h_rs, (unsigned)(row * (int)p.ldr + n) * 4u, 0, 0);
-                    const u32x2_t zq = __builtin_amdgcn_raw_buffer_load_b64(z_rs, (unsigned)(row * (int)p.ldaux + n) * 2u, 0, 0);
-                    const f32x4 hv = __builtin_bit_cast(f32x4, hq);
-                    const bf16x4 zv = __builtin_bit_cast(bf16x4, zq);
-                    f32x4 hn;
-                    for (int e = 0; e < 4; e++) { const float z = (float)zv[e]; hn[e] = (1.0f - z) * hv[e] + z * tanh_fast(acc[i][j][e]); }
-                    const bf16x4 hb = {(bf16_t)hn[0], (bf16_t)hn[1], (bf16_t)hn[2], (bf16_t)hn[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, hn), o_rs, (unsigned)(row * (int)p.ldo + n) * 4u, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, hb), o2_rs, (unsigned)(row * (int)p.ldo2 + n) * 2u, 0, 0);
-                }
-            goto tile_done;
-        }
-#endif
-#ifdef PP_EXP_GRU_GENERIC
-        if constexpr (EPI == EPI_GRU) {
-            prefetch();
-#pragma unroll
-            for (int j = 0; j < NX; j++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) store4<EPI>(p, em0 + wm * WROWS + j * 16 + (lane_e & 15), en0 + wn * 64 + i * 16 + (lane_e >> 4) * 4, acc[i][j]);
-            goto tile_done;
-        }
-#endif
         if constexpr (EPI == EPI_GRU) {
             // h' = (1 - z) h + z tanh(acc): the accumulators go through the staging region as in the fp32 path so that h, z and both
             // outputs are touched as whole row segments.  h / z of pass h+1 are requested before pass h's stores (two register sets),
@@ -741,9 +705,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
             prefetch();
 #pragma unroll
             for (int ps = 0; ps < NP; ps++) {
-#ifdef PP_EXP_GRU_NOAHEAD
-                if (ps > 0) { if (ps & 1) { P_GRU_LOAD(1, ps) } else { P_GRU_LOAD(0, ps) } }
-#endif
 #pragma unroll
                 for (int jj = 0; jj < PR / 16; jj++)
 #pragma unroll
@@ -751,19 +712,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
                         const int row = jj * 16 + (lane_e & 15), chunk = i * 4 + (lane_e >> 4);
                         *reinterpret_cast<f32x4*>(stage + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][ps * (PR / 16) + jj];
                     }
-#ifdef PP_EXP_GRU_SERIAL
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0x0070);
-                __builtin_amdgcn_sched_barrier(0);
-#else
                 if (ps == 0) { P_WAIT_OPERANDS() }
                 else __builtin_amdgcn_s_waitcnt(0x0F70 | ((PR / 2) & 15) | (((PR / 2) >> 4) << 14));      // the previous pass's 2 PR / 4 stores may still fly
-#endif
-#ifndef PP_EXP_GRU_NOAHEAD
                 if (ps + 1 < NP) {
                     if ((ps & 1) == 0) { P_GRU_LOAD(1, ps + 1) } else { P_GRU_LOAD(0, ps + 1) }
                 }
-#endif
 #pragma unroll
                 for (int rr = 0; rr < PR / 4; rr++) {
                     const int row = rr * 4 + rl;
@@ -814,12 +767,14 @@ static int cu_count() {
 bool pp_supported(const GemmDesc& d) {
     if (d.o_map.seg_rows != 0 || d.r_map.seg_rows != 0) return false;
     if (d.init_bf16 && !d.init_frag) return false;
-    if ((d.N & 3) != 0 || (d.ldw & 63) != 0) return false;      // (the weight pieces' swizzle is applied as offset ^ 64: rows of whole 128 bytes)
+    if ((d.ldw & 63) != 0) return false;      // (the weight pieces' swizzle is applied as offset ^ 64: rows of whole 128 bytes)
+    if ((d.N & 3) != 0 && !(d.epi == EPI_STORE && !d.frag_out && (d.N & 1) == 0)) return false;
     switch (d.epi) {
         case EPI_STORE:
         case EPI_GELU:
             if (d.frag_out) return true;
-            if ((d.N & 7) != 0 || (d.ldo & 7) != 0 || d.out_scale != 0.f) return false;
+            if ((d.ldo & 7) != 0 || d.out_scale != 0.f) return false;
+            if ((d.N & 7) != 0 && ((d.N & 1) != 0 || d.gate_from > 0 || d.resid_bf16 || d.tail_w)) return false;      // (plain stores only: see the N % 8 store)
             if (d.gate_from > 0 && ((d.gate_from & 63) != 0 || (d.ldaux & 7) != 0 || (d.ldo2 & 7) != 0)) return false;
             if (d.resid_bf16 && (d.ldrb & 7) != 0) return false;
             if (d.tail_w && (d.N != 256 || (d.ldtail & 3) != 0 || d.conv_KH == 0)) return false;
