@@ -375,8 +375,8 @@ def main():
                                      "time; executed_tflops counts only what the launches execute (the GRU convolutions' loop-invariant `inp` third is "
                                      "computed once per pair, not once per iteration)")
             return out
-        gemm = fam(0, "gemm_bf16_large_kernel<EPI,0,false> / gemm_bf16_kernel: plain bf16 MFMA GEMMs (ViT-g, Q-Former, TGB, projection)")
-        conv = fam(2, "gemm_bf16_large_kernel<EPI,0,true>: the same MFMA kernel as implicit-GEMM convolution (RAFT encoders + update block)")
+        gemm = fam(0, "gemm_bf16_pp_kernel<EPI,false,NWN> (persistent) / gemm_bf16_large_kernel / gemm_bf16_kernel / gemm_skinny_kernel: plain bf16 MFMA GEMMs (ViT-g, Q-Former, TGB, projection, LLM prefill + decode)")
+        conv = fam(2, "gemm_bf16_pp_kernel<EPI,true,NWN> (persistent; 64-wide tiles: gemm_bf16_large_kernel<EPI,0,true>): the same MFMA kernels as implicit-GEMM convolution (RAFT encoders + update block)")
         attn = fam(1, "attn_bf16_kernel")
         fams = [f for f in (gemm, conv) if f]
         if fams:

@@ -133,3 +133,47 @@ def test_bf16_prefill_runs_on_libvtgb_and_matches_the_blas_path():
             la, lb = own._head(last).float(), blas._head(x[:, -1]).float()
         assert (la - lb).abs().max().item() <= 3e-2 * max(1.0, lb.abs().max().item())
         assert a[:, 0].tolist() == b[:, 0].tolist() == lb.argmax(-1).tolist()
+
+
+def _t5(device, dtype=torch.float32):
+    from transformers import T5Config, T5ForConditionalGeneration
+    torch.manual_seed(0)
+    cfg = T5Config(vocab_size=200, d_model=64, d_kv=16, d_ff=96, num_layers=3, num_decoder_layers=3, num_heads=4, feed_forward_proj="gated-gelu",
+                   tie_word_embeddings=False, decoder_start_token_id=0, pad_token_id=0, eos_token_id=1)
+    lm = T5ForConditionalGeneration(cfg).eval()
+    for p in lm.parameters():
+        p.data.normal_(0, 0.3)
+    return lm.to(device=device, dtype=dtype)
+
+
+def _check_t5(device, use_graph):
+    """T5GreedyDecoder against HF generate at fp32: id for id, with and without EOS stopping (the eos id is one the model emits)."""
+    from videotgb_amd.decode import T5GreedyDecoder, make_decoder
+    lm = _t5(device)
+    g = torch.Generator().manual_seed(1)
+    emb = (torch.randn(3, 7, 64, generator=g) * 0.5).to(device)
+    mask = torch.ones(3, 7, dtype=torch.long, device=device)
+    dec = make_decoder(lm)
+    assert isinstance(dec, T5GreedyDecoder)
+    ref = lm.generate(inputs_embeds=emb, attention_mask=mask, do_sample=False, max_new_tokens=10, min_new_tokens=10)
+    out = dec.generate(emb, 10, use_graph=use_graph)
+    assert out.tolist() == ref.tolist()
+    eos = int(ref[0, 4])                              # a token row 0 emits at step 4: rows finish at different steps
+    ref = lm.generate(inputs_embeds=emb, attention_mask=mask, do_sample=False, max_new_tokens=10, eos_token_id=eos, pad_token_id=0)
+    out = dec.generate(emb, 10, use_graph=use_graph, eos_token_id=eos, pad_token_id=0)
+    assert out.tolist() == ref.tolist()
+    ref = lm.generate(inputs_embeds=emb, attention_mask=mask, do_sample=False, max_new_tokens=10, min_new_tokens=6, eos_token_id=eos, pad_token_id=0)
+    out = dec.generate(emb, 10, use_graph=use_graph, eos_token_id=eos, pad_token_id=0, min_new_tokens=6)
+    assert out.tolist() == ref.tolist()
+
+
+def test_t5_greedy_decoder_matches_hf_generate_cpu():
+    _check_t5("cpu", False)
+
+
+@pytest.mark.gpu
+def test_t5_greedy_decoder_hipgraph_matches_hf_generate_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    _check_t5("cuda:0", True)
+    _check_t5("cuda:0", False)

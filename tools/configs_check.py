@@ -65,6 +65,20 @@ def blip2_module(cls_name, tmp, dev):
     return m.to(dev).eval()
 
 
+def graph_leg(m, batch, out_hf, reps):
+    """The same eval_forward with the module's opt-in graph decoder (modules.fast_decode): same shape, same first generated token
+    (bf16, random weights: later greedy tokens can part from HF's at near ties -- the fp32 id-for-id check is tests/test_decode.py)."""
+    m.fast_decode = True
+    try:
+        out = m.eval_forward(batch)
+        assert tuple(out.shape) == tuple(out_hf.shape), (tuple(out.shape), tuple(out_hf.shape))
+        assert out[:, :2].tolist() == out_hf[:, :2].tolist()
+        assert getattr(m, "_graph_decoder", None) is not None
+        return timed(lambda: m.eval_forward(batch), n=reps)
+    finally:
+        m.fast_decode = False
+
+
 def c1(dev, tmp, B=32, reps=3, module=None):
     m = module if module is not None else blip2_module("LSTPBlip2Module", tmp, dev)
     nframe = 4
@@ -76,9 +90,10 @@ def c1(dev, tmp, B=32, reps=3, module=None):
     assert st["frame_idx"][0].tolist() == [3, 11, 19, 27] and st["of_logits"] is None, st["frame_idx"][0].tolist()
     assert tuple(out.shape) == (B, 17) or tuple(out.shape) == (B, 16), tuple(out.shape)      # 16 greedy tokens (+ the decoder start token)
     assert tuple(st["language_model_inputs"].shape) == (B, nframe * 32, 2048)
-    dt = timed(lambda: m.eval_forward(batch), n=reps)
+    dt_hf = timed(lambda: m.eval_forward(batch), n=reps)
+    dt = graph_leg(m, batch, out, reps)
     line = (f"C1 BLIP2-Flan-T5-xl, no sampler, 32 -> {nframe} frames (idx {st['frame_idx'][0].tolist()}), concat prefix {tuple(st['language_model_inputs'].shape)}, "
-            f"T5 greedy 16 tokens: {B / dt:.1f} clips/s at {B} clips per call (HF generate, eager)")
+            f"T5 greedy 16 tokens: {B / dt:.1f} clips/s at {B} clips per call (T5GreedyDecoder, hipGraph; HF generate, eager: {B / dt_hf:.1f})")
     print(line)
     return dict(clips_per_s=B / dt, frame_idx=st["frame_idx"][0].tolist(), line=line)
 
@@ -97,9 +112,10 @@ def c2(dev, tmp, B=32, reps=3, module=None):
     assert st["of_logits"].shape == (B, L, 2)
     assert tuple(st["language_model_inputs"].shape) == (B, nframe * 32, 2048) and tuple(st["frame_idx"].shape) == (B, nframe)
     assert bool((st["frame_idx"][:, 1:] >= st["frame_idx"][:, :-1]).all()) and int(st["frame_idx"].max()) < 32      # sorted candidate indices
-    dt = timed(lambda: m.eval_forward(batch), n=reps)
+    dt_hf = timed(lambda: m.eval_forward(batch), n=reps)
+    dt = graph_leg(m, batch, out, reps)
     line = (f"C2 BLIP2-Flan-T5-xl + TGB (fusion, flow length {L}, map B), 32 -> {nframe} frames, concat prefix {tuple(st['language_model_inputs'].shape)}, "
-            f"T5 greedy 16 tokens: {B / dt:.1f} clips/s at {B} clips per call (HF generate, eager)")
+            f"T5 greedy 16 tokens: {B / dt:.1f} clips/s at {B} clips per call (T5GreedyDecoder, hipGraph; HF generate, eager: {B / dt_hf:.1f})")
     print(line)
     return dict(clips_per_s=B / dt, line=line)
 

@@ -348,3 +348,189 @@ class GreedyDecoder:
             first_eos = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((B,), N, device=dev))
             out = out[:, : int(first_eos.max().item())]
         return out
+
+
+class T5GreedyDecoder:
+    """Greedy decode for the seq2seq language model of the BLIP-2 flavours (C1 / C2: Flan-T5 under ``language_model.generate``,
+    eval/utils/model.py:432-442; src/models/LSTP_blip2_module.py eval_forward).  HF's generate runs the T5 decoder stack eagerly
+    once per token (~1 000 launches per token at 24 layers); here the ENCODER runs once through HF's own module (one pass over
+    prefix ‖ prompt -- the seq2seq counterpart of the prefill), the cross-attention K / V of every decoder layer are projected
+    once, and ONE decoder step -- embedding, 24 x (self-attention over a static cache with T5's bucketed relative position bias,
+    cross-attention, gated-GELU feed-forward), final norm, lm_head, argmax, token / position feedback -- is captured into a
+    hipGraph and replayed.  The arithmetic is transformers' modeling_t5 (T5LayerNorm without mean subtraction, unscaled scores,
+    bias shared from the first block), so greedy ids equal HF generate's at fp32 (tests/test_decode.py).  Same EOS / pad /
+    min_new_tokens semantics and the same return convention as HF for encoder-decoder models: ids start with
+    ``decoder_start_token_id``.  Scope: greedy, all-ones encoder mask."""
+    MAX_STATES = 4
+
+    def __init__(self, lm):
+        cfg = lm.config
+        if getattr(cfg, "model_type", "") != "t5":
+            raise NotImplementedError("T5GreedyDecoder handles T5ForConditionalGeneration")
+        self.lm, self.cfg = lm, cfg
+        self.H, self.dk, self.D = cfg.num_heads, cfg.d_kv, cfg.d_model
+        self.eps = cfg.layer_norm_epsilon
+        self.start = cfg.decoder_start_token_id if cfg.decoder_start_token_id is not None else cfg.pad_token_id
+        self.layers = []
+        for blk in lm.decoder.block:
+            sa, ca, ff = blk.layer[0].SelfAttention, blk.layer[1].EncDecAttention, blk.layer[2].DenseReluDense
+            wqkv = torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], dim=0).contiguous()
+            gated = hasattr(ff, "wi_0")
+            wi = torch.cat([ff.wi_0.weight, ff.wi_1.weight], dim=0).contiguous() if gated else ff.wi.weight
+            self.layers.append(dict(ln0=blk.layer[0].layer_norm.weight, wqkv=wqkv, wo=sa.o.weight, ln1=blk.layer[1].layer_norm.weight,
+                                    cq=ca.q.weight, ck=ca.k.weight, cv=ca.v.weight, co=ca.o.weight, ln2=blk.layer[2].layer_norm.weight,
+                                    wi=wi, wff=ff.wo.weight, act=ff.act, gated=gated))
+        sa0 = lm.decoder.block[0].layer[0].SelfAttention
+        self.scaling = float(getattr(sa0, "scaling", 1.0) or 1.0)
+        self.bias_module = sa0
+        self.scale_out = bool(getattr(cfg, "scale_decoder_outputs", getattr(cfg, "tie_word_embeddings", False)))
+        self.graphs: Dict[tuple, dict] = {}
+
+    _pick = GreedyDecoder._pick
+    _emit = GreedyDecoder._emit
+
+    def _norm(self, x: Tensor, w: Tensor) -> Tensor:
+        # T5LayerNorm.forward: fp32 variance, no mean subtraction, no bias; cast to the weight's dtype when it is half / bf16
+        var = x.float().pow(2).mean(-1, keepdim=True)
+        y = x * torch.rsqrt(var + self.eps)
+        if w.dtype in (torch.float16, torch.bfloat16):
+            y = y.to(w.dtype)
+        return w * y
+
+    def _state(self, B, P, N, device, dtype, eos, pad, min_new):
+        key = (B, P, N, eos, pad, min_new)
+        st = self.graphs.pop(key, None)
+        if st is None:
+            while len(self.graphs) >= self.MAX_STATES:
+                self.graphs.pop(next(iter(self.graphs))).clear()
+            H, dk, L = self.H, self.dk, len(self.layers)
+            with torch.no_grad():
+                bias = self.bias_module.compute_bias(N, N, device=device)[0].permute(1, 0, 2).contiguous().to(dtype)      # [N (query), H, N (key)]
+            ar = torch.arange(N, device=device)
+            causal = torch.where(ar[None, :] <= ar[:, None], 0.0, torch.finfo(dtype).min).to(dtype)                      # [N, N]
+            st = dict(bias=bias + causal[:, None, :],
+                      kc=[torch.zeros(B, H, N, dk, device=device, dtype=dtype) for _ in range(L)],
+                      vc=[torch.zeros(B, H, N, dk, device=device, dtype=dtype) for _ in range(L)],
+                      ck=[torch.zeros(B, H, P, dk, device=device, dtype=dtype) for _ in range(L)],
+                      cv=[torch.zeros(B, H, P, dk, device=device, dtype=dtype) for _ in range(L)],
+                      tok=torch.zeros(B, dtype=torch.long, device=device), pos=torch.zeros(1, dtype=torch.long, device=device),
+                      step=torch.zeros(1, dtype=torch.long, device=device), out=torch.zeros(B, N, dtype=torch.long, device=device),
+                      fin=torch.zeros(B, dtype=torch.bool, device=device), graph=None, eos=eos, pad=pad, min_new=min_new)
+        self.graphs[key] = st
+        return st
+
+    def _decode_step(self, st):
+        """One token for every sequence, entirely on the device (captured): `tok` at decoder position `pos` -> next token."""
+        lm = self.lm
+        B, H, dk = st["tok"].shape[0], self.H, self.dk
+        x = lm.decoder.embed_tokens(st["tok"])                                                   # [B, D]
+        pos = st["pos"]
+        bias = st["bias"].index_select(0, pos)[0][None, :, None, :]                              # [1, H, 1, N]: relative bias + causal mask of this row
+        for li, w in enumerate(self.layers):
+            h = self._norm(x, w["ln0"])
+            qkv = F.linear(h, w["wqkv"]).view(B, 3, H, 1, dk)
+            st["kc"][li].index_copy_(2, pos, qkv[:, 1])
+            st["vc"][li].index_copy_(2, pos, qkv[:, 2])
+            sc = torch.matmul(qkv[:, 0], st["kc"][li].transpose(2, 3)) * self.scaling + bias     # [B, H, 1, N]
+            a = torch.matmul(F.softmax(sc, dim=-1), st["vc"][li])                                # [B, H, 1, dk]
+            x = x + F.linear(a.transpose(1, 2).reshape(B, H * dk), w["wo"])
+            h = self._norm(x, w["ln1"])
+            q = F.linear(h, w["cq"]).view(B, H, 1, dk)
+            sc = torch.matmul(q, st["ck"][li].transpose(2, 3)) * self.scaling                    # (no relative bias on cross-attention; mask all ones)
+            a = torch.matmul(F.softmax(sc, dim=-1), st["cv"][li])
+            x = x + F.linear(a.transpose(1, 2).reshape(B, H * dk), w["co"])
+            h = self._norm(x, w["ln2"])
+            if w["gated"]:
+                gu = F.linear(h, w["wi"])
+                half = gu.shape[-1] // 2
+                f = w["act"](gu[..., :half]) * gu[..., half:]
+            else:
+                f = w["act"](F.linear(h, w["wi"]))
+            x = x + F.linear(f.to(w["wff"].dtype), w["wff"])
+        h = self._norm(x, lm.decoder.final_layer_norm.weight)
+        if self.scale_out:
+            h = h * (self.D ** -0.5)
+        self._emit(st, F.linear(h, lm.lm_head.weight))
+
+    @torch.no_grad()
+    def generate(self, inputs_embeds: Tensor, max_new_tokens: int, use_graph: bool = True, eos_token_id=None, pad_token_id: int = 0,
+                 min_new_tokens: int = 0) -> Tensor:
+        """inputs_embeds [B, P, D] (encoder input, no padding) -> ids [B, 1 + n]: decoder_start_token_id, then n <= max_new_tokens
+        greedy tokens (n < max_new_tokens only when every row has emitted ``eos_token_id``), as HF generate returns them."""
+        B, P, _ = inputs_embeds.shape
+        N = max_new_tokens
+        dev, dt = inputs_embeds.device, inputs_embeds.dtype
+        if isinstance(eos_token_id, (list, tuple)):
+            if len(eos_token_id) != 1:
+                raise NotImplementedError("T5GreedyDecoder: one eos_token_id")
+            eos_token_id = eos_token_id[0]
+        st = self._state(B, P, N, dev, dt, eos_token_id, int(pad_token_id if pad_token_id is not None else 0), int(min_new_tokens or 0))
+        enc = self.lm.encoder(inputs_embeds=inputs_embeds, attention_mask=torch.ones(B, P, dtype=torch.long, device=dev)).last_hidden_state
+        for li, w in enumerate(self.layers):
+            st["ck"][li].copy_(F.linear(enc, w["ck"]).view(B, P, self.H, self.dk).transpose(1, 2))
+            st["cv"][li].copy_(F.linear(enc, w["cv"]).view(B, P, self.H, self.dk).transpose(1, 2))
+        st["fin"].zero_()
+        st["out"].fill_(st["pad"] if eos_token_id is not None else 0)
+        st["tok"].fill_(self.start)
+        st["pos"].zero_()
+        st["step"].zero_()
+        use_graph = use_graph and dev.type == "cuda"
+        if use_graph and st["graph"] is None:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._decode_step(st)                 # warm-up (handles, workspaces); state is reset below
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_step(st)
+            st["graph"] = g
+            st["fin"].zero_()
+            st["out"].fill_(st["pad"] if eos_token_id is not None else 0)
+            st["tok"].fill_(self.start)
+            st["pos"].zero_()
+            st["step"].zero_()
+        for i in range(N):
+            if eos_token_id is not None and i % 16 == 0 and i > 0 and bool(st["fin"].all()):
+                break
+            if use_graph:
+                st["graph"].replay()
+            else:
+                self._decode_step(st)
+        out = st["out"].clone()
+        if eos_token_id is not None:
+            is_eos = out == eos_token_id
+            first_eos = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((B,), N, device=dev))
+            out = out[:, : int(first_eos.max().item())]
+        return torch.cat([torch.full((B, 1), self.start, dtype=torch.long, device=dev), out], dim=1)
+
+
+def make_decoder(lm):
+    """The graph decoder for a language model: Llama-architecture causal LMs and T5 seq2seq LMs; NotImplementedError otherwise."""
+    if getattr(lm.config, "model_type", "") == "t5":
+        return T5GreedyDecoder(lm)
+    return GreedyDecoder(lm)
+
+
+_GREEDY_KEYS = {"max_new_tokens", "min_new_tokens", "do_sample", "num_beams", "eos_token_id", "pad_token_id", "use_cache", "temperature", "top_p",
+                "length_penalty", "repetition_penalty"}
+
+
+def graph_generate(owner, lm, inputs_embeds: Tensor, attention_mask: Tensor, generate_configs: dict):
+    """``lm.generate(inputs_embeds=..., attention_mask=..., **generate_configs)`` through the graph decoder when the configuration is
+    one it reproduces exactly -- greedy (no sampling, one beam, neutral penalties), ``max_new_tokens`` given, no padding, a Llama or
+    T5 language model -- else None (the caller then runs HF generate).  The decoder is cached on ``owner``."""
+    gc = dict(generate_configs or {})
+    if set(gc) - _GREEDY_KEYS or "max_new_tokens" not in gc or gc.get("do_sample", False) or gc.get("num_beams", 1) != 1:
+        return None
+    if gc.get("repetition_penalty", 1.0) != 1.0 or not inputs_embeds.is_cuda or not bool((attention_mask != 0).all()):
+        return None
+    try:
+        dec = getattr(owner, "_graph_decoder", None)
+        if dec is None or dec.lm is not lm:
+            dec = owner._graph_decoder = make_decoder(lm)
+    except NotImplementedError:
+        return None
+    g = getattr(lm, "generation_config", None)
+    return dec.generate(inputs_embeds, int(gc["max_new_tokens"]), eos_token_id=gc.get("eos_token_id", getattr(g, "eos_token_id", None)),
+                        pad_token_id=gc.get("pad_token_id", getattr(g, "pad_token_id", None)), min_new_tokens=int(gc.get("min_new_tokens", 0) or 0))

@@ -547,9 +547,9 @@ class _LSTPBase(nn.Module):
         inputs_embeds = torch.cat([lm_inputs, inputs_embeds.to(lm_dtype)], dim=1)
         if fast_decode and not do_sample and stopping_criteria is None and bool((attention_mask != 0).all()):
             # greedy, unpadded: hipGraph-replayed decode of the same HF weights (videotgb_amd/decode.py)
-            from .decode import GreedyDecoder
+            from .decode import make_decoder
             if getattr(self, "_decoder", None) is None or self._decoder.lm is not lm:
-                self._decoder = GreedyDecoder(lm)
+                self._decoder = make_decoder(lm)      # Llama (causal) or T5 (seq2seq, LSTP_blip2)
             gc = getattr(lm, "generation_config", None)     # HF generate's defaults (eos / pad from the generation config)
             outputs = self._decoder.generate(inputs_embeds, max_new_tokens,
                                              eos_token_id=gen_kwargs.pop("eos_token_id", getattr(gc, "eos_token_id", None)),

@@ -321,7 +321,12 @@ class _LSTPLightningBase(_Base):
             mask = torch.ones(lm_inputs.size()[:-1], dtype=torch.long, device=lm_inputs.device)
             attention_mask = torch.cat([mask, batch["question_attention_mask"]], dim=1)
             inputs_embeddings = torch.cat([lm_inputs, emb], dim=1)
-        outputs = lm.generate(inputs_embeds=inputs_embeddings, attention_mask=attention_mask, **self.generate_configs)
+        outputs = None
+        if getattr(self, "fast_decode", False):      # opt-in: hipGraph-replayed greedy decode of the same HF weights (decode.graph_generate)
+            from .decode import graph_generate
+            outputs = graph_generate(self, lm, inputs_embeddings, attention_mask, self.generate_configs)
+        if outputs is None:
+            outputs = lm.generate(inputs_embeds=inputs_embeddings, attention_mask=attention_mask, **self.generate_configs)
         if self.model.config.text_config.architectures[0] == "LLaMAForCausalLM":
             outputs[outputs == 0] = 2
         if return_stages:
