@@ -752,7 +752,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
 
 // ---------------------------------------------------------------------------------------
 static int g_cu_count = 0;
-static int cu_count() {
+int cu_count() {
     if (g_cu_count == 0) {
         int dev = 0, n = 0;
         (void)hipGetDevice(&dev);

@@ -258,7 +258,20 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
         const int HWo = g.Ho * g.Wo;
         if (g.stride != 1) VTGB_REQUIRE(bw[4] && bw[5], VTGB_EINVAL, "raft_encoder: block %d lacks its downsample weights", b);
         void* outb;
-        if (!inorm) {
+        // layer1 (64 -> 64 channels, stride 1) at bf16: the LDS-resident-rows kernel (conv64.hip); VTGB_CONV64=0 keeps the general kernel (A/B runs)
+        static const bool c64_on = !(getenv("VTGB_CONV64") && getenv("VTGB_CONV64")[0] == '0');
+        const bool c64 = c64_on && dt == VTGB_BF16 && g.C == 64 && g.Cpad == 64 && Cin_pad == 64 && g.stride == 1 && conv3x3_c64_supported(g.Ho, g.Wo);
+        if (c64 && !inorm) {
+            VTGB_TRY(launch_conv3x3_c64(x, bw[0], F(bw[1]), nullptr, nullptr, t1, nullptr, n, g.Ho, g.Wo, 1, 0, s));      // y = relu(bn1(conv1(x)))
+            outb = t2;
+            VTGB_TRY(launch_conv3x3_c64(t1, bw[2], F(bw[3]), nullptr, nullptr, outb, x, n, g.Ho, g.Wo, 1, 1, s));        // relu(x + relu(bn2(conv2(y))))
+        } else if (c64) {
+            VTGB_TRY(launch_conv3x3_c64(x, bw[0], F(bw[1]), cf, stats, nullptr, nullptr, n, g.Ho, g.Wo, 0, 0, s));
+            VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t1, 1, 0, stats, true));                            // y = relu(norm1(conv1(x)))
+            VTGB_TRY(launch_conv3x3_c64(t1, bw[2], F(bw[3]), cf, stats, nullptr, nullptr, n, g.Ho, g.Wo, 0, 0, s));
+            outb = t1;
+            VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, x, outb, 1, 1, stats, true));                                // relu(x + relu(norm2(conv2(y))))
+        } else if (!inorm) {
             VTGB_TRY(conv_bn(Mo, g, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), 1, nullptr, 0, t1));        // y = relu(bn1(conv1(x)))
             const void* res = x;
             outb = t2;                                                                                          // conv2 reads t1: it cannot be the output
