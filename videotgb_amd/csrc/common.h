@@ -194,6 +194,9 @@ struct AttnDesc {
 };
 int launch_attention(const AttnDesc& d, hipStream_t s);
 
+bool stem7x7_supported(int H, int W);
+int launch_stem7x7(const float* img, const void* w, const float* bias, float* out_f32, float* stats, void* out_bf16, int n_img, int H, int W, int relu,
+                   hipStream_t s);
 int cu_count();   // compute units of the current device (gemm_pp.hip)
 
 // conv64.hip: 3x3 / stride 1 / 64 -> 64 channels over NHWC bf16 with the input rows resident in LDS (RAFT encoders, layer1)

@@ -240,6 +240,207 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv64Params p) 
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The stem (7x7, stride 2, 3 -> 64 channels; extractor.py:128-130 with the input scaling of xraft.py:105-106) without its HBM
+// round trip.  Rounds 1-3a ran it as raft_stem_pack_kernel (a 128-channel "space to depth" image per half-resolution pixel: bf16
+// hi | lo pairs of x - 127.5 for a 4 x 2 input-column window, 3.2 MB per frame written) + a 4 x 1 implicit-GEMM convolution that read
+// that image back four times: 8.5 + 8.7 ms per 31-clip RAFT batch.  Here a persistent workgroup walks runs of output rows and builds
+// the SAME packed rows (same K order, same packed weights: vtgb.h) straight into an LDS ring of 5 rows x W/2 pixels x 256 bytes, one
+// row ahead of the row whose 4 vertical taps it multiplies; the wave's 32 x 512 weights live in registers (128 VGPRs) as in
+// conv3x3_c64_kernel.  16-byte chunks of a pixel's 256 bytes are XOR-swizzled by (X & 15): the 16 pixels of a fragment read hit 16
+// different chunk positions.
+// ---------------------------------------------------------------------------------------
+constexpr int ST_R = 5;
+struct StemParams {
+    const float* img;      // [n_img, 3, H, W] raw 0..255 (or CLIP-normalised floats: see raft_enc.hip)
+    const bf16_t* w;       // [64, 512]: k = chunk (hi | lo) * 256 + tY * 64 + (dX * 12 + py * 6 + px * 3 + c)
+    const float* bias;
+    float* out_f32;        // MODE 0: [n_img * H2 * W2, 64] + moments
+    float* stats;
+    bf16_t* out_bf16;      // MODE 1: relu -> bf16
+    int n_img, H, W, relu;
+    int parts, rows_per_part;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512) void stem7x7_kernel(const StemParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int H = p.H, W = p.W, H2 = H >> 1, W2 = W >> 1;
+    const int row_bytes = W2 * 256;
+    float* const xch = reinterpret_cast<float*>(ring + ST_R * row_bytes);
+    float* const bias_s = xch + 8 * 32 * 2;
+    if (tid < 64) bias_s[tid] = p.bias[tid];
+    // the 16 zero columns of every 64 (48 real values per tap): chunks 6, 7 (hi) and 14, 15 (lo) of every pixel, written once
+    for (int i = tid; i < ST_R * W2 * 4; i += 512) {
+        const int pxl = i >> 2, X = pxl % W2, c = 6 + (i & 1) + ((i & 2) << 2);      // 6, 7, 14, 15
+        *reinterpret_cast<uint4*>(ring + pxl * 256 + ((c ^ (X & 15)) << 4)) = make_uint4(0, 0, 0, 0);
+    }
+    // ---- weights: 16 k-steps of 32 (s = chunk * 8 + tY * 2 + half) x two 16-channel blocks
+    bf16x8 wf[16][2];
+#pragma unroll
+    for (int s_ = 0; s_ < 16; s_++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) wf[s_][i] = *reinterpret_cast<const bf16x8*>(p.w + (wn * 32 + i * 16 + fr) * 512 + s_ * 32 + fg * 8);
+    // ---- building a packed row: thread = (pixel X, column pair dX): 12 values (2 rows x 2 columns x 3 channels) as hi / lo bf16
+    const bool builder = tid < W2 * 4;
+    const int bX = tid >> 2, bdX = tid & 3, bcol = 2 * (bX + bdX - 2);        // first of the two input columns
+    const bool bcol_ok = builder && bcol >= 0 && bcol + 1 < W;                // (W even, bcol even: the pair is inside or outside together)
+    const int bcol_c = bcol < 0 ? 0 : bcol + 1 < W ? bcol : W - 2;            // clamped: the loads are unconditional, ST_WRITE zeroes what is outside
+    unsigned b_off[3];                                                         // LDS byte offsets of the three 8-byte pieces (hi; lo = chunk + 8)
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int off = bdX * 24 + q * 8;
+        b_off[q] = (unsigned)(bX * 256 + (((off >> 4) ^ (bX & 15)) << 4) + (off & 8));
+    }
+    // ---- fragment reads: pixel X = 32 wm + 16 j + fr, chunk (hl * 8 + half * 4 + fg) ^ (X & 15)
+    int px[2];
+    unsigned x_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        px[j] = wm * 32 + j * 16 + fr;
+        const int pc = px[j] < W2 ? px[j] : 0;
+        x_off[j] = (unsigned)(pc * 256 + ((fg ^ (pc & 15)) << 4));
+    }
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+    typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2_t;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int ES = MODE == 0 ? 4 : 2;
+    unsigned o_off[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) o_off[i][j] = px[j] < W2 ? (unsigned)(px[j] * 64 + wn * 32 + i * 16 + fg * 4) * ES : OOB;
+
+    const int n_units = p.n_img * p.parts;
+    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const int img = unit / p.parts, y0 = (unit - img * p.parts) * p.rows_per_part;
+        if (y0 >= H2) continue;
+        const int y1 = y0 + p.rows_per_part < H2 ? y0 + p.rows_per_part : H2;
+        const float* const ibase = p.img + (int64_t)img * 3 * H * W;
+        const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(MODE == 0 ? (void*)(p.out_f32 + (int64_t)img * H2 * W2 * 64) : (void*)(p.out_bf16 + (int64_t)img * H2 * W2 * 64),
+                                                             0, H2 * W2 * 64 * ES, 0x00020000);
+        float2 ld[6];
+        // packed row Yp <- input rows 2 Yp, 2 Yp + 1 (zeros outside the image)
+#define ST_LOAD(Yp)      /* unconditional loads from clamped addresses (conditional ones are serialised by hipcc: one vmcnt(0) each) */ \
+        {                                                                                                    \
+            const int yc_ = (Yp) < 0 ? 0 : (Yp) >= H2 ? H2 - 1 : (Yp);                                       \
+            _Pragma("unroll") for (int py = 0; py < 2; py++)                                                 \
+                _Pragma("unroll") for (int c = 0; c < 3; c++)                                                \
+                    ld[py * 3 + c] = *reinterpret_cast<const float2*>(ibase + ((int64_t)c * H + 2 * yc_ + py) * W + bcol_c); \
+        }
+#define ST_WRITE(Yp)                                                                                         \
+        if (builder) {                                                                                       \
+            const bool in_ = bcol_ok && (Yp) >= 0 && (Yp) < H2;                                              \
+            bf16_t hi[12], lo[12];                                                                           \
+            _Pragma("unroll") for (int py = 0; py < 2; py++)                                                 \
+                _Pragma("unroll") for (int c = 0; c < 3; c++) {                                              \
+                    const float d0 = in_ ? ld[py * 3 + c].x - 127.5f : 0.f, d1 = in_ ? ld[py * 3 + c].y - 127.5f : 0.f; \
+                    hi[py * 6 + c] = (bf16_t)d0; lo[py * 6 + c] = (bf16_t)(d0 - (float)hi[py * 6 + c]);      \
+                    hi[py * 6 + 3 + c] = (bf16_t)d1; lo[py * 6 + 3 + c] = (bf16_t)(d1 - (float)hi[py * 6 + 3 + c]); \
+                }                                                                                            \
+            char* const rb_ = ring + ((((Yp) % ST_R) + ST_R) % ST_R) * row_bytes;                            \
+            _Pragma("unroll") for (int q = 0; q < 3; q++) {                                                  \
+                *reinterpret_cast<bf16x4*>(rb_ + b_off[q]) = bf16x4{hi[q * 4], hi[q * 4 + 1], hi[q * 4 + 2], hi[q * 4 + 3]}; \
+                *reinterpret_cast<bf16x4*>(rb_ + (b_off[q] ^ 128)) = bf16x4{lo[q * 4], lo[q * 4 + 1], lo[q * 4 + 2], lo[q * 4 + 3]}; \
+            }                                                                                                \
+        }
+        __syncthreads();                                       // the previous unit's rows have been consumed (and the one-time zero / bias writes are done)
+        for (int yy = y0 - 2; yy <= y0 + 1; yy++) {            // the four rows of the first step (one load latency each: once per unit)
+            ST_LOAD(yy)
+            ST_WRITE(yy)
+        }
+        f32x4 s1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, s2[2] = {s1[0], s1[0]};
+        for (int y = y0; y < y1; y++) {
+            __syncthreads();                                   // rows y - 2 .. y + 1 are complete; everybody is done with row y - 3's slot
+            ST_LOAD(y + 2)                                     // in flight under this row's MFMAs
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tY = 0; tY < 4; tY++) {
+                const char* const rowp = ring + ((y + tY - 2 + ST_R) % ST_R) * row_bytes;
+#pragma unroll
+                for (int hl = 0; hl < 2; hl++)
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        const int s_ = hl * 8 + tY * 2 + half;
+                        const unsigned cx = (unsigned)((hl * 8 + half * 4) << 4);      // chunk index bits above fg: XORed in (16-byte units)
+                        const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(rowp + (x_off[0] ^ cx));
+                        const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(rowp + (x_off[1] ^ cx));
+#pragma unroll
+                        for (int i = 0; i < 2; i++) {
+                            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s_][i], x0, acc[i][0], 0, 0, 0);
+                            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s_][i], x1, acc[i][1], 0, 0, 0);
+                        }
+                    }
+            }
+            f32x4 b4[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) b4[i] = *reinterpret_cast<const f32x4*>(bias_s + wn * 32 + i * 16 + fg * 4);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const bool ok = o_off[i][j] != OOB;
+                    const unsigned off = ok ? o_off[i][j] + (unsigned)(y * W2 * 64 * ES) : OOB;
+                    f32x4 v = acc[i][j] + b4[i];
+                    if constexpr (MODE == 0) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), orsrc, off, 0, 0);
+                        const f32x4 vz = {ok ? v[0] : 0.f, ok ? v[1] : 0.f, ok ? v[2] : 0.f, ok ? v[3] : 0.f};
+                        s1[i] += vz;
+                        s2[i] += vz * vz;
+                    } else {
+                        if (p.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                        const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, pk), orsrc, off, 0, 0);
+                    }
+                }
+            ST_WRITE(y + 2)                                    // slot of row y - 3
+        }
+#undef ST_LOAD
+#undef ST_WRITE
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float a_ = s1[i][e], b_ = s2[i][e];
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) { a_ += __shfl_xor(a_, off); b_ += __shfl_xor(b_, off); }
+                    s1[i][e] = a_; s2[i][e] = b_;
+                }
+            __syncthreads();
+            if (fr == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        xch[(wave * 32 + i * 16 + fg * 4 + e) * 2] = s1[i][e];
+                        xch[(wave * 32 + i * 16 + fg * 4 + e) * 2 + 1] = s2[i][e];
+                    }
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const int ch = tid >> 1, which = tid & 1, wn_ = ch >> 5, c32 = ch & 31;
+                float t = 0.f;
+#pragma unroll
+                for (int m_ = 0; m_ < 4; m_++) t += xch[((wn_ * 4 + m_) * 32 + c32) * 2 + which];
+                float* const dst = p.stats + ((int64_t)img * 64 + ch) * 2 + which;
+                if (p.parts == 1) *dst = t;
+                else atomicAdd(dst, t);
+            }
+        }
+    }
+#endif
+}
+
 }   // namespace
 
 // x [n_img, H, W, 64] bf16 -> 3x3 / stride 1 / pad 1 convolution with w [64, 576] (+ bias): fp32 [.., 64] + moments (out_f32 != NULL) or bf16
@@ -270,6 +471,39 @@ int launch_conv3x3_c64(const void* in, const void* w, const float* bias, float* 
     } else {
         VTGB_FUNC_LDS_ONCE(a1, conv3x3_c64_kernel<1>, C64_LDS);
         hipLaunchKernelGGL(conv3x3_c64_kernel<1>, dim3(grid), dim3(512), C64_LDS, s, p);
+    }
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+// the stem on raw frames: img [n_img, 3, H, W] fp32 -> [n_img, H/2, W/2, 64]; packed weights [64, 512] (vtgb.h: vtgb_raft_encoder)
+bool stem7x7_supported(int H, int W) { return (H % 2) == 0 && (W % 2) == 0 && W / 2 >= 16 && W / 2 <= 112 && H / 2 >= 4; }
+
+int launch_stem7x7(const float* img, const void* w, const float* bias, float* out_f32, float* stats, void* out_bf16, int n_img, int H, int W, int relu,
+                   hipStream_t s) {
+    VTGB_REQUIRE(stem7x7_supported(H, W), VTGB_EUNSUPPORTED, "stem7x7: %d x %d unsupported", H, W);
+    const int H2 = H / 2, W2 = W / 2;
+    StemParams p;
+    p.img = img; p.w = (const bf16_t*)w; p.bias = bias; p.out_f32 = out_f32; p.stats = stats; p.out_bf16 = (bf16_t*)out_bf16;
+    p.n_img = n_img; p.H = H; p.W = W; p.relu = relu;
+    int parts = 1;
+    while ((int64_t)n_img * parts < 4 * cu_count() && H2 / (parts * 2) >= 14) parts *= 2;
+    p.rows_per_part = (H2 + parts - 1) / parts;
+    p.parts = (H2 + p.rows_per_part - 1) / p.rows_per_part;
+    const int64_t units = (int64_t)n_img * p.parts;
+    const int grid = units < cu_count() ? (int)units : cu_count();
+    if (out_f32 && p.parts > 1) VTGB_HIP(hipMemsetAsync(stats, 0, (size_t)n_img * 64 * 2 * sizeof(float), s));
+    const int lds = ST_R * W2 * 256 + 8 * 32 * 2 * 4 + 64 * 4;
+    const double flops = 2.0 * n_img * H2 * W2 * 64.0 * 147.0, exec = 2.0 * n_img * H2 * W2 * 64.0 * 512.0;
+    ProfScope prof(VTGB_PROF_CONV, flops, s, exec);
+    static DeviceOnce a0, a1;
+    if (out_f32) {
+        VTGB_REQUIRE(stats, VTGB_EINVAL, "stem7x7: fp32 output needs the moments buffer");
+        VTGB_FUNC_LDS_ONCE(a0, stem7x7_kernel<0>, ST_R * 112 * 256 + 8 * 32 * 2 * 4 + 64 * 4);
+        hipLaunchKernelGGL(stem7x7_kernel<0>, dim3(grid), dim3(512), lds, s, p);
+    } else {
+        VTGB_FUNC_LDS_ONCE(a1, stem7x7_kernel<1>, ST_R * 112 * 256 + 8 * 32 * 2 * 4 + 64 * 4);
+        hipLaunchKernelGGL(stem7x7_kernel<1>, dim3(grid), dim3(512), lds, s, p);
     }
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;

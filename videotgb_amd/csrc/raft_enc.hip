@@ -219,20 +219,31 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
         return st;
     };
     // ---- stem: repack, then a 4x1 implicit-GEMM convolution whose epilogue also yields the InstanceNorm moments
-    if (dt == VTGB_BF16)
-        hipLaunchKernelGGL(raft_stem_pack_kernel<bf16_t>, dim3((unsigned)((M2 * 4 + 255) / 256)), dim3(256), 0, s, a->images, (bf16_t*)act1, (bf16_t*)pad_page, M2,
-                           a->H, a->W);
-    else
-        hipLaunchKernelGGL(raft_stem_pack_kernel<float>, dim3((unsigned)((M2 * 4 + 255) / 256)), dim3(256), 0, s, a->images, (float*)act1, (float*)pad_page, M2,
-                           a->H, a->W);
-    {
-        float* sf = stats_for(stats, H2 * W2, 64);
-        const int cp = dt == VTGB_BF16 ? 128 : 64;            // bf16: hi | lo chunks (raft_stem_pack_kernel)
-        GemmDesc d = enc_conv(dt, (int)M2, 64, H2, W2, 1, cp, 1, H2, W2, act1, w[0], F(w[1]), cf, 64, pad_page, sf);
-        d.conv_KH = 4; d.K = 4 * cp; d.ldw = 4 * cp;
-        if (!inorm) { d.epi = VTGB_EPI_STORE; d.act = 1; d.out = act0; }        // relu(bn1(conv1(x))) straight to bf16
-        VTGB_TRY(launch_conv_gemm(d, s));
-        if (inorm) VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, sf != nullptr));
+    static const bool stem_on = !(getenv("VTGB_STEM64") && getenv("VTGB_STEM64")[0] == '0');      // (VTGB_STEM64=0: pack + implicit GEMM, for A/B runs)
+    if (stem_on && dt == VTGB_BF16 && stem7x7_supported(a->H, a->W)) {
+        // the stem on the raw frames (conv64.hip: the packed rows are built in LDS, no HBM round trip)
+        if (inorm) {
+            VTGB_TRY(launch_stem7x7(a->images, w[0], F(w[1]), cf, stats, nullptr, n, a->H, a->W, 0, s));
+            VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, true));
+        } else {
+            VTGB_TRY(launch_stem7x7(a->images, w[0], F(w[1]), nullptr, nullptr, act0, n, a->H, a->W, 1, s));     // relu(bn1(conv1(x))) straight to bf16
+        }
+    } else {
+        if (dt == VTGB_BF16)
+            hipLaunchKernelGGL(raft_stem_pack_kernel<bf16_t>, dim3((unsigned)((M2 * 4 + 255) / 256)), dim3(256), 0, s, a->images, (bf16_t*)act1, (bf16_t*)pad_page, M2,
+                               a->H, a->W);
+        else
+            hipLaunchKernelGGL(raft_stem_pack_kernel<float>, dim3((unsigned)((M2 * 4 + 255) / 256)), dim3(256), 0, s, a->images, (float*)act1, (float*)pad_page, M2,
+                               a->H, a->W);
+        {
+            float* sf = stats_for(stats, H2 * W2, 64);
+            const int cp = dt == VTGB_BF16 ? 128 : 64;            // bf16: hi | lo chunks (raft_stem_pack_kernel)
+            GemmDesc d = enc_conv(dt, (int)M2, 64, H2, W2, 1, cp, 1, H2, W2, act1, w[0], F(w[1]), cf, 64, pad_page, sf);
+            d.conv_KH = 4; d.K = 4 * cp; d.ldw = 4 * cp;
+            if (!inorm) { d.epi = VTGB_EPI_STORE; d.act = 1; d.out = act0; }        // relu(bn1(conv1(x))) straight to bf16
+            VTGB_TRY(launch_conv_gemm(d, s));
+            if (inorm) VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, sf != nullptr));
+        }
     }
     // ---- six residual blocks
     struct Stage { int C, Cpad, stride, Ho, Wo; };
