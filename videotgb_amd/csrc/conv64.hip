@@ -356,7 +356,12 @@ __global__ __launch_bounds__(512) void stem7x7_kernel(const StemParams p) {
         }
         f32x4 s1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, s2[2] = {s1[0], s1[0]};
         for (int y = y0; y < y1; y++) {
-            __syncthreads();                                   // rows y - 2 .. y + 1 are complete; everybody is done with row y - 3's slot
+            // rows y - 2 .. y + 1 are complete (LDS writes only: __syncthreads would also wait for the previous row's output stores,
+            // a memory round trip per row); everybody is done with row y - 3's slot
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
             ST_LOAD(y + 2)                                     // in flight under this row's MFMAs
             f32x4 acc[2][2];
 #pragma unroll
