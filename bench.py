@@ -83,8 +83,9 @@ def parse():
                     help="clips per RAFT call (pairs of that many clips form one batch; 31 clips = 249 ViT m-tiles / 9020 RAFT m-tiles: "
                          "few idle CUs in the last round of 256-row tiles)")
     ap.add_argument("--overlap", action="store_true",
-                    help="two HIP streams: the prefix stage of batch i+1 over the LLM decode of batch i (measured +7 % clips/s; off by "
-                         "default because concurrent kernels inflate the per-launch durations the roofline object is computed from)")
+                    help="two HIP streams: the prefix stage of batch i+1 over the LLM decode of batch i (round 3: +2 % clips/s -- the persistent "
+                         "convolution launches hold every CU, so the decode only fills their tails; off by default: the headline is K strictly "
+                         "sequential steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the (untimed) roofline pass that records per-launch HIP events")
     ap.add_argument("--prof-steps", type=int, default=2, help="steps of the untimed roofline pass")
