@@ -177,3 +177,29 @@ def test_t5_greedy_decoder_hipgraph_matches_hf_generate_gpu():
         pytest.skip("needs an MI355X")
     _check_t5("cuda:0", True)
     _check_t5("cuda:0", False)
+
+
+@pytest.mark.gpu
+def test_bf16_generate_issues_no_blas_kernel():
+    """SURVEY.md 8f-2 at bf16: prefill, decode steps and the first-token logits run on libvtgb.so -- the profiler sees no hipBLASLt /
+    rocBLAS (Tensile `Cijk_*`) kernel during GreedyDecoder.generate, eager or graph-replayed, at a batch of the throughput path's kind."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from torch.profiler import ProfilerActivity, profile
+    from videotgb_amd import llm
+    from videotgb_amd.decode import GreedyDecoder
+    dev = "cuda:0"
+    lm = llm.build_llama("tiny", torch.bfloat16, dev, seed=9, hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=4,
+                         num_hidden_layers=2, vocab_size=320)
+    emb = (torch.randn(12, 20, 512, device=dev) * 0.5).bfloat16()
+    dec = GreedyDecoder(lm)
+    dec.generate(emb, 4)                                   # capture outside the profile
+    for use_graph in (False, True):
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            dec.generate(emb, 4, use_graph=use_graph)
+            torch.cuda.synchronize()
+        names = {e.key for e in prof.key_averages()}
+        blas = sorted(n for n in names if n.startswith("Cijk_") or "Cijk_" in n or "rocblas" in n.lower() or "hipblaslt" in n.lower())
+        assert not blas, blas
+        if not use_graph:                                  # (graph replays show up as one launch; the eager run names the kernels)
+            assert any("gemm_skinny" in n for n in names) and any("gemm_bf16" in n for n in names) and any("attn_bf16" in n for n in names), sorted(names)[:40]
