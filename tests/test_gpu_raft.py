@@ -149,6 +149,34 @@ def test_raft_encoder_image_sizes(dev, tiny_sd, size, n, dtype):
     assert max(per) <= ENC_TOL[dtype]
 
 
+@pytest.mark.parametrize("enc", ["fnet", "cnet"])
+def test_raft_encoder_large_batch_matches_chunks(dev, tiny_sd, enc):
+    """conv64.hip / the stem cut images into runs of rows until the persistent grid is balanced; with >= 4 x 256 images per call a
+    workgroup owns whole images and STORES the InstanceNorm moments (no memset, no atomics).  1040 images in one call take that
+    path; the same images in chunks of 65 take the atomic one: same features up to the bf16 mode's run-to-run floor (a changed
+    summation order flips bf16 roundings by 1 ulp, which fnet's InstanceNorms amplify to ~5e-3 rel-RMS: DESIGN.md section 2; cnet has
+    no moments and agrees to rounding)."""
+    from videotgb_amd import ops
+    sd = tiny_sd["instructblip"][1]
+    rsd = {k[len("of_extractor."):]: v.to(dev) for k, v in sd.items() if k.startswith("of_extractor.")}
+    w = ops.RaftEncoderWeights(rsd, enc + ".", enc == "cnet", ops.dtype_code("bf16"))
+    fr = torch.randint(0, 256, (1040, 3, 64, 64), generator=torch.Generator().manual_seed(5)).float().to(dev)
+    full = ops.raft_encoder(w, fr, max_images=2048).float()          # one C call: 1040 >= 4 x 256 images
+    parts = torch.cat([ops.raft_encoder(w, fr[i:i + 65]).float() for i in range(0, 1040, 65)], dim=0)
+    assert torch.isfinite(full).all()
+    e = ((full - parts).pow(2).mean().sqrt() / parts.pow(2).mean().sqrt()).item()
+    print(f"[raft encoder {enc} 1040 images, one call vs 16 chunks] rel_rms={e:.3e}")
+    assert e <= (1.5e-2 if enc == "fnet" else 2e-3)
+    # and both against the oracle on the first images (the stored-moments path must be as close as the atomic one)
+    from oracle import vtgb_oracle as O
+    k = 6
+    ref = O.raft_encoder(sd, f"of_extractor.{enc}.", 2 * (fr[:k].cpu() / 255.0) - 1.0, "instance" if enc == "fnet" else "batch")
+    shape = lambda t: t[:k].cpu().view(k, 8, 8, 256).permute(0, 3, 1, 2)
+    e_full, e_parts = rel_rms(shape(full), ref), rel_rms(shape(parts), ref)
+    print(f"[... vs oracle on {k} images] one call {e_full:.3e}, chunks {e_parts:.3e}")
+    assert e_full <= ENC_TOL["bf16"] and e_parts <= ENC_TOL["bf16"]
+
+
 def float_frames(kind, n, size, seed):
     """Float-valued RAFT inputs: "randn" = SURVEY 8d's / bench.py's flow frames; "clip" = a moving texture after CLIP normalisation,
     what the eval path hands to RAFT (eval/inference.py:68 -> eval/utils/model.py:79): after 2*(x/255)-1 both are -1 +- 0.02."""
