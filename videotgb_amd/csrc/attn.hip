@@ -52,7 +52,7 @@ __device__ __forceinline__ bf16x8 rope8(bf16x8 v, const float* tab_row, int d0, 
     return o;
 }
 
-template <int HD, int NKP>
+template <int HD, int NKP, bool PLAIN>      // PLAIN: no key mask, not causal (the softmax does less per score)
 __global__ __launch_bounds__(NKP <= 9 ? 576 : 256) void attn_bf16_kernel(const AttnDesc p, const int tiles_per_split) {
     using C = AttnCfg<HD, NKP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -171,6 +171,34 @@ __global__ __launch_bounds__(NKP <= 9 ? 576 : 256) void attn_bf16_kernel(const A
         }
         // ---- softmax over keys: registers (t, r) x lane groups fg
         float mx = -INFINITY;
+        float sum = 0.f;
+        if constexpr (PLAIN) {
+            // no mask, not causal (the ViT: 7 936 heads x 17 tiles per call).  The loop is bound by the SIMD's VALU + MFMA issue, not by LDS
+            // (profiles/r03_attention_experiments.md): per score one max, one FMA, one v_exp_f32 (2^x: scale * log2(e) folded into the
+            // FMA) and one add instead of scale + mask, two causal selects, max, subtract, multiply, exp, add.  Only the tiles that
+            // reach past s_kv (wave-uniform test) mask their padded keys.  (scale > 0: max and scale commute.)
+            const float c = p.scale * 1.4426950408889634f;
+#pragma unroll
+            for (int t = 0; t < 2 * NKP; t++) {
+                if (t * 16 + 16 > p.s_kv) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) s[t][r] = t * 16 + fg * 4 + r < p.s_kv ? s[t][r] : -INFINITY;
+                }
+                mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mc = -mx * c;
+#pragma unroll
+            for (int t = 0; t < 2 * NKP; t++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], c, mc));
+                    s[t][r] = e;
+                    sum += e;
+                }
+            }
+        } else {
         const int klim = p.causal ? q + (p.s_kv - p.s_q) : 0x7fffffff;      // causal: query q sees keys <= q + (s_kv - s_q)
 #pragma unroll
         for (int t = 0; t < 2 * NKP; t++) {
@@ -184,7 +212,6 @@ __global__ __launch_bounds__(NKP <= 9 ? 576 : 256) void attn_bf16_kernel(const A
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 2 * NKP; t++) {
 #pragma unroll
@@ -193,6 +220,7 @@ __global__ __launch_bounds__(NKP <= 9 ? 576 : 256) void attn_bf16_kernel(const A
                 s[t][r] = e;
                 sum += e;
             }
+        }
         }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
@@ -305,11 +333,11 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnDesc p) {
     }
 }
 
-template <int HD, int NKP>
-static int launch_bf16(const AttnDesc& d, hipStream_t s) {
+template <int HD, int NKP, bool PLAIN>
+static int launch_bf16_v(const AttnDesc& d, hipStream_t s) {
     using C = AttnCfg<HD, NKP>;
     static DeviceOnce attr_set;
-    VTGB_FUNC_LDS_ONCE(attr_set, (attn_bf16_kernel<HD, NKP>), C::LDS);
+    VTGB_FUNC_LDS_ONCE(attr_set, (attn_bf16_kernel<HD, NKP, PLAIN>), C::LDS);
     const int n_qt = (d.s_q + 15) / 16;
     int splits = 1;
     while ((int64_t)d.batch * d.heads * splits < 256 && splits * 2 <= n_qt && splits < 4) splits *= 2;
@@ -320,9 +348,14 @@ static int launch_bf16(const AttnDesc& d, hipStream_t s) {
     const int rounds = (tps + max_waves - 1) / max_waves;
     const int waves = (tps + rounds - 1) / rounds;
     ProfScope prof(VTGB_PROF_ATTN, 4.0 * d.batch * d.heads * (double)d.s_q * d.s_kv * d.head_dim, s);
-    hipLaunchKernelGGL((attn_bf16_kernel<HD, NKP>), dim3(splits, d.heads, d.batch), dim3(64 * waves), C::LDS, s, d, tps);
+    hipLaunchKernelGGL((attn_bf16_kernel<HD, NKP, PLAIN>), dim3(splits, d.heads, d.batch), dim3(64 * waves), C::LDS, s, d, tps);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
+}
+
+template <int HD, int NKP>
+static int launch_bf16(const AttnDesc& d, hipStream_t s) {
+    return (!d.key_mask && !d.causal && d.scale > 0.f) ? launch_bf16_v<HD, NKP, true>(d, s) : launch_bf16_v<HD, NKP, false>(d, s);
 }
 
 int launch_attention(const AttnDesc& d, hipStream_t s) {
