@@ -126,6 +126,29 @@ __global__ __launch_bounds__(256) void llm_decode_attn_kernel(const T* __restric
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
     __syncthreads();
     const float inv = 1.0f / sum;
+    if constexpr (sizeof(T) == 2) {
+        if ((hd & 1) == 0) {
+            // a lane owns two adjacent channels: one 4-byte load per key (a key row = one coalesced 2 hd-byte read), four keys in flight
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+            for (int d = lane * 2; d < hd; d += 128) {
+                float a0 = 0.f, a1 = 0.f;
+                int key = 0;
+                for (; key + 4 <= n_keys; key += 4) {
+                    bf16x2_t v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const bf16x2_t*>(vr + (int64_t)(key + u) * hd + d);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { a0 = fmaf(sc[key + u], (float)v[u][0], a0); a1 = fmaf(sc[key + u], (float)v[u][1], a1); }
+                }
+                for (; key < n_keys; key++) {
+                    const bf16x2_t v = *reinterpret_cast<const bf16x2_t*>(vr + (int64_t)key * hd + d);
+                    a0 = fmaf(sc[key], (float)v[0], a0); a1 = fmaf(sc[key], (float)v[1], a1);
+                }
+                if (active) *reinterpret_cast<bf16x2_t*>(out + ((int64_t)b * nq + head) * hd + d) = bf16x2_t{(bf16_t)(a0 * inv), (bf16_t)(a1 * inv)};
+            }
+            return;
+        }
+    }
     for (int d = lane; d < hd; d += 64) {
         float acc = 0.f;
         for (int key = 0; key < n_keys; key++) acc = fmaf(sc[key], (float)vr[(int64_t)key * hd + d], acc);
