@@ -414,12 +414,15 @@ int vtgb_raft_encoder(const vtgb_raft_encoder_args* a, vtgb_stream_t stream);
  * captured hipGraph serves every step.
  *   vtgb_llm_rmsnorm:          x[rows,H] (+= delta, written back if delta != NULL); h = w * norm(x)
  *   vtgb_llm_rope_cache:       qkv[B, nq+2nkv, hd] -> q_out[B,nq,hd] rotated; K/V cache [B,nkv,tmax,hd] row *pos
+ *   vtgb_llm_rope_cache_prefill: qkv[B, S, (nq+2nkv)*hd]: q and k of every position rotated IN PLACE, k / v copied to cache rows 0..S-1
  *   vtgb_llm_decode_attention: out[B, nq*hd] = softmax(scale q K[0..*pos]^T) V[0..*pos]
  *   vtgb_llm_silu_mul:         act[rows, I] = silu(gu[:, :I]) * gu[:, I:]                       */
 int vtgb_llm_rmsnorm(int dtype, void* x, const void* delta, const void* w, void* h, int64_t rows, int32_t H, float eps,
                      vtgb_stream_t stream);
 int vtgb_llm_rope_cache(int dtype, const void* qkv, void* q_out, void* kc, void* vc, const void* cos_t, const void* sin_t,
                         const int64_t* pos, int32_t B, int32_t nq, int32_t nkv, int32_t hd, int32_t tmax, vtgb_stream_t stream);
+int vtgb_llm_rope_cache_prefill(int dtype, void* qkv, void* kc, void* vc, const void* cos_t, const void* sin_t, int32_t B, int32_t S, int32_t nq,
+                                int32_t nkv, int32_t hd, int32_t tmax, vtgb_stream_t stream);
 int vtgb_llm_decode_attention(int dtype, const void* q, const void* kc, const void* vc, void* out, const int64_t* pos, int32_t B,
                               int32_t nq, int32_t nkv, int32_t hd, int32_t tmax, float scale, vtgb_stream_t stream);
 int vtgb_llm_silu_mul(int dtype, const void* gu, void* act, int64_t rows, int32_t I, vtgb_stream_t stream);

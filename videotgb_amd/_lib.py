@@ -27,7 +27,7 @@ EXPORTS = [
     "vtgb_qformer_workspace_bytes", "vtgb_qformer_forward", "vtgb_pool_project_workspace_bytes",
     "vtgb_pool_project", "vtgb_tgb_workspace_bytes", "vtgb_tgb_forward", "vtgb_gemm", "vtgb_attention",
     "vtgb_layernorm", "vtgb_prof_enable", "vtgb_prof_reset", "vtgb_prof_summary", "vtgb_prof_executed_flops",
-    "vtgb_llm_rmsnorm", "vtgb_llm_rope_cache", "vtgb_llm_decode_attention", "vtgb_llm_silu_mul",
+    "vtgb_llm_rmsnorm", "vtgb_llm_rope_cache", "vtgb_llm_rope_cache_prefill", "vtgb_llm_decode_attention", "vtgb_llm_silu_mul",
     "vtgb_gemm_skinny_workspace_bytes", "vtgb_gemm_skinny", "vtgb_pack_skinny_weight_bytes", "vtgb_pack_skinny_weight",
     "vtgb_raft_update_workspace_bytes", "vtgb_raft_update", "vtgb_raft_encoder_workspace_bytes", "vtgb_raft_encoder",
     "vtgb_raft_corr_workspace_bytes", "vtgb_raft_corr", "vtgb_preprocess_frames", "vtgb_concat_text_io", "vtgb_shifted_ce_forward", "vtgb_shifted_ce_backward",
@@ -186,6 +186,7 @@ def lib() -> C.CDLL:
     L.vtgb_raft_corr_workspace_bytes.restype = sz
     L.vtgb_llm_rmsnorm.argtypes = [C.c_int, vp, vp, vp, vp, i64, i32, f32, vp]
     L.vtgb_llm_rope_cache.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.vtgb_llm_rope_cache_prefill.argtypes = [C.c_int, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.vtgb_llm_decode_attention.argtypes = [C.c_int, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]
     L.vtgb_llm_silu_mul.argtypes = [C.c_int, vp, vp, i64, i32, vp]
     L.vtgb_gemm_skinny.argtypes = [C.POINTER(GemmSkinnyArgs), vp]

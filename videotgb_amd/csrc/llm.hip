@@ -179,6 +179,45 @@ extern "C" int vtgb_llm_rmsnorm(int dtype, void* x, const void* delta, const voi
     return VTGB_OK;
 }
 
+// ---- the prefill's counterpart: rotary on q and k of EVERY position, in place in qkv [B, S, (nq + 2 nkv) * hd] (the attention then reads q
+// and k from there), k and v copied to the cache rows 0 .. S - 1.  One workgroup per (position, batch); bf16: a thread takes 8 channels of
+// the first half of a head together with their partners in the second half (16-byte loads and stores); HF's roundings (each product, then
+// the sum: LlamaRotaryEmbedding / apply_rotary_pos_emb in the model's dtype).
+template <typename T>
+__global__ __launch_bounds__(256) void llm_rope_cache_prefill_kernel(T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc, const T* __restrict__ cos_t,
+                                                                     const T* __restrict__ sin_t, int S, int nq, int nkv, int hd, int tmax) {
+    constexpr int V = 16 / (int)sizeof(T);                     // elements per 16-byte vector
+    typedef T TV __attribute__((ext_vector_type(V)));
+    const int spos = blockIdx.x, b = blockIdx.y, half = hd >> 1, cph = half / V;      // vectors per half head
+    T* const row = qkv + ((int64_t)b * S + spos) * (nq + 2 * nkv) * hd;
+    const T* const cr = cos_t + (int64_t)spos * hd;
+    const T* const sr = sin_t + (int64_t)spos * hd;
+    for (int it = threadIdx.x; it < (nq + nkv) * cph; it += blockDim.x) {
+        const int head = it / cph, d = (it - head * cph) * V;
+        T* const hp = row + head * hd;
+        const TV x0 = *reinterpret_cast<const TV*>(hp + d), x1 = *reinterpret_cast<const TV*>(hp + d + half);
+        const TV c0 = *reinterpret_cast<const TV*>(cr + d), c1 = *reinterpret_cast<const TV*>(cr + d + half);
+        const TV s0 = *reinterpret_cast<const TV*>(sr + d), s1 = *reinterpret_cast<const TV*>(sr + d + half);
+        TV o0, o1;
+#pragma unroll
+        for (int e = 0; e < V; e++) {
+            o0[e] = Cvt<T>::to(Cvt<T>::rnd(Cvt<T>::rnd((float)x0[e] * (float)c0[e]) + Cvt<T>::rnd(-(float)x1[e] * (float)s0[e])));
+            o1[e] = Cvt<T>::to(Cvt<T>::rnd(Cvt<T>::rnd((float)x1[e] * (float)c1[e]) + Cvt<T>::rnd((float)x0[e] * (float)s1[e])));
+        }
+        *reinterpret_cast<TV*>(hp + d) = o0;
+        *reinterpret_cast<TV*>(hp + d + half) = o1;
+        if (head >= nq) {
+            T* const kd = kc + (((int64_t)b * nkv + (head - nq)) * tmax + spos) * hd;
+            *reinterpret_cast<TV*>(kd + d) = o0;
+            *reinterpret_cast<TV*>(kd + d + half) = o1;
+        }
+    }
+    for (int it = threadIdx.x; it < nkv * (hd / V); it += blockDim.x) {
+        const int head = it / (hd / V), d = (it - head * (hd / V)) * V;
+        *reinterpret_cast<TV*>(vc + (((int64_t)b * nkv + head) * tmax + spos) * hd + d) = *reinterpret_cast<const TV*>(row + (nq + nkv + head) * hd + d);
+    }
+}
+
 extern "C" int vtgb_llm_rope_cache(int dtype, const void* qkv, void* q_out, void* kc, void* vc, const void* cos_t, const void* sin_t,
                                    const int64_t* pos, int32_t B, int32_t nq, int32_t nkv, int32_t hd, int32_t tmax, vtgb_stream_t s) {
     VTGB_REQUIRE(qkv && q_out && kc && vc && cos_t && sin_t && pos && B > 0 && nq > 0 && nkv > 0 && (hd % 2) == 0, VTGB_EINVAL, "llm_rope_cache: bad argument");
@@ -189,6 +228,21 @@ extern "C" int vtgb_llm_rope_cache(int dtype, const void* qkv, void* q_out, void
     else
         hipLaunchKernelGGL(llm_rope_cache_kernel<float>, grid, dim3(128), 0, s, (const float*)qkv, (float*)q_out, (float*)kc, (float*)vc,
                            (const float*)cos_t, (const float*)sin_t, pos, nq, nkv, hd, tmax);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+extern "C" int vtgb_llm_rope_cache_prefill(int dtype, void* qkv, void* kc, void* vc, const void* cos_t, const void* sin_t, int32_t B, int32_t S, int32_t nq,
+                                           int32_t nkv, int32_t hd, int32_t tmax, vtgb_stream_t s) {
+    VTGB_REQUIRE(qkv && kc && vc && cos_t && sin_t && B > 0 && S > 0 && S <= tmax && nq > 0 && nkv > 0, VTGB_EINVAL, "llm_rope_cache_prefill: bad argument");
+    VTGB_REQUIRE(dtype == VTGB_BF16 ? (hd % 16) == 0 : (hd % 8) == 0, VTGB_EUNSUPPORTED, "llm_rope_cache_prefill: head_dim=%d (16-byte vectors per half head)", hd);
+    const dim3 grid(S, B);
+    if (dtype == VTGB_BF16)
+        hipLaunchKernelGGL(llm_rope_cache_prefill_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, (const bf16_t*)cos_t, (const bf16_t*)sin_t,
+                           S, nq, nkv, hd, tmax);
+    else
+        hipLaunchKernelGGL(llm_rope_cache_prefill_kernel<float>, grid, dim3(256), 0, s, (float*)qkv, (float*)kc, (float*)vc, (const float*)cos_t, (const float*)sin_t, S,
+                           nq, nkv, hd, tmax);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }

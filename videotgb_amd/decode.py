@@ -122,7 +122,7 @@ class GreedyDecoder:
 
     def _use_hip_prefill(self, x: Tensor, P: int) -> bool:
         return (self.fused and x.is_cuda and x.dtype == torch.bfloat16 and self.nq_eq_nkv and P <= self.PREFILL_MAX_TOKENS
-                and self.hd % 8 == 0 and self.hd <= 128 and self.cfg.hidden_size % 64 == 0 and self.inter % 64 == 0)
+                and self.hd % 16 == 0 and self.hd <= 128 and self.cfg.hidden_size % 64 == 0 and self.inter % 64 == 0)
 
     @property
     def nq_eq_nkv(self) -> bool:
@@ -139,16 +139,14 @@ class GreedyDecoder:
         x = x.reshape(M, H).clone()
         h = torch.empty_like(x)
         act = torch.empty(M, self.inter, dtype=x.dtype, device=x.device)
-        cos, sin = st["cos"][:P, None, :], st["sin"][:P, None, :]
         delta = None
         for li, (ln1, wqkv, wo, ln2, wgu, wd) in enumerate(self.layers):
             L.check(lib.vtgb_llm_rmsnorm(L.BF16, x.data_ptr(), None if delta is None else delta.data_ptr(), ln1.data_ptr(), h.data_ptr(),
                                          M, H, self.eps, stream))
             qkv = ops.gemm(h, wqkv).view(B, P, 3 * nh, hd)
-            qk = qkv[:, :, : 2 * nh]
-            qk.copy_(qk * cos + _rot_half(qk) * sin)                               # rotary on q and k together, in place
-            st["kc"][li][:, :, :P].copy_(qkv[:, :, nh: 2 * nh].transpose(1, 2))
-            st["vc"][li][:, :, :P].copy_(qkv[:, :, 2 * nh:].transpose(1, 2))
+            # rotary on q and k in place + k / v into the cache rows 0 .. P-1: one launch (HF's bf16 roundings)
+            L.check(lib.vtgb_llm_rope_cache_prefill(L.BF16, qkv.data_ptr(), st["kc"][li].data_ptr(), st["vc"][li].data_ptr(), st["cos"].data_ptr(),
+                                                    st["sin"].data_ptr(), B, P, nh, nh, hd, st["tmax"], stream))
             flat = qkv.view(B, P, 3 * nh * hd)
             a = ops.attention(flat[:, :, : nh * hd], flat[:, :, nh * hd: 2 * nh * hd], flat[:, :, 2 * nh * hd:], nh, float(hd) ** -0.5,
                               causal=True)
