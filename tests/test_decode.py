@@ -203,3 +203,34 @@ def test_bf16_generate_issues_no_blas_kernel():
         assert not blas, blas
         if not use_graph:                                  # (graph replays show up as one launch; the eager run names the kernels)
             assert any("gemm_skinny" in n for n in names) and any("gemm_bf16" in n for n in names) and any("attn_bf16" in n for n in names), sorted(names)[:40]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_rope_cache_prefill_kernel_matches_hf_rotary_bit_for_bit(dtype):
+    """vtgb_llm_rope_cache_prefill against transformers' apply_rotary_pos_emb arithmetic (q * cos + rotate_half(q) * sin in the model's
+    dtype: each product and the sum rounded) and the cache fill of the torch prefill: identical bits."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import ctypes as C
+    from videotgb_amd import _lib as L
+    from videotgb_amd.decode import _rot_half
+    dev = "cuda:0"
+    B, S, nh, hd, tmax = 3, 21, 4, 128, 64
+    g = torch.Generator(device=dev).manual_seed(0)
+    qkv = torch.randn(B, S, 3 * nh, hd, generator=g, device=dev).to(dtype)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, device=dev, dtype=torch.float32) / hd))
+    fr = torch.arange(tmax, device=dev, dtype=torch.float32)[:, None] * inv[None]
+    emb = torch.cat((fr, fr), dim=-1)
+    cos, sin = emb.cos().to(dtype), emb.sin().to(dtype)
+    qk = qkv[:, :, : 2 * nh]
+    ref_qk = qk * cos[:S, None, :] + _rot_half(qk) * sin[:S, None, :]
+    kc = torch.zeros(B, nh, tmax, hd, device=dev, dtype=dtype)
+    vc = torch.zeros_like(kc)
+    got = qkv.clone()
+    code = L.BF16 if dtype == torch.bfloat16 else L.F32
+    L.check(L.lib().vtgb_llm_rope_cache_prefill(code, got.data_ptr(), kc.data_ptr(), vc.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, S, nh, nh, hd, tmax,
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert torch.equal(got[:, :, : 2 * nh], ref_qk) and torch.equal(got[:, :, 2 * nh:], qkv[:, :, 2 * nh:])
+    assert torch.equal(kc[:, :, :S], ref_qk[:, :, nh:].transpose(1, 2)) and torch.equal(vc[:, :, :S], qkv[:, :, 2 * nh:].transpose(1, 2))
+    assert not kc[:, :, S:].any() and not vc[:, :, S:].any()

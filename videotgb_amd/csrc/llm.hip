@@ -20,7 +20,13 @@ template <> struct Cvt<float> {
 };
 template <> struct Cvt<bf16_t> {
     static __device__ __forceinline__ bf16_t to(float v) { return (bf16_t)v; }
-    static __device__ __forceinline__ float rnd(float v) { return (float)(bf16_t)v; }
+    // round-to-nearest-even to bf16 precision, by hand: hipcc may keep the excess precision of a float -> __bf16 -> float round trip (it
+    // did in the rotary kernels: one product stayed unrounded and fused into an FMA, 1 ulp off HF's bf16 arithmetic in 7 % of the values)
+    static __device__ __forceinline__ float rnd(float v) {
+        unsigned u = __float_as_uint(v);
+        if ((u & 0x7F800000u) != 0x7F800000u) u += 0x7FFFu + ((u >> 16) & 1u);      // (Inf / NaN pass through)
+        return __uint_as_float(u & 0xFFFF0000u);
+    }
 };
 
 // ---- x (+= delta) ; h = rmsnorm(x) * w.   One workgroup per row.
@@ -56,6 +62,7 @@ template <typename T>
 __global__ __launch_bounds__(128) void llm_rope_cache_kernel(const T* __restrict__ qkv, T* __restrict__ q_out, T* __restrict__ kc,
                                                              T* __restrict__ vc, const T* __restrict__ cos_t, const T* __restrict__ sin_t,
                                                              const int64_t* __restrict__ pos_p, int nq, int nkv, int hd, int tmax) {
+#pragma clang fp contract(off)      // fp32: mul, mul, add are three roundings in the reference -- no FMA
     const int b = blockIdx.y, head = blockIdx.x;   // head in [0, nq + 2 nkv)
     const int64_t pos = *pos_p;
     const T* src = qkv + ((int64_t)b * (nq + 2 * nkv) + head) * hd;
@@ -66,7 +73,8 @@ __global__ __launch_bounds__(128) void llm_rope_cache_kernel(const T* __restrict
         if (head < nq + nkv) {
             const float c = (float)cos_t[pos * hd + d], sn = (float)sin_t[pos * hd + d];
             const float rot = d < half ? -(float)src[d + half] : (float)src[d - half];
-            outv = Cvt<T>::rnd(Cvt<T>::rnd(v * c) + Cvt<T>::rnd(rot * sn));
+            const float pa = Cvt<T>::rnd(v * c), pb = Cvt<T>::rnd(rot * sn);      // (contract(off): the reference's three roundings, no FMA)
+            outv = Cvt<T>::rnd(pa + pb);
         }
         if (head < nq) q_out[((int64_t)b * nq + head) * hd + d] = Cvt<T>::to(outv);
         else if (head < nq + nkv) kc[(((int64_t)b * nkv + (head - nq)) * tmax + pos) * hd + d] = Cvt<T>::to(outv);
@@ -186,6 +194,7 @@ extern "C" int vtgb_llm_rmsnorm(int dtype, void* x, const void* delta, const voi
 template <typename T>
 __global__ __launch_bounds__(256) void llm_rope_cache_prefill_kernel(T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc, const T* __restrict__ cos_t,
                                                                      const T* __restrict__ sin_t, int S, int nq, int nkv, int hd, int tmax) {
+#pragma clang fp contract(off)      // fp32: mul, mul, add are three roundings in the reference -- no FMA
     constexpr int V = 16 / (int)sizeof(T);                     // elements per 16-byte vector
     typedef T TV __attribute__((ext_vector_type(V)));
     const int spos = blockIdx.x, b = blockIdx.y, half = hd >> 1, cph = half / V;      // vectors per half head
@@ -201,8 +210,11 @@ __global__ __launch_bounds__(256) void llm_rope_cache_prefill_kernel(T* __restri
         TV o0, o1;
 #pragma unroll
         for (int e = 0; e < V; e++) {
-            o0[e] = Cvt<T>::to(Cvt<T>::rnd(Cvt<T>::rnd((float)x0[e] * (float)c0[e]) + Cvt<T>::rnd(-(float)x1[e] * (float)s0[e])));
-            o1[e] = Cvt<T>::to(Cvt<T>::rnd(Cvt<T>::rnd((float)x1[e] * (float)c1[e]) + Cvt<T>::rnd((float)x0[e] * (float)s1[e])));
+            // plain operators under `fp contract(off)` (the __fmul_rn / __fadd_rn of the HIP headers are inlined WITH their contract flags)
+            const float p00 = Cvt<T>::rnd((float)x0[e] * (float)c0[e]), p01 = Cvt<T>::rnd(-(float)x1[e] * (float)s0[e]);
+            const float p10 = Cvt<T>::rnd((float)x1[e] * (float)c1[e]), p11 = Cvt<T>::rnd((float)x0[e] * (float)s1[e]);
+            o0[e] = Cvt<T>::to(Cvt<T>::rnd(p00 + p01));
+            o1[e] = Cvt<T>::to(Cvt<T>::rnd(p10 + p11));
         }
         *reinterpret_cast<TV*>(hp + d) = o0;
         *reinterpret_cast<TV*>(hp + d + half) = o1;
