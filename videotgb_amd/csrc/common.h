@@ -11,6 +11,16 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// v rounded (to nearest even) to bf16 precision, as a float -- on the bits: hipcc may keep the excess precision of a float -> __bf16 ->
+// float cast round trip, which would turn a hi | lo split (lo = v - hi) into lo = 0
+#if defined(__HIPCC__)
+__device__ __forceinline__ float bf16_round(float v) {
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7F800000u) != 0x7F800000u) u += 0x7FFFu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xFFFF0000u);
+}
+#endif
+
 // ---------------------------------------------------------------------------------------
 // error plumbing (thread-local message, negative return codes; include/vtgb.h)
 // ---------------------------------------------------------------------------------------

@@ -340,8 +340,9 @@ __global__ __launch_bounds__(512) void stem7x7_kernel(const StemParams p) {
             _Pragma("unroll") for (int py = 0; py < 2; py++)                                                 \
                 _Pragma("unroll") for (int c = 0; c < 3; c++) {                                              \
                     const float d0 = in_ ? ld[py * 3 + c].x - 127.5f : 0.f, d1 = in_ ? ld[py * 3 + c].y - 127.5f : 0.f; \
-                    hi[py * 6 + c] = (bf16_t)d0; lo[py * 6 + c] = (bf16_t)(d0 - (float)hi[py * 6 + c]);      \
-                    hi[py * 6 + 3 + c] = (bf16_t)d1; lo[py * 6 + 3 + c] = (bf16_t)(d1 - (float)hi[py * 6 + 3 + c]); \
+                    const float h0_ = bf16_round(d0), h1_ = bf16_round(d1);                                  \
+                    hi[py * 6 + c] = (bf16_t)h0_; lo[py * 6 + c] = (bf16_t)(d0 - h0_);                       \
+                    hi[py * 6 + 3 + c] = (bf16_t)h1_; lo[py * 6 + 3 + c] = (bf16_t)(d1 - h1_);               \
                 }                                                                                            \
             char* const rb_ = ring + ((((Yp) % ST_R) + ST_R) % ST_R) * row_bytes;                            \
             _Pragma("unroll") for (int q = 0; q < 3; q++) {                                                  \

@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void raft_stem_pack_kernel(const float* __rest
                 const float raw = ok ? img[((n * 3 + c) * H + row) * W + col] : 0.f;
                 if constexpr (PAIR) {
                     const float d = ok ? raw - 127.5f : 0.f;
-                    v[e] = (T)d;
-                    l[e] = (T)(d - (float)v[e]);
+                    const float hf = bf16_round(d);      // (on the bits: see common.h)
+                    v[e] = (T)hf;
+                    l[e] = (T)(d - hf);
                 } else {
                     v[e] = (T)(ok ? 2.0f * (raw / 255.0f) - 1.0f : 0.f);
                 }
