@@ -13,17 +13,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnDesc p) {
     const int nchunk = p.D >> 2;
     // grid-stride over rows: a bounded grid of resident workgroups walks the rows (one workgroup per 4 rows exits after
     // ~2 us and the dispatcher, not HBM, then sets the pace: 2.9 TB/s on the ViT's 255 k x 1408 rows)
-    // gamma / beta stay in registers across the rows a wave walks (they were re-read -- as many bytes as the row itself -- per row)
-    float4 gm[8], bt[8];
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const int ch = c * 64 + lane;
-        gm[c] = bt[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ch < nchunk) {
-            gm[c] = *reinterpret_cast<const float4*>(p.gamma + ch * 4);
-            bt[c] = *reinterpret_cast<const float4*>(p.beta + ch * 4);
-        }
+    // gamma / beta are staged once per workgroup in LDS (r3; rounds 1-2 kept them in 64 registers per lane, which capped the kernel at 4
+    // waves per SIMD: a wave walks its rows serially -- load, two reductions, store -- so the bytes in flight are waves x one row, and
+    // the launch ran at 3.6 TB/s)
+    __shared__ float4 gms[512], bts[512];
+    for (int ch = threadIdx.x; ch < nchunk; ch += 256) {
+        gms[ch] = *reinterpret_cast<const float4*>(p.gamma + ch * 4);
+        bts[ch] = *reinterpret_cast<const float4*>(p.beta + ch * 4);
     }
+    __syncthreads();
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < p.M; row += (int64_t)gridDim.x * 4) {
     const float* x = p.x + map_row(p.x_map, row) * p.ldx;
     float4 v[8];
@@ -55,7 +53,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnDesc p) {
     for (int c = 0; c < 8; c++) {
         const int ch = c * 64 + lane;
         if (ch < nchunk) {
-            const float4 g = gm[c], b = bt[c];
+            const float4 g = gms[ch], b = bts[ch];
             float4 y;
             y.x = (v[c].x - mean) * rstd * g.x + b.x;
             y.y = (v[c].y - mean) * rstd * g.y + b.y;
@@ -81,7 +79,7 @@ int launch_layernorm(const LnDesc& d, hipStream_t s) {
     VTGB_REQUIRE(d.M > 0 && d.D > 0 && (d.D % 4) == 0 && d.D <= 2048 && (d.ldx % 4) == 0 && (d.ldo % 4) == 0, VTGB_EUNSUPPORTED,
                  "layernorm: D=%d must be a multiple of 4, <= 2048 (ldx=%lld ldo=%lld)", d.D, (long long)d.ldx, (long long)d.ldo);
     const int64_t blocks = (d.M + 3) / 4;
-    dim3 grid((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16));      // <= 16 resident workgroups per CU, each walking rows
+    dim3 grid((unsigned)(blocks < 256 * 10 ? blocks : 256 * 10));      // 10 resident workgroups per CU (16 KB of LDS each), each walking rows
     if (d.dtype == VTGB_BF16)
         hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, s, d);
     else
