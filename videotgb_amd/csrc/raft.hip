@@ -255,25 +255,42 @@ __global__ __launch_bounds__(256) void raft_convf1_f32_kernel(const float* __res
 // GEMM with the taps moved to the OUTPUT side: P[m][tap*2 + o] = <FH[m], w[o][tap]> for every pixel (one pass
 // over FH on the MFMA kernel, N = 18 padded to 32), then delta[m][o] = sum_tap P[m + offset(tap)][tap*2 + o]
 // over the in-image neighbours -- 72 bytes per pixel instead of nine 512-byte rows.
+// One workgroup per image (r3): the 18 used columns of the image's P rows are staged tap-major in LDS with coalesced 16-byte loads, then
+// every pixel gathers its 9 taps from LDS (consecutive lanes = consecutive pixels = consecutive banks).  Rounds 1-2 gathered straight
+// from global memory -- nine 8-byte loads per pixel, each touching 64 different 128-byte rows per wave instruction: 0.29 ms per launch
+// for 0.33 GB.  Same taps in the same order: bit-identical flow.
 __global__ __launch_bounds__(256) void raft_flow_head2_kernel(const float* __restrict__ P, const float* __restrict__ b, float* __restrict__ flow,
                                                               int64_t M, int H8, int W8) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    const int pix = (int)(m % (H8 * W8)), y = pix / W8, x = pix - y * W8;
-    float a0 = b[0], a1 = b[1];
+    extern __shared__ float fh2_ps[];                      // [18][HW]
+    const int HW = H8 * W8, tid = threadIdx.x;
+    const int64_t m0 = (int64_t)blockIdx.x * HW;
+    for (int i = tid; i < HW * 5; i += 256) {               // floats 0 .. 19 of every pixel's 32-float row
+        const int px = i / 5, j = i - px * 5;
+        const float4 v = *reinterpret_cast<const float4*>(P + (m0 + px) * 32 + j * 4);
+        const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int tap = 0; tap < 9; tap++) {
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        if ((unsigned)(y + dy) < (unsigned)H8 && (unsigned)(x + dx) < (unsigned)W8) {
-            const float2 v = *reinterpret_cast<const float2*>(P + (m + dy * W8 + dx) * 32 + tap * 2);
-            a0 += v.x;
-            a1 += v.y;
-        }
+        for (int q = 0; q < 4; q++)
+            if (j * 4 + q < 18) fh2_ps[(j * 4 + q) * HW + px] = e[q];
     }
-    float2* f = reinterpret_cast<float2*>(flow + m * 2);
-    float2 o = *f;
-    o.x += a0; o.y += a1;
-    *f = o;
+    __syncthreads();
+    const float b0 = b[0], b1 = b[1];
+    for (int pix = tid; pix < HW; pix += 256) {
+        const int y = pix / W8, x = pix - y * W8;
+        float a0 = b0, a1 = b1;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            if ((unsigned)(y + dy) < (unsigned)H8 && (unsigned)(x + dx) < (unsigned)W8) {
+                const int q = pix + dy * W8 + dx;
+                a0 += fh2_ps[(tap * 2) * HW + q];
+                a1 += fh2_ps[(tap * 2 + 1) * HW + q];
+            }
+        }
+        float2* f = reinterpret_cast<float2*>(flow + (m0 + pix) * 2);
+        float2 o = *f;
+        o.x += a0; o.y += a1;
+        *f = o;
+    }
 }
 
 // upsample_flow (xraft.py:88-99): softmax over the 9 mask logits of each fine pixel, convex combination of
@@ -390,6 +407,9 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     auto F = [](const void* p) { return (const float*)p; };
     auto E = [es](char* p, int64_t elems) { return (void*)(p + elems * (int64_t)es); };   // element offset into an activation buffer
     const dim3 lk_grid((unsigned)((M + 4 * CL_PIX - 1) / (4 * CL_PIX)));
+    const size_t fh2_lds = (size_t)18 * HW * sizeof(float);
+    VTGB_REQUIRE(fh2_lds <= 160 * 1024, VTGB_EUNSUPPORTED, "raft_update: %d x %d coarse pixels per image exceed the flow head's LDS image", H8, W8);
+    VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_flow_head2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fh2_lds));
     if (hoist) {
         // start maps = bias + conv(inp): X[:, 0:128] holds relu(cnet[:, 128:]) (raft_init_kernel); same taps as the GRU halves
         for (int half = 0; half < 2; half++) {
@@ -455,7 +475,7 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
             d.algo_flops = 2.0 * Mi * 256.0 * (9 * 128) + 2.0 * Mi * 32.0 * 256.0;
             VTGB_TRY(launch_conv_gemm(d, s));
         }
-        hipLaunchKernelGGL(raft_flow_head2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, P2, F(w[21]), flow, M, H8, W8);
+        hipLaunchKernelGGL(raft_flow_head2_kernel, dim3((unsigned)a->n_pairs), dim3(256), fh2_lds, s, P2, F(w[21]), flow, M, H8, W8);
     }
     // ---- mask head of the last iteration (update.py:129-132,143) and convex upsample (xraft.py:88-99)
     VTGB_TRY(launch_conv_gemm(conv_desc(dt, Mi, 256, H8, W8, 3, 3, 128, 128, hb, 128, nullptr, 0, w[22], F(w[23]), VTGB_EPI_STORE, 1, FH, 256, zero), s));
