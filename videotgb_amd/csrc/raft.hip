@@ -297,13 +297,16 @@ __global__ __launch_bounds__(256) void raft_flow_head2_kernel(const float* __res
 // the 3x3 neighbourhood of 8 * flow (zero padded unfold).  mask [M, 576] fp32 with channel = k*64 + sy*8 + sx.
 __global__ void raft_upsample_kernel(const float* __restrict__ flow, const float* __restrict__ mask, float* __restrict__ up, int64_t n_img,
                                      int H8, int W8) {
+    // a wave = one coarse pixel, lane = (sy, sx): the 9 mask reads of a wave are 256 contiguous bytes each (r3; a thread per fine pixel in
+    // row order read 32-byte pieces of 8 different coarse pixels per wave instruction: 2.6 TB/s on the 5.3 GB of mask logits)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int HF = 8 * H8, WF = 8 * W8;
     if (i >= n_img * HF * WF) return;
-    const int X = (int)(i % WF), Y = (int)((i / WF) % HF);
-    const int64_t n = i / ((int64_t)WF * HF);
-    const int x = X >> 3, sx = X & 7, y = Y >> 3, sy = Y & 7;
-    const int64_t m = (n * H8 + y) * W8 + x;
+    const int64_t m = i >> 6;
+    const int sx = (int)(i & 7), sy = (int)((i >> 3) & 7);
+    const int x = (int)(m % W8), y = (int)((m / W8) % H8);
+    const int64_t n = m / ((int64_t)W8 * H8);
+    const int X = x * 8 + sx, Y = y * 8 + sy;
     float lg[9], mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
