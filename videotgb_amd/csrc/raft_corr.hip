@@ -29,37 +29,48 @@ constexpr int CORR_D = 256;
 constexpr int CORR_F1H_LD = CORR_D + 8;    // half elements per LDS row of the image-1 tile (528 B: 16 rows -> 16 bank groups)
 constexpr int CORR_F1F_LD = CORR_D + 4;    // fp32 variant
 
-struct CorrLds { int ldS, n1, n2, n3; size_t bytes; };
-static inline CorrLds corr_lds(int H8, int W8, bool f32) {
+struct CorrLds { int ldS, n1, n2, n3, tp; size_t bytes; };
+// tp: image-1 rows per workgroup.  bf16 mode: 32 when the slice fits LDS (every workgroup streams ALL of image 2 from L2 -- 400 KB at
+// 28 x 28 -- so 32 rows halve the launch's L2 traffic: 58 GB per 2 945 pairs at 16 rows was what bound it), else 16; fp32 mode: 16.
+static inline CorrLds corr_lds_tp(int H8, int W8, bool f32, int tp) {
     CorrLds c;
     const int HW = H8 * W8;
     c.ldS = (HW + 15) / 16 * 16 + 4;
     c.n1 = (H8 / 2) * (W8 / 2);
     c.n2 = (H8 / 4) * (W8 / 4);
     c.n3 = (H8 / 8) * (W8 / 8);
-    c.bytes = (size_t)16 * (c.ldS + c.n1 + c.n2) * 4 + (f32 ? 16 * CORR_F1F_LD * 4 : 16 * CORR_F1H_LD * 2);
+    c.tp = tp;
+    c.bytes = (size_t)tp * (c.ldS + c.n1 + c.n2) * 4 + (f32 ? tp * CORR_F1F_LD * 4 : tp * CORR_F1H_LD * 2);
     return c;
 }
+static inline CorrLds corr_lds(int H8, int W8, bool f32) {
+    if (!f32) {
+        const CorrLds c32 = corr_lds_tp(H8, W8, false, 32);
+        if (c32.bytes <= 160 * 1024) return c32;
+    }
+    return corr_lds_tp(H8, W8, f32, 16);
+}
 
-template <bool F32, typename OT>
-__global__ __launch_bounds__(256) void raft_corr_kernel(const vtgb_raft_corr_args a, const half_t* __restrict__ fh, const int ldS, const int n1,
+template <bool F32, typename OT, int TP>
+__global__ __launch_bounds__(TP * 16) void raft_corr_kernel(const vtgb_raft_corr_args a, const half_t* __restrict__ fh, const int ldS, const int n1,
                                                         const int n2) {
     extern __shared__ __attribute__((aligned(16))) char corr_sm[];
     const int H = a.H8, W = a.W8, HW = H * W;
     float* const S = reinterpret_cast<float*>(corr_sm);
-    float* const S1 = S + 16 * ldS;
-    float* const S2 = S1 + 16 * n1;
-    char* const f1s = reinterpret_cast<char*>(S2 + 16 * n2);
+    constexpr int NT = TP * 16;      // threads: 4 waves per 16 image-1 rows
+    float* const S1 = S + TP * ldS;
+    float* const S2 = S1 + TP * n1;
+    char* const f1s = reinterpret_cast<char*>(S2 + TP * n2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n = blockIdx.y;
-    const int p0 = blockIdx.x * 16;
+    const int p0 = blockIdx.x * TP;
     const int64_t img = (n / a.pairs_per_clip) * a.frames_per_clip + n % a.pairs_per_clip;
     const int64_t i1 = img + a.first_off, i2 = img + a.second_off;
     // ---- image-1 tile -> LDS (rows past the image: the last row again; their outputs are never stored)
     if constexpr (F32) {
         const float* f1 = a.fmap + i1 * HW * CORR_D;
         float* dst = reinterpret_cast<float*>(f1s);
-        for (int i = tid; i < 16 * (CORR_D / 4); i += 256) {
+        for (int i = tid; i < TP * (CORR_D / 4); i += NT) {
             const int r = i / (CORR_D / 4), c = i - r * (CORR_D / 4);
             const int p = min(p0 + r, HW - 1);
             *reinterpret_cast<float4*>(dst + r * CORR_F1F_LD + c * 4) = *reinterpret_cast<const float4*>(f1 + (int64_t)p * CORR_D + c * 4);
@@ -67,7 +78,7 @@ __global__ __launch_bounds__(256) void raft_corr_kernel(const vtgb_raft_corr_arg
     } else {
         const half_t* f1 = fh + i1 * HW * CORR_D;
         half_t* dst = reinterpret_cast<half_t*>(f1s);
-        for (int i = tid; i < 16 * (CORR_D / 8); i += 256) {
+        for (int i = tid; i < TP * (CORR_D / 8); i += NT) {
             const int r = i / (CORR_D / 8), c = i - r * (CORR_D / 8);
             const int p = min(p0 + r, HW - 1);
             *reinterpret_cast<half8*>(dst + r * CORR_F1H_LD + c * 8) = *reinterpret_cast<const half8*>(f1 + (int64_t)p * CORR_D + c * 8);
@@ -78,7 +89,8 @@ __global__ __launch_bounds__(256) void raft_corr_kernel(const vtgb_raft_corr_arg
     if constexpr (F32) {
         const float* f2 = a.fmap + i2 * HW * CORR_D;
         const float* f1l = reinterpret_cast<const float*>(f1s);
-        for (int q = tid; q < HW; q += 256) {
+        static_assert(!F32 || TP == 16, "the fp32 path keeps 16 accumulators per thread");
+        for (int q = tid; q < HW; q += NT) {
             const float* row = f2 + (int64_t)q * CORR_D;
             float acc[16];
 #pragma unroll
@@ -101,9 +113,12 @@ __global__ __launch_bounds__(256) void raft_corr_kernel(const vtgb_raft_corr_arg
         const half_t* f2 = fh + i2 * HW * CORR_D;
         const half_t* f1l = reinterpret_cast<const half_t*>(f1s);
         const int fr = lane & 15, fg = lane >> 4;
-        half8 bfrag[CORR_D / 32];
+        constexpr int NH = TP / 16, NW = NT / 64;      // 16-row halves of the tile; waves
+        half8 bfrag[NH][CORR_D / 32];
 #pragma unroll
-        for (int ks = 0; ks < CORR_D / 32; ks++) bfrag[ks] = *reinterpret_cast<const half8*>(f1l + fr * CORR_F1H_LD + ks * 32 + fg * 8);
+        for (int h = 0; h < NH; h++)
+#pragma unroll
+            for (int ks = 0; ks < CORR_D / 32; ks++) bfrag[h][ks] = *reinterpret_cast<const half8*>(f1l + (h * 16 + fr) * CORR_F1H_LD + ks * 32 + fg * 8);
         const int n_qt = (HW + 15) >> 4;
         // image-2 fragments come straight from L2: the loads of q-tile t+1 are in flight while tile t's MFMAs run (without the
         // prefetch every q-tile waited out a full L2 round trip: the kernel was latency-bound at 0.6 TB/s of output)
@@ -115,46 +130,49 @@ __global__ __launch_bounds__(256) void raft_corr_kernel(const vtgb_raft_corr_arg
             for (int ks = 0; ks < CORR_D / 32; ks++) dst[ks] = *reinterpret_cast<const half8*>(row + ks * 32);
         };
         auto compute = [&](int qt, const half8 (&src)[CORR_D / 32]) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < CORR_D / 32; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(src[ks], bfrag[ks], acc, 0, 0, 0);
-            // D: rows fg * 4 + r = q within the tile, column fr = p
-            *reinterpret_cast<f32x4*>(S + fr * ldS + qt * 16 + fg * 4) = acc * a.scale;
+            for (int h = 0; h < NH; h++) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < CORR_D / 32; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(src[ks], bfrag[h][ks], acc, 0, 0, 0);
+                // D: rows fg * 4 + r = q within the tile, column fr = p
+                *reinterpret_cast<f32x4*>(S + (h * 16 + fr) * ldS + qt * 16 + fg * 4) = acc * a.scale;
+            }
         };
         int qt = wave;
         if (qt < n_qt) load_a(qt, afrag[0]);
-        for (; qt < n_qt; qt += 8) {
-            if (qt + 4 < n_qt) load_a(qt + 4, afrag[1]);
+        for (; qt < n_qt; qt += 2 * NW) {
+            if (qt + NW < n_qt) load_a(qt + NW, afrag[1]);
             compute(qt, afrag[0]);
-            if (qt + 4 < n_qt) {
-                if (qt + 8 < n_qt) load_a(qt + 8, afrag[0]);
-                compute(qt + 4, afrag[1]);
+            if (qt + NW < n_qt) {
+                if (qt + 2 * NW < n_qt) load_a(qt + 2 * NW, afrag[0]);
+                compute(qt + NW, afrag[1]);
             }
         }
     }
     __syncthreads();
     // ---- the four levels.  Row p of level l is [n * HW + p0 + p][n_l]: the tile's outputs are one contiguous span.
-    const int rows = min(16, HW - p0);
+    const int rows = min(TP, HW - p0);
     OT* const o0 = reinterpret_cast<OT*>(a.levels[0]) + (n * HW + p0) * (int64_t)HW;
     if ((HW & 7) == 0) {
         // 8 consecutive q per lane: 16-byte (half) / 2 x 16-byte (fp32) stores -- element-wise 2-byte stores made this
         // write-out (3/4 of the kernel's bytes) the longest phase of the kernel
         typedef OT OT8 __attribute__((ext_vector_type(8)));
-        for (int i = tid * 8; i < rows * HW; i += 256 * 8) {
+        for (int i = tid * 8; i < rows * HW; i += NT * 8) {
             const int p = i / HW, q = i - p * HW;
             const f32x4 lo = *reinterpret_cast<const f32x4*>(S + p * ldS + q), hi = *reinterpret_cast<const f32x4*>(S + p * ldS + q + 4);
             const OT8 v = {(OT)lo[0], (OT)lo[1], (OT)lo[2], (OT)lo[3], (OT)hi[0], (OT)hi[1], (OT)hi[2], (OT)hi[3]};
             *reinterpret_cast<OT8*>(o0 + i) = v;
         }
     } else {
-        for (int i = tid; i < rows * HW; i += 256) {
+        for (int i = tid; i < rows * HW; i += NT) {
             const int p = i / HW, q = i - p * HW;
             o0[i] = (OT)S[p * ldS + q];
         }
     }
     const int w1 = W / 2, w2 = W / 4, w3 = W / 8, n3 = (H / 8) * w3;
     OT* const o1 = reinterpret_cast<OT*>(a.levels[1]) + (n * HW + p0) * (int64_t)n1;
-    for (int i = tid; i < rows * n1; i += 256) {
+    for (int i = tid; i < rows * n1; i += NT) {
         const int p = i / n1, r = i - p * n1, y = r / w1, x = r - y * w1;
         const float* s = S + p * ldS + (2 * y) * W + 2 * x;
         const float v = (((s[0] + s[1]) + s[W]) + s[W + 1]) * 0.25f;
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(256) void raft_corr_kernel(const vtgb_raft_corr_arg
     }
     __syncthreads();
     OT* const o2 = reinterpret_cast<OT*>(a.levels[2]) + (n * HW + p0) * (int64_t)n2;
-    for (int i = tid; i < rows * n2; i += 256) {
+    for (int i = tid; i < rows * n2; i += NT) {
         const int p = i / n2, r = i - p * n2, y = r / w2, x = r - y * w2;
         const float* s = S1 + p * n1 + (2 * y) * w1 + 2 * x;
         const float v = (((s[0] + s[1]) + s[w1]) + s[w1 + 1]) * 0.25f;
@@ -172,7 +190,7 @@ __global__ __launch_bounds__(256) void raft_corr_kernel(const vtgb_raft_corr_arg
     }
     __syncthreads();
     OT* const o3 = reinterpret_cast<OT*>(a.levels[3]) + (n * HW + p0) * (int64_t)n3;
-    for (int i = tid; i < rows * n3; i += 256) {
+    for (int i = tid; i < rows * n3; i += NT) {
         const int p = i / n3, r = i - p * n3, y = r / w3, x = r - y * w3;
         const float* s = S2 + p * n2 + (2 * y) * w2 + 2 * x;
         o3[i] = (OT)((((s[0] + s[1]) + s[w2]) + s[w2 + 1]) * 0.25f);
@@ -205,18 +223,23 @@ extern "C" int vtgb_raft_corr(const vtgb_raft_corr_args* a, vtgb_stream_t stream
     const bool f32 = a->dtype == VTGB_F32;
     const CorrLds c = corr_lds(a->H8, a->W8, f32);
     const int HW = a->H8 * a->W8;
-    const dim3 grid((unsigned)((HW + 15) / 16), (unsigned)a->n_pairs);
+    const dim3 grid((unsigned)((HW + c.tp - 1) / c.tp), (unsigned)a->n_pairs);
     if (f32) {
-        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_kernel<true, float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.bytes));
-        hipLaunchKernelGGL((raft_corr_kernel<true, float>), grid, dim3(256), c.bytes, stream, *a, nullptr, c.ldS, c.n1, c.n2);
+        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_kernel<true, float, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.bytes));
+        hipLaunchKernelGGL((raft_corr_kernel<true, float, 16>), grid, dim3(256), c.bytes, stream, *a, nullptr, c.ldS, c.n1, c.n2);
     } else {
         const size_t need = vtgb_raft_corr_workspace_bytes(a);
         VTGB_REQUIRE(a->workspace && a->workspace_bytes >= need, VTGB_EWORKSPACE, "raft_corr: workspace %zu < %zu bytes", a->workspace_bytes, need);
         half_t* fh = reinterpret_cast<half_t*>(a->workspace);
         const int64_t n4 = (int64_t)a->n_images * HW * CORR_D / 4;
         hipLaunchKernelGGL(cast_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a->fmap, fh, n4);
-        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_kernel<false, half_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.bytes));
-        hipLaunchKernelGGL((raft_corr_kernel<false, half_t>), grid, dim3(256), c.bytes, stream, *a, fh, c.ldS, c.n1, c.n2);
+        if (c.tp == 32) {
+            VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_kernel<false, half_t, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.bytes));
+            hipLaunchKernelGGL((raft_corr_kernel<false, half_t, 32>), grid, dim3(512), c.bytes, stream, *a, fh, c.ldS, c.n1, c.n2);
+        } else {
+            VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_kernel<false, half_t, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.bytes));
+            hipLaunchKernelGGL((raft_corr_kernel<false, half_t, 16>), grid, dim3(256), c.bytes, stream, *a, fh, c.ldS, c.n1, c.n2);
+        }
     }
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
