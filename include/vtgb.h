@@ -31,7 +31,8 @@ extern "C" {
 
 typedef struct ihipStream_t* vtgb_stream_t; /* == hipStream_t */
 
-#define VTGB_VERSION 300
+#define VTGB_VERSION 300 /* round 3: stem weight hi|lo layout; vtgb_attention_args.causal; vtgb_gemm_skinny without workspace when unsplit;
+                            vtgb_llm_rope_cache_prefill; vtgb_attn_train_forward / backward; vtgb_comm_* / vtgb_allreduce_f32 */
 
 #define VTGB_OK 0
 #define VTGB_EINVAL (-1)       /* bad argument (NULL pointer, unsupported size, bad mode) */
