@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr
                                                                int64_t M, int H8, int W8) {
     __shared__ float win[4][4][104];   // [wave][level][10 x 10 window | wx | wy | pad]
     __shared__ __attribute__((aligned(16))) OT stage[4][2][384];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (readfirstlane: the wave index -- and with it the pixel index, its image coordinates and the four 64-bit level bases -- is
+    // wave-uniform; told so, hipcc keeps that arithmetic on the scalar unit instead of 64 lanes of v_mad_u64_u32: r3)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wy0 = lane / 10, wx0 = lane - wy0 * 10;                 // window element `lane`
     const int e1 = lane < 36 ? lane + 64 : 99;                        // window element `lane + 64` (lanes >= 36 repeat the last one)
     const int wy1 = e1 / 10, wx1 = e1 - wy1 * 10;
