@@ -59,7 +59,7 @@ __global__ __launch_bounds__(NKP <= 9 ? 576 : 256) void attn_bf16_kernel(const A
     char* Ks = smem;
     char* Vs = smem + C::K_BYTES;
     float* maskv = reinterpret_cast<float*>(smem + C::K_BYTES + C::V_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nthreads = blockDim.x, nwaves = nthreads >> 6;
     const int head = blockIdx.y, b = blockIdx.z;
     const int hd = p.head_dim;
     const bf16_t* __restrict__ Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.q_batch + head * hd;
@@ -287,7 +287,7 @@ __device__ __forceinline__ float rope_elem(const float* x, int d, const float* t
 __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnDesc p) {
     __shared__ float qs[4][F32_MAX_HD];
     __shared__ float sc[4][F32_MAX_KV];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t total = (int64_t)p.batch * p.heads * p.s_q;
     int64_t row = (int64_t)blockIdx.x * 4 + wave;
     const bool active = row < total;

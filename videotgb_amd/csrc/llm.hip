@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void llm_decode_attn_kernel(const T* __restric
                                                               T* __restrict__ out, const int64_t* __restrict__ pos_p, int B, int nq, int nkv,
                                                               int hd, int tmax, float scale) {
     extern __shared__ float dsm[];   // per wave: hd floats of q + (tmax) scores
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (uniform: batch / head / cache bases on the scalar unit)
     const int64_t idx = (int64_t)blockIdx.x * 4 + wave;
     const bool active = idx < (int64_t)B * nq;
     const int64_t id = active ? idx : (int64_t)B * nq - 1;

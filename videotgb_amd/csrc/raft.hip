@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void raft_convf1_kernel(const float* __restric
                                                           bf16_t* __restrict__ f1, bf16_t* __restrict__ X, int64_t M, int H8, int W8) {
     extern __shared__ __attribute__((aligned(16))) char cf1_smem[];
     bf16_t* const ws = reinterpret_cast<bf16_t*>(cf1_smem);              // [128][CF1_LD]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* const cst = cf1_smem + 128 * CF1_LD * 2 + wave * 4096;         // [16 px][128 ch] bf16, 16-byte chunks XOR px
     for (int i = tid; i < 128 * (CF1_K / 8); i += 256) {
         const int row = i / (CF1_K / 8), c = i - row * (CF1_K / 8);

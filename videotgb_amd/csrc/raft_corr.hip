@@ -61,7 +61,7 @@ __global__ __launch_bounds__(TP * 16) void raft_corr_kernel(const vtgb_raft_corr
     float* const S1 = S + TP * ldS;
     float* const S2 = S1 + TP * n1;
     char* const f1s = reinterpret_cast<char*>(S2 + TP * n2);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t n = blockIdx.y;
     const int p0 = blockIdx.x * TP;
     const int64_t img = (n / a.pairs_per_clip) * a.frames_per_clip + n % a.pairs_per_clip;
