@@ -21,7 +21,7 @@
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ void raft_init_kernel(const float* __restrict__ net, const float* __restrict__ inp, const float* __restrict__ cnet_nhwc,
-                                 float* __restrict__ h32, T* __restrict__ hb, T* __restrict__ X, float* __restrict__ flow,
+                                 float* __restrict__ h32, T* __restrict__ hb, T* __restrict__ hlo, T* __restrict__ X, float* __restrict__ flow,
                                  const float* __restrict__ flow_init, int64_t M, int HW) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * 128) return;
@@ -32,8 +32,14 @@ __global__ void raft_init_kernel(const float* __restrict__ net, const float* __r
     // from the context encoder's pixel-major output
     const float hv = cnet_nhwc ? tanhf(cnet_nhwc[m * 256 + c]) : net[(n * 128 + c) * HW + p];
     const float iv = cnet_nhwc ? fmaxf(cnet_nhwc[m * 256 + 128 + c], 0.f) : inp[(n * 128 + c) * HW + p];
-    h32[i] = hv;
-    hb[i] = (T)hv;
+    if (hlo) {      // fused GRU (gru_fused.hip): the hidden state as a bf16 pair hi | lo instead of fp32 + bf16
+        const float hi = bf16_round(hv);
+        hb[i] = (T)hi;
+        hlo[i] = (T)(hv - hi);
+    } else {
+        h32[i] = hv;
+        hb[i] = (T)hv;
+    }
     X[m * 256 + c] = (T)iv;
     if (c < 2) {   // flow = coords1 - coords0: zero, or flow_init [n, 2, H8, W8] (xraft.py:131-132)
         const float f0 = flow_init ? flow_init[(n * 2 + c) * HW + p] : 0.f;
@@ -344,6 +350,19 @@ static GemmDesc conv_desc(int dt, int M, int N, int H, int W, int KH, int KW, in
     return d;
 }
 
+// gru_fused.hip: one launch per SepConvGRU half-step (bf16 mode with the hoisted `inp` third)
+bool gru_fused_supported(int n_img, int H, int W);
+void gru_fused_startmap_bytes(int n_img, int H, int W, int vert, size_t* szr, size_t* sq);
+size_t gru_fused_packed_w_bytes(int gate_blocks);
+int launch_gru_pack_w(const void* w_rowmajor, void* packed, int gate_blocks, int rot, hipStream_t s);
+int launch_gru_startmap(int n_img, int H, int W, int vert, const void* zr_rowmajor, const void* q_rowmajor, void* szr, void* sq, hipStream_t s);
+int launch_gru_half(int n_img, int H, int W, int vert, void* hb, void* hlo, const void* X, const void* wzr_packed, const void* wq_packed, const void* szr,
+                    const void* sq, hipStream_t s);
+static int g_gru_fused = 1;   // (experiments: 0 keeps the two-launch half-step of rounds 1-3)
+#ifdef VTGB_DEBUG_HOOKS
+extern "C" void vtgb_debug_set_gru_fused(int v) { g_gru_fused = v; }
+#endif
+
 static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     VTGB_REQUIRE(a, VTGB_EINVAL, "raft_update: NULL args");
     VTGB_REQUIRE(a->dtype == VTGB_BF16 || a->dtype == VTGB_F32, VTGB_EINVAL, "raft_update: bad dtype %d", a->dtype);
@@ -356,7 +375,10 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     const int64_t M = (int64_t)a->n_pairs * HW;
     VTGB_REQUIRE(M < (1ll << 31), VTGB_EUNSUPPORTED, "raft_update: too many pixels");
     // activations: bf16 (VTGB_BF16) or fp32 (VTGB_F32); typed access through char* + element size
-    float* h32 = (float*)ws.take(M * 128 * 4);
+    // bf16 mode with the hoisted `inp` third and whole lines that fit a tile: the fused half-step kernel (hidden state hi | lo in bf16)
+    const bool fused = !f32 && g_gru_fused && a->weights && a->weights[26] != nullptr && gru_fused_supported(a->n_pairs, H8, W8);
+    float* h32 = fused ? nullptr : (float*)ws.take(M * 128 * 4);
+    char* hlo = fused ? (char*)ws.take(M * 128 * es) : nullptr;
     char* hb = (char*)ws.take(M * 128 * es);
     char* X = (char*)ws.take(M * 256 * es);
     char* corrf = (char*)ws.take(M * 384 * es);
@@ -373,7 +395,17 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     const bool hoist = !f32 && a->weights && a->weights[26] != nullptr;
     bf16_t* inp_zr[2] = {nullptr, nullptr};
     bf16_t* inp_q[2] = {nullptr, nullptr};
-    if (!f32) {
+    void *gw_zr[2] = {nullptr, nullptr}, *gw_q[2] = {nullptr, nullptr};      // fused: weights in MFMA fragment order
+    if (fused) {
+        for (int half = 0; half < 2; half++) {
+            size_t b_zr = 0, b_q = 0;
+            gru_fused_startmap_bytes(a->n_pairs, H8, W8, half, &b_zr, &b_q);   // fragment order of the fused kernel's tiles (whole lines)
+            inp_zr[half] = (bf16_t*)ws.take(b_zr);
+            inp_q[half] = (bf16_t*)ws.take(b_q);
+            gw_zr[half] = ws.take(gru_fused_packed_w_bytes(4));
+            gw_q[half] = ws.take(gru_fused_packed_w_bytes(2));
+        }
+    } else if (!f32) {
         for (int half = 0; half < 2; half++) {
             const int64_t Mt = (M + 255) / 256 * 256;   // fragment order: whole 256-row tiles
             inp_zr[half] = (bf16_t*)ws.take(Mt * 256 * 2);
@@ -401,9 +433,9 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     VTGB_HIP(hipMemsetAsync(zero, 0, 256, s));
     const dim3 init_grid((unsigned)((M * 128 + 255) / 256));
     if (f32)
-        hipLaunchKernelGGL(raft_init_kernel<float>, init_grid, dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, h32, (float*)hb, (float*)X, flow, a->flow_init, M, HW);
+        hipLaunchKernelGGL(raft_init_kernel<float>, init_grid, dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, h32, (float*)hb, (float*)nullptr, (float*)X, flow, a->flow_init, M, HW);
     else
-        hipLaunchKernelGGL(raft_init_kernel<bf16_t>, init_grid, dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, h32, (bf16_t*)hb, (bf16_t*)X, flow, a->flow_init, M, HW);
+        hipLaunchKernelGGL(raft_init_kernel<bf16_t>, init_grid, dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, h32, (bf16_t*)hb, (bf16_t*)hlo, (bf16_t*)X, flow, a->flow_init, M, HW);
     const int Mi = (int)M;
     const size_t cf1_lds = 128 * CF1_LD * 2 + 4 * 4096;
     if (!f32)
@@ -424,6 +456,17 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
             GemmDesc mq = conv_desc(dt, Mi, 128, H8, W8, kh, kw, 128, 128, X, 256, nullptr, 0, w[27 + 2 * half], F(w[wi + 3]), VTGB_EPI_STORE, 0,
                                     inp_q[half], 128, zero);
             mz.algo_flops = mq.algo_flops = -1.0;   // their work is credited to the 20 per-iteration launches (the reference's form)
+            if (fused) {
+                // row-major into the (still idle) z|r and r * h buffers, then re-ordered for the fused kernel's tiles; the GRU weights
+                // into fragment order (q: chunk order x0, x1, rh0, rh1)
+                mz.out = ZR; mz.ldo = 256; mq.out = RH; mq.ldo = 128;
+                VTGB_TRY(launch_conv_gemm(mz, s));
+                VTGB_TRY(launch_conv_gemm(mq, s));
+                VTGB_TRY(launch_gru_startmap(a->n_pairs, H8, W8, half, ZR, RH, inp_zr[half], inp_q[half], s));
+                VTGB_TRY(launch_gru_pack_w(w[wi], gw_zr[half], 4, 0, s));
+                VTGB_TRY(launch_gru_pack_w(w[wi + 2], gw_q[half], 2, 2, s));
+                continue;
+            }
             mz.frag_out = mq.frag_out = 1;          // kept as the MFMA leaves them: the GRU launches read them back the same way
             VTGB_TRY(launch_conv_gemm(mz, s));
             VTGB_TRY(launch_conv_gemm(mq, s));
@@ -452,6 +495,10 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
         // ---- SepConvGRU (update.py:50-65): horizontal (1x5) then vertical (5x1)
         for (int half = 0; half < 2; half++) {
             const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1, wi = 10 + 4 * half;
+            if (fused) {
+                VTGB_TRY(launch_gru_half(a->n_pairs, H8, W8, half, hb, hlo, X, gw_zr[half], gw_q[half], inp_zr[half], inp_q[half], s));
+                continue;
+            }
             // z -> ZR[:, :128]; r is multiplied by h in the epilogue and lands in RH (update.py:55,62)
             // input channels [h(128) | inp(128) | motion(126) + flow(2)]; hoisted form: [h | motion + flow] = 256 channels, the
             // second operand starts at column 128 of X, bias and the inp term come from the start map
