@@ -36,7 +36,22 @@ if hasattr(lib, "vtgb_debug_set_gru_dbg"):
     ops.raft_update(w, None, None, pyr, iters=1, cnet_nhwc=cnet, hw=(H8, W8))
     torch.cuda.synchronize()
     lib.vtgb_debug_set_gru_dbg(ctypes.c_void_p(0))
-    d = dbg.cpu().double()
+    raw = dbg.cpu()
+    hw = (raw[:, 0] >> 48) & 0xFFFF
+    xcc = (raw[:, 0] >> 44) & 0xF
+    raw = raw & 0xFFFFFFFFFFF
+    import collections
+    cu = ((xcc << 16) | (hw & 0xFF00)).tolist()      # (xcc, se, sh, cu)
+    slot = (hw & 0xF).tolist()
+    t1 = raw[:, 1].tolist()
+    by = collections.defaultdict(list)
+    for i in range(n_tiles):
+        by[cu[i]].append((t1[i], slot[i], i))
+    print(f"   CUs seen {len(by)}, wave-slot histogram {collections.Counter(slot).most_common(6)}")
+    k = sorted(by)[3]
+    ev = sorted(by[k])[:12]
+    print("   one CU, S1 start stamps (cycles rel.), slot:", [(e[0] - ev[0][0], e[1]) for e in ev])
+    d = raw.double()
     ph = (d[:, 1:] - d[:, :-1])
     ok = (d[:, 7] > 0)
     names = ["load+wait", "S1 k-loop", "drain+bar", "E1+bar", "S2 k-loop", "lo+bar", "E2"]

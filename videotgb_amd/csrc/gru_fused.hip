@@ -155,15 +155,18 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
 #ifndef GF_ABL
 #define GF_ABL 0      /* timing-only variants (tools/exp/gru_abl.sh; results are WRONG by construction): 1 no weight loads, 2 no fragment reads, 4 no address arithmetic, 8 no MFMAs, 16 phase stamps */
 #endif
-#define GF_W_ISSUE(REG, NB, RS, VOFF, STEPBYTES, tap)                                                                          \
+#define GF_W_ISSUE_H(REGH, NB, RS, VOFF, STEPBYTES, step)      /* the NB fragments of k-step `step` (= 2 tap + k-half) */      \
     if constexpr (!(GF_ABL & 1)) {                                                                                             \
-        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) {                                                                  \
-            const int so_ = __builtin_amdgcn_readfirstlane(((tap) * 2 + ks_) * (STEPBYTES));                                   \
-            _Pragma("unroll") for (int i_ = 0; i_ < NB; i_++) {                                                                \
-                const int so_i_ = so_ + i_ * 1024;                                                                             \
-                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(REG[ks_][i_]) : "v"(VOFF), "s"(RS), "s"(so_i_) : "memory"); \
-            }                                                                                                                  \
+        const int so_ = __builtin_amdgcn_readfirstlane((step) * (STEPBYTES));                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < NB; i_++) {                                                                    \
+            const int so_i_ = so_ + i_ * 1024;                                                                                 \
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(REGH[i_]) : "v"(VOFF), "s"(RS), "s"(so_i_) : "memory"); \
         }                                                                                                                      \
+    }
+#define GF_W_ISSUE(REG, NB, RS, VOFF, STEPBYTES, tap)                                                                          \
+    {                                                                                                                          \
+        GF_W_ISSUE_H(REG[0], NB, RS, VOFF, STEPBYTES, (tap) * 2)                                                               \
+        GF_W_ISSUE_H(REG[1], NB, RS, VOFF, STEPBYTES, (tap) * 2 + 1)                                                           \
     }
 #define GF_W_DRAIN(REG, NB)   /* the ring's last (out-of-range) requests have returned: the registers may be reused */        \
     {                                                                                                                          \
@@ -171,11 +174,10 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
         _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++)                                                                    \
             _Pragma("unroll") for (int i_ = 0; i_ < NB; i_++) asm volatile("" : "+v"(REG[ks_][i_]));                           \
     }
-#define GF_W_WAIT(REG, NB)                                                                                                     \
+#define GF_W_WAIT_H(REGH, NB)     /* everything but the three younger k-steps' fragments has landed */                         \
     {                                                                                                                          \
-        if constexpr (!(GF_ABL & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");                             \
-        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++)                                                                    \
-            _Pragma("unroll") for (int i_ = 0; i_ < NB; i_++) asm volatile("" : "+v"(REG[ks_][i_]));                           \
+        if constexpr (!(GF_ABL & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NB) : "memory");                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < NB; i_++) asm volatile("" : "+v"(REGH[i_]));                                   \
     }
     // ---- k-loop: the 20 taps as 280 (row block, k-half) pairs, each one fragment read + NB MFMAs.  The reads run D - 1 pairs ahead of
     // their MFMAs through a ring of D fragments (LDS latency under the wave's own MFMAs; a tap boundary is not a bubble), the address of a
@@ -189,36 +191,46 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
     })
 #define GF_KLOOP(ACC, RA, RB, NB, D, RS, VOFF, STEPBYTES, ROT)                                                                 \
     {                                                                                                                          \
+        /* pair p of a tap: k-half p / 7, row block p % 7 -- the two updates of an accumulator block are 7 pairs apart (hipcc, left to */ \
+        /* itself, put them back to back with the accumulator renamed in between: every MFMA then waited out its predecessor's write-back, */ \
+        /* 32 cycles per MFMA measured); the order is pinned with sched_barrier */                                              \
         bf16x8 xr_[D];                                                                                                         \
-        int a_pf_ = 0;                                                                                                         \
+        int a_j_[GF_JF];                                                                                                       \
         _Pragma("unroll") for (int q_ = 0; q_ < D - 1; q_++) {                                                                 \
-            if ((q_ & 1) == 0) a_pf_ = GF_FRAG_ADDR(0, q_ >> 1, ROT);                                                          \
-            if constexpr (GF_ABL & 2) asm volatile("" : "=v"(xr_[q_]) : "v"(a_pf_));                                           \
-            else xr_[q_] = *reinterpret_cast<const bf16x8*>(smem + (a_pf_ ^ ((q_ & 1) * 64)));                                 \
+            if (q_ < 7) a_j_[q_] = GF_FRAG_ADDR(0, q_, ROT);                                                                   \
+            if constexpr (GF_ABL & 2) asm volatile("" : "=v"(xr_[q_]) : "v"(a_j_[q_ % 7]));                                    \
+            else xr_[q_] = *reinterpret_cast<const bf16x8*>(smem + (a_j_[q_ % 7] ^ ((q_ / 7) * 64)));                          \
         }                                                                                                                      \
         for (int tp = 0; tp < 10; tp++) {           /* taps 2 tp (ring entry RA), 2 tp + 1 (RB): chunk-major, tap-minor = the weights' K order */ \
             _Pragma("unroll") for (int P_ = 0; P_ < 28; P_++) {                                                                \
-                if (P_ == 0) GF_W_WAIT(RA, NB)                                                                                 \
-                if (P_ == 14) GF_W_WAIT(RB, NB)                                                                                \
+                if (P_ == 0) GF_W_WAIT_H(RA[0], NB)                                                                            \
+                if (P_ == 7) GF_W_WAIT_H(RA[1], NB)                                                                            \
+                if (P_ == 14) GF_W_WAIT_H(RB[0], NB)                                                                           \
+                if (P_ == 21) GF_W_WAIT_H(RB[1], NB)                                                                           \
                 {                                                                                                              \
                     const int Q_ = P_ + D - 1, tapq_ = 2 * tp + Q_ / 14, pq_ = Q_ % 14;                                        \
-                    if ((pq_ & 1) == 0) a_pf_ = GF_FRAG_ADDR(tapq_, pq_ >> 1, ROT);                                            \
-                    if constexpr (GF_ABL & 2) asm volatile("" : "+v"(xr_[Q_ % D]) : "v"(a_pf_));                               \
-                    else xr_[Q_ % D] = *reinterpret_cast<const bf16x8*>(smem + (a_pf_ ^ ((pq_ & 1) * 64)));                    \
+                    if (pq_ < 7) a_j_[pq_] = GF_FRAG_ADDR(tapq_, pq_, ROT);                                                    \
+                    if constexpr (GF_ABL & 2) asm volatile("" : "+v"(xr_[Q_ % D]) : "v"(a_j_[pq_ % 7]));                       \
+                    else xr_[Q_ % D] = *reinterpret_cast<const bf16x8*>(smem + (a_j_[pq_ % 7] ^ ((pq_ / 7) * 64)));            \
                 }                                                                                                              \
                 _Pragma("unroll") for (int i = 0; i < NB; i++) {                                                               \
-                    const bf16x8 wf_ = __builtin_bit_cast(bf16x8, P_ < 14 ? RA[P_ & 1][i] : RB[P_ & 1][i]);                    \
-                    if constexpr (GF_ABL & 8) asm volatile("" : "+v"(ACC[i][(P_ % 14) >> 1]) : "v"(wf_), "v"(xr_[P_ % D]));   \
-                    else ACC[i][(P_ % 14) >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf_, xr_[P_ % D], ACC[i][(P_ % 14) >> 1], 0, 0, 0); \
+                    const bf16x8 wf_ = __builtin_bit_cast(bf16x8, P_ < 14 ? RA[(P_ % 14) / 7][i] : RB[(P_ % 14) / 7][i]);      \
+                    if constexpr (GF_ABL & 8) asm volatile("" : "+v"(ACC[i][P_ % 7]) : "v"(wf_), "v"(xr_[P_ % D]));           \
+                    else ACC[i][P_ % 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf_, xr_[P_ % D], ACC[i][P_ % 7], 0, 0, 0);  \
                 }                                                                                                              \
-                if (P_ == 13) GF_W_ISSUE(RA, NB, RS, VOFF, STEPBYTES, 2 * tp + 2)      /* (taps 20, 21: beyond the descriptor's range -- no traffic) */ \
-                if (P_ == 27) GF_W_ISSUE(RB, NB, RS, VOFF, STEPBYTES, 2 * tp + 3)                                              \
+                /* a k-step's fragments are re-requested for two taps on as soon as its 7 pairs are done: 3 k-steps (21 pairs) of lead */ \
+                if (P_ == 6) GF_W_ISSUE_H(RA[0], NB, RS, VOFF, STEPBYTES, 4 * tp + 4)  /* (taps 20, 21: beyond the descriptor's range -- no traffic) */ \
+                if (P_ == 13) GF_W_ISSUE_H(RA[1], NB, RS, VOFF, STEPBYTES, 4 * tp + 5)                                         \
+                if (P_ == 20) GF_W_ISSUE_H(RB[0], NB, RS, VOFF, STEPBYTES, 4 * tp + 6)                                         \
+                if (P_ == 27) GF_W_ISSUE_H(RB[1], NB, RS, VOFF, STEPBYTES, 4 * tp + 7)                                         \
+                __builtin_amdgcn_sched_barrier(0);                                                                             \
             }                                                                                                                  \
         }                                                                                                                      \
     }
 #define GF_STAMP(k_)                                                                                                           \
     if constexpr (GF_ABL & 16) {                                                                                               \
-        if (p.dbg && wave == 0 && lane == 0) p.dbg[(int64_t)tile * 8 + (k_)] = __builtin_amdgcn_s_memtime();                  \
+        if (p.dbg && wave == 0 && lane == 0)                                                                                   \
+            p.dbg[(int64_t)tile * 8 + (k_)] = ((k_) == 0 ? ((unsigned long long)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xFFFF) << 48) | ((unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF) << 44) : 0ull) | (__builtin_amdgcn_s_memtime() & 0xFFFFFFFFFFFull); \
     }
 
     int tile = (int)blockIdx.x;
@@ -464,7 +476,10 @@ int launch_gru_half(int n_img, int H, int W, int vert, void* hb, void* hlo, cons
     const int lds = 4 * p.img_bytes;
     static DeviceOnce attr;
     VTGB_FUNC_LDS_ONCE(attr, gru_half_kernel, 4 * GF_MAX_IMG);
-    const int grid = p.n_tiles < 2 * cu_count() ? p.n_tiles : 2 * cu_count();      // two workgroups per CU: one's memory phases under the other's k-loops
+#ifndef GF_WG_PER_CU
+#define GF_WG_PER_CU 2
+#endif
+    const int grid = p.n_tiles < GF_WG_PER_CU * cu_count() ? p.n_tiles : GF_WG_PER_CU * cu_count();      // two workgroups per CU: one's memory phases under the other's k-loops
     const double M = (double)n_img * H * W;
     ProfScope prof(VTGB_PROF_CONV, 2.0 * M * 384.0 * (5 * 384), s, 2.0 * M * 384.0 * (5 * 256));
     hipLaunchKernelGGL(gru_half_kernel, dim3(grid), dim3(256), lds, s, p);
