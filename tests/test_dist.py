@@ -73,6 +73,70 @@ def test_two_rank_clip_sharding_and_grad_allreduce():
     assert w0 == w1 == 3.0 and b0 == b1 == 30.0                         # sum over ranks, one flat collective
 
 
+def _uneven_worker(rank, world, port, q):
+    """Rank 1's LAST layer (= the first segments in reverse order) receives no gradient; a parameter's hook fires twice on rank 0."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from videotgb_amd import dist as vd
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 4))
+    bucket = vd.FlatGradBucket(net.parameters(), segment_bytes=128)
+    x = torch.full((2, 8), float(rank + 1))
+    bucket.zero_()
+    bucket.arm(average=False)
+    order = []
+    orig = bucket._launch
+    bucket._launch = lambda si: (order.append(si), orig(si))[1]
+    if rank == 0:
+        net(x).sum().backward()
+        bucket._on_grad(net[2].bias)                                 # a second firing of an already counted hook: must not launch anything early
+    else:
+        h = net[1](net[0](x))                                            # the last layer takes no part on this rank: its gradients stay zero
+        h.sum().backward()
+    bucket.all_reduce(average=False)
+    # expected sums, computed locally
+    ref = [torch.zeros_like(p) for p in net.parameters()]
+    for r_ in range(world):
+        net2 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 4))
+        net2.load_state_dict(net.state_dict())
+        xx = torch.full((2, 8), float(r_ + 1))
+        (net2(xx).sum() if r_ == 0 else net2[1](net2[0](xx)).sum()).backward()
+        for g, p in zip(ref, net2.parameters()):
+            if p.grad is not None:
+                g += p.grad
+    ok = all(torch.allclose(p.grad, g, rtol=1e-6, atol=1e-6) for p, g in zip(net.parameters(), ref))
+    q.put((rank, ok, order, len(bucket.segments)))
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_launches_segments_in_index_order_on_every_rank():
+    """Round-3 ADVICE: collectives pair by issue order -- a rank with a gradient-less parameter must issue the same sequence."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (_, ok0, o0, n0), (_, ok1, o1, n1) = out
+    assert ok0 and ok1
+    assert n0 == n1 and n0 > 2 and o0 == o1 == list(range(n0))           # same sequence on both ranks, every segment exactly once
+
+
+def test_flat_bucket_rejects_non_fp32_parameters_and_disagreeing_average():
+    from videotgb_amd import dist as vd
+    lin = torch.nn.Linear(4, 4).to(torch.bfloat16)
+    with pytest.raises(TypeError, match="fp32"):
+        vd.FlatGradBucket(lin.parameters())
+    b = vd.FlatGradBucket(torch.nn.Linear(4, 4).parameters())
+    b.arm(average=True)
+    with pytest.raises(ValueError, match="disagree"):
+        b.all_reduce(average=False)
+
+
 def test_split_list_matches_reference_semantics():
     from videotgb_amd.dist import get_chunk, split_list
     assert split_list(list(range(10)), 4) == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9]]

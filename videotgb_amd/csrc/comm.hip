@@ -19,6 +19,7 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    char why[256] = {0};      // why RCCL could not be used (the failing dlopen's dlerror(), or the missing symbols)
 };
 Rccl g_rccl;
 std::once_flag g_once;
@@ -29,7 +30,13 @@ void load_rccl() {
         g_rccl.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         if (g_rccl.h) break;
     }
-    for (int i = 0; !g_rccl.h && i < 3; i++) g_rccl.h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    for (int i = 0; !g_rccl.h && i < 3; i++) {
+        g_rccl.h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!g_rccl.h) {      // dlerror() clears itself when read: capture the reason of THIS failure now
+            const char* e = dlerror();
+            snprintf(g_rccl.why, sizeof(g_rccl.why), "%s", e ? e : "dlopen failed");
+        }
+    }
     if (!g_rccl.h) return;
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.h, "ncclCommInitRank");
@@ -37,10 +44,11 @@ void load_rccl() {
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(g_rccl.h, "ncclAllReduce");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.h, "ncclGetErrorString");
     g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce && g_rccl.GetErrorString;
+    if (!g_rccl.ok) snprintf(g_rccl.why, sizeof(g_rccl.why), "the library lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce / ncclGetErrorString");
 }
 int need_rccl() {
     std::call_once(g_once, load_rccl);
-    VTGB_REQUIRE(g_rccl.ok, VTGB_EUNSUPPORTED, "RCCL is not available in this process (librccl.so not found: %s)", dlerror() ? dlerror() : "missing symbols");
+    VTGB_REQUIRE(g_rccl.ok, VTGB_EUNSUPPORTED, "RCCL is not available in this process (%s)", g_rccl.why[0] ? g_rccl.why : "librccl.so not found");
     return VTGB_OK;
 }
 }   // namespace

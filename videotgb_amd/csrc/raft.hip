@@ -301,6 +301,29 @@ __global__ __launch_bounds__(256) void raft_flow_head2_kernel(const float* __res
     }
 }
 
+// The same sum with the taps gathered straight from global memory (the form of rounds 1-2): images whose 18 x H8 x W8 floats do not fit
+// the LDS image (> 2275 coarse pixels, e.g. 384 x 384 frames).  Same taps in the same order: the same flow bit for bit.
+__global__ __launch_bounds__(256) void raft_flow_head2_gather_kernel(const float* __restrict__ P, const float* __restrict__ b, float* __restrict__ flow,
+                                                                     int64_t M, int H8, int W8) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int HW = H8 * W8, pix = (int)(m % HW), y = pix / W8, x = pix - y * W8;
+    float a0 = b[0], a1 = b[1];
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        if ((unsigned)(y + dy) < (unsigned)H8 && (unsigned)(x + dx) < (unsigned)W8) {
+            const float2 v = *reinterpret_cast<const float2*>(P + (m + dy * W8 + dx) * 32 + tap * 2);
+            a0 += v.x;
+            a1 += v.y;
+        }
+    }
+    float2* f = reinterpret_cast<float2*>(flow + m * 2);
+    float2 o = *f;
+    o.x += a0; o.y += a1;
+    *f = o;
+}
+
 // upsample_flow (xraft.py:88-99): softmax over the 9 mask logits of each fine pixel, convex combination of
 // the 3x3 neighbourhood of 8 * flow (zero padded unfold).  mask [M, 576] fp32 with channel = k*64 + sy*8 + sx.
 __global__ void raft_upsample_kernel(const float* __restrict__ flow, const float* __restrict__ mask, float* __restrict__ up, int64_t n_img,
@@ -445,8 +468,11 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     auto E = [es](char* p, int64_t elems) { return (void*)(p + elems * (int64_t)es); };   // element offset into an activation buffer
     const dim3 lk_grid((unsigned)((M + 4 * CL_PIX - 1) / (4 * CL_PIX)));
     const size_t fh2_lds = (size_t)18 * HW * sizeof(float);
-    VTGB_REQUIRE(fh2_lds <= 160 * 1024, VTGB_EUNSUPPORTED, "raft_update: %d x %d coarse pixels per image exceed the flow head's LDS image", H8, W8);
-    VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_flow_head2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fh2_lds));
+    const bool fh2_in_lds = fh2_lds <= 160 * 1024;      // else: the global-gather form (any image size, as in rounds 1-2)
+    if (fh2_in_lds) {
+        static DeviceOnce fh2_attr;
+        VTGB_FUNC_LDS_ONCE(fh2_attr, raft_flow_head2_kernel, 160 * 1024);
+    }
     if (hoist) {
         // start maps = bias + conv(inp): X[:, 0:128] holds relu(cnet[:, 128:]) (raft_init_kernel); same taps as the GRU halves
         for (int half = 0; half < 2; half++) {
@@ -527,7 +553,8 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
             d.algo_flops = 2.0 * Mi * 256.0 * (9 * 128) + 2.0 * Mi * 32.0 * 256.0;
             VTGB_TRY(launch_conv_gemm(d, s));
         }
-        hipLaunchKernelGGL(raft_flow_head2_kernel, dim3((unsigned)a->n_pairs), dim3(256), fh2_lds, s, P2, F(w[21]), flow, M, H8, W8);
+        if (fh2_in_lds) hipLaunchKernelGGL(raft_flow_head2_kernel, dim3((unsigned)a->n_pairs), dim3(256), fh2_lds, s, P2, F(w[21]), flow, M, H8, W8);
+        else hipLaunchKernelGGL(raft_flow_head2_gather_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, P2, F(w[21]), flow, M, H8, W8);
     }
     // ---- mask head of the last iteration (update.py:129-132,143) and convex upsample (xraft.py:88-99)
     VTGB_TRY(launch_conv_gemm(conv_desc(dt, Mi, 256, H8, W8, 3, 3, 128, 128, hb, 128, nullptr, 0, w[22], F(w[23]), VTGB_EPI_STORE, 1, FH, 256, zero), s));

@@ -43,6 +43,13 @@ def _rot_half(x: Tensor) -> Tensor:
     return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
 
 
+def weights_key(lm):
+    """(in-place version, storage address) of every parameter: the decoders hold re-packed COPIES of the language model's weights
+    (concatenated q|k|v, tiled decode weights, captured graphs), so an optimizer step, a load_state_dict or a `.data` swap on
+    the model must retire the decoder (round-3 ADVICE) -- models.generate compares this key before every use."""
+    return tuple((p._version, p.data_ptr()) for p in lm.parameters())
+
+
 class GreedyDecoder:
     MAX_STATES = 4
 
@@ -51,6 +58,7 @@ class GreedyDecoder:
         if "llama" not in cfg.model_type:
             raise NotImplementedError("GreedyDecoder handles Llama-architecture models; use HF generate otherwise")
         self.lm, self.cfg = lm, cfg
+        self.key = weights_key(lm)
         self.nh, self.nkv = cfg.num_attention_heads, cfg.num_key_value_heads
         self.hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
         self.eps = cfg.rms_norm_eps
@@ -366,6 +374,7 @@ class T5GreedyDecoder:
         if getattr(cfg, "model_type", "") != "t5":
             raise NotImplementedError("T5GreedyDecoder handles T5ForConditionalGeneration")
         self.lm, self.cfg = lm, cfg
+        self.key = weights_key(lm)
         self.H, self.dk, self.D = cfg.num_heads, cfg.d_kv, cfg.d_model
         self.eps = cfg.layer_norm_epsilon
         self.start = cfg.decoder_start_token_id if cfg.decoder_start_token_id is not None else cfg.pad_token_id
@@ -525,7 +534,7 @@ def graph_generate(owner, lm, inputs_embeds: Tensor, attention_mask: Tensor, gen
         return None
     try:
         dec = getattr(owner, "_graph_decoder", None)
-        if dec is None or dec.lm is not lm:
+        if dec is None or dec.lm is not lm or dec.key != weights_key(lm):
             dec = owner._graph_decoder = make_decoder(lm)
     except NotImplementedError:
         return None

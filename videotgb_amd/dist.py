@@ -104,10 +104,19 @@ class FlatGradBucket:
       whose gradients are to be exchanged (the last micro-batch of an accumulation window): post-accumulate-grad hooks count a
       segment's parameters and launch its all-reduce on a side stream (RCCL through the C ABI when ``comm`` is given, else
       ``torch.distributed`` with ``async_op``) under the remaining backward.  ``all_reduce()`` launches what is left (segments
-      holding parameters that received no gradient) and waits."""
+      holding parameters that received no gradient) and waits.
+    * Collectives are matched across ranks by ISSUE ORDER, so segments are always launched in index order: segment s goes out
+      only once segments 0..s-1 have (a later segment that completes first stays pending), and ``all_reduce()`` flushes the
+      rest in index order.  A rank on which some parameter got no gradient this step (the Q-Former when every clip of the rank
+      has width 0) therefore issues the same sequence as its peers, just later.  Readiness is a SET of parameter ids per
+      segment: a hook that fires twice (a second backward, a tied weight under re-entrant checkpointing) cannot launch early."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], segment_bytes: int = 64 << 20, comm: "RcclComm" = None):
         self.params = [p for p in params if p.requires_grad]
+        bad = [tuple(p.shape) for p in self.params if p.dtype != torch.float32]
+        if bad:      # p.grad = <fp32 view> would raise "assigned grad has data of a different type" deep inside _attach
+            raise TypeError(f"FlatGradBucket: trainable parameters must be fp32 (the bucket is one flat fp32 buffer); got {len(bad)} "
+                            f"non-fp32 parameter(s), first shape {bad[0]} -- keep LoRA / prefix stages in fp32 or cast their master copy")
         sizes = [p.numel() for p in self.params]
         n = sum(sizes)
         dev = self.params[0].device if self.params else torch.device("cpu")
@@ -134,8 +143,9 @@ class FlatGradBucket:
                 self._seg_of[k] = si
         self._index = {id(p): k for k, p in enumerate(self.params)}
         self._armed = False
-        self._ready = [0] * len(self.segments)
+        self._ready = [set() for _ in self.segments]
         self._launched = [False] * len(self.segments)
+        self._next = 0                                   # segments [0, _next) have been launched
         self._works = []
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._average = True
@@ -161,8 +171,9 @@ class FlatGradBucket:
     def arm(self, average: bool = True) -> None:
         """The next backward's gradients are final: start each segment's all-reduce as soon as its parameters have theirs."""
         self._armed, self._average = True, average
-        self._ready = [0] * len(self.segments)
+        self._ready = [set() for _ in self.segments]
         self._launched = [False] * len(self.segments)
+        self._next = 0
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         if not self._armed:
@@ -175,10 +186,18 @@ class FlatGradBucket:
             v.copy_(p.grad)
             p.grad = v
         si = self._seg_of[k]
-        self._ready[si] += 1
+        self._ready[si].add(k)
+        self._launch_ready()
+
+    def _complete(self, si: int) -> bool:
         lo, hi = self.segments[si]
-        if self._ready[si] == hi - lo and not self._launched[si]:
-            self._launch(si)
+        return len(self._ready[si]) == hi - lo
+
+    def _launch_ready(self) -> None:
+        """Launch, in index order, every complete segment whose predecessors have all been launched."""
+        while self._next < len(self.segments) and self._complete(self._next):
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, si: int) -> None:
         self._launched[si] = True
@@ -200,10 +219,13 @@ class FlatGradBucket:
         received no gradient this step), wait for all of them; ``flat`` then holds the sum (mean) over the ranks."""
         if not self._armed:
             self.arm(average)
+        elif average != self._average:
+            raise ValueError(f"FlatGradBucket: arm(average={self._average}) and all_reduce(average={average}) disagree "
+                             "(segments already in flight were launched with the armed value)")
         self._attach()
-        for si in range(len(self.segments)):
-            if not self._launched[si]:
-                self._launch(si)
+        for si in range(self._next, len(self.segments)):      # what the hooks did not launch, in index order
+            self._launch(si)
+        self._next = len(self.segments)
         rank, world = rank_world()
         if self.comm is not None:
             torch.cuda.current_stream(self.flat.device).wait_stream(self._side)

@@ -82,15 +82,16 @@ class _Stage(nn.Module):
         self._table_cache = None
         self._table_key = None
 
-    # The packed (bf16) weight table is a cache of the parameters: keyed on their in-place version counters, so an optimizer
-    # step (Lightning's or anyone's) invalidates it and nothing else does -- no per-forward repack, no stale table in
-    # validation_step after a training step (round-2 ADVICE).
+    # The packed (bf16) weight table is a cache of the parameters: keyed on (in-place version counter, storage address) of EVERY
+    # parameter and buffer, trainable or frozen -- an optimizer step, a parent's load_state_dict (nn.Module calls the child's
+    # _load_from_state_dict, not its load_state_dict), Lightning restoring a checkpoint, or `param.data = ...` all invalidate it
+    # and nothing else does: no per-forward repack, no stale table (round-2 / round-3 ADVICE).  A tuple compare per forward.
     def _versions(self):
-        return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        return tuple((p._version, p.data_ptr()) for p in self.parameters()) + tuple((b._version, b.data_ptr()) for b in self.buffers())
 
     @property
     def _table(self):
-        if self._table_cache is not None and self._trainable() and self._versions() != self._table_key:
+        if self._table_cache is not None and self._versions() != self._table_key:
             self._table_cache = None
         return self._table_cache
 
@@ -547,16 +548,16 @@ class _LSTPBase(nn.Module):
         inputs_embeds = torch.cat([lm_inputs, inputs_embeds.to(lm_dtype)], dim=1)
         if fast_decode and not do_sample and stopping_criteria is None and bool((attention_mask != 0).all()):
             # greedy, unpadded: hipGraph-replayed decode of the same HF weights (videotgb_amd/decode.py)
-            from .decode import make_decoder
-            if getattr(self, "_decoder", None) is None or self._decoder.lm is not lm:
+            from .decode import make_decoder, weights_key
+            if getattr(self, "_decoder", None) is None or self._decoder.lm is not lm or self._decoder.key != weights_key(lm):
                 self._decoder = make_decoder(lm)      # Llama (causal) or T5 (seq2seq, LSTP_blip2)
             gc = getattr(lm, "generation_config", None)     # HF generate's defaults (eos / pad from the generation config)
-            outputs = self._decoder.generate(inputs_embeds, max_new_tokens,
-                                             eos_token_id=gen_kwargs.pop("eos_token_id", getattr(gc, "eos_token_id", None)),
-                                             pad_token_id=gen_kwargs.pop("pad_token_id", getattr(gc, "pad_token_id", None)),
-                                             min_new_tokens=gen_kwargs.pop("min_new_tokens", 0))
-            if gen_kwargs:      # (nothing is dropped silently: what the graph decoder does not implement must go through HF generate)
+            eos = gen_kwargs.pop("eos_token_id", getattr(gc, "eos_token_id", None))
+            pad = gen_kwargs.pop("pad_token_id", getattr(gc, "pad_token_id", None))
+            min_new = gen_kwargs.pop("min_new_tokens", 0)
+            if gen_kwargs:      # (nothing is dropped silently -- and nothing is decoded first: what the graph decoder does not implement must go through HF generate)
                 raise TypeError(f"generate(fast_decode=True) does not take {sorted(gen_kwargs)}; call with fast_decode=False")
+            outputs = self._decoder.generate(inputs_embeds, max_new_tokens, eos_token_id=eos, pad_token_id=pad, min_new_tokens=min_new)
         else:
             outputs = lm.generate(inputs_embeds=inputs_embeds, attention_mask=attention_mask, do_sample=do_sample,
                                   temperature=temperature, max_new_tokens=max_new_tokens, use_cache=use_cache,
