@@ -31,7 +31,8 @@ extern "C" {
 
 typedef struct ihipStream_t* vtgb_stream_t; /* == hipStream_t */
 
-#define VTGB_VERSION 300 /* round 3: stem weight hi|lo layout; vtgb_attention_args.causal; vtgb_gemm_skinny without workspace when unsplit;
+#define VTGB_VERSION 400 /* round 4: vtgb_llm_attention_rows / vtgb_llm_gated_act (the T5 language model of the BLIP-2 flavours on own kernels:
+                            eval/utils/model.py:427-437), vtgb_llm_rope_cache with NULL tables = plain cache append; 300 = round 3: stem weight hi|lo layout; vtgb_attention_args.causal; vtgb_gemm_skinny without workspace when unsplit;
                             vtgb_llm_rope_cache_prefill; vtgb_attn_train_forward / backward; vtgb_comm_* / vtgb_allreduce_f32 */
 
 #define VTGB_OK 0
@@ -414,7 +415,7 @@ int vtgb_raft_encoder(const vtgb_raft_encoder_args* a, vtgb_stream_t stream);
  * activation dtype (VTGB_BF16 / VTGB_F32); `pos` is a DEVICE int64 (current position), so one
  * captured hipGraph serves every step.
  *   vtgb_llm_rmsnorm:          x[rows,H] (+= delta, written back if delta != NULL); h = w * norm(x)
- *   vtgb_llm_rope_cache:       qkv[B, nq+2nkv, hd] -> q_out[B,nq,hd] rotated; K/V cache [B,nkv,tmax,hd] row *pos
+ *   vtgb_llm_rope_cache:       qkv[B, nq+2nkv, hd] -> q_out[B,nq,hd] rotated; K/V cache [B,nkv,tmax,hd] row *pos (cos_t = sin_t = NULL: no rotary)
  *   vtgb_llm_rope_cache_prefill: qkv[B, S, (nq+2nkv)*hd]: q and k of every position rotated IN PLACE, k / v copied to cache rows 0..S-1
  *   vtgb_llm_decode_attention: out[B, nq*hd] = softmax(scale q K[0..*pos]^T) V[0..*pos]
  *   vtgb_llm_silu_mul:         act[rows, I] = silu(gu[:, :I]) * gu[:, I:]                       */
@@ -427,6 +428,28 @@ int vtgb_llm_rope_cache_prefill(int dtype, void* qkv, void* kc, void* vc, const 
 int vtgb_llm_decode_attention(int dtype, const void* q, const void* kc, const void* vc, void* out, const int64_t* pos, int32_t B,
                               int32_t nq, int32_t nkv, int32_t hd, int32_t tmax, float scale, vtgb_stream_t stream);
 int vtgb_llm_silu_mul(int dtype, const void* gu, void* act, int64_t rows, int32_t I, vtgb_stream_t stream);
+
+/* The seq2seq language model of the BLIP-2 flavours (Flan-T5 under `language_model.generate`: eval/utils/model.py:427-437,
+ * src/models/components/xblip2.py:1553-1556) with transformers' modeling_t5 arithmetic: T5LayerNorm = vtgb_llm_rmsnorm (no mean, no
+ * bias), projections = vtgb_gemm / vtgb_gemm_skinny, cache append = vtgb_llm_rope_cache with cos_t = sin_t = NULL, and
+ *   vtgb_llm_attention_rows: out[r, h, :] = softmax_k(scale q[r, h] . k[b, h, key] + bias[qpos, h, key]) v[b, h, key, :] over independent
+ *     query rows r (b = r / rows_per_batch).  Keys [0, n_keys), or [0, *pos] with bias row *pos when `pos` (a DEVICE int64) is given --
+ *     the decoder's self-attention over its static cache; pos == NULL: query position r % rows_per_batch -- the encoder's
+ *     self-attention (rows = B x P, token-major q|k|v) and the decoder's cross-attention (bias NULL).  All strides in elements;
+ *     heads are `head_dim` apart in q / out; `bias` has the activation dtype; scores and weights are rounded to it where HF does
+ *     (softmax itself in fp32).  t_pad >= the largest key count (sizes the kernel's score buffer).
+ *   vtgb_llm_gated_act: act[r, i] = f(gu[r, i]) (* gu[r, I + i] if gated); kind 0 SiLU, 1 gelu_new (Flan-T5's gated-gelu), 2 ReLU, 3 erf-GELU */
+typedef struct {
+    int32_t dtype, rows, heads, head_dim, rows_per_batch, n_keys, t_pad;
+    float scale;
+    const void* q;   int64_t q_row;
+    const void* k;   const void* v;   int64_t kv_batch, kv_head, kv_tok;
+    const void* bias; int64_t bias_pos, bias_head;
+    const int64_t* pos;
+    void* out;       int64_t o_row;
+} vtgb_llm_attn_rows_args;
+int vtgb_llm_attention_rows(const vtgb_llm_attn_rows_args* a, vtgb_stream_t stream);
+int vtgb_llm_gated_act(int dtype, const void* gu, void* act, int64_t rows, int32_t I, int32_t kind, int32_t gated, vtgb_stream_t stream);
 
 /* Skinny GEMM of the decode step: out[M, N] = x[M, K] . w[N, K]^T, bf16 operands, M <= 128 (one token per
  * clip), K a multiple of 64 -- what `F.linear(h, weight)` (hipBLASLt) computes under `language_model.generate`

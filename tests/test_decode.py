@@ -180,19 +180,77 @@ def test_t5_greedy_decoder_hipgraph_matches_hf_generate_gpu():
 
 
 @pytest.mark.gpu
-def test_bf16_generate_issues_no_blas_kernel():
-    """SURVEY.md 8f-2 at bf16: prefill, decode steps and the first-token logits run on libvtgb.so -- the profiler sees no hipBLASLt /
-    rocBLAS (Tensile `Cijk_*`) kernel during GreedyDecoder.generate, eager or graph-replayed, at a batch of the throughput path's kind."""
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_t5_generate_runs_on_libvtgb_and_issues_no_blas_kernel(dtype):
+    """SURVEY.md 8f-2, the T5 half (C1 / C2: Flan-T5 under language_model.generate, eval/utils/model.py:427-437): encoder, cross-attention
+    K / V, every decoder step and the lm_head run on libvtgb.so -- vtgb_gemm / vtgb_gemm_skinny, vtgb_llm_rmsnorm (T5LayerNorm),
+    vtgb_llm_attention_rows (relative position bias), vtgb_llm_gated_act (gated-gelu) -- no hipBLASLt / rocBLAS kernel in the profile,
+    eager or graph-replayed.  fp32: ids equal HF generate's, id for id; bf16: the first generated token (before two bf16 arithmetics
+    can part at a near tie) and the encoder output within bf16 rounding."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from torch.profiler import ProfilerActivity, profile
+    from transformers import T5Config, T5ForConditionalGeneration
+    from videotgb_amd.decode import T5GreedyDecoder
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    cfg = T5Config(vocab_size=320, d_model=256, d_kv=64, d_ff=512, num_layers=2, num_decoder_layers=2, num_heads=4, feed_forward_proj="gated-gelu",
+                   tie_word_embeddings=False, decoder_start_token_id=0, pad_token_id=0, eos_token_id=1)
+    lm = T5ForConditionalGeneration(cfg).eval()
+    for p in lm.parameters():
+        p.data.normal_(0, 0.05)
+    for n, p in lm.named_parameters():
+        if "layer_norm" in n:
+            p.data.fill_(1.0)
+    lm = lm.to(device=dev, dtype=dtype)
+    B, P, N = 6, 21, 5
+    emb = (torch.randn(B, P, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(4)) * 0.5).to(dtype)
+    mask = torch.ones(B, P, dtype=torch.long, device=dev)
+    dec = T5GreedyDecoder(lm)
+    ref = lm.generate(inputs_embeds=emb, attention_mask=mask, do_sample=False, max_new_tokens=N, min_new_tokens=N)
+    out = dec.generate(emb, N, eos_token_id=1, pad_token_id=0, min_new_tokens=N)      # (captures the graph outside the profile; HF masks EOS below min_new_tokens)
+    if dtype == torch.float32:
+        assert out.tolist() == ref.tolist()
+    else:
+        assert out[:, :2].tolist() == ref[:, :2].tolist()
+    with torch.no_grad():
+        enc_ref = lm.encoder(inputs_embeds=emb, attention_mask=mask).last_hidden_state.float().reshape(B * P, -1)
+        enc = dec._encode_hip(emb).float()
+    tol = 2e-4 if dtype == torch.float32 else 5e-2      # bf16: a few ulps of the output scale (two orders of rounding; observed 3.2e-2)
+    assert (enc - enc_ref).abs().max().item() <= tol * max(1.0, enc_ref.abs().max().item())
+    for use_graph in (False, True):
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            dec.generate(emb, N, use_graph=use_graph)
+            torch.cuda.synchronize()
+        names = {e.key for e in prof.key_averages()}
+        blas = sorted(n for n in names if "Cijk_" in n or "rocblas" in n.lower() or "hipblaslt" in n.lower())
+        assert not blas, blas
+        if not use_graph:
+            assert any("llm_attn_rows" in n for n in names) and any("llm_gated_act" in n for n in names) and any("llm_rmsnorm" in n for n in names), sorted(names)[:40]
+            assert any(("gemm_skinny" in n) if dtype == torch.bfloat16 else ("gemm_f32" in n) for n in names), sorted(names)[:40]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,kv_heads", [(torch.bfloat16, 4), (torch.float32, 4), (torch.float32, 2)])
+def test_generate_issues_no_blas_kernel(dtype, kv_heads):
+    """prefill, decode steps and the first-token logits run on libvtgb.so -- the profiler sees no hipBLASLt /
+    rocBLAS (Tensile `Cijk_*`) kernel during GreedyDecoder.generate, eager or graph-replayed, at a batch of the throughput path's kind.
+    bf16 = the throughput mode; fp32 = the exactness mode whose ids are compared token for token with HF generate (round 4: on
+    vtgb_gemm's fp32 kernel, the fp32 attention and the vtgb_llm_* kernels; grouped-query heads included) -- ids checked here too."""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     from torch.profiler import ProfilerActivity, profile
     from videotgb_amd import llm
     from videotgb_amd.decode import GreedyDecoder
     dev = "cuda:0"
-    lm = llm.build_llama("tiny", torch.bfloat16, dev, seed=9, hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=4,
+    lm = llm.build_llama("tiny", dtype, dev, seed=9, hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=kv_heads,
                          num_hidden_layers=2, vocab_size=320)
-    emb = (torch.randn(12, 20, 512, device=dev) * 0.5).bfloat16()
+    emb = (torch.randn(12, 20, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(4)) * 0.5).to(dtype)
     dec = GreedyDecoder(lm)
+    if dtype == torch.float32:
+        ref = lm.generate(inputs_embeds=emb, attention_mask=torch.ones(12, 20, dtype=torch.long, device=dev), do_sample=False, max_new_tokens=4,
+                          min_new_tokens=4, use_cache=True)
+        assert dec.generate(emb, 4, eos_token_id=2, pad_token_id=0, min_new_tokens=4).tolist() == ref.tolist()      # (HF masks EOS below min_new_tokens)
     dec.generate(emb, 4)                                   # capture outside the profile
     for use_graph in (False, True):
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
@@ -202,7 +260,10 @@ def test_bf16_generate_issues_no_blas_kernel():
         blas = sorted(n for n in names if n.startswith("Cijk_") or "Cijk_" in n or "rocblas" in n.lower() or "hipblaslt" in n.lower())
         assert not blas, blas
         if not use_graph:                                  # (graph replays show up as one launch; the eager run names the kernels)
-            assert any("gemm_skinny" in n for n in names) and any("gemm_bf16" in n for n in names) and any("attn_bf16" in n for n in names), sorted(names)[:40]
+            if dtype == torch.bfloat16:
+                assert any("gemm_skinny" in n for n in names) and any("gemm_bf16" in n for n in names) and any("attn_bf16" in n for n in names), sorted(names)[:40]
+            else:
+                assert any("gemm_f32" in n for n in names) and any("attn_f32" in n for n in names) and any("llm_decode_attn" in n for n in names), sorted(names)[:40]
 
 
 @pytest.mark.gpu

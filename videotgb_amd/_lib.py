@@ -28,6 +28,7 @@ EXPORTS = [
     "vtgb_pool_project", "vtgb_tgb_workspace_bytes", "vtgb_tgb_forward", "vtgb_gemm", "vtgb_attention",
     "vtgb_layernorm", "vtgb_prof_enable", "vtgb_prof_reset", "vtgb_prof_summary", "vtgb_prof_executed_flops",
     "vtgb_llm_rmsnorm", "vtgb_llm_rope_cache", "vtgb_llm_rope_cache_prefill", "vtgb_llm_decode_attention", "vtgb_llm_silu_mul",
+    "vtgb_llm_attention_rows", "vtgb_llm_gated_act",
     "vtgb_gemm_skinny_workspace_bytes", "vtgb_gemm_skinny", "vtgb_pack_skinny_weight_bytes", "vtgb_pack_skinny_weight",
     "vtgb_raft_update_workspace_bytes", "vtgb_raft_update", "vtgb_raft_encoder_workspace_bytes", "vtgb_raft_encoder",
     "vtgb_raft_corr_workspace_bytes", "vtgb_raft_corr", "vtgb_preprocess_frames", "vtgb_concat_text_io", "vtgb_shifted_ce_forward", "vtgb_shifted_ce_backward",
@@ -139,6 +140,12 @@ class AttentionArgs(C.Structure):
                 ("out_tok_stride", i64), ("out_batch_stride", i64), ("causal", i32)]
 
 
+class LlmAttnRowsArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("rows", i32), ("heads", i32), ("head_dim", i32), ("rows_per_batch", i32), ("n_keys", i32), ("t_pad", i32),
+                ("scale", f32), ("q", vp), ("q_row", i64), ("k", vp), ("v", vp), ("kv_batch", i64), ("kv_head", i64), ("kv_tok", i64),
+                ("bias", vp), ("bias_pos", i64), ("bias_head", i64), ("pos", vp), ("out", vp), ("o_row", i64)]
+
+
 class LayerNormArgs(C.Structure):
     _fields_ = [("dtype", i32), ("M", i32), ("D", i32), ("eps", f32), ("x", vp), ("gamma", vp), ("beta", vp),
                 ("out_f32", vp), ("out_act", vp)]
@@ -189,6 +196,10 @@ def lib() -> C.CDLL:
     L.vtgb_llm_rope_cache_prefill.argtypes = [C.c_int, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.vtgb_llm_decode_attention.argtypes = [C.c_int, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]
     L.vtgb_llm_silu_mul.argtypes = [C.c_int, vp, vp, i64, i32, vp]
+    L.vtgb_llm_attention_rows.argtypes = [C.POINTER(LlmAttnRowsArgs), vp]
+    L.vtgb_llm_attention_rows.restype = C.c_int
+    L.vtgb_llm_gated_act.argtypes = [C.c_int, vp, vp, i64, i32, i32, i32, vp]
+    L.vtgb_llm_gated_act.restype = C.c_int
     L.vtgb_gemm_skinny.argtypes = [C.POINTER(GemmSkinnyArgs), vp]
     L.vtgb_gemm_skinny.restype = C.c_int
     L.vtgb_gemm_skinny_workspace_bytes.argtypes = [C.POINTER(GemmSkinnyArgs)]

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(128) void llm_rope_cache_kernel(const T* __restrict
     for (int d = threadIdx.x; d < hd; d += blockDim.x) {
         const float v = (float)src[d];
         float outv = v;
-        if (head < nq + nkv) {
+        if (head < nq + nkv && cos_t) {      // (cos_t == NULL: no rotary -- T5's decoder: q passed through, k / v appended)
             const float c = (float)cos_t[pos * hd + d], sn = (float)sin_t[pos * hd + d];
             const float rot = d < half ? -(float)src[d + half] : (float)src[d - half];
             const float pa = Cvt<T>::rnd(v * c), pb = Cvt<T>::rnd(rot * sn);      // (contract(off): the reference's three roundings, no FMA)
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void llm_rope_cache_prefill_kernel(T* __restri
 
 extern "C" int vtgb_llm_rope_cache(int dtype, const void* qkv, void* q_out, void* kc, void* vc, const void* cos_t, const void* sin_t,
                                    const int64_t* pos, int32_t B, int32_t nq, int32_t nkv, int32_t hd, int32_t tmax, vtgb_stream_t s) {
-    VTGB_REQUIRE(qkv && q_out && kc && vc && cos_t && sin_t && pos && B > 0 && nq > 0 && nkv > 0 && (hd % 2) == 0, VTGB_EINVAL, "llm_rope_cache: bad argument");
+    VTGB_REQUIRE(qkv && q_out && kc && vc && ((cos_t == nullptr) == (sin_t == nullptr)) && pos && B > 0 && nq > 0 && nkv > 0 && (hd % 2) == 0, VTGB_EINVAL, "llm_rope_cache: bad argument");
     const dim3 grid(nq + 2 * nkv, B);
     if (dtype == VTGB_BF16)
         hipLaunchKernelGGL(llm_rope_cache_kernel<bf16_t>, grid, dim3(128), 0, s, (const bf16_t*)qkv, (bf16_t*)q_out, (bf16_t*)kc, (bf16_t*)vc,
@@ -283,6 +283,108 @@ extern "C" int vtgb_llm_silu_mul(int dtype, const void* gu, void* act, int64_t r
         hipLaunchKernelGGL(llm_silu_mul_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)gu, (bf16_t*)act, rows, I);
     else
         hipLaunchKernelGGL(llm_silu_mul_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)gu, (float*)act, rows, I);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+// ---- attention of independent query rows over strided K / V with an additive per-(query position, head, key) bias: the T5 language
+// model of the BLIP-2 flavours (transformers' modeling_t5: unscaled scores + bucketed relative position bias, softmax in fp32).  One
+// wave per (row, head), 4 per workgroup.  Row r belongs to K/V batch r / rows_per_batch and query position r % rows_per_batch; it sees
+// keys [0, n_keys) -- n_keys fixed, or *pos + 1 (decode step over a static cache, bias row *pos).  Covers the decoder's self-attention
+// (rows_per_batch 1, cache [B, H, N, dk], bias), its cross-attention (fixed n_keys = encoder length, no bias) and the ENCODER's
+// self-attention (rows = B x P straight out of the q|k|v projection: token-major strides, bias row = query position).
+template <typename T>
+__global__ __launch_bounds__(256) void llm_attn_rows_kernel(const vtgb_llm_attn_rows_args a) {
+    extern __shared__ float dsm[];   // per wave: hd floats of q + t_pad scores
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hd = a.head_dim, nq = a.heads;
+    const int64_t idx = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t total = (int64_t)a.rows * nq;
+    const int64_t id = idx < total ? idx : total - 1;
+    const int64_t r = id / nq;
+    const int head = (int)(id - r * nq);
+    const int64_t b = r / a.rows_per_batch;
+    const int qpos = a.pos ? (int)(*a.pos) : (int)(r - b * a.rows_per_batch);
+    const int n_keys = a.pos ? (int)(*a.pos) + 1 : a.n_keys;
+    float* qs = dsm + wave * (hd + a.t_pad);
+    float* sc = qs + hd;
+    const T* qr = reinterpret_cast<const T*>(a.q) + r * a.q_row + (int64_t)head * hd;
+    const T* kr = reinterpret_cast<const T*>(a.k) + b * a.kv_batch + (int64_t)head * a.kv_head;
+    const T* vr = reinterpret_cast<const T*>(a.v) + b * a.kv_batch + (int64_t)head * a.kv_head;
+    const T* br = a.bias ? reinterpret_cast<const T*>(a.bias) + (int64_t)qpos * a.bias_pos + (int64_t)head * a.bias_head : nullptr;
+    for (int d = lane; d < hd; d += 64) qs[d] = (float)qr[d];
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int key = lane; key < n_keys; key += 64) {
+        const T* k = kr + (int64_t)key * a.kv_tok;
+        float dot = 0.f;
+        for (int d = 0; d < hd; d++) dot = fmaf(qs[d], (float)k[d], dot);
+        dot = Cvt<T>::rnd(dot * a.scale);                    // HF: scores in the model's dtype ...
+        if (br) dot = Cvt<T>::rnd(dot + (float)br[key]);     // ... += position_bias, softmax in fp32
+        sc[key] = dot;
+        mx = fmaxf(mx, dot);
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.f;
+    for (int key = lane; key < n_keys; key += 64) {
+        const float e = expf(sc[key] - mx);
+        sc[key] = e;
+        sum += e;
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    if (idx < total) {
+        T* o = reinterpret_cast<T*>(a.out) + r * a.o_row + (int64_t)head * hd;
+        for (int d = lane; d < hd; d += 64) {
+            float acc = 0.f;
+            for (int key = 0; key < n_keys; key++) acc = fmaf(Cvt<T>::rnd(sc[key] * inv), (float)vr[(int64_t)key * a.kv_tok + d], acc);      // (weights as the model's dtype holds them)
+            o[d] = Cvt<T>::to(acc);
+        }
+    }
+}
+
+extern "C" int vtgb_llm_attention_rows(const vtgb_llm_attn_rows_args* a, vtgb_stream_t s) {
+    VTGB_REQUIRE(a && a->q && a->k && a->v && a->out && a->rows > 0 && a->heads > 0 && a->head_dim > 0 && a->rows_per_batch > 0, VTGB_EINVAL,
+                 "llm_attention_rows: bad argument");
+    VTGB_REQUIRE(a->pos || a->n_keys > 0, VTGB_EINVAL, "llm_attention_rows: n_keys or pos");
+    VTGB_REQUIRE(a->t_pad >= (a->pos ? 1 : a->n_keys) && a->t_pad <= DEC_MAX_T && a->head_dim <= 256, VTGB_EUNSUPPORTED,
+                 "llm_attention_rows: t_pad=%d head_dim=%d outside [n_keys .. %d], <= 256", a->t_pad, a->head_dim, DEC_MAX_T);
+    const size_t lds = 4 * (size_t)(a->head_dim + a->t_pad) * sizeof(float);
+    const dim3 grid((unsigned)(((int64_t)a->rows * a->heads + 3) / 4));
+    if (a->dtype == VTGB_BF16) hipLaunchKernelGGL(llm_attn_rows_kernel<bf16_t>, grid, dim3(256), lds, s, *a);
+    else hipLaunchKernelGGL(llm_attn_rows_kernel<float>, grid, dim3(256), lds, s, *a);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+// ---- feed-forward activations of the language models: act[r, i] = f(gu[r, i]) (* gu[r, I + i] when gated).  kind 0 SiLU (Llama's SwiGLU = vtgb_llm_silu_mul),
+// 1 gelu_new (T5 v1.1 / Flan-T5 "gated-gelu": 0.5 x (1 + tanh(sqrt(2 / pi) (x + 0.044715 x^3)))), 2 ReLU (original T5), 3 exact GELU.
+template <typename T>
+__global__ void llm_gated_act_kernel(const T* __restrict__ gu, T* __restrict__ act, int64_t rows, int I, int kind, int gated) {
+    const int64_t n = rows * I;
+    const int ld = gated ? 2 * I : I;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / I, c = i - r * I;
+        const float g = (float)gu[r * ld + c];
+        float f;
+        if (kind == 0) f = g / (1.0f + expf(-g));
+        else if (kind == 1) f = 0.5f * g * (1.0f + tanhf(0.7978845608028654f * (g + 0.044715f * g * g * g)));
+        else if (kind == 2) f = fmaxf(g, 0.f);
+        else f = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+        f = Cvt<T>::rnd(f);
+        act[i] = gated ? Cvt<T>::to(f * (float)gu[r * ld + I + c]) : Cvt<T>::to(f);
+    }
+}
+
+extern "C" int vtgb_llm_gated_act(int dtype, const void* gu, void* act, int64_t rows, int32_t I, int32_t kind, int32_t gated, vtgb_stream_t s) {
+    VTGB_REQUIRE(gu && act && rows > 0 && I > 0 && kind >= 0 && kind <= 3, VTGB_EINVAL, "llm_gated_act: bad argument");
+    int64_t blocks = (rows * I + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == VTGB_BF16)
+        hipLaunchKernelGGL(llm_gated_act_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)gu, (bf16_t*)act, rows, I, kind, gated);
+    else
+        hipLaunchKernelGGL(llm_gated_act_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)gu, (float*)act, rows, I, kind, gated);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }

@@ -20,7 +20,7 @@ Greedy ids are checked token-for-token against HF generate at fp32 (tests/test_d
 """
 from __future__ import annotations
 
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -122,14 +122,20 @@ class GreedyDecoder:
         gu = F.linear(h, wgu)
         return x + F.linear(F.silu(gu[..., : self.inter]) * gu[..., self.inter:], wd)
 
-    # Prefill on libvtgb.so (bf16): the four projections of a layer through the persistent MFMA GEMM (vtgb_gemm; M = B*P rows), the
-    # causal attention through vtgb_attention (head_dim 128, whole K/V of a head in LDS), RMSNorm(+residual) and SwiGLU through
-    # the vtgb_llm_* kernels of the decode step -- no BLAS library call is left on the f2 path at the throughput batch.  fp32
-    # (the mode whose ids are compared token-for-token with HF generate) keeps the reference's own BLAS/SDPA arithmetic.
+    # Prefill on libvtgb.so: the four projections of a layer through vtgb_gemm (bf16: the persistent MFMA kernel, M = B*P rows; fp32:
+    # the FMA kernel), the causal attention through vtgb_attention (bf16: head_dim <= 128, whole K/V of a head in LDS; fp32: the
+    # exactness kernel), RMSNorm(+residual), rotary + cache fill and SwiGLU through the vtgb_llm_* kernels of the decode step -- no
+    # BLAS library call is left on the f2 path, in either dtype (round 4: the fp32 mode, whose ids are compared token for token with
+    # HF generate, runs on libvtgb.so too; grouped-query models repeat K / V heads for the attention call).
     PREFILL_MAX_TOKENS = 288
+    PREFILL_MAX_TOKENS_F32 = 1024
 
     def _use_hip_prefill(self, x: Tensor, P: int) -> bool:
-        return (self.fused and x.is_cuda and x.dtype == torch.bfloat16 and self.nq_eq_nkv and P <= self.PREFILL_MAX_TOKENS
+        if not (self.fused and x.is_cuda):
+            return False
+        if x.dtype == torch.float32:
+            return P <= self.PREFILL_MAX_TOKENS_F32 and self.hd % 2 == 0 and self.hd <= 128
+        return (x.dtype == torch.bfloat16 and self.nq_eq_nkv and P <= self.PREFILL_MAX_TOKENS
                 and self.hd % 16 == 0 and self.hd <= 128 and self.cfg.hidden_size % 64 == 0 and self.inter % 64 == 0)
 
     @property
@@ -143,25 +149,30 @@ class GreedyDecoder:
         lib = L.lib()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         B, _, H = x.shape
-        nh, hd, M = self.nh, self.hd, B * P
+        nh, nkv, hd, M = self.nh, self.nkv, self.hd, B * P
+        code = L.BF16 if x.dtype == torch.bfloat16 else L.F32
         x = x.reshape(M, H).clone()
         h = torch.empty_like(x)
         act = torch.empty(M, self.inter, dtype=x.dtype, device=x.device)
         delta = None
         for li, (ln1, wqkv, wo, ln2, wgu, wd) in enumerate(self.layers):
-            L.check(lib.vtgb_llm_rmsnorm(L.BF16, x.data_ptr(), None if delta is None else delta.data_ptr(), ln1.data_ptr(), h.data_ptr(),
+            L.check(lib.vtgb_llm_rmsnorm(code, x.data_ptr(), None if delta is None else delta.data_ptr(), ln1.data_ptr(), h.data_ptr(),
                                          M, H, self.eps, stream))
-            qkv = ops.gemm(h, wqkv).view(B, P, 3 * nh, hd)
-            # rotary on q and k in place + k / v into the cache rows 0 .. P-1: one launch (HF's bf16 roundings)
-            L.check(lib.vtgb_llm_rope_cache_prefill(L.BF16, qkv.data_ptr(), st["kc"][li].data_ptr(), st["vc"][li].data_ptr(), st["cos"].data_ptr(),
-                                                    st["sin"].data_ptr(), B, P, nh, nh, hd, st["tmax"], stream))
-            flat = qkv.view(B, P, 3 * nh * hd)
-            a = ops.attention(flat[:, :, : nh * hd], flat[:, :, nh * hd: 2 * nh * hd], flat[:, :, 2 * nh * hd:], nh, float(hd) ** -0.5,
-                              causal=True)
+            qkv = ops.gemm(h, wqkv).view(B, P, nh + 2 * nkv, hd)
+            # rotary on q and k in place + k / v into the cache rows 0 .. P-1: one launch (HF's roundings in the model's dtype)
+            L.check(lib.vtgb_llm_rope_cache_prefill(code, qkv.data_ptr(), st["kc"][li].data_ptr(), st["vc"][li].data_ptr(), st["cos"].data_ptr(),
+                                                    st["sin"].data_ptr(), B, P, nh, nkv, hd, st["tmax"], stream))
+            flat = qkv.view(B, P, (nh + 2 * nkv) * hd)
+            q_, k_, v_ = flat[:, :, : nh * hd], flat[:, :, nh * hd: (nh + nkv) * hd], flat[:, :, (nh + nkv) * hd:]
+            if nkv != nh:      # grouped-query attention: every K / V head serves nh / nkv query heads (a copy; the kernel takes equal head counts)
+                rep = nh // nkv
+                k_ = k_.reshape(B, P, nkv, 1, hd).expand(B, P, nkv, rep, hd).reshape(B, P, nh * hd)
+                v_ = v_.reshape(B, P, nkv, 1, hd).expand(B, P, nkv, rep, hd).reshape(B, P, nh * hd)
+            a = ops.attention(q_, k_, v_, nh, float(hd) ** -0.5, causal=True)
             o = ops.gemm(a.view(M, nh * hd), wo)
-            L.check(lib.vtgb_llm_rmsnorm(L.BF16, x.data_ptr(), o.data_ptr(), ln2.data_ptr(), h.data_ptr(), M, H, self.eps, stream))
+            L.check(lib.vtgb_llm_rmsnorm(code, x.data_ptr(), o.data_ptr(), ln2.data_ptr(), h.data_ptr(), M, H, self.eps, stream))
             gu = ops.gemm(h, wgu)
-            L.check(lib.vtgb_llm_silu_mul(L.BF16, gu.data_ptr(), act.data_ptr(), M, self.inter, stream))
+            L.check(lib.vtgb_llm_silu_mul(code, gu.data_ptr(), act.data_ptr(), M, self.inter, stream))
             delta = ops.gemm(act, wd)
         last = (x.view(B, P, H)[:, -1] + delta.view(B, P, H)[:, -1])
         return last
@@ -171,7 +182,14 @@ class GreedyDecoder:
         if h.is_cuda and h.dim() == 2 and self._use_skinny(h.shape[0], h.dtype):
             from . import ops
             return ops.gemm_skinny(h.contiguous(), self._skinny_weights()[-1])      # the first token's logits: same kernel as the decode step's
+        if h.is_cuda and h.dim() == 2 and self.fused and h.dtype in (torch.float32, torch.bfloat16) and self._gemm_ok(h.dtype):
+            from . import ops
+            return ops.gemm(h.contiguous(), self.lm.lm_head.weight)                 # fp32 (exactness mode) / batches beyond the skinny kernel: vtgb_gemm
         return F.linear(h, self.lm.lm_head.weight)
+
+    def _gemm_ok(self, dtype) -> bool:
+        """vtgb_gemm takes these projections: any shape at fp32; bf16 needs 8-aligned rows."""
+        return dtype == torch.float32 or (self.cfg.hidden_size % 8 == 0 and self.inter % 8 == 0 and (self.nh * self.hd) % 8 == 0)
 
     def _state(self, B: int, P: int, N: int, device, dtype, eos=None, pad=0, min_new=0):
         # The cache length is bucketed (multiples of 64) and the true prompt length is device data (`pos`): an eval loop over real
@@ -235,6 +253,11 @@ class GreedyDecoder:
 
             def lin(xin, li, which, buf):      # which: 0 qkv, 1 o, 2 gate|up, 3 down
                 return ops.gemm_skinny(xin, sw[li][which], out=st[buf], workspace=ws)
+        elif self._gemm_ok(x.dtype):
+            from . import ops
+
+            def lin(xin, li, which, buf):      # fp32 (exactness mode) and batches beyond the skinny kernel: libvtgb.so's own GEMM, no BLAS
+                return ops.gemm(xin, self.layers[li][(1, 2, 4, 5)[which]])
         else:
             def lin(xin, li, which, buf):
                 return F.linear(xin, self.layers[li][(1, 2, 4, 5)[which]])
@@ -255,6 +278,8 @@ class GreedyDecoder:
                                      self.eps, stream))
         if skinny:
             self._emit(st, ops.gemm_skinny(h, sw[-1], out=st["sk_logits"], workspace=ws))
+        elif self._gemm_ok(x.dtype):
+            self._emit(st, ops.gemm(h, self.lm.lm_head.weight))
         else:
             self._emit(st, F.linear(h, self.lm.lm_head.weight))
 
@@ -369,7 +394,9 @@ class T5GreedyDecoder:
     ``decoder_start_token_id``.  Scope: greedy, all-ones encoder mask."""
     MAX_STATES = 4
 
-    def __init__(self, lm):
+    _ACT_KIND = {"silu": 0, "swish": 0, "gelu_new": 1, "relu": 2, "gelu": 3}
+
+    def __init__(self, lm, fused: bool = True):
         cfg = lm.config
         if getattr(cfg, "model_type", "") != "t5":
             raise NotImplementedError("T5GreedyDecoder handles T5ForConditionalGeneration")
@@ -378,20 +405,134 @@ class T5GreedyDecoder:
         self.H, self.dk, self.D = cfg.num_heads, cfg.d_kv, cfg.d_model
         self.eps = cfg.layer_norm_epsilon
         self.start = cfg.decoder_start_token_id if cfg.decoder_start_token_id is not None else cfg.pad_token_id
+        self.act_kind = self._ACT_KIND.get(getattr(cfg, "dense_act_fn", None))
         self.layers = []
         for blk in lm.decoder.block:
             sa, ca, ff = blk.layer[0].SelfAttention, blk.layer[1].EncDecAttention, blk.layer[2].DenseReluDense
             wqkv = torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], dim=0).contiguous()
             gated = hasattr(ff, "wi_0")
             wi = torch.cat([ff.wi_0.weight, ff.wi_1.weight], dim=0).contiguous() if gated else ff.wi.weight
+            ckv = torch.cat([ca.k.weight, ca.v.weight], dim=0).contiguous()
             self.layers.append(dict(ln0=blk.layer[0].layer_norm.weight, wqkv=wqkv, wo=sa.o.weight, ln1=blk.layer[1].layer_norm.weight,
-                                    cq=ca.q.weight, ck=ca.k.weight, cv=ca.v.weight, co=ca.o.weight, ln2=blk.layer[2].layer_norm.weight,
+                                    cq=ca.q.weight, ck=ca.k.weight, cv=ca.v.weight, ckv=ckv, co=ca.o.weight, ln2=blk.layer[2].layer_norm.weight,
                                     wi=wi, wff=ff.wo.weight, act=ff.act, gated=gated))
+        # the ENCODER's layers (round 4: prefix || prompt are encoded on libvtgb.so too -- rounds 2-3 called HF's module)
+        self.enc_layers = []
+        for blk in lm.encoder.block:
+            sa, ff = blk.layer[0].SelfAttention, blk.layer[1].DenseReluDense
+            gated = hasattr(ff, "wi_0")
+            self.enc_layers.append(dict(ln0=blk.layer[0].layer_norm.weight, wqkv=torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], dim=0).contiguous(),
+                                        wo=sa.o.weight, ln1=blk.layer[1].layer_norm.weight,
+                                        wi=torch.cat([ff.wi_0.weight, ff.wi_1.weight], dim=0).contiguous() if gated else ff.wi.weight,
+                                        wff=ff.wo.weight, gated=gated))
         sa0 = lm.decoder.block[0].layer[0].SelfAttention
         self.scaling = float(getattr(sa0, "scaling", 1.0) or 1.0)
         self.bias_module = sa0
+        self.enc_bias_module = lm.encoder.block[0].layer[0].SelfAttention
         self.scale_out = bool(getattr(cfg, "scale_decoder_outputs", getattr(cfg, "tie_word_embeddings", False)))
+        self.fused = fused
         self.graphs: Dict[tuple, dict] = {}
+        self._sk: Dict[int, object] = {}          # id(weight) -> its tiled copy for vtgb_gemm_skinny (built on first use)
+
+    # ---- libvtgb.so building blocks (round 4: no torch.matmul / F.linear / F.softmax left in the T5 path on the device; the arithmetic is
+    # transformers' modeling_t5 with its rounding points: T5LayerNorm = vtgb_llm_rmsnorm, unscaled scores + relative bias, fp32 softmax)
+    MAX_KEYS = 2048
+
+    def _hip(self, x: Tensor) -> bool:
+        return (self.fused and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and self.act_kind is not None
+                and (x.dtype == torch.float32 or (self.D % 8 == 0 and (self.H * self.dk) % 8 == 0 and self.cfg.d_ff % 8 == 0)))
+
+    def _lin(self, x: Tensor, w: Tensor, ws: Optional[Tensor] = None) -> Tensor:
+        """x [M, K] @ w[N, K]^T on libvtgb.so: the weight-streaming skinny GEMM for a decode step's rows (bf16, M <= 128, K % 64 == 0), else vtgb_gemm."""
+        from . import ops
+        M, K = x.shape
+        if x.dtype == torch.bfloat16 and M <= 128 and K % 64 == 0:
+            sk = self._sk.get(id(w))
+            if sk is None:
+                sk = self._sk[id(w)] = ops.SkinnyWeight(w)
+            return ops.gemm_skinny(x, sk, workspace=ws)
+        return ops.gemm(x, w)
+
+    def _rms(self, x: Tensor, delta: Optional[Tensor], w: Tensor, h: Tensor) -> None:
+        import ctypes as C
+        from . import _lib as L
+        code = L.BF16 if x.dtype == torch.bfloat16 else L.F32
+        L.check(L.lib().vtgb_llm_rmsnorm(code, x.data_ptr(), None if delta is None else delta.data_ptr(), w.data_ptr(), h.data_ptr(), x.shape[0], x.shape[1],
+                                         self.eps, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def _attn_rows(self, q: Tensor, q_row: int, k: Tensor, v: Tensor, kv_strides, rows: int, rows_per_batch: int, n_keys: int, t_pad: int,
+                   bias: Optional[Tensor], bias_strides, pos: Optional[Tensor]) -> Tensor:
+        import ctypes as C
+        from . import _lib as L
+        out = torch.empty(rows, self.H * self.dk, dtype=q.dtype, device=q.device)
+        a = L.LlmAttnRowsArgs(L.BF16 if q.dtype == torch.bfloat16 else L.F32, rows, self.H, self.dk, rows_per_batch, n_keys, t_pad, self.scaling,
+                              q.data_ptr(), q_row, k.data_ptr(), v.data_ptr(), kv_strides[0], kv_strides[1], kv_strides[2],
+                              None if bias is None else bias.data_ptr(), bias_strides[0], bias_strides[1], None if pos is None else pos.data_ptr(),
+                              out.data_ptr(), self.H * self.dk)
+        L.check(L.lib().vtgb_llm_attention_rows(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
+
+    def _ffn(self, h: Tensor, w: dict, ws: Optional[Tensor] = None) -> Tensor:
+        import ctypes as C
+        from . import _lib as L
+        gu = self._lin(h, w["wi"], ws)
+        I = gu.shape[1] // 2 if w["gated"] else gu.shape[1]
+        act = torch.empty(h.shape[0], I, dtype=h.dtype, device=h.device)
+        L.check(L.lib().vtgb_llm_gated_act(L.BF16 if h.dtype == torch.bfloat16 else L.F32, gu.data_ptr(), act.data_ptr(), h.shape[0], I, self.act_kind,
+                                           1 if w["gated"] else 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return self._lin(act, w["wff"], ws)
+
+    def _encode_hip(self, inputs_embeds: Tensor) -> Tensor:
+        """T5Stack (encoder) on libvtgb.so: [B, P, D] -> last_hidden_state [B * P, D] (all-ones mask; bias of block 0 shared by every block)."""
+        B, P, D = inputs_embeds.shape
+        HD = self.H * self.dk
+        x = inputs_embeds.reshape(B * P, D).clone()
+        h = torch.empty_like(x)
+        with torch.no_grad():
+            bias = self.enc_bias_module.compute_bias(P, P, device=x.device)[0].to(x.dtype).contiguous()      # [H, P (query), P (key)]
+        delta = None
+        for w in self.enc_layers:
+            self._rms(x, delta, w["ln0"], h)
+            qkv = self._lin(h, w["wqkv"])                                                                    # [B P, 3 H dk], token-major
+            a = self._attn_rows(qkv, 3 * HD, qkv[:, HD:], qkv[:, 2 * HD:], (P * 3 * HD, self.dk, 3 * HD), B * P, P, P, P, bias, (P, P * P), None)
+            o = self._lin(a, w["wo"])
+            self._rms(x, o, w["ln1"], h)
+            delta = self._ffn(h, w)
+        enc = torch.empty_like(x)
+        self._rms(x, delta, self.lm.encoder.final_layer_norm.weight, enc)
+        return enc
+
+    def _decode_step_hip(self, st):
+        """One token for every sequence on libvtgb.so (captured): per layer 6 projections (skinny GEMM), T5 norm x 3, cache append,
+        self-attention over the static cache with the relative bias row of *pos, cross-attention over the projected encoder states, gated act."""
+        import ctypes as C
+        from . import _lib as L
+        lib, lm = L.lib(), self.lm
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        B, H, dk, N, P = st["tok"].shape[0], self.H, self.dk, st["N"], st["P"]
+        HD = H * dk
+        x, h, q = st["x"], st["h"], st["q"]
+        x.copy_(lm.decoder.embed_tokens(st["tok"]))
+        code = L.BF16 if x.dtype == torch.bfloat16 else L.F32
+        ws, pos = st.get("sk_ws"), st["pos"]
+        delta = None
+        for li, w in enumerate(self.layers):
+            self._rms(x, delta, w["ln0"], h)
+            qkv = self._lin(h, w["wqkv"], ws)                                                                # [B, 3 H dk] = [B, (q | k | v heads), dk]
+            L.check(lib.vtgb_llm_rope_cache(code, qkv.data_ptr(), q.data_ptr(), st["kc"][li].data_ptr(), st["vc"][li].data_ptr(), None, None,
+                                            pos.data_ptr(), B, H, H, dk, N, stream))                         # (no rotary: cache append)
+            a = self._attn_rows(q, HD, st["kc"][li], st["vc"][li], (H * N * dk, N * dk, dk), B, 1, 0, N, st["rel"], (N, N * N), pos)
+            o = self._lin(a, w["wo"], ws)
+            self._rms(x, o, w["ln1"], h)
+            cq = self._lin(h, w["cq"], ws)
+            ckv = st["ckv"][li]                                                                              # [B P, 2 H dk]: k | v of the encoder states
+            a = self._attn_rows(cq, HD, ckv, ckv[:, HD:], (P * 2 * HD, dk, 2 * HD), B, 1, P, P, None, (0, 0), None)
+            o = self._lin(a, w["co"], ws)
+            self._rms(x, o, w["ln2"], h)
+            delta = self._ffn(h, w, ws)
+        self._rms(x, delta, lm.decoder.final_layer_norm.weight, h)
+        hh = h * (self.D ** -0.5) if self.scale_out else h
+        self._emit(st, self._lin(hh, lm.lm_head.weight, ws))
 
     _pick = GreedyDecoder._pick
     _emit = GreedyDecoder._emit
@@ -415,7 +556,9 @@ class T5GreedyDecoder:
                 bias = self.bias_module.compute_bias(N, N, device=device)[0].permute(1, 0, 2).contiguous().to(dtype)      # [N (query), H, N (key)]
             ar = torch.arange(N, device=device)
             causal = torch.where(ar[None, :] <= ar[:, None], 0.0, torch.finfo(dtype).min).to(dtype)                      # [N, N]
-            st = dict(bias=bias + causal[:, None, :],
+            st = dict(bias=bias + causal[:, None, :], rel=bias.permute(1, 0, 2).contiguous(), N=N, P=P,      # rel [H, N (query), N (key)]: the kernel's layout (causality = its key range)
+                      x=torch.zeros(B, self.D, device=device, dtype=dtype), h=torch.zeros(B, self.D, device=device, dtype=dtype),
+                      q=torch.zeros(B, H * dk, device=device, dtype=dtype), ckv=[None] * L,
                       kc=[torch.zeros(B, H, N, dk, device=device, dtype=dtype) for _ in range(L)],
                       vc=[torch.zeros(B, H, N, dk, device=device, dtype=dtype) for _ in range(L)],
                       ck=[torch.zeros(B, H, P, dk, device=device, dtype=dtype) for _ in range(L)],
@@ -423,11 +566,20 @@ class T5GreedyDecoder:
                       tok=torch.zeros(B, dtype=torch.long, device=device), pos=torch.zeros(1, dtype=torch.long, device=device),
                       step=torch.zeros(1, dtype=torch.long, device=device), out=torch.zeros(B, N, dtype=torch.long, device=device),
                       fin=torch.zeros(B, dtype=torch.bool, device=device), graph=None, eos=eos, pad=pad, min_new=min_new)
+            if device.type == "cuda" and dtype == torch.bfloat16 and self.fused and B <= 128:
+                from . import ops
+                shapes = [(3 * H * dk, self.D), (self.D, H * dk), (H * dk, self.D), (self.layers[0]["wi"].shape[0], self.D), (self.D, self.cfg.d_ff),
+                          (self.lm.lm_head.weight.shape[0], self.D)]
+                need = max([ops.gemm_skinny_workspace_bytes(B, n, k) for n, k in shapes if k % 64 == 0] + [0])
+                if need:
+                    st["sk_ws"] = torch.zeros(need, dtype=torch.uint8, device=device)
         self.graphs[key] = st
         return st
 
     def _decode_step(self, st):
         """One token for every sequence, entirely on the device (captured): `tok` at decoder position `pos` -> next token."""
+        if self._hip(st["x"]):
+            return self._decode_step_hip(st)
         lm = self.lm
         B, H, dk = st["tok"].shape[0], self.H, self.dk
         x = lm.decoder.embed_tokens(st["tok"])                                                   # [B, D]
@@ -472,10 +624,15 @@ class T5GreedyDecoder:
                 raise NotImplementedError("T5GreedyDecoder: one eos_token_id")
             eos_token_id = eos_token_id[0]
         st = self._state(B, P, N, dev, dt, eos_token_id, int(pad_token_id if pad_token_id is not None else 0), int(min_new_tokens or 0))
-        enc = self.lm.encoder(inputs_embeds=inputs_embeds, attention_mask=torch.ones(B, P, dtype=torch.long, device=dev)).last_hidden_state
-        for li, w in enumerate(self.layers):
-            st["ck"][li].copy_(F.linear(enc, w["ck"]).view(B, P, self.H, self.dk).transpose(1, 2))
-            st["cv"][li].copy_(F.linear(enc, w["cv"]).view(B, P, self.H, self.dk).transpose(1, 2))
+        if self._hip(inputs_embeds) and P <= self.MAX_KEYS and N <= self.MAX_KEYS:
+            enc = self._encode_hip(inputs_embeds)                                   # [B P, D]
+            for li, w in enumerate(self.layers):
+                st["ckv"][li] = self._lin(enc, w["ckv"])                           # cross-attention K | V of every decoder layer, once: [B P, 2 H dk]
+        else:
+            enc = self.lm.encoder(inputs_embeds=inputs_embeds, attention_mask=torch.ones(B, P, dtype=torch.long, device=dev)).last_hidden_state
+            for li, w in enumerate(self.layers):
+                st["ck"][li].copy_(F.linear(enc, w["ck"]).view(B, P, self.H, self.dk).transpose(1, 2))
+                st["cv"][li].copy_(F.linear(enc, w["cv"]).view(B, P, self.H, self.dk).transpose(1, 2))
         st["fin"].zero_()
         st["out"].fill_(st["pad"] if eos_token_id is not None else 0)
         st["tok"].fill_(self.start)
