@@ -74,14 +74,19 @@ __device__ __forceinline__ int gf_swz(int slot, int chunk) { return slot * 128 +
 
 // a, b rounded (nearest even) to bf16: one v_cvt_pk_bf16_f32; .x / .y are the rounded values as floats, .z the packed pair
 typedef __attribute__((ext_vector_type(2))) __bf16 gf_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float gf_f32x2;
 __device__ __forceinline__ unsigned gf_pack2(float a, float b) {
-    const gf_bf16x2 t = {(bf16_t)a, (bf16_t)b};      // (one v_cvt_pk_bf16_f32; the unpacking below works on the bits, so no excess precision survives)
+    const gf_f32x2 v = {a, b};
+    const gf_bf16x2 t = __builtin_convertvector(v, gf_bf16x2);      // (one v_cvt_pk_bf16_f32; the unpacking below works on the bits, so no excess precision survives)
     return __builtin_bit_cast(unsigned, t);
 }
 __device__ __forceinline__ float gf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float gf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 
 __device__ __forceinline__ float gf_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+// tanh for the candidate state: 1 - 2 / (exp(2x) + 1) on the hardware exp / rcp (gemm_dev.h's tanh_fast asks for the correctly rounded
+// reciprocal: a 10-instruction division sequence per value, a quarter of this kernel's update phase)
+__device__ __forceinline__ float gf_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v) + 1.0f); }
 
 // pixel index of (line gl of the batch, position pos in the line)
 __device__ __forceinline__ int gf_pixel(const GruHalfParams& p, int gl, int pos) {
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
                 const unsigned zz = zpk[j][e], hh = hpk[j][e], ll = lo_t[j][e];
                 const float za = gf_lo(zz), zb = gf_hi(zz);
                 const float ha = gf_lo(hh) + gf_lo(ll), hb_ = gf_hi(hh) + gf_hi(ll);
-                const float na = (1.0f - za) * ha + za * tanh_fast(acc2[bi][j][r0]), nb = (1.0f - zb) * hb_ + zb * tanh_fast(acc2[bi][j][r0 + 1]);
+                const float na = (1.0f - za) * ha + za * gf_tanh(acc2[bi][j][r0]), nb = (1.0f - zb) * hb_ + zb * gf_tanh(acc2[bi][j][r0 + 1]);
                 const unsigned hi2 = gf_pack2(na, nb);
                 hi_o[e] = hi2;
                 lo_o[e] = gf_pack2(na - gf_lo(hi2), nb - gf_hi(hi2));
