@@ -11,30 +11,38 @@
 // at 4.65 TB/s: HBM-bound), and each launch paid its own prologue / epilogue per tile.  Here:
 //
 //  * Whole LINES per tile.  A 1x5 convolution never crosses an image row, a 5x1 never an image column: a tile is NL whole
-//    lines (rows or columns, of any images) = up to 224 pixels = 14 MFMA row blocks, so r * h of the tile's own pixels is all
+//    lines (rows or columns, of any images) = up to 112 pixels = 7 MFMA row blocks, so r * h of the tile's own pixels is all
 //    the q convolution needs: no halo, no recomputation.
-//  * Tap reuse in LDS.  The tile's activations are staged ONCE: four 64-channel chunk images [slot][64 ch] (h0, h1, x0, x1),
-//    a line's pixels in consecutive 128-byte slots with two zero slots between lines (and in front of the first), so that tap
-//    d of pixel s is slot s + d -- zero padding is the image.  The fragments of all five taps are read from shifted
-//    addresses (16-byte chunks XOR-swizzled by (slot >> 1) & 7, computed per read on the vector unit under the MFMAs).
+//  * Tap reuse in LDS.  The tile's activations are staged ONCE (LDS-DMA): four 64-channel chunk images [slot][64 ch] (h0, h1, x0,
+//    x1), a line's pixels in consecutive 128-byte slots with two zero slots between lines (and in front of the first), so that
+//    tap d of pixel s is slot s + d -- zero padding is the image (out-of-range DMA lanes).  The fragments of all five taps are
+//    read from shifted addresses (16-byte chunks XOR-swizzled by (slot >> 1) & 7); the 35 (tap, row block) addresses of a lane
+//    live in a small LDS table built once per workgroup, a tap's eight entries are two ds_read_b128 a tap ahead.
 //  * Weights never touch LDS.  They are re-packed once per call in MFMA fragment order per (k-step, wave column, block): a
-//    wave loads its own fragments with fully coalesced 1 KiB buffer loads straight into a two-tap register ring
-//    (inline asm, hand-counted vmcnt), so the k-loops have NO barrier and no LDS-DMA: eight free-running waves, each
-//    alternating 7 fragment reads with 28 (z|r) or 14 (q) MFMAs.
+//    wave loads its own fragments with fully coalesced 1 KiB buffer loads straight into a four-k-step register ring
+//    (inline asm, hand-counted vmcnt, three k-steps of lead), so the k-loops have NO barrier and no LDS-DMA: free-running waves,
+//    each alternating one fragment read with 4 (z|r) or 2 (q) MFMAs, reads six pairs ahead of their MFMAs.
 //  * The half-step stays on the CU: after the z|r k-loop a wave holds z and r of its 112 pixels x 32 channels; z is kept
-//    (packed bf16, as rounds 1-3 stored it), r * h overwrites h IN PLACE in the h chunk images (h itself is kept in
-//    registers for the update), the q k-loop reads [x0, x1, rh0, rh1] from the same images, and the epilogue applies the
-//    GRU update.  The output-channel order of the packed weights is chosen so that a lane's two accumulator blocks are 8
-//    CONSECUTIVE channels of one pixel: every global access of the epilogues is a 16-byte access, 64 contiguous bytes per
-//    pixel and wave instruction, no staging.
+//    (packed bf16, as rounds 1-3 stored it), r * h overwrites h IN PLACE in the h chunk images, the q k-loop reads
+//    [x0, x1, rh0, rh1] from the same images, and the epilogue applies the GRU update.  The output-channel order of the packed
+//    weights is chosen so that a lane's two accumulator blocks are 8 CONSECUTIVE channels of one pixel: every global access of
+//    the epilogues is a 16-byte access, 64 contiguous bytes per pixel and wave instruction, no staging.
 //  * The hidden state is kept as a bf16 pair hi | lo (hi = bf16(h) is what every convolution consumes anyway, lo =
-//    bf16(h - hi): 16 significant bits) instead of an fp32 copy next to the bf16 one: 512 instead of 768 bytes written
-//    and 256 instead of 512 read per pixel and half-step.
-//  * Persistent workgroups (one per CU: the images take 124-148 KiB); the next tile's images are requested (LDS-DMA) as soon
-//    as the last fragment of this tile has been read, in front of the GRU update's stores.
+//    bf16(h - hi): 16 significant bits) instead of an fp32 copy next to the bf16 one.
+//  * Two persistent 4-wave workgroups per CU (74-78 KiB of LDS each): one's loads, gates and stores run beside the other's
+//    k-loops; the next tile's images are requested as soon as the last fragment of this tile has been read, in front of the
+//    GRU update's arithmetic and stores.
 //
-// HBM per pixel and half-step: 512 (h hi, x) + 768 (start maps) + 256 (lo) + 512 (hi', lo') = 2 KiB, against 3.8 KiB for the
+// HBM per pixel and half-step: 512 (h hi, x) + 768 (start maps) + 512 (hi, lo) + 512 (hi', lo') = 2.25 KiB, against 3.8 KiB for the
 // two launches; MFMA work unchanged (2 x 5 x 256 x 384 FLOP per pixel executed, 2 x 5 x 384 x 384 algorithmic).
+//
+// Measured (bench batch, 2.31 M pixels; profiles/r04_gru_*.log; tools/exp/gru_abl.sh builds timing-only ablations and in-kernel
+// phase stamps): 2.99 ms (two launches) -> 2.27 ms per half-step.  What the stamps showed on the way: a wave alone on its SIMD
+// is INSTRUCTION-ISSUE bound in this loop (~11 instructions per 4 MFMAs; 30 k cycles for 18 k cycles of MFMA), two workgroups
+// per CU recover 1.56 x in cycles but the chip then clocks 1.63 instead of 2.15 GHz; the W stream (8.6 KB per pixel out of L2)
+// and the per-CU fill rate of ~30 GB/s are the same as the implicit-GEMM kernel's (5 taps of A through the DMA path there,
+// weights through registers here); hipcc chaining an accumulator's two updates back to back cost 2 x on the k-loop; spilled
+// registers reloaded behind the image DMAs serialised the update phase; priorities and a half-tile stagger were zero-sum.
 #include <string.h>
 
 #include "common.h"
@@ -45,7 +53,7 @@ namespace {
 constexpr int GF_JF = 7;                       // MFMA row blocks per wave = per tile: 112 rows (four waves along the channels)
 constexpr int GF_ROWS = GF_JF * 16;
 constexpr int GF_WAVES = 4;
-constexpr int GF_MAX_IMG = 19 * 1024;          // bytes per chunk image (<= 152 slots): two workgroups (4 images each) share a CU's 160 KiB
+constexpr int GF_MAX_IMG = 17 * 1024;          // bytes per chunk image (<= 152 slots): two workgroups (4 images each) share a CU's 160 KiB
 constexpr unsigned GF_OOB = 0x80000000u;
 
 typedef __attribute__((__vector_size__(4 * sizeof(int)))) int gf_i32x4;
@@ -107,15 +115,26 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
     const int IMG = p.img_bytes, L2 = p.L + 2;
     const int rows_valid = p.NL * p.L;
 
-    // ---- per-lane row constants: row r = wm * 112 + j * 16 + fr of the tile -> (line, position) -> slot; rows beyond the tile's
-    // lines use the dummy slot (zeros; five zero slots around it)
-    int slot_j[GF_JF];
+    // ---- fragment address table in LDS, built once per workgroup: tbl[lane][tap t][row block j] = byte offset, inside a chunk image, of
+    // k-half 0 of this lane's fragment row of block j shifted by tap t - 2 (slot * 128 + swizzled 16-byte chunk of lane >> 4); k-half 1 is
+    // that offset ^ 64.  Rows beyond the tile's lines use the dummy slot (zeros; five zero slots around it).  The k-loops read a tap's
+    // eight entries with two ds_read_b128 (lane stride 160 B: conflict-free) instead of forming every address on the vector unit --
+    // a wave alone on its SIMD is issue-bound: 3.5 of the ~11 instructions per (row block, k-half) pair were address arithmetic.
+    char* const tbl = smem + 4 * IMG;
+    {
 #pragma unroll
-    for (int j = 0; j < GF_JF; j++) {
-        const int r = j * 16 + fr;
-        const int l = gf_div((uint32_t)r, p.divL_mul, p.divL_sh), pos = r - l * p.L;
-        slot_j[j] = r < rows_valid ? 2 + l * L2 + pos : 2 + p.NL * L2 + 2;
+        for (int j = 0; j < 8; j++) {
+            const int r = j * 16 + fr;
+            const int l = gf_div((uint32_t)r, p.divL_mul, p.divL_sh), pos = r - l * p.L;
+            const int slot = (j < GF_JF && r < rows_valid) ? 2 + l * L2 + pos : 2 + p.NL * L2 + 2;
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                const int sp = slot + t - 2;
+                if (wave == 0) *reinterpret_cast<int*>(tbl + lane * 160 + t * 32 + j * 4) = sp * 128 + ((((sp >> 1) ^ fg) & 7) << 4);
+            }
+        }
     }
+    const int tbl_lane = 4 * IMG + lane * 160;      // (byte offset of this lane's table rows)
     // ---- LDS-DMA pieces (8 slots x 128 B each): this wave stages pieces wave + 8 i of every image
     const int n_pieces = IMG >> 10;
     const gf_i32x4 wzr_rs = {__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)p.wzr), __builtin_amdgcn_readfirstlane((int)(((uint64_t)p.wzr >> 32) & 0xFFFFu)),
@@ -158,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
     // ---- weight ring: two taps (2 x 2 k-steps) of fragments in registers; loads are inline asm (hipcc would drain a ring it
     // cannot see through), waits are counted by hand: each tap is NB * 2 loads, issued in tap order
 #ifndef GF_ABL
-#define GF_ABL 0      /* timing-only variants (tools/exp/gru_abl.sh; results are WRONG by construction): 1 no weight loads, 2 no fragment reads, 4 no address arithmetic, 8 no MFMAs, 16 phase stamps */
+#define GF_ABL 0      /* timing-only variants (tools/exp/gru_abl.sh; results are WRONG by construction): 1 no weight loads, 2 no fragment reads, 4 no address arithmetic, 8 no MFMAs, 16 phase stamps, 32 no state stores, 64 no image DMA after the first tile */
 #endif
 #define GF_W_ISSUE_H(REGH, NB, RS, VOFF, STEPBYTES, step)      /* the NB fragments of k-step `step` (= 2 tap + k-half) */      \
     if constexpr (!(GF_ABL & 1)) {                                                                                             \
@@ -184,39 +203,47 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
         if constexpr (!(GF_ABL & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NB) : "memory");                             \
         _Pragma("unroll") for (int i_ = 0; i_ < NB; i_++) asm volatile("" : "+v"(REGH[i_]));                                   \
     }
-    // ---- k-loop: the 20 taps as 280 (row block, k-half) pairs, each one fragment read + NB MFMAs.  The reads run D - 1 pairs ahead of
-    // their MFMAs through a ring of D fragments (LDS latency under the wave's own MFMAs; a tap boundary is not a bubble), the address of a
-    // row block's k-half 0 is formed on the vector unit (5 operations) and k-half 1 is that address ^ 64.
-#define GF_FRAG_ADDR(tap_, j_, ROT)                                                                                            \
-    ({                                                                                                                         \
-        int s_ = slot_j[j_];                                                                                                   \
-        asm volatile("" : "+v"(s_));              /* (opaque: hipcc otherwise keeps 3-4 partial address terms per row block alive across the loop) */ \
-        const int c_ = (tap_) / 5, sp_ = s_ + ((tap_) - c_ * 5 - 2);                                                           \
-        (GF_ABL & 4) ? s_ * 128 : (((c_ > 3 ? 3 : c_) + ROT) & 3) * IMG + sp_ * 128 + ((((sp_ >> 1) ^ fg) & 7) << 4);          \
-    })
+    // ---- k-loop: the 20 taps as 280 (row block, k-half) pairs, each one fragment read + NB MFMAs.  Pair p of a tap: k-half p / 7, row
+    // block p % 7 -- the two updates of an accumulator block are 7 pairs apart (hipcc, left to itself, put them back to back with the
+    // accumulator renamed in between: every MFMA then waited out its predecessor's write-back, 32 cycles per MFMA measured); the order is
+    // pinned with sched_barrier.  The reads run D - 1 pairs ahead of their MFMAs through a ring of D fragments (LDS latency under the
+    // wave's own MFMAs; a tap boundary is not a bubble); a pair's address is one v_add / v_xad on its table entry (image base, ^ 64 for
+    // k-half 1); the table rows of a tap (two ds_read_b128) are requested a tap ahead.
+#define GF_TBL_LOAD(AT, tap_)                                                                                                  \
+    {                                                                                                                          \
+        const int t_ = (tap_) % 5;                                                                                             \
+        const char* const r_ = smem + tbl_lane + t_ * 32;                                                                      \
+        AT[0] = *reinterpret_cast<const gf_i32x4*>(r_);                                                                        \
+        AT[1] = *reinterpret_cast<const gf_i32x4*>(r_ + 16);                                                                   \
+    }
+#define GF_IMG_OFF(tap_, ROT) ((((((tap_) / 5) > 3 ? 3 : ((tap_) / 5)) + ROT) & 3) * IMG)
 #define GF_KLOOP(ACC, RA, RB, NB, D, RS, VOFF, STEPBYTES, ROT)                                                                 \
     {                                                                                                                          \
-        /* pair p of a tap: k-half p / 7, row block p % 7 -- the two updates of an accumulator block are 7 pairs apart (hipcc, left to */ \
-        /* itself, put them back to back with the accumulator renamed in between: every MFMA then waited out its predecessor's write-back, */ \
-        /* 32 cycles per MFMA measured); the order is pinned with sched_barrier */                                              \
         bf16x8 xr_[D];                                                                                                         \
-        int a_j_[GF_JF];                                                                                                       \
+        gf_i32x4 ata_[2], atb_[2];               /* table rows of the even / odd tap in flight: entries [j >> 2][j & 3] */      \
+        GF_TBL_LOAD(ata_, 0)                                                                                                   \
+        GF_TBL_LOAD(atb_, 1)                                                                                                   \
         _Pragma("unroll") for (int q_ = 0; q_ < D - 1; q_++) {                                                                 \
-            if (q_ < 7) a_j_[q_] = GF_FRAG_ADDR(0, q_, ROT);                                                                   \
-            if constexpr (GF_ABL & 2) asm volatile("" : "=v"(xr_[q_]) : "v"(a_j_[q_ % 7]));                                    \
-            else xr_[q_] = *reinterpret_cast<const bf16x8*>(smem + (a_j_[q_ % 7] ^ ((q_ / 7) * 64)));                          \
+            const int a_ = (GF_ABL & 4) ? 0 : (ata_[(q_ % 7) >> 2][(q_ % 7) & 3] ^ ((q_ / 7) * 64)) + GF_IMG_OFF(0, ROT);      \
+            if constexpr (GF_ABL & 2) asm volatile("" : "=v"(xr_[q_]) : "v"(a_));                                              \
+            else xr_[q_] = *reinterpret_cast<const bf16x8*>(smem + a_);                                                        \
         }                                                                                                                      \
         for (int tp = 0; tp < 10; tp++) {           /* taps 2 tp (ring entry RA), 2 tp + 1 (RB): chunk-major, tap-minor = the weights' K order */ \
+            const int ioa_ = GF_IMG_OFF(2 * tp, ROT), iob_ = GF_IMG_OFF(2 * tp + 1, ROT), ioc_ = GF_IMG_OFF(2 * tp + 2, ROT);  \
             _Pragma("unroll") for (int P_ = 0; P_ < 28; P_++) {                                                                \
                 if (P_ == 0) GF_W_WAIT_H(RA[0], NB)                                                                            \
                 if (P_ == 7) GF_W_WAIT_H(RA[1], NB)                                                                            \
                 if (P_ == 14) GF_W_WAIT_H(RB[0], NB)                                                                           \
                 if (P_ == 21) GF_W_WAIT_H(RB[1], NB)                                                                           \
+                /* the even tap's rows are last used by the prefetch of pair 13 (P_ = 13 - (D - 1)): re-request them for tap 2 tp + 2; the odd tap's after pair 27 */ \
+                if (P_ == 14 - (D - 1)) GF_TBL_LOAD(ata_, 2 * tp + 2)                                                          \
+                if (P_ == 28 - (D - 1)) GF_TBL_LOAD(atb_, 2 * tp + 3)                                                          \
                 {                                                                                                              \
-                    const int Q_ = P_ + D - 1, tapq_ = 2 * tp + Q_ / 14, pq_ = Q_ % 14;                                        \
-                    if (pq_ < 7) a_j_[pq_] = GF_FRAG_ADDR(tapq_, pq_, ROT);                                                    \
-                    if constexpr (GF_ABL & 2) asm volatile("" : "+v"(xr_[Q_ % D]) : "v"(a_j_[pq_ % 7]));                       \
-                    else xr_[Q_ % D] = *reinterpret_cast<const bf16x8*>(smem + (a_j_[pq_ % 7] ^ ((pq_ / 7) * 64)));            \
+                    const int Q_ = P_ + D - 1, pq_ = Q_ % 14;                                                                  \
+                    const int e_ = Q_ < 14 ? ata_[(pq_ % 7) >> 2][(pq_ % 7) & 3] : Q_ < 28 ? atb_[(pq_ % 7) >> 2][(pq_ % 7) & 3] : ata_[(pq_ % 7) >> 2][(pq_ % 7) & 3]; \
+                    const int a_ = (GF_ABL & 4) ? 0 : (e_ ^ ((pq_ / 7) * 64)) + (Q_ < 14 ? ioa_ : Q_ < 28 ? iob_ : ioc_);      \
+                    if constexpr (GF_ABL & 2) asm volatile("" : "+v"(xr_[Q_ % D]) : "v"(a_));                                  \
+                    else xr_[Q_ % D] = *reinterpret_cast<const bf16x8*>(smem + a_);                                            \
                 }                                                                                                              \
                 _Pragma("unroll") for (int i = 0; i < NB; i++) {                                                               \
                     const bf16x8 wf_ = __builtin_bit_cast(bf16x8, P_ < 14 ? RA[(P_ % 14) / 7][i] : RB[(P_ % 14) / 7][i]);      \
@@ -232,6 +259,10 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
             }                                                                                                                  \
         }                                                                                                                      \
     }
+#ifndef GF_PRIO
+#define GF_PRIO 0      /* experiments: 1 = the k-loops at s_setprio 1 (gates / update at 0), 2 = the reverse */
+#endif
+#define GF_PRIO_K(on_) { if constexpr (GF_PRIO == 1) __builtin_amdgcn_s_setprio((on_) ? 1 : 0); if constexpr (GF_PRIO == 2) __builtin_amdgcn_s_setprio((on_) ? 0 : 1); }
 #define GF_STAMP(k_)                                                                                                           \
     if constexpr (GF_ABL & 16) {                                                                                               \
         if (p.dbg && wave == 0 && lane == 0)                                                                                   \
@@ -265,7 +296,9 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
         __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): this wave's image pieces have landed (and the ring's first taps)
         GF_PHASE_BARRIER()                          // ... and everybody else's
         GF_STAMP(1)
+        GF_PRIO_K(1)
         GF_KLOOP(acc, wa, wb, 4, 7, wzr_rs, w1_voff, 16384, 0)
+        GF_PRIO_K(0)
         GF_STAMP(2)
         GF_W_DRAIN(wa, 4)
         GF_W_DRAIN(wb, 4)
@@ -273,15 +306,10 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
         gf_i32x4 qa[2][2], qb[2][2];
         GF_W_ISSUE(qa, 2, wq_rs, w2_voff, 8192, 0)
         GF_W_ISSUE(qb, 2, wq_rs, w2_voff, 8192, 1)
-        uint4 sq_t[GF_JF];
-        {
-            const uint4* src = p.sq + ((int64_t)(tile * GF_WAVES + wave) * GF_JF) * 64 + lane;
-#pragma unroll
-            for (int j = 0; j < GF_JF; j++) sq_t[j] = src[j * 64];
-        }
         GF_PHASE_BARRIER()                          // every wave has read its last h fragment
         GF_STAMP(3)
-        gf_u32x4 zpk[GF_JF], hpk[GF_JF];            // 8 bf16 each: z and h of this lane's 8 channels of row block j
+        gf_u32x4 zpk[GF_JF];                        // 8 bf16: z of this lane's 8 channels of row block j (h is re-read in the update phase: 28 registers
+                                                    // across the q k-loop cost spills whose reloads waited behind the next tile's image DMAs)
         f32x4 acc2[2][GF_JF];
         {
             int lane_e = lane;
@@ -290,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
 #pragma unroll
             for (int j = 0; j < GF_JF; j++) {
                 // (LDS is accessed as bf16x8 everywhere: a store through another type would not alias the k-loops' fragment reads for hipcc)
-                bf16x8* const hp = reinterpret_cast<bf16x8*>(himg + gf_swz(slot_j[j], (wn & 1) * 4 + (lane_e >> 4)));
+                bf16x8* const hp = reinterpret_cast<bf16x8*>(himg + (*reinterpret_cast<const int*>(smem + 4 * IMG + lane_e * 160 + 2 * 32 + j * 4) ^ ((wn & 1) * 64)));
                 const gf_u32x4 h8 = __builtin_bit_cast(gf_u32x4, *hp);
                 gf_u32x4 z8, rh8;
 #pragma unroll
@@ -302,23 +330,29 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
                 }
                 *hp = __builtin_bit_cast(bf16x8, rh8);
                 zpk[j] = z8;
-                hpk[j] = h8;
-                const gf_u32x4 v = __builtin_bit_cast(gf_u32x4, sq_t[j]);
-                acc2[0][j] = f32x4{gf_lo(v[0]), gf_hi(v[0]), gf_lo(v[1]), gf_hi(v[1])};
-                acc2[1][j] = f32x4{gf_lo(v[2]), gf_hi(v[2]), gf_lo(v[3]), gf_hi(v[3])};
+                acc2[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};      // (q's start map -- bias + the hoisted `inp` term -- is added in the update phase: 28 registers
+                acc2[1][j] = f32x4{0.f, 0.f, 0.f, 0.f};      //  fewer across the gates, where z, h and the accumulators of both stages overlap)
             }
         }
         GF_PHASE_BARRIER()                          // r * h of every wave is in the images
         GF_STAMP(4)
         // ================= q: chunk order x0, x1, rh0, rh1 (images 2, 3, 0, 1)
+        GF_PRIO_K(1)
         GF_KLOOP(acc2, qa, qb, 2, 7, wq_rs, w2_voff, 8192, 2)
+        GF_PRIO_K(0)
         GF_STAMP(5)
         // ================= GRU update: h = hi + lo; h' = (1 - z) h + z tanh(q); hi' | lo' stored in place
         const int mb = tile_base(tile);
         const auto lo_rs = __builtin_amdgcn_make_buffer_rsrc(p.hlo + (int64_t)mb * 128, 0, 0x7FFFFF00, 0x00020000);
         const auto hi_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.hb) + (int64_t)mb * 128, 0, 0x7FFFFF00, 0x00020000);
         unsigned off_j[GF_JF];
-        gf_u32x4 lo_t[GF_JF];
+        gf_u32x4 lo_t[GF_JF], hpk[GF_JF];
+        gf_u32x4 sq_t[GF_JF];
+        {
+            const gf_u32x4* src = reinterpret_cast<const gf_u32x4*>(p.sq) + ((int64_t)(tile * GF_WAVES + wave) * GF_JF) * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < GF_JF; j++) sq_t[j] = src[j * 64];
+        }
         {
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
@@ -329,6 +363,7 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
                 const bool ok = r < rows_valid && gl < p.n_lines;
                 off_j[j] = ok ? (unsigned)((gf_pixel(p, gl, pos) - mb) * 256 + wn * 64 + (lane_e >> 4) * 16) : GF_OOB;
                 lo_t[j] = __builtin_amdgcn_raw_buffer_load_b128(lo_rs, off_j[j], 0, 0);
+                hpk[j] = __builtin_amdgcn_raw_buffer_load_b128(hi_rs, off_j[j], 0, 0);
             }
         }
         GF_PHASE_BARRIER()                          // every wave has read its last fragment: the images are free
@@ -337,24 +372,27 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
         GF_W_DRAIN(qa, 2)                           // (vmcnt(0): the lo rows are here too -- the DMA pieces below must not sit in front of their wait)
         GF_W_DRAIN(qb, 2)
 #pragma unroll
-        for (int j = 0; j < GF_JF; j++) asm volatile("" : "+v"(lo_t[j]));
-        if (next < p.n_tiles) issue_images(next);
+        for (int j = 0; j < GF_JF; j++) { asm volatile("" : "+v"(lo_t[j])); asm volatile("" : "+v"(sq_t[j])); asm volatile("" : "+v"(hpk[j])); }
+        if (next < p.n_tiles && !(GF_ABL & 64)) issue_images(next);
 #pragma unroll
         for (int j = 0; j < GF_JF; j++) {
             gf_u32x4 hi_o, lo_o;
 #pragma unroll
             for (int e = 0; e < 4; e++) {           // dword e: channels 2 e, 2 e + 1
                 const int bi = e >> 1, r0 = 2 * (e & 1);
-                const unsigned zz = zpk[j][e], hh = hpk[j][e], ll = lo_t[j][e];
+                const unsigned zz = zpk[j][e], hh = hpk[j][e], ll = lo_t[j][e], ss = sq_t[j][e];
                 const float za = gf_lo(zz), zb = gf_hi(zz);
                 const float ha = gf_lo(hh) + gf_lo(ll), hb_ = gf_hi(hh) + gf_hi(ll);
-                const float na = (1.0f - za) * ha + za * gf_tanh(acc2[bi][j][r0]), nb = (1.0f - zb) * hb_ + zb * gf_tanh(acc2[bi][j][r0 + 1]);
+                const float na = (1.0f - za) * ha + za * gf_tanh(acc2[bi][j][r0] + gf_lo(ss)), nb = (1.0f - zb) * hb_ + zb * gf_tanh(acc2[bi][j][r0 + 1] + gf_hi(ss));
                 const unsigned hi2 = gf_pack2(na, nb);
                 hi_o[e] = hi2;
                 lo_o[e] = gf_pack2(na - gf_lo(hi2), nb - gf_hi(hi2));
             }
-            __builtin_amdgcn_raw_buffer_store_b128(hi_o, hi_rs, off_j[j], 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(lo_o, lo_rs, off_j[j], 0, 0);
+            if constexpr (GF_ABL & 32) { asm volatile("" :: "v"(hi_o), "v"(lo_o)); }
+            else {
+                __builtin_amdgcn_raw_buffer_store_b128(hi_o, hi_rs, off_j[j], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(lo_o, lo_rs, off_j[j], 0, 0);
+            }
         }
         GF_STAMP(7)
         if (next >= p.n_tiles) break;
@@ -478,9 +516,9 @@ int launch_gru_half(int n_img, int H, int W, int vert, void* hb, void* hlo, cons
 #if (GF_ABL & 16)
     p.dbg = g_gru_dbg;
 #endif
-    const int lds = 4 * p.img_bytes;
+    const int lds = 4 * p.img_bytes + 64 * 160;      // four chunk images + the fragment address table
     static DeviceOnce attr;
-    VTGB_FUNC_LDS_ONCE(attr, gru_half_kernel, 4 * GF_MAX_IMG);
+    VTGB_FUNC_LDS_ONCE(attr, gru_half_kernel, 4 * GF_MAX_IMG + 64 * 160);
 #ifndef GF_WG_PER_CU
 #define GF_WG_PER_CU 2
 #endif
