@@ -239,6 +239,41 @@ def test_raft_sensitive_weights_vs_reference(dev, dtype):
             assert ef <= FLOAT_ENC_TOL[dtype], (tag, ef)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_raft_224_sensitive_weights_vs_reference(dev, dtype):
+    """Full frame size (224 x 224 -> 28 x 28 coarse pixels: the geometry the fused GRU half-step, conv64 and the stem kernel run at in
+    the bench), input-sensitive weights, 20 iterations, against the REFERENCE's own flow (tests/golden/raft224_sensitive.npz,
+    make_golden.py [raft224]: every 4th fine pixel) -- round-3 VERDICT: the full-size check had been HIP vs oracle only."""
+    from videotgb_amd import models, synth
+    g = load_golden("raft224_sensitive")
+    assert torch.equal(synth.moving_texture_u8(3, 224, 7), g["frames_u8"])
+    sd = {k[len("of_extractor."):]: v for k, v in synth.raft_sensitive_state_dict(0).items()}
+    r = models.Raft(dtype)
+    r.load_state_dict(sd, strict=True)
+    r.to(dev)
+    f = synth.clip_normalise(g["frames_u8"])
+    got = r(f[:-1].to(dev), f[1:].to(dev), iters=20).cpu()
+    probe, ref = got[:, :, ::4, ::4], g["flow_probe"]
+    e, mx = rel_rms(probe, ref), float((probe - ref).abs().max())
+    print(f"[raft 224 sensitive {dtype}] flow rel_rms={e:.3e} max|diff|={mx:.3e} max|ref|={float(g['flow_absmax']):.3e}")
+    assert e <= SENS_FLOW_TOL[dtype] and mx <= 5 * SENS_FLOW_TOL[dtype] * float(g["flow_absmax"])
+    if dtype == "f32":      # the clip path (forward_clips: consecutive frames of one clip) computes the same two pairs
+        clip = r.forward_clips(f[None].to(dev), iters=20).cpu()
+        assert rel_rms(clip.reshape(got.shape)[:, :, ::4, ::4], ref) <= SENS_FLOW_TOL[dtype]
+
+
+def test_raft_all_iteration_flows(dev, tiny_sd):
+    """RAFT.forward(test_mode=False) (xraft.py:146-156): every iteration's upsampled flow, against the reference's flows after 5 and 20
+    iterations (tests/golden/tiny_raft.npz) and the test-mode call."""
+    g = load_golden("tiny_raft")
+    fr = deq(g, "frames_q8").to(dev)
+    r = make(dev, tiny_sd, "f32")
+    flows = r(fr[:-1], fr[1:], iters=20, test_mode=False)
+    assert isinstance(flows, list) and len(flows) == 20
+    assert rel_rms(flows[4].cpu(), g["flow_iters5"]) <= FLOW_TOL["f32"] and rel_rms(flows[19].cpu(), g["flow_iters20"]) <= FLOW_TOL["f32"]
+    assert torch.equal(flows[19], r(fr[:-1], fr[1:], iters=20))
+
+
 def test_raft_float_valued_frames(dev, tiny_sd):
     """The eval path feeds RAFT CLIP-normalised floats (eval/inference.py:68 -> eval/utils/model.py:79), not 0..255
     integers: after 2*(x/255)-1 the image is -1 +- 0.02.  Flow level, default weights, both modes (the encoder-level and

@@ -120,6 +120,18 @@ def sensitive_inputs(g):
     return {"a": g["frames_a_f16"].float(), "b": synth.clip_normalise(u8), "c": u8.float()}
 
 
+def test_raft_224_fixture_contract():
+    """tests/golden/raft224_sensitive.npz (make_golden.py [raft224]): the frame generator is part of the fixture's contract, the probes are
+    finite and move (a flow of a translated texture), and one coarse row of the oracle's RAFT agrees with the reference's flow at the probe
+    points would take minutes on CPU -- the oracle is pinned at 128 x 128 above; here only the contract."""
+    from videotgb_amd import synth
+    g = load_golden("raft224_sensitive")
+    assert torch.equal(synth.moving_texture_u8(3, 224, 7), g["frames_u8"])
+    assert tuple(g["flow_probe"].shape) == (2, 2, 56, 56) and torch.isfinite(g["flow_probe"]).all()
+    assert float(g["flow_probe"].abs().max()) <= float(g["flow_absmax"]) and float(g["flow_absmax"]) > 0.5
+    assert g["flow_sha256"].numel() == 32
+
+
 def test_raft_sensitive_weights_vs_reference():
     """The input-sensitive RAFT weight set (synth.raft_sensitive_state_dict): the oracle against the reference RAFT's flows
     (float-valued frames, CLIP-normalised frames, integer frames) and fnet feature maps (every 4th channel)."""

@@ -314,15 +314,18 @@ class Raft(nn.Module):
     @torch.no_grad()
     def forward(self, image1, image2, iters=20, flow_init=None, upsample=True, test_mode=True):
         """RAFT.forward (xraft.py:102-156): image1 / image2 [N, 3, H, W] (0..255 convention), H and W multiples of 8
-        (InputPadder) -> flow_up [N, 2, H, W]."""
-        if not (test_mode and upsample):
-            raise NotImplementedError("Raft: only test_mode=True, upsample=True (the last iteration's upsampled flow) is built")
+        (InputPadder) -> flow_up [N, 2, H, W]; ``test_mode=False``: the list of every iteration's upsampled flow (:146-156; `upsample`
+        is as unused as in the reference).  The update kernel keeps only the last iteration's mask head, so the per-iteration list
+        re-runs the recurrence with 1, 2, ... iters iterations (identical states: iteration i never sees a later one) -- RAFT is
+        frozen in every module of the path, so this form exists for interface parity, not speed."""
         upd, fw, cw = self._hip_tables()
         n, _, h, w = image1.shape
         h8, w8 = h // 8, w // 8
         fmap = ops.raft_encoder(fw, torch.cat([image1, image2], 0))                           # fnet([image1, image2]) (:115)
         cmap = ops.raft_encoder(cw, image1)
         pyr = ops.raft_corr(fmap, n, h8, w8, n, n, 0, n, self.code)
+        if not test_mode:
+            return [ops.raft_update(upd, None, None, pyr, i + 1, cnet_nhwc=cmap, hw=(h8, w8), flow_init=flow_init) for i in range(iters)]
         return ops.raft_update(upd, None, None, pyr, iters, cnet_nhwc=cmap, hw=(h8, w8), flow_init=flow_init)
 
 
