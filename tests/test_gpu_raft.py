@@ -271,7 +271,7 @@ def test_raft_all_iteration_flows(dev, tiny_sd):
     flows = r(fr[:-1], fr[1:], iters=20, test_mode=False)
     assert isinstance(flows, list) and len(flows) == 20
     assert rel_rms(flows[4].cpu(), g["flow_iters5"]) <= FLOW_TOL["f32"] and rel_rms(flows[19].cpu(), g["flow_iters20"]) <= FLOW_TOL["f32"]
-    assert torch.equal(flows[19], r(fr[:-1], fr[1:], iters=20))
+    assert rel_rms(flows[19].cpu(), r(fr[:-1], fr[1:], iters=20).cpu()) <= 1e-5      # (not bit-equal: InstanceNorm moments are accumulated with atomics)
 
 
 def test_raft_float_valued_frames(dev, tiny_sd):
