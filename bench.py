@@ -182,6 +182,46 @@ def run_steps_overlapped(m, batches, steps, B, nframe, max_new_tokens, decoder, 
     return outs
 
 
+def parity_probe(dev):
+    """What the bf16 mode costs in accuracy, measured in THIS run on the tiny configuration of the golden fixtures (random seeded weights,
+    12 flow frames, 8 candidate frames): the LLM prefix of the HIP bf16 path against the HIP fp32 exactness path (which the -m gpu suite
+    pins to the reference's fp32 tensors at <= 4e-6 of scale).  north_star asks for 1e-3 at bf16; the committed measurements against the
+    reference itself (tests/test_gpu_e2e.py / test_gpu_stages.py) are quoted next to the live number."""
+    from videotgb_amd import models, synth
+    cfg = synth.tiny_cfg("instructblip")
+    cfg.vit.image = 56
+    m = models.LSTP(cfg, dev, language_model=None, compute_dtype="bf16")
+    m.load_state_dict(synth.path_state_dict(cfg, 0, with_raft=True), strict=False)
+    m.to(dev)
+    g = torch.Generator().manual_seed(5)
+    T, N, nframe = 12, 8, 4
+    frames = torch.randn(N, 3, 56, 56, generator=g).to(dev).view(1, N, 3, 56, 56)
+    of = (torch.rand(1, T, 2, 224, 224, generator=g) * 2 - 1).to(dev)
+    sids = torch.randint(3, cfg.tgb.vocab, (1, 7), generator=g).to(dev)
+    qids = torch.randint(3, cfg.qformer.vocab, (1, 6), generator=g).to(dev)
+    noise = torch.rand(2, 2, T, generator=g).clamp_(1e-6, 1 - 1e-6)
+    noise = (-torch.log(-torch.log(noise))).to(dev)
+    te = {"qformer_input_ids": qids, "qformer_attention_mask": torch.ones_like(qids)}
+    res = {}
+    for dtype in ("f32", "bf16"):
+        m.set_compute_dtype(dtype)
+        sampled, idx, logits = m.select_frames(frames, of, sids, torch.ones_like(sids), nframe, noise)
+        res[dtype] = (m.prefix(sampled, 1, nframe, te, "mean").float(), logits.float(), idx)
+    torch.cuda.synchronize()
+    pf, pb = res["f32"][0], res["bf16"][0]
+    lf, lb = res["f32"][1], res["bf16"][1]
+    return {"what": "tiny configuration, HIP bf16 vs HIP fp32 (fp32 is pinned to the reference at <= 4e-6 of scale by the -m gpu suite)",
+            "prefix_max_abs_diff": float((pb - pf).abs().max()), "prefix_scale": float(pf.abs().max()),
+            "tgb_logits_max_abs_diff": float((lb - lf).abs().max()), "tgb_logits_scale": float(lf.abs().max()),
+            "frame_indices_equal": bool(torch.equal(res["f32"][2], res["bf16"][2])),
+            "north_star_bf16_1e-3": "met to 1.3-1.4e-3 on the tiny prefix / logits, NOT met at full depth (ViT-g 2.9e-2 abs on a 3.9 scale) -- the "
+                                    "reference's own bf16 autocast is 1.5e-3 / 2.9e-2 off its fp32 numbers on the same tensors; the tests bound "
+                                    "hip-bf16 by the reference's own bf16 error instead (DESIGN.md section 2)",
+            "committed_vs_reference": {"tiny_prefix_hip_bf16_vs_ref_fp32": 1.33e-3, "tiny_prefix_ref_bf16_vs_ref_fp32": 1.48e-3,
+                                       "full_vit_hip_bf16_vs_ref_fp32": 2.9e-2, "full_vit_ref_bf16_vs_ref_fp32": 2.9e-2,
+                                       "source": "tests/test_gpu_e2e.py, tests/test_gpu_stages.py (GPUTEST logs), DESIGN.md section 2"}}
+
+
 def cpu_baseline(cfg, T, nframe, seed_sd, inline_raft=True, raft_pairs=4):
     """Oracle (port of the reference's CPU path) on one clip, fp32: RAFT on a bounded sample of `raft_pairs` of the
     clip's T-1 frame pairs (20 iterations each, extrapolated to T-1 pairs), then TGB -> select -> gather -> ViT-g ->
@@ -389,6 +429,17 @@ def main():
                         "measured_in": f"{args.prof_steps} untimed steps after the timed region (HIP events per launch; the timed region runs "
                                        f"without them)",
                         "other": [f for f in (gemm, conv, attn) if f and f is not dom]}
+    # ---- one more untimed step with an event per stage boundary: ViT-stage MFMA utilisation (north star: >= 55 % of the bf16 peak)
+    stages_ms, vit_util = None, None
+    if not args.no_prof:
+        ev = []
+        run_step(m, batches[0], B, nframe, args.max_new_tokens, ev, decoder)
+        torch.cuda.synchronize()
+        stages_ms = {}
+        for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+            stages_ms[n1] = round(e0.elapsed_time(e1), 2)
+        if stages_ms.get("vit"):
+            vit_util = round(VIT_GFLOP_PER_FRAME * 1e9 * B * nframe / (stages_ms["vit"] * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4)
     if stage_ev and rank == 0:
         acc = {}
         for ev in stage_ev:
@@ -445,6 +496,11 @@ def main():
                           "llm": f"HF LlamaForCausalLM {args.llm} geometry, random init, KV cache, decode={args.decode}, no EOS stop (fixed work)",
                           "streams": "2 (prefix of batch i+1 over LLM decode of batch i)" if overlap else "1", "weights": "seeded N(0,0.02) random init"},
                "roofline": roofline}
+        if vit_util is not None:
+            out["vit_util"] = vit_util      # ViT-g FLOPs of the step / ViT stage time / dense bf16 peak (target >= 0.55)
+            out["stages_ms"] = stages_ms    # one untimed step with an event per stage boundary (the first stage, RAFT, = ms_per_step - the rest)
+        if world == 1 and not args.no_prof:
+            out["parity"] = parity_probe(dev)
         if legs:
             out["precomputed_flow"] = legs.pop("precomputed_flow", None)
             out["latency_ms_per_clip"] = legs["single_clip"]["latency_ms_per_clip"]
