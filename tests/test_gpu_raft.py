@@ -87,8 +87,8 @@ def test_raft_single_iteration_and_flow_init(dev, tiny_sd, dtype):
     e = rel_rms(got, ref)
     print(f"[raft {dtype} flow_init] rel_rms={e:.3e}")
     assert e <= (1e-5 if dtype == "f32" else 2e-2)
-    with pytest.raises(NotImplementedError):
-        r(fr[:-1].to(dev), fr[1:].to(dev), test_mode=False)
+    flows = r(fr[:-1].to(dev), fr[1:].to(dev), iters=2, test_mode=False)      # (round 4: the all-iteration form exists; test_raft_all_iteration_flows checks it)
+    assert isinstance(flows, list) and len(flows) == 2
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

@@ -16,7 +16,7 @@
 //  * Tap reuse in LDS.  The tile's activations are staged ONCE (LDS-DMA): four 64-channel chunk images [slot][64 ch] (h0, h1, x0,
 //    x1), a line's pixels in consecutive 128-byte slots with two zero slots between lines (and in front of the first), so that
 //    tap d of pixel s is slot s + d -- zero padding is the image (out-of-range DMA lanes).  The fragments of all five taps are
-//    read from shifted addresses (16-byte chunks XOR-swizzled by (slot >> 1) & 7); the 35 (tap, row block) addresses of a lane
+//    read from shifted addresses (16-byte chunks rotated by 2 (slot >> 1): conflict-free for any window of 16 slots); the 35 (tap, row block) addresses of a lane
 //    live in a small LDS table built once per workgroup, a tap's eight entries are two ds_read_b128 a tap ahead.
 //  * Weights never touch LDS.  They are re-packed once per call in MFMA fragment order per (k-step, wave column, block): a
 //    wave loads its own fragments with fully coalesced 1 KiB buffer loads straight into a four-k-step register ring
@@ -78,7 +78,12 @@ struct GruHalfParams {
 __device__ __forceinline__ int gf_div(uint32_t n, uint32_t mul, uint32_t sh) { return (int)((__umulhi(n, mul) + n) >> sh); }
 
 // slot -> byte offset of 16-byte chunk `chunk` (0..7) inside a chunk image
-__device__ __forceinline__ int gf_swz(int slot, int chunk) { return slot * 128 + ((chunk ^ ((slot >> 1) & 7)) << 4); }
+// (16-byte chunk c of slot s sits at position (c + 2 (s >> 1)) & 7 of the slot's 128 bytes -- a ROTATION by twice the slot pair, not the
+// XOR by (s >> 1) & 7 of the GEMM kernels' images: fragment rows here start at ANY slot (taps shift them by -2 .. 2), and the XOR form is
+// conflict-free only for windows that start at a multiple of 4 slots -- PMC: 162 M LDS bank-conflict cycles per launch, 17 x the
+// implicit-GEMM kernel's.  With the rotation the two lane groups of a ds_read_b128 (chunk c: rows 0-3, 12-15; chunk c + 1: rows 4-11)
+// land on even / odd positions for every window of 16 consecutive slots, and k-half 1 (chunk + 4) is still the address ^ 64.)
+__device__ __forceinline__ int gf_swz(int slot, int chunk) { return slot * 128 + (((chunk + 2 * (slot >> 1)) & 7) << 4); }
 
 // a, b rounded (nearest even) to bf16: one v_cvt_pk_bf16_f32; .x / .y are the rounded values as floats, .z the packed pair
 typedef __attribute__((ext_vector_type(2))) __bf16 gf_bf16x2;
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
 #pragma unroll
             for (int t = 0; t < 5; t++) {
                 const int sp = slot + t - 2;
-                if (wave == 0) *reinterpret_cast<int*>(tbl + lane * 160 + t * 32 + j * 4) = sp * 128 + ((((sp >> 1) ^ fg) & 7) << 4);
+                if (wave == 0) *reinterpret_cast<int*>(tbl + lane * 160 + t * 32 + j * 4) = gf_swz(sp, fg);
             }
         }
     }
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
                 const int s = pi * 8 + (lane_p >> 3), s2 = s - 2;
                 const int l = s2 >= 0 ? gf_div((uint32_t)s2, p.divL2_mul, p.divL2_sh) : 0, pos = s2 - l * L2, gl = tile * p.NL + l;
                 const bool ok = s2 >= 0 && pos < p.L && l < p.NL && gl < p.n_lines;
-                const int dc = ((lane_p & 7) ^ ((s >> 1) & 7)) * 16;    // the data chunk that lands in position lane & 7 of slot s
+                const int dc = (((lane_p & 7) - 2 * (s >> 1)) & 7) * 16;    // the data chunk that lands in position lane & 7 of slot s (gf_swz)
                 const int mrel = ok ? gf_pixel(p, gl, pos) - mb : 0;
                 const unsigned vh = ok ? (unsigned)(mrel * 256 + dc) : GF_OOB, vx = ok ? (unsigned)(mrel * 512 + 256 + dc) : GF_OOB;
                 char* const dst = smem + pi * 1024;
