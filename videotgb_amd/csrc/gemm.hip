@@ -982,7 +982,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc p) {
 }
 
 // round 3: the persistent ping-pong form of the large kernel (gemm_pp.hip); VTGB_GEMM_OLD=1 keeps the one-tile-per-workgroup kernel
-template <int EPI, bool CONV, int NWN>
+template <int EPI, bool CONV, int NWN, int WF = 4>
 int launch_large_pp(const GemmDesc& d, hipStream_t s);
 bool pp_supported(const GemmDesc& d);
 static bool use_old_large() {
@@ -1117,6 +1117,12 @@ static int launch_large_forced(const GemmDesc& d, hipStream_t s) {
     VTGB_REQUIRE(!d.tail_w || nwn == 4, VTGB_EUNSUPPORTED, "conv gemm: the fused 1x1 tail needs the 256-wide tile (forced tile %d)", nwn);
     VTGB_REQUIRE(!(d.frag_out || d.init_frag) || nwn == nwn_shape, VTGB_EUNSUPPORTED,
                  "conv gemm: fragment-order start maps need the producer's and the consumer's tile shape to agree (forced tile %d, shape rule %d)", nwn, nwn_shape);
+    if constexpr (EPI == EPI_STORE && CONV) {
+        // 128 < N <= 192 (RAFT's convc2: 192 channels): the 256 x 192 tile whose eight waves all multiply (gemm_pp.hip, WF = 3)
+        if (g_conv_nwn == 0 && d.N > 128 && d.N <= 192 && (d.N & 7) == 0 && !use_old_large() && pp_supported(d) && !d.frag_out && !d.init_bf16 && d.gate_from == 0 &&
+            !d.resid_bf16 && !d.tail_w && pp_class_enabled(EPI, CONV, 4, false))
+            return launch_large_pp<EPI, CONV, 4, 3>(d, s);
+    }
     if (nwn == 1) return launch_large_nwn<EPI, CONV, 1>(d, s);
     if (nwn == 2) {
         // The 512 x 128 tile (same wave tile as 256 x 256) measured NO faster than 256 x 128 on RAFT's 128-channel

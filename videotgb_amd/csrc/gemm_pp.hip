@@ -35,15 +35,20 @@ constexpr int P_AOP = 256 * P_BK * 2;   // 32 KiB activation slot (256 rows)
 #define P_STORE128(data, rs, lane_off, soff) __builtin_amdgcn_raw_buffer_store_b128(data, rs, (lane_off) + (unsigned)(soff), 0, 0)
 #define P_STORE64(data, rs, lane_off, soff) __builtin_amdgcn_raw_buffer_store_b64(data, rs, (lane_off) + (unsigned)(soff), 0, 0)
 
-template <int EPI, bool CONV, int NWN, bool TAIL = false, bool PING = !CONV>
+// WF = 16-column weight fragments per wave: 4 (64-column wave tiles: every instantiation but one) or 3 -- the 256 x 192 tile of RAFT's convc2
+// (3x3, 256 -> 192 channels; update.py:79): on the 256-wide tile two of its eight waves held only padding, and since waves w and w + 4
+// share a SIMD two SIMDs carried twice the MFMA work of the other two; with 48-column wave tiles all eight waves multiply (round 4).
+template <int EPI, bool CONV, int NWN, bool TAIL = false, bool PING = !CONV, int WF = 4>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G, const int total_blocks) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NX = 2 * NWN;          // activation fragments per wave: wave tile = (16 NX) x 64
     constexpr int WROWS = 16 * NX;
     constexpr int MW = 8 / NWN;          // waves along M
-    constexpr int T_BM = 256, T_BN = 64 * NWN;
+    constexpr int WC = 16 * WF;          // columns per wave
+    constexpr int T_BM = 256, T_BN = WC * NWN;
     constexpr int A_OP = P_AOP, W_OP = T_BN * 128;
-    constexpr int AI = 4, WI = NWN;      // LDS-DMA instructions per wave and k-tile
+    constexpr int AI = 4, WI = T_BN / 64;      // LDS-DMA instructions per wave and k-tile
+    static_assert(WF == 4 || (WF == 3 && NWN == 4 && EPI == EPI_STORE && CONV && !TAIL && !PING), "48-column wave tiles: the plain bf16-store convolution only");
     constexpr int A_SLOTS = 3;
     constexpr bool WHOLE = PING && NWN < 4;   // ping-pong on narrow tiles: one compute segment per k-tile (both halves), three weight slots
     constexpr int W_SLOTS = WHOLE ? 3 : 2;
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
 #define P_TILE_SETUP()                                                                                                       \
     {                                                                                                                        \
         m0 = mt * T_BM; n0 = nt * T_BN;                                                                                      \
-        wave_active = (n0 + wn * 64 < p.N) && (m0 + wm * WROWS < p.M);                                                       \
+        wave_active = (n0 + wn * WC < p.N) && (m0 + wm * WROWS < p.M);                                                       \
         /* weight rows beyond N lie outside the descriptor's range: their LDS rows read as zeros (columns that are never stored) */ \
         w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W + (int64_t)n0 * p.ldw), 0, (int)(min(T_BN, p.N - n0) * p.ldw * 2), 0x00020000); \
         {                                                                                                                    \
@@ -156,16 +161,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
     // swizzle term ((row >> 1) & 7 does not see multiples of 16), and the second 32-deep half is chunk index ^ 4 = byte offset ^ 64:
     // two registers per operand instead of 8 + 2 NX, the rest are ds_read immediates
     constexpr int NH = (WHOLE || !PING) ? 2 : 1;   // fragment sets: one 32-deep half (ping-pong at NWN = 4), else two
-    bf16x8 wf[NH][4], xf[NH][NX];
+    bf16x8 wf[NH][WF], xf[NH][NX];
 #define P_READ(H, as_, ws_, ks)                                                                          \
     if (wave_active) {                                                                                   \
         const char* const wp_ = (ws_) + (w_off0 ^ ((ks) * 64));                                          \
         const char* const xp_ = (as_) + (x_off0 ^ ((ks) * 64));                                          \
-        _Pragma("unroll") for (int i = 0; i < 4; i++) wf[H][i] = *reinterpret_cast<const bf16x8*>(wp_ + i * 2048); \
+        _Pragma("unroll") for (int i = 0; i < WF; i++) wf[H][i] = *reinterpret_cast<const bf16x8*>(wp_ + i * 2048); \
         _Pragma("unroll") for (int j = 0; j < NX; j++) xf[H][j] = *reinterpret_cast<const bf16x8*>(xp_ + j * 2048); \
     }
 #define P_MFMAS(H)                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 4; i++)                                                    \
+        _Pragma("unroll") for (int i = 0; i < WF; i++)                                                   \
             _Pragma("unroll") for (int j = 0; j < NX; j++)                                               \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[H][i], xf[H][j], acc[i][j], 0, 0, 0);
 #define P_COMPUTE()                                                                                      \
@@ -190,14 +195,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
         // accumulators -- were what hipcc pushed into scratch, and every reload is a serial memory round trip)
         int lane_k = lane;
         asm volatile("" : "+v"(lane_k));
-        const int w_off0 = swz(wn * 64 + (lane_k & 15), lane_k >> 4), x_off0 = swz(wm * WROWS + (lane_k & 15), lane_k >> 4);
+        const int w_off0 = swz(wn * WC + (lane_k & 15), lane_k >> 4), x_off0 = swz(wm * WROWS + (lane_k & 15), lane_k >> 4);
         // ================= accumulator start values, behind the first k-tile's DMAs (bias once per column group; start maps)
-        f32x4 acc[4][NX];
+        f32x4 acc[WF][NX];
         {
-            f32x4 b4[4];
+            f32x4 b4[WF];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int n = n0 + wn * 64 + i * 16 + fg * 4;
+            for (int i = 0; i < WF; i++) {
+                const int n = n0 + wn * WC + i * 16 + fg * 4;
                 b4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (p.bias && n + 3 < p.N) b4[i] = *reinterpret_cast<const f32x4*>(p.bias + n);
                 else if (p.bias && n < p.N) {                                                    // (N % 4 != 0: plain bf16 stores only, pp_supported)
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
 #pragma unroll
                 for (int j = 0; j < NX; j++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < WF; i++) {
                         const bf16x4 t = tq[j * 4 + i];
                         acc[i][j] = b4[i] + f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
                     }
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
 #pragma unroll
                 for (int j = 0; j < NX; j++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) acc[i][j] = b4[i];
+                    for (int i = 0; i < WF; i++) acc[i][j] = b4[i];
             }
         }
         if constexpr (!PING) {
@@ -259,14 +264,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
     {                                                                                                    \
         const char* const wp_ = (ws_) + (w_off0 ^ ((ks) * 64));                                          \
         const char* const xp_ = (as_) + (x_off0 ^ ((ks) * 64));                                          \
-        _Pragma("unroll") for (int i = 0; i < 4; i++) wf[H][i] = *reinterpret_cast<const bf16x8*>(wp_ + i * 2048); \
+        _Pragma("unroll") for (int i = 0; i < WF; i++) wf[H][i] = *reinterpret_cast<const bf16x8*>(wp_ + i * 2048); \
         _Pragma("unroll") for (int j = 0; j < NX; j++) xf[H][j] = *reinterpret_cast<const bf16x8*>(xp_ + j * 2048); \
     }
 #define P_SCHED_IL(PIECES)                                                                               \
-    if constexpr ((PIECES) > 0 && (4 * NX) % (PIECES) == 0) {                                            \
+    if constexpr ((PIECES) > 0 && (WF * NX) % (PIECES) == 0) {                                           \
         _Pragma("unroll") for (int g_ = 0; g_ < (PIECES); g_++) {                                        \
             __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);               /* one LDS-DMA piece */     \
-            __builtin_amdgcn_sched_group_barrier(0x008, (4 * NX) / (PIECES), 0);   /* its share of the half's MFMAs */ \
+            __builtin_amdgcn_sched_group_barrier(0x008, (WF * NX) / (PIECES), 0);   /* its share of the half's MFMAs */ \
         }                                                                                                \
     }
 #define P_LITER(DEFER, WCOND, WAIT4)                                                                     \
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
 #pragma unroll
                     for (int j = 0; j < NX; j++)
 #pragma unroll
-                        for (int i = 0; i < 4; i++) {
+                        for (int i = 0; i < WF; i++) {
                             f32x4 v = acc[i][j];
                             if (p.act) {
 #pragma unroll
@@ -505,8 +510,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
             // ResidualBlock skip) of ALL passes are requested first, then the next tile's first k-tile; one counted wait.
             constexpr int RP = SB / 128 < WROWS ? SB / 128 : WROWS, NP = WROWS / RP, JB = RP / 16;
             const bool gated = EPI == EPI_STORE && p.gate_from > 0, resd = EPI == EPI_STORE && !gated && p.resid_bf16 != nullptr;
-            const int ch0 = lane_e & 7, nn = en0 + wn * 64 + ch0 * 8;
-            const bool to_out2 = gated && (en0 + wn * 64) >= p.gate_from;     // wave-uniform (gate_from % 64 == 0): this wave's columns are r -> r * h
+            const int ch0 = lane_e & 7, nn = ch0 * 8 < WC ? en0 + wn * WC + ch0 * 8 : 0x40000000;      // (48-column wave tiles: chunks 6, 7 of a staged row do not exist)
+            const bool to_out2 = gated && (en0 + wn * WC) >= p.gate_from;     // wave-uniform (gate_from % 64 == 0): this wave's columns are r -> r * h
             const int col = to_out2 ? nn - p.gate_from : nn;
             const int64_t ld_o = to_out2 ? p.ldo2 : p.ldo;
             const auto o_rs = tile_rsrc(to_out2 ? p.out2 : p.out, ld_o, 2);
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
 #pragma unroll
                 for (int jj = 0; jj < JB; jj++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < WF; i++) {
                         f32x4 v = acc[i][ps * JB + jj];
                         if constexpr (EPI == EPI_GELU) {
 #pragma unroll
@@ -789,12 +794,23 @@ bool pp_supported(const GemmDesc& d) {
     return false;
 }
 
-template <int EPI, bool CONV, int NWN>
+template <int EPI, bool CONV, int NWN, int WF>
 int launch_large_pp(const GemmDesc& d, hipStream_t s) {
-    constexpr int T_BM = 256, T_BN = 64 * NWN;
+    constexpr int T_BM = 256, T_BN = 16 * WF * NWN;
     static_assert(NWN == 4 || NWN == 2, "the 64-wide tile (two workgroups per CU) stays with gemm_bf16_large_kernel");
     constexpr bool PING = !CONV;
     constexpr int LDS = 3 * P_AOP + ((PING && NWN < 4) ? 3 : 2) * T_BN * 128;
+    if constexpr (WF == 3) {      // RAFT's convc2: N = 192 as ONE 256 x 192 tile per m-tile, eight waves of 128 x 48
+        static DeviceOnce attr3;
+        VTGB_FUNC_LDS_ONCE(attr3, (gemm_bf16_pp_kernel<EPI, CONV, NWN, false, PING, 3>), LDS);
+        const int m_tiles3 = (d.M + T_BM - 1) / T_BM, n_tiles3 = (d.N + T_BN - 1) / T_BN, total3 = m_tiles3 * n_tiles3;
+        const int grid3 = total3 < cu_count() ? total3 : cu_count();
+        const double ef = 2.0 * d.M * d.N * d.K;
+        ProfScope prof(VTGB_PROF_CONV, d.algo_flops > 0 ? d.algo_flops : ef, s, ef);
+        hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, CONV, NWN, false, PING, 3>), dim3(grid3), dim3(512), LDS, s, d, m_tiles3, n_tiles3, 8, total3);
+        VTGB_HIP(hipGetLastError());
+        return VTGB_OK;
+    } else {
     const int m_tiles = (d.M + T_BM - 1) / T_BM, n_tiles = (d.N + T_BN - 1) / T_BN;
     const int G = 8;                                                   // m-tiles per group of the tile order (see the kernel)
     const int total = m_tiles * n_tiles;
@@ -816,10 +832,12 @@ int launch_large_pp(const GemmDesc& d, hipStream_t s) {
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, CONV, NWN>), dim3(grid), dim3(512), LDS, s, d, m_tiles, n_tiles, G, total);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
+    }
 }
 
 // explicit entry points used by gemm.hip (one per instantiation it dispatches to)
-#define PP_INST(EPI, CONV, NWN) template int launch_large_pp<EPI, CONV, NWN>(const GemmDesc&, hipStream_t);
+#define PP_INST(EPI, CONV, NWN) template int launch_large_pp<EPI, CONV, NWN, 4>(const GemmDesc&, hipStream_t);
+template int launch_large_pp<EPI_STORE, true, 4, 3>(const GemmDesc&, hipStream_t);
 PP_INST(EPI_STORE, false, 4) PP_INST(EPI_GELU, false, 4) PP_INST(EPI_RESID_F32, false, 4) PP_INST(EPI_STORE_F32, false, 4)
 PP_INST(EPI_STORE, false, 2) PP_INST(EPI_STORE_F32, false, 2)
 PP_INST(EPI_STORE, true, 4) PP_INST(EPI_STORE, true, 2)
