@@ -274,6 +274,21 @@ def test_raft_all_iteration_flows(dev, tiny_sd):
     assert rel_rms(flows[19].cpu(), r(fr[:-1], fr[1:], iters=20).cpu()) <= 1e-5      # (not bit-equal: InstanceNorm moments are accumulated with atomics)
 
 
+@pytest.mark.parametrize("n,h8,w8,iters", [(300, 28, 28, 6), (7, 16, 16, 20), (5, 9, 13, 12)])
+def test_raft_update_is_bit_reproducible(dev, n, h8, w8, iters):
+    """vtgb_raft_update has no atomics: calls on the same inputs agree BIT FOR BIT -- a guard against races in the hand-synchronised kernels
+    (the fused GRU half-step's in-place r * h, its LDS-DMA images and register rings; the persistent GEMM's epilogue staging)."""
+    from videotgb_amd import ops, synth
+    sd = {k[len("of_extractor."):]: v.to(dev) for k, v in synth.synth_state_dict(synth.raft_shapes("of_extractor."), 0).items()}
+    w = ops.RaftWeights(sd, "update_block.", ops.BF16)
+    g = torch.Generator(device=dev).manual_seed(n)
+    cnet = torch.randn(n, h8 * w8, 256, generator=g, device=dev)
+    pyr = [torch.randn(n * h8 * w8, 1, max(h8 >> l, 1), max(w8 >> l, 1), generator=g, device=dev).half() for l in range(4)]
+    outs = [ops.raft_update(w, None, None, pyr, iters=iters, cnet_nhwc=cnet, hw=(h8, w8)).clone() for _ in range(3)]
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_raft_float_valued_frames(dev, tiny_sd):
     """The eval path feeds RAFT CLIP-normalised floats (eval/inference.py:68 -> eval/utils/model.py:79), not 0..255
     integers: after 2*(x/255)-1 the image is -1 +- 0.02.  Flow level, default weights, both modes (the encoder-level and
