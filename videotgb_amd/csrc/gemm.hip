@@ -985,16 +985,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc p) {
 template <int EPI, bool CONV, int NWN, int WF = 4>
 int launch_large_pp(const GemmDesc& d, hipStream_t s);
 bool pp_supported(const GemmDesc& d);
+// (A/B switches -- VTGB_GEMM_OLD=1, VTGB_PP_MASK=<bits> -- exist only in builds with -DVTGB_DEBUG_HOOKS: the production library reads no
+// environment variable)
 static bool use_old_large() {
+#ifdef VTGB_DEBUG_HOOKS
     static int v = -1;
     if (v < 0) { const char* e = getenv("VTGB_GEMM_OLD"); v = (e && e[0] == '1') ? 1 : 0; }
     return v == 1;
+#else
+    return false;
+#endif
 }
 // bisecting aid: VTGB_PP_MASK = bit set of launch classes that may use the persistent kernel (default: all)
 //   1 plain GEMM   2 conv 256-wide bf16 store   4 conv + fused 1x1 tail   8 conv 128-wide bf16 store   16 GRU   32 conv fp32 store
 static bool pp_class_enabled(int epi, bool conv, int nwn, bool tail) {
+#ifdef VTGB_DEBUG_HOOKS
     static int mask = -1;
     if (mask < 0) { const char* e = getenv("VTGB_PP_MASK"); mask = e ? atoi(e) : 63; }
+#else
+    const int mask = 63;
+#endif
     int c;
     if (!conv) c = 1;
     else if (epi == EPI_GRU) c = 16;

@@ -220,7 +220,11 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
         return st;
     };
     // ---- stem: repack, then a 4x1 implicit-GEMM convolution whose epilogue also yields the InstanceNorm moments
-    static const bool stem_on = !(getenv("VTGB_STEM64") && getenv("VTGB_STEM64")[0] == '0');      // (VTGB_STEM64=0: pack + implicit GEMM, for A/B runs)
+#ifdef VTGB_DEBUG_HOOKS
+    static const bool stem_on = !(getenv("VTGB_STEM64") && getenv("VTGB_STEM64")[0] == '0');      // (VTGB_STEM64=0: pack + implicit GEMM, for A/B runs; debug-hook builds only)
+#else
+    constexpr bool stem_on = true;
+#endif
     if (stem_on && dt == VTGB_BF16 && stem7x7_supported(a->H, a->W)) {
         // the stem on the raw frames (conv64.hip: the packed rows are built in LDS, no HBM round trip)
         if (inorm) {
@@ -271,7 +275,11 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
         if (g.stride != 1) VTGB_REQUIRE(bw[4] && bw[5], VTGB_EINVAL, "raft_encoder: block %d lacks its downsample weights", b);
         void* outb;
         // layer1 (64 -> 64 channels, stride 1) at bf16: the LDS-resident-rows kernel (conv64.hip); VTGB_CONV64=0 keeps the general kernel (A/B runs)
-        static const bool c64_on = !(getenv("VTGB_CONV64") && getenv("VTGB_CONV64")[0] == '0');
+#ifdef VTGB_DEBUG_HOOKS
+        static const bool c64_on = !(getenv("VTGB_CONV64") && getenv("VTGB_CONV64")[0] == '0');      // (debug-hook builds only)
+#else
+        constexpr bool c64_on = true;
+#endif
         const bool c64 = c64_on && dt == VTGB_BF16 && g.C == 64 && g.Cpad == 64 && Cin_pad == 64 && g.stride == 1 && conv3x3_c64_supported(g.Ho, g.Wo);
         if (c64 && !inorm) {
             VTGB_TRY(launch_conv3x3_c64(x, bw[0], F(bw[1]), nullptr, nullptr, t1, nullptr, n, g.Ho, g.Wo, 1, 0, s));      // y = relu(bn1(conv1(x)))
