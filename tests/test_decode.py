@@ -213,6 +213,15 @@ def test_t5_generate_runs_on_libvtgb_and_issues_no_blas_kernel(dtype):
         assert out.tolist() == ref.tolist()
     else:
         assert out[:, :2].tolist() == ref[:, :2].tolist()
+    if dtype == torch.float32:
+        # a second call REPLAYS the captured graph on new inputs (the cross-attention K | V live in the state's buffers), and a shorter prompt
+        # reuses the same state (encoder length is device data; lengths are bucketed by 64)
+        for P2 in (P, P - 4):
+            emb2 = (torch.randn(B, P2, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(40 + P2)) * 0.5).to(dtype)
+            ref2 = lm.generate(inputs_embeds=emb2, attention_mask=torch.ones(B, P2, dtype=torch.long, device=dev), do_sample=False, max_new_tokens=N,
+                               min_new_tokens=N)
+            assert dec.generate(emb2, N, eos_token_id=1, pad_token_id=0, min_new_tokens=N).tolist() == ref2.tolist()
+        assert len(dec.graphs) == 1
     with torch.no_grad():
         enc_ref = lm.encoder(inputs_embeds=emb, attention_mask=mask).last_hidden_state.float().reshape(B * P, -1)
         enc = dec._encode_hip(emb).float()

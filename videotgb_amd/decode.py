@@ -509,7 +509,7 @@ class T5GreedyDecoder:
         from . import _lib as L
         lib, lm = L.lib(), self.lm
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        B, H, dk, N, P = st["tok"].shape[0], self.H, self.dk, st["N"], st["P"]
+        B, H, dk, N, Pb = st["tok"].shape[0], self.H, self.dk, st["N"], st["Pb"]
         HD = H * dk
         x, h, q = st["x"], st["h"], st["q"]
         x.copy_(lm.decoder.embed_tokens(st["tok"]))
@@ -525,8 +525,8 @@ class T5GreedyDecoder:
             o = self._lin(a, w["wo"], ws)
             self._rms(x, o, w["ln1"], h)
             cq = self._lin(h, w["cq"], ws)
-            ckv = st["ckv"][li]                                                                              # [B P, 2 H dk]: k | v of the encoder states
-            a = self._attn_rows(cq, HD, ckv, ckv[:, HD:], (P * 2 * HD, dk, 2 * HD), B, 1, P, P, None, (0, 0), None)
+            ckv = st["ckv"][li].view(B * Pb, 2 * HD)                                                         # k | v of the encoder states, rows [0, *plen] of every batch entry valid
+            a = self._attn_rows(cq, HD, ckv, ckv[:, HD:], (Pb * 2 * HD, dk, 2 * HD), B, 1, 0, Pb, None, (0, 0), st["plen"])
             o = self._lin(a, w["co"], ws)
             self._rms(x, o, w["ln2"], h)
             delta = self._ffn(h, w, ws)
@@ -546,7 +546,12 @@ class T5GreedyDecoder:
         return w * y
 
     def _state(self, B, P, N, device, dtype, eos, pad, min_new):
-        key = (B, P, N, eos, pad, min_new)
+        # On libvtgb.so the encoder length is DEVICE data (`plen`, read by the cross-attention kernel) and the cross-attention K | V live in
+        # persistent buffers of a bucketed length (multiples of 64): an eval loop over real questions of varying length reuses a handful of
+        # captured graphs (round-3 VERDICT: the state keyed on the exact P).  The torch path (CPU, fused=False) keeps exact-P caches.
+        hip = self._hip(torch.empty(0, device=device, dtype=dtype)) and P <= self.MAX_KEYS and N <= self.MAX_KEYS
+        Pb = -(-P // 64) * 64 if hip else P
+        key = (B, Pb, N, eos, pad, min_new, hip)
         st = self.graphs.pop(key, None)
         if st is None:
             while len(self.graphs) >= self.MAX_STATES:
@@ -556,13 +561,16 @@ class T5GreedyDecoder:
                 bias = self.bias_module.compute_bias(N, N, device=device)[0].permute(1, 0, 2).contiguous().to(dtype)      # [N (query), H, N (key)]
             ar = torch.arange(N, device=device)
             causal = torch.where(ar[None, :] <= ar[:, None], 0.0, torch.finfo(dtype).min).to(dtype)                      # [N, N]
-            st = dict(bias=bias + causal[:, None, :], rel=bias.permute(1, 0, 2).contiguous(), N=N, P=P,      # rel [H, N (query), N (key)]: the kernel's layout (causality = its key range)
+            st = dict(bias=bias + causal[:, None, :], rel=bias.permute(1, 0, 2).contiguous(), N=N, Pb=Pb, hip=hip,      # rel [H, N (query), N (key)]: the kernel's layout (causality = its key range)
                       x=torch.zeros(B, self.D, device=device, dtype=dtype), h=torch.zeros(B, self.D, device=device, dtype=dtype),
-                      q=torch.zeros(B, H * dk, device=device, dtype=dtype), ckv=[None] * L,
+                      q=torch.zeros(B, H * dk, device=device, dtype=dtype),
+                      # cross-attention K | V of every decoder layer [B, Pb, 2 H dk] (fixed addresses: the captured graph reads them) and the encoder length - 1
+                      ckv=[torch.zeros(B, Pb, 2 * H * dk, device=device, dtype=dtype) for _ in range(L)] if hip else [None] * L,
+                      plen=torch.zeros(1, dtype=torch.long, device=device),
                       kc=[torch.zeros(B, H, N, dk, device=device, dtype=dtype) for _ in range(L)],
                       vc=[torch.zeros(B, H, N, dk, device=device, dtype=dtype) for _ in range(L)],
-                      ck=[torch.zeros(B, H, P, dk, device=device, dtype=dtype) for _ in range(L)],
-                      cv=[torch.zeros(B, H, P, dk, device=device, dtype=dtype) for _ in range(L)],
+                      ck=[] if hip else [torch.zeros(B, H, P, dk, device=device, dtype=dtype) for _ in range(L)],
+                      cv=[] if hip else [torch.zeros(B, H, P, dk, device=device, dtype=dtype) for _ in range(L)],
                       tok=torch.zeros(B, dtype=torch.long, device=device), pos=torch.zeros(1, dtype=torch.long, device=device),
                       step=torch.zeros(1, dtype=torch.long, device=device), out=torch.zeros(B, N, dtype=torch.long, device=device),
                       fin=torch.zeros(B, dtype=torch.bool, device=device), graph=None, eos=eos, pad=pad, min_new=min_new)
@@ -578,7 +586,7 @@ class T5GreedyDecoder:
 
     def _decode_step(self, st):
         """One token for every sequence, entirely on the device (captured): `tok` at decoder position `pos` -> next token."""
-        if self._hip(st["x"]):
+        if st["hip"]:
             return self._decode_step_hip(st)
         lm = self.lm
         B, H, dk = st["tok"].shape[0], self.H, self.dk
@@ -624,10 +632,11 @@ class T5GreedyDecoder:
                 raise NotImplementedError("T5GreedyDecoder: one eos_token_id")
             eos_token_id = eos_token_id[0]
         st = self._state(B, P, N, dev, dt, eos_token_id, int(pad_token_id if pad_token_id is not None else 0), int(min_new_tokens or 0))
-        if self._hip(inputs_embeds) and P <= self.MAX_KEYS and N <= self.MAX_KEYS:
+        if st["hip"]:
             enc = self._encode_hip(inputs_embeds)                                   # [B P, D]
-            for li, w in enumerate(self.layers):
-                st["ckv"][li] = self._lin(enc, w["ckv"])                           # cross-attention K | V of every decoder layer, once: [B P, 2 H dk]
+            st["plen"].fill_(P - 1)
+            for li, w in enumerate(self.layers):                                    # cross-attention K | V of every decoder layer, once, into the graph's buffers
+                st["ckv"][li][:, :P].copy_(self._lin(enc, w["ckv"]).view(B, P, 2 * self.H * self.dk))
         else:
             enc = self.lm.encoder(inputs_embeds=inputs_embeds, attention_mask=torch.ones(B, P, dtype=torch.long, device=dev)).last_hidden_state
             for li, w in enumerate(self.layers):
