@@ -31,7 +31,8 @@ extern "C" {
 
 typedef struct ihipStream_t* vtgb_stream_t; /* == hipStream_t */
 
-#define VTGB_VERSION 400 /* round 4: vtgb_llm_attention_rows / vtgb_llm_gated_act (the T5 language model of the BLIP-2 flavours on own kernels:
+#define VTGB_VERSION 401 /* 401: vtgb_gemm_train / vtgb_col_sum_f32 / vtgb_layernorm_train_* / vtgb_gelu_* (the training graph without operand copies or torch
+                            elementwise passes); 400 = round 4: vtgb_llm_attention_rows / vtgb_llm_gated_act (the T5 language model of the BLIP-2 flavours on own kernels:
                             eval/utils/model.py:427-437), vtgb_llm_rope_cache with NULL tables = plain cache append; 300 = round 3: stem weight hi|lo layout; vtgb_attention_args.causal; vtgb_gemm_skinny without workspace when unsplit;
                             vtgb_llm_rope_cache_prefill; vtgb_attn_train_forward / backward; vtgb_comm_* / vtgb_allreduce_f32 */
 
@@ -504,6 +505,66 @@ typedef struct {
 } vtgb_attn_train_args;
 int vtgb_attn_train_forward(const vtgb_attn_train_args* a, vtgb_stream_t stream);
 int vtgb_attn_train_backward(const vtgb_attn_train_args* a, vtgb_stream_t stream);
+
+/* ---- the rest of the training graph (config C5 / the SF flavours) -------------------------------------
+ * vtgb_gemm_train: out[M, N] fp32 = op(a) . op(b) (+ bias[N]) for the three GEMMs of a linear layer under autograd
+ *   (nn.Linear inside InstructBlipQFormerLayer xinstructblip.py:814-883, RopeBertLayer xropebert.py:450-533 and their backward):
+ *     forward  y  = x W^T     a = x  [M, K] k-contiguous, b = W  [N, K] k-contiguous
+ *     dgrad    dX = dY W      a = dY [M, N'] k-contiguous (contraction N'), b = W read k-MAJOR (element (k_out, n') at W + n' * ldw + k_out)
+ *     wgrad    dW = dY^T X    a = dY read k-major (element (n, m) at dY + m * ld + n), b = X read k-major
+ *   x_kmajor = 0: element (row, k) at p + row * ld + k;  1: at p + k * ld + row.  x_dtype: storage, VTGB_F32 or VTGB_BF16 -- operands are
+ *   used where they lie (no transposed or converted copy).  compute = VTGB_BF16: operands rounded to bf16 on the way into LDS, MFMA, fp32
+ *   accumulation;  VTGB_F32: fp32 FMA with the contraction summed in index order (the exactness mode).  Any M, N, K, ld (16-byte aligned
+ *   pointers and ld take the vector path).  Few output tiles under a long contraction (weight gradients): with the workspace given the
+ *   contraction is cut into slices, summed afterwards in slice order (deterministic); without it the launch is unsplit.
+ * vtgb_col_sum_f32: out[n] = sum_m x[m, n] in a fixed order (bias gradients).
+ * vtgb_layernorm_train_forward: sum = x * mask + resid (mask = multiplicative dropout mask or NULL; resid or NULL; `sum` may be NULL when
+ *   both are), y = LayerNorm(sum) * gamma + beta, mean / rstd [rows] kept for the backward.  _backward: from dy, sum (= x when there was no
+ *   mask and no residual), mean, rstd, gamma -> ds (gradient of sum = of resid), dx = ds * mask (only with a mask; else dx = ds), dgamma,
+ *   dbeta [D] -- summed per workgroup in row order into `partial` [vtgb_layernorm_train_partials(rows), 2, D] and then over the partials
+ *   in order (deterministic).  D % 4 == 0, D <= 2048.
+ * vtgb_gelu_forward / _backward: y = x Phi(x) (erf form, F.gelu's default) and dx = dy (Phi(x) + x phi(x)); n fp32 values. */
+typedef struct {
+    int32_t compute, M, N, K;
+    const void* a;
+    int64_t lda;
+    int32_t a_dtype, a_kmajor;
+    const void* b;
+    int64_t ldb;
+    int32_t b_dtype, b_kmajor;
+    const float* bias; /* [N] or NULL */
+    float* out;
+    int64_t ldo;
+    void* workspace;   /* vtgb_gemm_train_workspace_bytes() bytes, or NULL */
+    size_t workspace_bytes;
+} vtgb_gemm_train_args;
+size_t vtgb_gemm_train_workspace_bytes(const vtgb_gemm_train_args* a);
+int vtgb_gemm_train(const vtgb_gemm_train_args* a, vtgb_stream_t stream);
+int vtgb_col_sum_f32(const float* x, int64_t ldx, int32_t M, int32_t N, float* out, vtgb_stream_t stream);
+typedef struct {
+    int32_t rows, D;
+    float eps;
+    const float* x;
+    const float* mask;
+    const float* resid;
+    const float* gamma;
+    const float* beta;
+    float* sum;
+    float* y;
+    float* mean;
+    float* rstd;
+    const float* dy; /* backward only from here */
+    float* ds;
+    float* dx;
+    float* dgamma;
+    float* dbeta;
+    float* partial;
+} vtgb_layernorm_train_args;
+int32_t vtgb_layernorm_train_partials(int32_t rows);
+int vtgb_layernorm_train_forward(const vtgb_layernorm_train_args* a, vtgb_stream_t stream);
+int vtgb_layernorm_train_backward(const vtgb_layernorm_train_args* a, vtgb_stream_t stream);
+int vtgb_gelu_forward(const float* x, float* y, int64_t n, vtgb_stream_t stream);
+int vtgb_gelu_backward(const float* x, const float* dy, float* dx, int64_t n, vtgb_stream_t stream);
 
 /* ---- gradient exchange (config C5; the one collective of the path) ------------------------------------------------
  * Thin wrapper over RCCL (SURVEY.md 8b "later: vtgb_allreduce_f32", 8e): replaces what Lightning's DDPStrategy does for the reference

@@ -286,3 +286,133 @@ def test_dropout_masks_are_injectable_and_replayable(dev, tiny_sd):
     assert torch.equal(p1, p2)                                                                          # replay: bit-identical
     frac = sum(float((v == 0).float().mean()) for v in d1.drawn.values()) / len(d1.drawn)
     assert 0.05 < frac < 0.15
+
+
+# ----------------------------------------------------------------------------- train_ops.hip: operands in place, LayerNorm / GELU both ways
+def _as_stored(t, dtype, pad, shift):
+    """t as a view with leading dimension > width (pad) and/or a base that is not 16-byte aligned (shift): the kernel's scalar path."""
+    r, c = t.shape
+    buf = torch.zeros(r * (c + pad) + shift + 8, dtype=dtype, device=t.device)
+    v = buf[shift: shift + r * (c + pad)].view(r, c + pad)[:, :c]
+    v.copy_(t.to(dtype))
+    return v
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 70, 50), (257, 768, 1408), (64, 192, 20), (1, 5, 3), (96, 200, 3001)])      # the last: split contraction
+@pytest.mark.parametrize("compute", ["bf16", "f32"])
+def test_gemm_train_reads_operands_in_place(dev, M, N, K, compute):
+    """vtgb_gemm_train in all four layout pairs x storage types, aligned and not, vs float64 on the operands as the kernel rounds them
+    (bf16 compute: products of bf16 values are exact in fp32, so only the summation order differs: 2e-6 of sum |a||b|; fp32: same bound)."""
+    from videotgb_amd import _lib as L, train
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g).to(dev)
+    b = torch.randn(N, K, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    code = L.BF16 if compute == "bf16" else L.F32
+    n = 0
+    for a_km in (False, True):
+        for b_km in (False, True):
+            for a_dt in (torch.float32, torch.bfloat16):
+                for b_dt in (torch.float32, torch.bfloat16):
+                    for pad, shift in ((0, 0), (3, 1)):
+                        sa = _as_stored(a.t() if a_km else a, a_dt, pad, shift)
+                        sb = _as_stored(b.t() if b_km else b, b_dt, pad, shift)
+                        out = train.gemm_train(sa, a_km, sb, b_km, bias if n % 2 == 0 else None, code)
+                        ra = (sa.t() if a_km else sa)
+                        rb = (sb.t() if b_km else sb)
+                        if compute == "bf16":
+                            ra, rb = ra.bfloat16(), rb.bfloat16()
+                        ra, rb = ra.double(), rb.double()
+                        want = ra @ rb.t() + (bias.double() if n % 2 == 0 else 0.0)
+                        bound = 2e-6 * (ra.abs() @ rb.abs().t() + 1.0)
+                        assert out.shape == (M, N) and out.dtype == torch.float32
+                        assert ((out.double() - want).abs() <= bound).all(), (a_km, b_km, a_dt, b_dt, pad, shift, (out.double() - want).abs().max().item())
+                        n += 1
+    with pytest.raises(ValueError):
+        train.gemm_train(a, False, b[:, :-1], False, None, code)
+
+
+def test_col_sum_is_deterministic_and_exact_to_rounding(dev):
+    from videotgb_amd import train
+    x = torch.randn(1031, 777, device=dev)
+    s1, s2 = train.col_sum(x), train.col_sum(x)
+    assert torch.equal(s1, s2)
+    assert (s1.double() - x.double().sum(0)).abs().max() <= 1e-5 * x.abs().sum(0).max()
+    v = x[:, 5:300]                                              # a column slice: leading dimension 777
+    assert (train.col_sum(v).double() - v.double().sum(0)).abs().max() <= 1e-5 * x.abs().sum(0).max()
+
+
+@pytest.mark.parametrize("D", [48, 768, 1408, 2048])
+@pytest.mark.parametrize("use_resid,use_mask", [(False, False), (True, False), (True, True), (False, True)])
+def test_layernorm_train_forward_backward_vs_torch_autograd(dev, D, use_resid, use_mask):
+    """LayerNorm(x * mask + resid) both ways vs the torch graph the reference runs (dropout -> add -> nn.LayerNorm) in float64."""
+    from videotgb_amd import train
+    g = torch.Generator().manual_seed(D)
+    rows = (3, 37)
+    x = (torch.randn(*rows, D, generator=g) * 2 + 0.5).to(dev).requires_grad_(True)
+    r = torch.randn(*rows, D, generator=g).to(dev).requires_grad_(True) if use_resid else None
+    m = ((torch.rand(*rows, D, generator=g) >= 0.1).float() / 0.9).to(dev) if use_mask else None
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev).requires_grad_(True)
+    beta = (0.1 * torch.randn(D, generator=g)).to(dev).requires_grad_(True)
+    w = torch.randn(*rows, D, generator=g).to(dev)
+    y = train.layer_norm(x, gamma, beta, 1e-12, r, m)
+    (y * w).sum().backward()
+    leaves = [x, gamma, beta] + ([r] if use_resid else [])
+    got = [t.grad.clone() for t in leaves]
+    x64, g64, b64 = (t.detach().double().requires_grad_(True) for t in (x, gamma, beta))
+    r64 = r.detach().double().requires_grad_(True) if use_resid else None
+    s = x64 * (m.double() if use_mask else 1.0) + (r64 if use_resid else 0.0)
+    y64 = torch.nn.functional.layer_norm(s, (D,), g64, b64, 1e-12)
+    (y64 * w.double()).sum().backward()
+    assert (y.double() - y64).abs().max() <= 2e-6 * y64.abs().max()
+    for t, ref in zip(got, [x64, g64, b64] + ([r64] if use_resid else [])):
+        assert (t.double() - ref.grad).abs().max() <= 5e-6 * ref.grad.abs().max(), (t.shape, (t.double() - ref.grad).abs().max().item())
+    # deterministic parameter gradients: a second backward gives the same bits
+    for t in leaves:
+        t.grad = None
+    (train.layer_norm(x, gamma, beta, 1e-12, r, m) * w).sum().backward()
+    assert torch.equal(gamma.grad, got[1]) and torch.equal(beta.grad, got[2])
+
+
+def test_gelu_train_forward_backward_vs_torch(dev):
+    from videotgb_amd import train
+    for n in (7, 1024, 4099 * 3):
+        x = (torch.randn(n, device=dev) * 3).requires_grad_(True)
+        w = torch.randn(n, device=dev)
+        y = train.gelu(x)
+        (y * w).sum().backward()
+        x64 = x.detach().double().requires_grad_(True)
+        y64 = torch.nn.functional.gelu(x64)
+        (y64 * w.double()).sum().backward()
+        assert (y.double() - y64).abs().max() <= 1e-6 * (1 + y64.abs().max())
+        assert (x.grad.double() - x64.grad).abs().max() <= 2e-6 * (1 + x64.grad.abs().max())
+
+
+def test_training_graph_issues_no_blas_and_no_torch_layernorm_kernel(dev, tiny_sd):
+    """The Q-Former training graph forward + backward: every GEMM, attention, LayerNorm and GELU launch is the library's -- no
+    hipBLASLt / rocBLAS kernel (Cijk_*), no torch layer_norm / GELU kernel, and no operand copy kernels for the GEMMs' sake."""
+    from torch.profiler import ProfilerActivity, profile
+    from test_gpu_e2e import build
+    from videotgb_amd import train
+    m, cfg = build("instructblip", tiny_sd, dev, "f32")
+    pm = m.model
+    train.enable_prefix_training(pm)
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(8, (cfg.vit.image // cfg.vit.patch) ** 2 + 1, cfg.vit.hidden, generator=g).to(dev)
+    ids = torch.randint(3, cfg.qformer.vocab, (8, 6), generator=g).to(dev)
+
+    def step(code):
+        out = train.prefix_with_grad(pm, img, ids, torch.ones_like(ids), [4, 4], "mean", compute_dtype=code, dropout=train.Dropout(0.1, generator=torch.Generator(device=dev).manual_seed(1)))
+        out.square().sum().backward()
+
+    for code in ("f32", "bf16"):
+        step(code)
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step(code)
+            torch.cuda.synchronize()
+        names = [e.key for e in prof.key_averages() if e.device_time_total > 0]
+        assert any("tg_mfma_kernel" in n or "tg_f32_kernel" in n for n in names), names
+        assert any("ln_train_fwd_kernel" in n for n in names) and any("ln_train_bwd_kernel" in n for n in names) and any("gelu_bwd_kernel" in n for n in names)
+        bad = [n for n in names if "Cijk_" in n or "layer_norm" in n.lower() or "GeluCUDAKernel" in n or "GeluBackward" in n]
+        assert not bad, bad

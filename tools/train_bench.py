@@ -45,5 +45,27 @@ if local == 0:
     print(f"C5 micro-batch B={B} x {world} GPU(s), S={P + Li + Lo - 1}, trainable {n_train} params ({n_train * 4 / 1e6:.0f} MB fp32 gradient bucket"
           f"{', adapters only' if lora_only else ''}): {dt * 1e3:.1f} ms per micro-batch incl. the prefix path ({B * world / dt:.1f} sequences/s), "
           f"loss {loss.item():.3f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+if local == 0 and "--no-profile" not in sys.argv:
+    # where one micro-batch's device time goes, and the rate of the prefix graph's own GEMMs (forward + dgrad + wgrad, operands in place)
+    from torch.profiler import ProfilerActivity, profile
+    train.GEMM_FLOPS[0] = 0.0
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        micro(); torch.cuda.synchronize()
+    fam = {"own training GEMM (tg_*)": 0.0, "own attention / LayerNorm / GELU / CE (training)": 0.0, "own inference kernels (frozen ViT-g ...)": 0.0,
+           "torch: LLM GEMMs (hipBLASLt)": 0.0, "torch: other": 0.0}
+    for e in prof.key_averages():
+        t, k = e.device_time_total / 1e3, e.key
+        if t <= 0: continue
+        if "tg_mfma_kernel" in k or "tg_f32_kernel" in k or "tg_split_reduce" in k: fam["own training GEMM (tg_*)"] += t
+        elif any(x in k for x in ("attn_train", "ln_train", "gelu_fwd", "gelu_bwd", "col_sum", "shifted_ce", "concat_text_io")): fam["own attention / LayerNorm / GELU / CE (training)"] += t
+        elif any(x in k for x in ("gemm_bf16", "attn_bf16", "layernorm_kernel", "gemm_skinny", "vit_", "pool_", "qformer")): fam["own inference kernels (frozen ViT-g ...)"] += t
+        elif "Cijk_" in k: fam["torch: LLM GEMMs (hipBLASLt)"] += t
+        else: fam["torch: other"] += t
+    tot = sum(fam.values())
+    print("   device time of one micro-batch: " + "; ".join(f"{k} {v:.1f} ms ({100 * v / tot:.0f} %)" for k, v in fam.items()))
+    tg = fam["own training GEMM (tg_*)"]
+    if tg > 0:
+        tf = train.GEMM_FLOPS[0] / (tg * 1e-3) / 1e12
+        print(f"   prefix-graph GEMMs: {train.GEMM_FLOPS[0] / 1e12:.2f} TFLOP in {tg:.1f} ms = {tf:.0f} TFLOP/s = {100 * tf / 2500:.1f} % of the 2.5 PFLOP/s dense bf16 peak")
 if world > 1:
     dist.barrier(); dist.destroy_process_group()

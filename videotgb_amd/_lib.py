@@ -34,6 +34,8 @@ EXPORTS = [
     "vtgb_raft_corr_workspace_bytes", "vtgb_raft_corr", "vtgb_preprocess_frames", "vtgb_concat_text_io", "vtgb_shifted_ce_forward", "vtgb_shifted_ce_backward",
     "vtgb_comm_unique_id", "vtgb_comm_init", "vtgb_comm_destroy", "vtgb_allreduce_f32",
     "vtgb_attn_train_forward", "vtgb_attn_train_backward",
+    "vtgb_gemm_train", "vtgb_gemm_train_workspace_bytes", "vtgb_col_sum_f32", "vtgb_layernorm_train_partials", "vtgb_layernorm_train_forward", "vtgb_layernorm_train_backward",
+    "vtgb_gelu_forward", "vtgb_gelu_backward",
 ]
 COMM_ID_BYTES = 128
 
@@ -44,6 +46,16 @@ class AttnTrainArgs(C.Structure):
     _fields_ = [("batch", i32), ("heads", i32), ("head_dim", i32), ("s_q", i32), ("s_kv", i32), ("q", vp), ("k", vp), ("v", vp),
                 ("q_tok", i64), ("kv_tok", i64), ("q_batch", i64), ("kv_batch", i64), ("key_mask", vp), ("drop", vp), ("scale", f32),
                 ("out", vp), ("o_tok", i64), ("o_batch", i64), ("lse", vp), ("dout", vp), ("dq", vp), ("dk", vp), ("dv", vp), ("delta", vp)]
+
+
+class GemmTrainArgs(C.Structure):
+    _fields_ = [("compute", i32), ("M", i32), ("N", i32), ("K", i32), ("a", vp), ("lda", i64), ("a_dtype", i32), ("a_kmajor", i32),
+                ("b", vp), ("ldb", i64), ("b_dtype", i32), ("b_kmajor", i32), ("bias", vp), ("out", vp), ("ldo", i64), ("workspace", vp), ("workspace_bytes", sz)]
+
+
+class LayerNormTrainArgs(C.Structure):
+    _fields_ = [("rows", i32), ("D", i32), ("eps", f32), ("x", vp), ("mask", vp), ("resid", vp), ("gamma", vp), ("beta", vp), ("sum", vp),
+                ("y", vp), ("mean", vp), ("rstd", vp), ("dy", vp), ("ds", vp), ("dx", vp), ("dgamma", vp), ("dbeta", vp), ("partial", vp)]
 
 
 class VtgbError(RuntimeError):
@@ -210,6 +222,19 @@ def lib() -> C.CDLL:
     L.vtgb_pack_skinny_weight.restype = C.c_int
     for fn in (L.vtgb_attn_train_forward, L.vtgb_attn_train_backward):
         fn.argtypes = [C.POINTER(AttnTrainArgs), vp]
+        fn.restype = C.c_int
+    L.vtgb_gemm_train.argtypes = [C.POINTER(GemmTrainArgs), vp]
+    L.vtgb_gemm_train_workspace_bytes.argtypes = [C.POINTER(GemmTrainArgs)]
+    L.vtgb_gemm_train_workspace_bytes.restype = sz
+    L.vtgb_col_sum_f32.argtypes = [vp, i64, i32, i32, vp, vp]
+    L.vtgb_layernorm_train_partials.argtypes = [i32]
+    L.vtgb_layernorm_train_partials.restype = i32
+    for fn in (L.vtgb_layernorm_train_forward, L.vtgb_layernorm_train_backward):
+        fn.argtypes = [C.POINTER(LayerNormTrainArgs), vp]
+    L.vtgb_gelu_forward.argtypes = [vp, vp, i64, vp]
+    L.vtgb_gelu_backward.argtypes = [vp, vp, vp, i64, vp]
+    for fn in (L.vtgb_gemm_train, L.vtgb_col_sum_f32, L.vtgb_layernorm_train_forward, L.vtgb_layernorm_train_backward, L.vtgb_gelu_forward,
+               L.vtgb_gelu_backward):
         fn.restype = C.c_int
     L.vtgb_comm_unique_id.argtypes = [vp]
     L.vtgb_comm_init.argtypes = [C.POINTER(vp), vp, i32, i32]

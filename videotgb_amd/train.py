@@ -12,7 +12,9 @@
   Q-Former, ``query_tokens`` and ``language_projection`` train together with the adapters.  ``prefix_with_grad`` (and, for the
   SF flavours, ``tgb_with_grad``) build the TRAINING forward as an autograd graph whose linear layers run forward, dgrad and
   wgrad on the library's own GEMM kernel (``_HipLinear``) and whose attentions run on ``train_attn.hip`` forward and backward
-  (``_HipAttention``); LayerNorm / GELU / adds are elementwise torch ops.  The fused inference stages (vtgb_qformer_forward,
+  (``_HipAttention``); LayerNorm with its residual add and dropout mask (``_HipLayerNorm``) and GELU (``_HipGelu``) are own kernels forward
+  and backward too -- what is left to torch is indexing (embedding gathers, ``cat``, slices, the TGB's rotary shuffle) and the mean
+  pool.  The fused inference stages (vtgb_qformer_forward,
   vtgb_tgb_forward) keep no activations and have no dropout: they serve eval.  Dropout (Q-Former / TGB hidden and
   attention-probability dropout 0.1; LoRA dropout inside ``LoraLinear``) enters as injectable masks (``Dropout``).
 
@@ -87,43 +89,148 @@ def shifted_cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
 
 
 # ----------------------------------------------------------------------------- own-kernel autograd building blocks
-def _gemm_nt(a: Tensor, w: Tensor, bias: Optional[Tensor], code: int) -> Tensor:
-    """a [M, K] . w [N, K]^T (+ bias) -> fp32 [M, N] on the library's GEMM kernels (vtgb_gemm): fp32 FMA kernel (exactness mode)
-    or bf16 MFMA with fp32 accumulation.  bf16 operands need a contraction length that is a multiple of 8: zero padded here."""
-    from . import ops
-    a, w = a.contiguous(), w.contiguous()
-    if code == L.F32:
-        return ops.gemm(a.float(), w.float(), None if bias is None else bias.float().contiguous(), L.EPI_STORE_F32)
-    k = a.shape[1]
-    if k % 8:
-        pad = 8 - k % 8
-        a, w = nn.functional.pad(a, (0, pad)), nn.functional.pad(w, (0, pad))
-    return ops.gemm(a.to(torch.bfloat16), w.to(torch.bfloat16), None if bias is None else bias.float().contiguous(), L.EPI_STORE_F32)
+def _operand(t: Tensor) -> Tensor:
+    """A GEMM operand as the kernel can read it in place: fp32 or bf16, 2-D, unit stride along its rows (any leading dimension)."""
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.float()
+    if t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+GEMM_FLOPS = [0.0]      # 2 M N K of every gemm_train launch since the caller last reset it (tools/train_bench.py: achieved TFLOP/s)
+
+
+def gemm_train(a: Tensor, a_kmajor: bool, b: Tensor, b_kmajor: bool, bias: Optional[Tensor], code: int) -> Tensor:
+    """out [M, N] fp32 = op(a) . op(b) (+ bias) on vtgb_gemm_train, the operands read where they lie.  ``a`` is stored [M, K]
+    (``a_kmajor`` False) or [K, M] (True); ``b`` is stored [N, K] or [K, N].  ``code``: L.BF16 (operands rounded to bf16 inside the
+    kernel, MFMA, fp32 accumulation) or L.F32 (fp32 FMA, exactness mode)."""
+    _need_cuda(a, b)
+    a, b = _operand(a), _operand(b)
+    K, M = (a.shape[0], a.shape[1]) if a_kmajor else (a.shape[1], a.shape[0])
+    Kb, N = (b.shape[0], b.shape[1]) if b_kmajor else (b.shape[1], b.shape[0])
+    if K != Kb:
+        raise ValueError(f"gemm_train: contraction lengths differ ({K} and {Kb})")
+    bias = None if bias is None else bias.float().contiguous()
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    g = L.GemmTrainArgs(code, M, N, K, a.data_ptr(), a.stride(0), dtype_code(a.dtype), int(a_kmajor), b.data_ptr(), b.stride(0),
+                        dtype_code(b.dtype), int(b_kmajor), None if bias is None else bias.data_ptr(), out.data_ptr(), out.stride(0), None, 0)
+    need = L.lib().vtgb_gemm_train_workspace_bytes(C.byref(g))
+    if need:
+        ws = torch.empty(need, dtype=torch.uint8, device=a.device)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), need
+    L.check(L.lib().vtgb_gemm_train(C.byref(g), _stream()))
+    GEMM_FLOPS[0] += 2.0 * M * N * K
+    return out
+
+
+def col_sum(x: Tensor) -> Tensor:
+    """Column sums of an fp32 matrix in a fixed order (vtgb_col_sum_f32): the bias gradient of a linear layer."""
+    _need_cuda(x)
+    x = x.float()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+    L.check(L.lib().vtgb_col_sum_f32(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(), _stream()))
+    return out
 
 
 class _HipLinear(torch.autograd.Function):
-    """y = x W^T + b with forward, dgrad and wgrad on the library's own GEMM kernel (no torch.matmul):
-    dX [M, K] = dY [M, N] . (W^T) [K, N]^T;  dW [N, K] = dY^T [N, M] . (X^T) [K, M]^T;  db = column sums of dY."""
+    """y = x W^T + b with forward, dgrad and wgrad on vtgb_gemm_train (no torch.matmul, and no transposed or converted copy of an
+    operand):  dX [M, K] = dY [M, N] . W [N, K] (W read k-major);  dW [N, K] = dY^T . X (both read k-major);  db = column sums of dY."""
 
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor], code: int):
         x2 = x.reshape(-1, x.shape[-1])
         ctx.save_for_backward(x2, w)
         ctx.code, ctx.has_bias, ctx.shape = code, b is not None, x.shape
-        return _gemm_nt(x2, w, b, code).reshape(*x.shape[:-1], w.shape[0])
+        return gemm_train(x2, False, w, False, b, code).reshape(*x.shape[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, gy: Tensor):
         x2, w = ctx.saved_tensors
-        g2 = gy.reshape(-1, gy.shape[-1]).float().contiguous()
+        g2 = gy.reshape(-1, gy.shape[-1])
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _gemm_nt(g2, w.t(), None, ctx.code).reshape(ctx.shape)
+            gx = gemm_train(g2, False, w, True, None, ctx.code).reshape(ctx.shape)
         if ctx.needs_input_grad[1]:
-            gw = _gemm_nt(g2.t(), x2.t(), None, ctx.code)
+            gw = gemm_train(g2, True, x2, True, None, ctx.code)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.sum(0)
+            gb = col_sum(g2)
         return gx, gw, gb, None
+
+
+class _HipLayerNorm(torch.autograd.Function):
+    """y = LayerNorm(x * mask + resid) on vtgb_layernorm_train_forward / _backward: the post-LN residual sites (``LayerNorm(dropout(dense(h))
+    + input)``: BertSelfOutput / BertOutput, xinstructblip.py:707, :788, xropebert.py:542-582) in one pass each way; ``mask`` is the
+    multiplicative dropout mask (or None), ``resid`` the residual (or None: a plain LayerNorm)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, resid: Optional[Tensor], mask: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float):
+        _need_cuda(x)
+        D = x.shape[-1]
+        x2 = x.reshape(-1, D).float().contiguous()
+        r2 = None if resid is None else resid.expand_as(x).reshape(-1, D).float().contiguous()
+        m2 = None if mask is None else mask.expand_as(x).reshape(-1, D).float().contiguous()
+        g, b = gamma.float().contiguous(), beta.float().contiguous()
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        s = torch.empty_like(x2) if (r2 is not None or m2 is not None) else None
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        a = L.LayerNormTrainArgs(rows, D, float(eps), x2.data_ptr(), None if m2 is None else m2.data_ptr(), None if r2 is None else r2.data_ptr(),
+                                 g.data_ptr(), b.data_ptr(), None if s is None else s.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                 None, None, None, None, None, None)
+        L.check(L.lib().vtgb_layernorm_train_forward(C.byref(a), _stream()))
+        ctx.save_for_backward(x2 if s is None else s, m2, g, mean, rstd)
+        ctx.eps, ctx.shape, ctx.has_resid = float(eps), x.shape, resid is not None
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        s, m2, g, mean, rstd = ctx.saved_tensors
+        rows, D = s.shape
+        dy = gy.reshape(rows, D).float().contiguous()
+        ds = torch.empty_like(s)
+        dx = torch.empty_like(s) if m2 is not None else None
+        dgamma = torch.empty(D, dtype=torch.float32, device=s.device)
+        dbeta = torch.empty_like(dgamma)
+        partial = torch.empty(L.lib().vtgb_layernorm_train_partials(rows), 2, D, dtype=torch.float32, device=s.device)
+        a = L.LayerNormTrainArgs(rows, D, ctx.eps, None, None if m2 is None else m2.data_ptr(), None, g.data_ptr(), None, s.data_ptr(), None,
+                                 mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), ds.data_ptr(), None if dx is None else dx.data_ptr(),
+                                 dgamma.data_ptr(), dbeta.data_ptr(), partial.data_ptr())
+        L.check(L.lib().vtgb_layernorm_train_backward(C.byref(a), _stream()))
+        ds = ds.view(ctx.shape)
+        return (ds if dx is None else dx.view(ctx.shape)), (ds if ctx.has_resid else None), None, dgamma, dbeta, None
+
+
+class _HipGelu(torch.autograd.Function):
+    """F.gelu (erf form) forward and backward on vtgb_gelu_forward / _backward."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        _need_cuda(x)
+        x = x.float().contiguous()
+        y = torch.empty_like(x)
+        L.check(L.lib().vtgb_gelu_forward(x.data_ptr(), y.data_ptr(), x.numel(), _stream()))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        (x,) = ctx.saved_tensors
+        gy = gy.float().contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.lib().vtgb_gelu_backward(x.data_ptr(), gy.data_ptr(), dx.data_ptr(), x.numel(), _stream()))
+        return dx
+
+
+def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, resid: Optional[Tensor] = None, mask: Optional[Tensor] = None) -> Tensor:
+    return _HipLayerNorm.apply(x, resid, mask, gamma, beta, eps)
+
+
+def gelu(x: Tensor) -> Tensor:
+    return _HipGelu.apply(x) if x.numel() else x
 
 
 class _HipAttention(torch.autograd.Function):
@@ -197,10 +304,9 @@ def _qformer_graph(sd: Dict[str, Tensor], query_tokens: Tensor, image_embeds: Te
     """The Q-Former as an autograd graph over the LIVE parameters ``sd`` (names relative to ``model.qformer.``):
     InstructBlipQFormerModel.forward xinstructblip.py:1122-1242 (``input_ids`` given: embeddings :1018-1046, text FFN branch)
     / Blip2QFormerModel.forward xblip2.py:1063-1174.  Every linear layer runs forward, dgrad and wgrad on the library's GEMM
-    kernel (_HipLinear), every attention on train_attn.hip (_HipAttention); LayerNorm / GELU / residual adds are elementwise
-    torch ops.  Dropout sites: embeddings (:1045), attention probabilities (:679), attention output (:707), FFN output (:788).
+    kernel (_HipLinear: operands read in place, no transposed / converted copies), every attention on train_attn.hip
+    (_HipAttention), every ``LayerNorm(dropout(dense(.)) + input)`` site and every GELU on train_ops.hip.  Dropout sites: embeddings (:1045), attention probabilities (:679), attention output (:707), FFN output (:788).
     -> [n, n_query, hidden]."""
-    F = nn.functional
     n = image_embeds.shape[0]
     q = query_tokens.expand(n, -1, -1)
     nq = q.shape[1]
@@ -208,18 +314,19 @@ def _qformer_graph(sd: Dict[str, Tensor], query_tokens: Tensor, image_embeds: Te
     def lin(name, x):
         return _HipLinear.apply(x, sd[name + ".weight"], sd[name + ".bias"], code)
 
-    def ln(name, x):
-        return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], eps)
+    def ln(name, x, resid=None, site=None):
+        """LayerNorm(dropout_site(x) + resid) in one kernel each way"""
+        mask = None if site is None else drop.mask(site, x.shape, x.device)
+        return layer_norm(x, sd[name + ".weight"], sd[name + ".bias"], eps, resid, mask)
 
     def attn(ap, site, hidden, kv, key_mask):
         qq, kk, vv = lin(ap + "attention.query", hidden), lin(ap + "attention.key", kv), lin(ap + "attention.value", kv)
         dm = drop.mask(site + ".probs", (hidden.shape[0], heads, hidden.shape[1], kv.shape[1]), hidden.device)
         ctx = _HipAttention.apply(qq, kk, vv, heads, 1.0 / math.sqrt(qq.shape[-1] // heads), key_mask, dm)
-        return ln(ap + "output.LayerNorm", drop(site + ".out", lin(ap + "output.dense", ctx)) + hidden)
+        return ln(ap + "output.LayerNorm", lin(ap + "output.dense", ctx), hidden, site + ".out")
 
     def ffn(lp, site, inter, outp, x):
-        h = drop(site, lin(lp + outp + ".dense", F.gelu(lin(lp + inter + ".dense", x))))
-        return ln(lp + outp + ".LayerNorm", h + x)
+        return ln(lp + outp + ".LayerNorm", lin(lp + outp + ".dense", gelu(lin(lp + inter + ".dense", x))), x, site)
 
     if input_ids is not None:
         lt = input_ids.shape[1]
@@ -308,8 +415,9 @@ def _tgb_graph(sd: Dict[str, Tensor], of: Tensor, of_mask: Tensor, text_ids: Ten
     def lin(name, x):
         return _HipLinear.apply(x, sd[name + ".weight"], sd[name + ".bias"], code)
 
-    def ln(name, x, e=eps):
-        return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], e)
+    def ln(name, x, e=eps, resid=None, site=None):
+        mask = None if site is None else drop.mask(site, x.shape, x.device)
+        return layer_norm(x, sd[name + ".weight"], sd[name + ".bias"], e, resid, mask)
 
     patches = of.float().reshape(b * l, c, hh // ps, ps, ww // ps, ps).permute(0, 2, 4, 1, 3, 5).reshape(b * l, -1, c * ps * ps)   # [BL, 196, 512]
     fcw, fcb = sd[te + "fc.weight"].reshape(-1), sd[te + "fc.bias"].reshape(())
@@ -337,7 +445,7 @@ def _tgb_graph(sd: Dict[str, Tensor], of: Tensor, of_mask: Tensor, text_ids: Ten
         vv = lin(ap + "self.value", kv)
         dm = drop.mask(site + ".probs", (hidden.shape[0], heads, hidden.shape[1], kv.shape[1]), hidden.device)
         ctx = _HipAttention.apply(qq, kk, vv, heads, 1.0 / math.sqrt(hd), key_mask, dm)
-        return ln(ap + "output.LayerNorm", drop(site + ".out", lin(ap + "output.dense", ctx)) + hidden)
+        return ln(ap + "output.LayerNorm", lin(ap + "output.dense", ctx), eps, hidden, site + ".out")
 
     n_layers = 0
     while f"encoder.layer.{n_layers}.attention.self.query.weight" in sd:
@@ -355,8 +463,8 @@ def _tgb_graph(sd: Dict[str, Tensor], of: Tensor, of_mask: Tensor, text_ids: Ten
         a = attn(lp + "attention.", f"layer.{i}.attention", x, x, self_mask, pos, pos)
         if i >= fusion_layer:
             a = attn(lp + "crossattention.", f"layer.{i}.crossattention", a, t, cross_mask, pos, cpos)
-        hmid = F.gelu(lin(lp + "intermediate.dense", a))
-        x = ln(lp + "output.LayerNorm", drop(f"layer.{i}.ffn", lin(lp + "output.dense", hmid)) + a)
+        hmid = gelu(lin(lp + "intermediate.dense", a))
+        x = ln(lp + "output.LayerNorm", lin(lp + "output.dense", hmid), eps, a, f"layer.{i}.ffn")
     logits = lin("mrc_head", x[:, 1:-1])
     return x, logits
 
