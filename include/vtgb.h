@@ -517,7 +517,7 @@ int vtgb_attn_train_backward(const vtgb_attn_train_args* a, vtgb_stream_t stream
  *   accumulation;  VTGB_F32: fp32 FMA with the contraction summed in index order (the exactness mode).  Any M, N, K, ld (16-byte aligned
  *   pointers and ld take the vector path).  Few output tiles under a long contraction (weight gradients): with the workspace given the
  *   contraction is cut into slices, summed afterwards in slice order (deterministic); without it the launch is unsplit.
- * vtgb_col_sum_f32: out[n] = sum_m x[m, n] in a fixed order (bias gradients).
+ * vtgb_col_sum_f32: out[n] = sum_m x[m, n] in a fixed order (bias gradients); `partial` = fp32 workspace [vtgb_col_sum_parts(M), N].
  * vtgb_layernorm_train_forward: sum = x * mask + resid (mask = multiplicative dropout mask or NULL; resid or NULL; `sum` may be NULL when
  *   both are), y = LayerNorm(sum) * gamma + beta, mean / rstd [rows] kept for the backward.  _backward: from dy, sum (= x when there was no
  *   mask and no residual), mean, rstd, gamma -> ds (gradient of sum = of resid), dx = ds * mask (only with a mask; else dx = ds), dgamma,
@@ -540,7 +540,8 @@ typedef struct {
 } vtgb_gemm_train_args;
 size_t vtgb_gemm_train_workspace_bytes(const vtgb_gemm_train_args* a);
 int vtgb_gemm_train(const vtgb_gemm_train_args* a, vtgb_stream_t stream);
-int vtgb_col_sum_f32(const float* x, int64_t ldx, int32_t M, int32_t N, float* out, vtgb_stream_t stream);
+int32_t vtgb_col_sum_parts(int32_t M);
+int vtgb_col_sum_f32(const float* x, int64_t ldx, int32_t M, int32_t N, float* out, float* partial, vtgb_stream_t stream);
 typedef struct {
     int32_t rows, D;
     float eps;

@@ -61,6 +61,9 @@ if local == 0 and "--no-profile" not in sys.argv:
         elif any(x in k for x in ("gemm_bf16", "attn_bf16", "layernorm_kernel", "gemm_skinny", "vit_", "pool_", "qformer")): fam["own inference kernels (frozen ViT-g ...)"] += t
         elif "Cijk_" in k: fam["torch: LLM GEMMs (hipBLASLt)"] += t
         else: fam["torch: other"] += t
+    if "--kernels" in sys.argv:
+        for e in sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:30]:
+            print(f"      {e.device_time_total / 1e3:8.2f} ms x{e.count:5d}  {e.key[:150]}")
     tot = sum(fam.values())
     print("   device time of one micro-batch: " + "; ".join(f"{k} {v:.1f} ms ({100 * v / tot:.0f} %)" for k, v in fam.items()))
     tg = fam["own training GEMM (tg_*)"]

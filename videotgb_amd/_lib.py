@@ -34,7 +34,7 @@ EXPORTS = [
     "vtgb_raft_corr_workspace_bytes", "vtgb_raft_corr", "vtgb_preprocess_frames", "vtgb_concat_text_io", "vtgb_shifted_ce_forward", "vtgb_shifted_ce_backward",
     "vtgb_comm_unique_id", "vtgb_comm_init", "vtgb_comm_destroy", "vtgb_allreduce_f32",
     "vtgb_attn_train_forward", "vtgb_attn_train_backward",
-    "vtgb_gemm_train", "vtgb_gemm_train_workspace_bytes", "vtgb_col_sum_f32", "vtgb_layernorm_train_partials", "vtgb_layernorm_train_forward", "vtgb_layernorm_train_backward",
+    "vtgb_gemm_train", "vtgb_gemm_train_workspace_bytes", "vtgb_col_sum_parts", "vtgb_col_sum_f32", "vtgb_layernorm_train_partials", "vtgb_layernorm_train_forward", "vtgb_layernorm_train_backward",
     "vtgb_gelu_forward", "vtgb_gelu_backward",
 ]
 COMM_ID_BYTES = 128
@@ -226,7 +226,9 @@ def lib() -> C.CDLL:
     L.vtgb_gemm_train.argtypes = [C.POINTER(GemmTrainArgs), vp]
     L.vtgb_gemm_train_workspace_bytes.argtypes = [C.POINTER(GemmTrainArgs)]
     L.vtgb_gemm_train_workspace_bytes.restype = sz
-    L.vtgb_col_sum_f32.argtypes = [vp, i64, i32, i32, vp, vp]
+    L.vtgb_col_sum_f32.argtypes = [vp, i64, i32, i32, vp, vp, vp]
+    L.vtgb_col_sum_parts.argtypes = [i32]
+    L.vtgb_col_sum_parts.restype = i32
     L.vtgb_layernorm_train_partials.argtypes = [i32]
     L.vtgb_layernorm_train_partials.restype = i32
     for fn in (L.vtgb_layernorm_train_forward, L.vtgb_layernorm_train_backward):

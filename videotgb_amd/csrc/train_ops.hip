@@ -289,16 +289,27 @@ __global__ __launch_bounds__(256) void tg_f32_kernel(const TgF32Params p) {
 }
 
 // ============================================================================ column sums
-// out[n] = sum_m x[m, n]: 64 columns per workgroup, four row phases each summed in row order, combined in phase order.
-__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, int64_t ldx, int M, int N, float* __restrict__ out) {
-    __shared__ float part[4][64];
+// out[n] = sum_m x[m, n]: the rows are cut into `parts` runs; a workgroup sums one run of 64 columns (four row phases in row order, combined in
+// phase order) into part[run][n], a second launch adds the runs in order.  (One launch over whole columns was 12 workgroups for a 768-wide
+// gradient: ~100 us per bias gradient, as long as the weight-gradient GEMM beside it.)
+constexpr int CS_ROWS = 128;        // rows per run
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, int64_t ldx, int M, int N, float* __restrict__ part) {
+    __shared__ float ph[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, n = blockIdx.x * 64 + tx;
+    const int m0 = blockIdx.y * CS_ROWS, m1 = min(M, m0 + CS_ROWS);
     float s = 0.f;
     if (n < N)
-        for (int m = ty; m < M; m += 4) s += x[(int64_t)m * ldx + n];
-    part[ty][tx] = s;
+        for (int m = m0 + ty; m < m1; m += 4) s += x[(int64_t)m * ldx + n];
+    ph[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && n < N) out[n] = ((part[0][tx] + part[1][tx]) + part[2][tx]) + part[3][tx];
+    if (ty == 0 && n < N) part[(int64_t)blockIdx.y * N + n] = ((ph[0][tx] + ph[1][tx]) + ph[2][tx]) + ph[3][tx];
+}
+__global__ __launch_bounds__(256) void col_sum_reduce_kernel(const float* __restrict__ part, int parts, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int i = 0; i < parts; i++) s += part[(int64_t)i * N + n];
+    out[n] = s;
 }
 
 // ============================================================================ LayerNorm (training)
@@ -546,10 +557,15 @@ extern "C" size_t vtgb_gemm_train_workspace_bytes(const vtgb_gemm_train_args* g)
     return sp > 1 ? (size_t)sp * g->M * g->N * sizeof(float) : 0;
 }
 
-extern "C" int vtgb_col_sum_f32(const float* x, int64_t ldx, int32_t M, int32_t N, float* out, vtgb_stream_t stream) {
-    VTGB_REQUIRE(x && out && M > 0 && N > 0 && ldx >= N, VTGB_EINVAL, "col_sum_f32: x=%p out=%p M=%d N=%d ldx=%lld", (const void*)x, (void*)out, M, N,
-                 (long long)ldx);
-    hipLaunchKernelGGL(col_sum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, M, N, out);
+extern "C" int32_t vtgb_col_sum_parts(int32_t M) { return M > 0 ? (M + CS_ROWS - 1) / CS_ROWS : 0; }
+
+extern "C" int vtgb_col_sum_f32(const float* x, int64_t ldx, int32_t M, int32_t N, float* out, float* partial, vtgb_stream_t stream) {
+    VTGB_REQUIRE(x && out && partial && M > 0 && N > 0 && ldx >= N, VTGB_EINVAL, "col_sum_f32: x=%p out=%p partial=%p M=%d N=%d ldx=%lld", (const void*)x,
+                 (void*)out, (void*)partial, M, N, (long long)ldx);
+    const int parts = vtgb_col_sum_parts(M);
+    hipLaunchKernelGGL(col_sum_kernel, dim3((N + 63) / 64, parts), dim3(256), 0, (hipStream_t)stream, x, ldx, M, N, partial);
+    VTGB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(col_sum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, parts, N, out);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }

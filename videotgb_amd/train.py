@@ -131,7 +131,8 @@ def col_sum(x: Tensor) -> Tensor:
     if x.stride(1) != 1:
         x = x.contiguous()
     out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
-    L.check(L.lib().vtgb_col_sum_f32(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(), _stream()))
+    part = torch.empty(L.lib().vtgb_col_sum_parts(x.shape[0]), x.shape[1], dtype=torch.float32, device=x.device)
+    L.check(L.lib().vtgb_col_sum_f32(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(), part.data_ptr(), _stream()))
     return out
 
 
