@@ -59,29 +59,53 @@ __global__ void raft_init_kernel(const float* __restrict__ net, const float* __r
 // ---------------------------------------------------------------------------------------
 struct CorrPyr { const void* lvl[4]; int h[4], w[4]; };
 
-constexpr int CL_PIX = 8;   // pixels per wave (the per-lane tap tables are built once and reused)
-// Software-pipelined over the wave's pixels: the 8 window loads of pixel i + 1 (unconditional, clamped addresses: hipcc can
-// then count them) are in flight while pixel i is interpolated out of LDS; the flow of all CL_PIX pixels is fetched by one load
-// up front; the 384 outputs of a pixel leave through an LDS staging row as ONE 16-byte store per lane (48 lanes; was six 2-byte
-// stores per lane -- the store path is per-instruction bound).
+constexpr int CL_PIX = 16;  // pixels per wave (the per-lane tables are built once and reused; 4 levels x 16 pixels = one lane each below)
+// Software-pipelined over the wave's pixels: the 8 window loads of pixel i + 1 are in flight while pixel i is interpolated out of
+// LDS; the 384 outputs of a pixel leave through an LDS staging row as ONE 16-byte store per lane (48 lanes; was six 2-byte stores
+// per lane -- the store path is per-instruction bound).
+// r4: the kernel was VALU-bound, not HBM-bound (218 vector instructions per pixel and wave = 250 cycles per pixel and CU = its
+// whole 1.08 ms; it moves 4.4 GB).  Now (~90): the wave-uniform part of a pixel's work -- its coordinates, the four levels' window
+// origins, byte offsets and fractions -- is computed ONCE for all 16 pixels x 4 levels, one (pixel, level) per lane, and read back
+// with v_readlane (64 lanes of floorf / divisions per pixel and level before); the window loads go through a buffer descriptor of
+// the pixel's own correlation map, whose range check returns the zeros of the padding (rows above / below fall outside by
+// themselves, columns left / right get an out-of-range offset): no 64-bit address arithmetic, no validity bits carried to the
+// deposit; the bilinear form is P + wy (Q - P) on the packed pairs the LDS reads deliver, then one more lerp along x; only the last
+// 64 taps carry a guard.
+typedef float lk_f32x2 __attribute__((ext_vector_type(2)));
+template <typename CT>
+__device__ __forceinline__ CT lk_load(__amdgpu_buffer_rsrc_t r, unsigned off);
+template <>
+__device__ __forceinline__ _Float16 lk_load<_Float16>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
+}
+template <>
+__device__ __forceinline__ float lk_load<float>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
 template <typename CT, typename OT>
 __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr, const float* __restrict__ flow, OT* __restrict__ out,
                                                                int64_t M, int H8, int W8) {
     __shared__ float win[4][4][104];   // [wave][level][10 x 10 window | wx | wy | pad]
     __shared__ __attribute__((aligned(16))) OT stage[4][2][384];
-    // (readfirstlane: the wave index -- and with it the pixel index, its image coordinates and the four 64-bit level bases -- is
-    // wave-uniform; told so, hipcc keeps that arithmetic on the scalar unit instead of 64 lanes of v_mad_u64_u32: r3)
+    // (readfirstlane: the wave index -- and with it the pixel index and the level bases -- is wave-uniform; told so, hipcc keeps that
+    // arithmetic on the scalar unit: r3)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wy0 = lane / 10, wx0 = lane - wy0 * 10;                 // window element `lane`
     const int e1 = lane < 36 ? lane + 64 : 99;                        // window element `lane + 64` (lanes >= 36 repeat the last one)
     const int wy1 = e1 / 10, wx1 = e1 - wy1 * 10;
-    // output k = kk * 64 + lane = level * 81 + i * 9 + j  (i: x offset, j: y offset): LDS offsets, fixed per lane
+    int la[4], lb[4];                                                 // byte offsets of the lane's two window elements from the window origin
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        la[l] = (wy0 * pyr.w[l] + wx0) * (int)sizeof(CT);
+        lb[l] = (wy1 * pyr.w[l] + wx1) * (int)sizeof(CT);
+    }
+    // output k = kk * 64 + lane = level * 81 + i * 9 + j  (i: x offset, j: y offset): LDS offsets, fixed per lane; k >= 324: zero
     int tap_off[6], frac_off[6];
 #pragma unroll
     for (int kk = 0; kk < 6; kk++) {
         const int k = kk * 64 + lane;
         const int l = k / 81, t = k - l * 81, i = t / 9, j = t - i * 9;
-        tap_off[kk] = k < 324 ? l * 104 + j * 10 + i : -1;
+        tap_off[kk] = k < 324 ? l * 104 + j * 10 + i : 0;
         frac_off[kk] = (k < 324 ? l : 0) * 104 + 100;
     }
     float* const wv = &win[wave][0][0];
@@ -90,47 +114,54 @@ __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr
     if (m_first >= M) return;                                         // wave-uniform
     const int npx = (int)(M - m_first < CL_PIX ? M - m_first : CL_PIX);
     const int p_first = (int)(m_first % HW);                          // one 64-bit division per wave, not per pixel
-    // flows of the wave's pixels: lane i holds pixel i's
-    const float2 flv = *reinterpret_cast<const float2*>(flow + (m_first + (lane < npx ? lane : 0)) * 2);
+    // lane = 4 * pixel + level: window origin (x, byte offset) and fractions of that pixel at that level (corr.py:36-43 with
+    // bilinear_sampler's align_corners coordinates, utils.py:58-71)
+    int sx0, sbase;
+    float sqx, sqy;
+    {
+        const int spi = (lane >> 2) < npx ? (lane >> 2) : npx - 1, sl = lane & 3;
+        int p = p_first + spi;                                        // pixel inside its image (CL_PIX <= HW)
+        p = p >= HW ? p - HW : p;
+        const float2 f = *reinterpret_cast<const float2*>(flow + (m_first + spi) * 2);
+        const float cx = (float)(p % W8) + f.x, cy = (float)(p / W8) + f.y;
+        const float sc = 1.0f / (float)(1 << sl);
+        const float xs = cx * sc, ys = cy * sc, x0f = floorf(xs), y0f = floorf(ys);
+        // (far outside the map the whole window is padding; clamped so that the byte offsets below stay far from 32-bit wrap-around)
+        const int x0 = (int)fminf(fmaxf(x0f, -32768.f), 32768.f) - 4, y0 = (int)fminf(fmaxf(y0f, -32768.f), 32768.f) - 4;
+        const int wl = sl == 0 ? pyr.w[0] : sl == 1 ? pyr.w[1] : sl == 2 ? pyr.w[2] : pyr.w[3];
+        sx0 = x0;
+        sbase = (y0 * wl + x0) * (int)sizeof(CT);
+        sqx = xs - x0f; sqy = ys - y0f;
+    }
     CT cur[8], nxt[8];
-    float fx[4], fy[4], nfx[4], nfy[4];
-    int cur_ok, nxt_ok;
-    // the window of pixel pi: 2 loads per level into r[2 l], r[2 l + 1]; fractions into qx / qy
-#define CL_FETCH(pi, r, qx, qy)                                                                         \
+    // the window of pixel pi: 2 loads per level into r[2 l], r[2 l + 1]
+#define CL_FETCH(pi, r)                                                                                 \
     {                                                                                                   \
-        r##_ok = 0;                                                                                     \
         const int64_t m = m_first + (pi);                                                               \
-        int p = p_first + (pi);                          /* pixel inside its image (CL_PIX <= HW) */    \
-        p = p >= HW ? p - HW : p;                                                                       \
-        const float cx = (float)(p % W8) + __shfl(flv.x, (pi)), cy = (float)(p / W8) + __shfl(flv.y, (pi)); \
         _Pragma("unroll") for (int l = 0; l < 4; l++) {                                                 \
-            const int hl = pyr.h[l], wl = pyr.w[l];                                                     \
-            const CT* img = reinterpret_cast<const CT*>(pyr.lvl[l]) + m * (int64_t)(hl * wl);           \
-            const float sc = 1.0f / (float)(1 << l);                                                    \
-            const float xs = cx * sc, ys = cy * sc, x0f = floorf(xs), y0f = floorf(ys);                 \
-            const int x0 = (int)x0f - 4, y0 = (int)y0f - 4;                                             \
-            const int ya = y0 + wy0, xa = x0 + wx0, yb = y0 + wy1, xb = x0 + wx1;                       \
-            const bool oka = (unsigned)ya < (unsigned)hl && (unsigned)xa < (unsigned)wl;                \
-            const bool okb = (unsigned)yb < (unsigned)hl && (unsigned)xb < (unsigned)wl;                \
-            r[2 * l] = img[oka ? ya * wl + xa : 0];          /* raw: the out-of-window select waits until the deposit */ \
-            r[2 * l + 1] = img[okb ? yb * wl + xb : 0];                                                 \
-            r##_ok |= ((int)oka << (2 * l)) | ((int)okb << (2 * l + 1));                                \
-            qx[l] = xs - x0f; qy[l] = ys - y0f;                                                         \
+            const int hw = pyr.h[l] * pyr.w[l];                                                         \
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<CT*>(reinterpret_cast<const CT*>(pyr.lvl[l]) + m * (int64_t)hw), 0, \
+                                                              hw * (int)sizeof(CT), 0x00020000);        \
+            const int x0 = __builtin_amdgcn_readlane(sx0, (pi) * 4 + l), b0 = __builtin_amdgcn_readlane(sbase, (pi) * 4 + l); \
+            const unsigned oa = (unsigned)(x0 + wx0) < (unsigned)pyr.w[l] ? (unsigned)(b0 + la[l]) : 0xFFFFFFF0u; \
+            const unsigned ob = (unsigned)(x0 + wx1) < (unsigned)pyr.w[l] ? (unsigned)(b0 + lb[l]) : 0xFFFFFFF0u; \
+            r[2 * l] = lk_load<CT>(rs, oa);                                                             \
+            r[2 * l + 1] = lk_load<CT>(rs, ob);                                                         \
         }                                                                                               \
     }
-#define CL_DEPOSIT(r, qx, qy)                                                                           \
+#define CL_DEPOSIT(pi, r)                                                                               \
     _Pragma("unroll") for (int l = 0; l < 4; l++) {                                                     \
-        wv[l * 104 + lane] = (r##_ok >> (2 * l)) & 1 ? (float)r[2 * l] : 0.f;                           \
-        if (lane < 36) wv[l * 104 + lane + 64] = (r##_ok >> (2 * l + 1)) & 1 ? (float)r[2 * l + 1] : 0.f; \
-        if (lane == 63) { wv[l * 104 + 100] = qx[l]; wv[l * 104 + 101] = qy[l]; }                       \
-    }
+        wv[l * 104 + lane] = (float)r[2 * l];                                                           \
+        if (lane < 36) wv[l * 104 + lane + 64] = (float)r[2 * l + 1];                                   \
+    }                                                                                                   \
+    if ((lane >> 2) == (pi)) { wv[(lane & 3) * 104 + 100] = sqx; wv[(lane & 3) * 104 + 101] = sqy; }
     constexpr int CHUNKS = 384 * (int)sizeof(OT) / 16;
 #define CL_STORE(pi)                                                                                    \
     _Pragma("unroll") for (int c = lane; c < CHUNKS; c += 64)                                           \
         *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out + (m_first + (pi)) * 384) + c * 16) =     \
             *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(&stage[wave][(pi) & 1][0]) + c * 16);
-    CL_FETCH(0, cur, fx, fy)
-    CL_DEPOSIT(cur, fx, fy)
+    CL_FETCH(0, cur)
+    CL_DEPOSIT(0, cur)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // the windows are private to this wave
     // iteration pi: store pixel pi - 1 (staged last time) | issue the window loads of pixel pi + 1 | interpolate pixel pi out of
     // LDS into the other staging row | wait for the loads (the only vmcnt wait of the iteration: the store in front of them
@@ -138,19 +169,19 @@ __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr
     for (int pi = 0; pi < npx; pi++) {
         if (pi > 0) { CL_STORE(pi - 1) }
         const int pn = pi + 1 < npx ? pi + 1 : pi;                    // (the last iteration re-fetches its own pixel: no tail branch)
-        CL_FETCH(pn, nxt, nfx, nfy)
+        CL_FETCH(pn, nxt)
 #pragma unroll
         for (int kk = 0; kk < 6; kk++) {
-            float v = 0.f;
-            if (tap_off[kk] >= 0) {
-                const float wx = wv[frac_off[kk]], wy = wv[frac_off[kk] + 1];
-                const float* q = wv + tap_off[kk];
-                v = (1.f - wy) * ((1.f - wx) * q[0] + wx * q[1]) + wy * ((1.f - wx) * q[10] + wx * q[11]);
-            }
+            const float wx = wv[frac_off[kk]], wy = wv[frac_off[kk] + 1];
+            const float* q = wv + tap_off[kk];
+            const lk_f32x2 top = {q[0], q[1]}, bot = {q[10], q[11]};
+            const lk_f32x2 c = top + wy * (bot - top);                // both columns interpolated along y (packed)
+            float v = c[0] + wx * (c[1] - c[0]);
+            if (kk == 5) v = lane < 4 ? v : 0.f;                      // k >= 324: the zero padding of K
             stage[wave][pi & 1][kk * 64 + lane] = (OT)v;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // window reads done, staging row written
-        CL_DEPOSIT(nxt, nfx, nfy)
+        CL_DEPOSIT(pn, nxt)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     CL_STORE(npx - 1)
