@@ -135,12 +135,14 @@ __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr
     }
     CT cur[8], nxt[8];
     // the window of pixel pi: 2 loads per level into r[2 l], r[2 l + 1]
+    const CT* lvl0[4];                                                // the wave's first pixel's maps (64-bit arithmetic once per wave)
+#pragma unroll
+    for (int l = 0; l < 4; l++) lvl0[l] = reinterpret_cast<const CT*>(pyr.lvl[l]) + m_first * (int64_t)(pyr.h[l] * pyr.w[l]);
 #define CL_FETCH(pi, r)                                                                                 \
     {                                                                                                   \
-        const int64_t m = m_first + (pi);                                                               \
         _Pragma("unroll") for (int l = 0; l < 4; l++) {                                                 \
             const int hw = pyr.h[l] * pyr.w[l];                                                         \
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<CT*>(reinterpret_cast<const CT*>(pyr.lvl[l]) + m * (int64_t)hw), 0, \
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<CT*>(lvl0[l] + (unsigned)((pi) * hw)), 0, \
                                                               hw * (int)sizeof(CT), 0x00020000);        \
             const int x0 = __builtin_amdgcn_readlane(sx0, (pi) * 4 + l), b0 = __builtin_amdgcn_readlane(sbase, (pi) * 4 + l); \
             const unsigned oa = (unsigned)(x0 + wx0) < (unsigned)pyr.w[l] ? (unsigned)(b0 + la[l]) : 0xFFFFFFF0u; \
@@ -188,6 +190,178 @@ __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr
 #undef CL_STORE
 #undef CL_FETCH
 #undef CL_DEPOSIT
+}
+
+// ---------------------------------------------------------------------------------------
+// Correlation lookup + convc1 (update.py:88-91: cor = relu(convc1(corr)), a 1x1 convolution 324 -> 256) in ONE launch (r4, bf16 mode).
+// After the lookup's instruction diet (above) the pair was HBM-bound on a round trip: the lookup wrote 384 bf16 taps per pixel
+// (1.77 GB per launch at the bench batch) that convc1 read straight back.  Here a workgroup takes 64 pixels: its eight waves look
+// up 8 pixels each -- the same per-pixel code, four pixels' window loads in flight per wave since only 16 waves fit a CU -- and
+// deposit the taps as rows of a [64][352] bf16 operand tile in LDS (row pitch 784 B: ds_read_b128 of 16 rows spreads over all
+// banks); then wave w multiplies the tile with its 32 output channels' weights, streamed from L2 in MFMA fragment order (packed
+// once per call, 176 KB shared by every workgroup; 11 k-steps of 32, K = 324 zero-padded to 352 instead of 384), adds the bias,
+// applies the ReLU and the tile leaves through LDS as whole 512-byte rows.  Two workgroups per CU: one's lookup runs beside the
+// other's MFMA phase.  Traffic per launch 2.7 GB of windows + 1.2 GB out (was 4.4 + 2.95 GB over two launches).
+// ---------------------------------------------------------------------------------------
+constexpr int LC_PX = 64, LC_LDA = 392, LC_KS = 11, LC_LDO = 264, LC_WAVES = 8, LC_WPX = LC_PX / LC_WAVES;
+constexpr int LC_A_BYTES = LC_PX * LC_LDA * 2;
+constexpr int LC_LDS = LC_A_BYTES + LC_WAVES * 4 * 104 * 4;
+constexpr size_t LC_WPK_BYTES = (size_t)LC_WAVES * LC_KS * 2 * 1024;
+
+// packed[((w * 11 + ks) * 2 + i) * 64 + lane][e] = W[w * 32 + i * 16 + (lane & 15)][ks * 32 + (lane >> 4) * 8 + e]   (W row-major [256][384])
+__global__ __launch_bounds__(256) void raft_lkc1_pack_w_kernel(const bf16_t* __restrict__ w, bf16x8* __restrict__ packed) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= LC_WAVES * LC_KS * 2 * 64) return;
+    const int lane = idx & 63, i = (idx >> 6) & 1, ks = (idx >> 7) % LC_KS, wv = (idx >> 7) / LC_KS;
+    packed[idx] = *reinterpret_cast<const bf16x8*>(w + (int64_t)(wv * 32 + i * 16 + (lane & 15)) * 384 + ks * 32 + (lane >> 4) * 8);
+}
+
+template <typename CT>
+__global__ __launch_bounds__(512, 2) void raft_lookup_convc1_kernel(const CorrPyr pyr, const float* __restrict__ flow, const bf16x8* __restrict__ wpk,
+                                                                    const float* __restrict__ bias, bf16_t* __restrict__ c1, int64_t M, int H8, int W8) {
+    extern __shared__ __attribute__((aligned(16))) char lc_smem[];
+    bf16_t* const At = reinterpret_cast<bf16_t*>(lc_smem);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* const wv = reinterpret_cast<float*>(lc_smem + LC_A_BYTES) + wave * (4 * 104);
+    const int fr = lane & 15, fg = lane >> 4;
+    // this wave's weight fragments of the first three k-steps: in flight during the whole lookup phase
+    const bf16x8* wp = wpk + (int64_t)wave * LC_KS * 2 * 64 + lane;
+    bf16x8 wf[4][2];                                                  // ring of four k-steps: three in flight ahead of the one multiplied
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) wf[k][i] = wp[(k * 2 + i) * 64];
+    const int wy0 = lane / 10, wx0 = lane - wy0 * 10;
+    const int e1 = lane < 36 ? lane + 64 : 99;
+    const int wy1 = e1 / 10, wx1 = e1 - wy1 * 10;
+    int la[4], lb[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        la[l] = (wy0 * pyr.w[l] + wx0) * (int)sizeof(CT);
+        lb[l] = (wy1 * pyr.w[l] + wx1) * (int)sizeof(CT);
+    }
+    int tap_off[6], frac_off[6];
+#pragma unroll
+    for (int kk = 0; kk < 6; kk++) {
+        const int k = kk * 64 + lane;
+        const int l = k / 81, t = k - l * 81, i = t / 9, j = t - i * 9;
+        tap_off[kk] = k < 324 ? l * 104 + j * 10 + i : 0;
+        frac_off[kk] = (k < 324 ? l : 0) * 104 + 100;
+    }
+    const int HW = H8 * W8;
+    const int64_t m_tile = (int64_t)blockIdx.x * LC_PX, m_first = m_tile + wave * LC_WPX;
+    const int npx = (int)(M - m_first < LC_WPX ? (M - m_first > 0 ? M - m_first : 0) : LC_WPX);   // (a trailing wave may have none: its rows are never stored)
+    if (npx > 0) {
+        const int p_first = (int)(m_first % HW);
+        int sx0, sbase;
+        float sqx, sqy;
+        {
+            const int spi = (lane >> 2) < npx ? (lane >> 2) : npx - 1, sl = lane & 3;
+            int p = p_first + spi;
+            p = p >= HW ? p - HW : p;
+            const float2 f = *reinterpret_cast<const float2*>(flow + (m_first + spi) * 2);
+            const float cx = (float)(p % W8) + f.x, cy = (float)(p / W8) + f.y;
+            const float sc = 1.0f / (float)(1 << sl);
+            const float xs = cx * sc, ys = cy * sc, x0f = floorf(xs), y0f = floorf(ys);
+            const int x0 = (int)fminf(fmaxf(x0f, -32768.f), 32768.f) - 4, y0 = (int)fminf(fmaxf(y0f, -32768.f), 32768.f) - 4;
+            const int wl = sl == 0 ? pyr.w[0] : sl == 1 ? pyr.w[1] : sl == 2 ? pyr.w[2] : pyr.w[3];
+            sx0 = x0;
+            sbase = (y0 * wl + x0) * (int)sizeof(CT);
+            sqx = xs - x0f; sqy = ys - y0f;
+        }
+        CT r[4][8];
+        const CT* lvl0[4];                                            // the wave's first pixel's maps (64-bit arithmetic once per wave)
+#pragma unroll
+        for (int l = 0; l < 4; l++) lvl0[l] = reinterpret_cast<const CT*>(pyr.lvl[l]) + m_first * (int64_t)(pyr.h[l] * pyr.w[l]);
+#define LC_FETCH(pi, d)                                                                                 \
+    {                                                                                                   \
+        _Pragma("unroll") for (int l = 0; l < 4; l++) {                                                 \
+            const int hw = pyr.h[l] * pyr.w[l];                                                         \
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<CT*>(lvl0[l] + (unsigned)((pi) * hw)), 0, \
+                                                              hw * (int)sizeof(CT), 0x00020000);        \
+            const int x0 = __builtin_amdgcn_readlane(sx0, (pi) * 4 + l), b0 = __builtin_amdgcn_readlane(sbase, (pi) * 4 + l); \
+            const unsigned oa = (unsigned)(x0 + wx0) < (unsigned)pyr.w[l] ? (unsigned)(b0 + la[l]) : 0xFFFFFFF0u; \
+            const unsigned ob = (unsigned)(x0 + wx1) < (unsigned)pyr.w[l] ? (unsigned)(b0 + lb[l]) : 0xFFFFFFF0u; \
+            r[d][2 * l] = lk_load<CT>(rs, oa);                                                          \
+            r[d][2 * l + 1] = lk_load<CT>(rs, ob);                                                      \
+        }                                                                                               \
+    }
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int pf = d < npx ? d : npx - 1;
+            LC_FETCH(pf, d)
+        }
+        // branch-free over all the wave's rows (hipcc's wait counting gives up across a conditional refill: it then waited out every load
+        // right after issuing it); rows past the wave's last pixel -- only in the launch's last tile -- repeat that pixel and are never stored
+        for (int pb = 0; pb < LC_WPX; pb += 4) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const int pi = pb + d;
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                    wv[l * 104 + lane] = (float)r[d][2 * l];
+                    if (lane < 36) wv[l * 104 + lane + 64] = (float)r[d][2 * l + 1];
+                }
+                if ((lane >> 2) == (pi < npx ? pi : npx - 1)) { wv[(lane & 3) * 104 + 100] = sqx; wv[(lane & 3) * 104 + 101] = sqy; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int pf = pi + 4 < npx ? pi + 4 : npx - 1;
+                LC_FETCH(pf, d)
+                bf16_t* arow = At + (wave * LC_WPX + pi) * LC_LDA + lane;
+#pragma unroll
+                for (int kk = 0; kk < 6; kk++) {
+                    const float wx = wv[frac_off[kk]], wy = wv[frac_off[kk] + 1];
+                    const float* q = wv + tap_off[kk];
+                    const lk_f32x2 top = {q[0], q[1]}, bot = {q[10], q[11]};
+                    const lk_f32x2 c = top + wy * (bot - top);
+                    float v = c[0] + wx * (c[1] - c[0]);
+                    if (kk == 5) v = lane < 4 ? v : 0.f;
+                    arow[kk * 64] = (bf16_t)v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+#undef LC_FETCH
+    }
+    __syncthreads();
+    // ---- [64 pixels][352] x this wave's [32 channels][352]^T
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + wave * 32 + i * 16 + fg * 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = b;
+    }
+#pragma unroll
+    for (int ks = 0; ks < LC_KS; ks++) {
+        if (ks + 3 < LC_KS) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) wf[(ks + 3) & 3][i] = wp[((ks + 3) * 2 + i) * 64];
+        }
+        bf16x8 af[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) af[j] = *reinterpret_cast<const bf16x8*>(At + (j * 16 + fr) * LC_LDA + ks * 32 + fg * 8);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 3][i], af[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();                                                  // every wave has read the operand tile: it becomes the output tile
+    bf16_t* const Ot = At;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const f32x4 v = acc[i][j];
+            const bf16x4 o = {(bf16_t)fmaxf(v[0], 0.f), (bf16_t)fmaxf(v[1], 0.f), (bf16_t)fmaxf(v[2], 0.f), (bf16_t)fmaxf(v[3], 0.f)};
+            *reinterpret_cast<bf16x4*>(Ot + (j * 16 + fr) * LC_LDO + wave * 32 + i * 16 + fg * 4) = o;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int idx = it * 512 + threadIdx.x, px = idx >> 5, c = idx & 31;
+        if (m_tile + px < M)
+            *reinterpret_cast<uint4*>(c1 + (m_tile + px) * 256 + c * 8) = *reinterpret_cast<const uint4*>(Ot + px * LC_LDO + c * 8);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -413,8 +587,13 @@ int launch_gru_startmap(int n_img, int H, int W, int vert, const void* zr_rowmaj
 int launch_gru_half(int n_img, int H, int W, int vert, void* hb, void* hlo, const void* X, const void* wzr_packed, const void* wq_packed, const void* szr,
                     const void* sq, hipStream_t s);
 static int g_gru_fused = 1;   // (experiments: 0 keeps the two-launch half-step of rounds 1-3)
+#ifndef VTGB_LK_FUSED
+#define VTGB_LK_FUSED 1
+#endif
+static int g_lk_fused = VTGB_LK_FUSED;    // (experiments: 0 keeps the separate lookup and convc1 launches; tools/exp/build_variant.sh -DVTGB_LK_FUSED=0)
 #ifdef VTGB_DEBUG_HOOKS
 extern "C" void vtgb_debug_set_gru_fused(int v) { g_gru_fused = v; }
+extern "C" void vtgb_debug_set_lk_fused(int v) { g_lk_fused = v; }
 #endif
 
 static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
@@ -435,7 +614,9 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     char* hlo = fused ? (char*)ws.take(M * 128 * es) : nullptr;
     char* hb = (char*)ws.take(M * 128 * es);
     char* X = (char*)ws.take(M * 256 * es);
-    char* corrf = (char*)ws.take(M * 384 * es);
+    const bool lk_fused = !f32 && g_lk_fused;                        // lookup + convc1 in one launch (bf16 mode)
+    char* corrf = lk_fused ? nullptr : (char*)ws.take(M * 384 * es);
+    void* w1pk = lk_fused ? ws.take(LC_WPK_BYTES) : nullptr;
     char* c1 = (char*)ws.take(M * 256 * es);
     char* CF = (char*)ws.take(M * 256 * es);
     char* f1 = (char*)ws.take(M * 128 * es);
@@ -504,6 +685,12 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
         static DeviceOnce fh2_attr;
         VTGB_FUNC_LDS_ONCE(fh2_attr, raft_flow_head2_kernel, 160 * 1024);
     }
+    if (lk_fused) {
+        static DeviceOnce lc_attr_h, lc_attr_f;
+        VTGB_FUNC_LDS_ONCE(lc_attr_h, raft_lookup_convc1_kernel<_Float16>, LC_LDS);
+        VTGB_FUNC_LDS_ONCE(lc_attr_f, raft_lookup_convc1_kernel<float>, LC_LDS);
+        hipLaunchKernelGGL(raft_lkc1_pack_w_kernel, dim3((LC_WAVES * LC_KS * 2 * 64 + 255) / 256), dim3(256), 0, s, (const bf16_t*)w[0], (bf16x8*)w1pk);
+    }
     if (hoist) {
         // start maps = bias + conv(inp): X[:, 0:128] holds relu(cnet[:, 128:]) (raft_init_kernel); same taps as the GRU halves
         for (int half = 0; half < 2; half++) {
@@ -531,13 +718,19 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     }
     for (int it = 0; it < a->iters; it++) {
         // ---- BasicMotionEncoder (update.py:88-97)
-        if (f32)
-            hipLaunchKernelGGL((raft_corr_lookup_kernel<float, float>), lk_grid, dim3(256), 0, s, pyr, flow, (float*)corrf, M, H8, W8);
-        else if (a->corr_f16)
-            hipLaunchKernelGGL((raft_corr_lookup_kernel<_Float16, bf16_t>), lk_grid, dim3(256), 0, s, pyr, flow, (bf16_t*)corrf, M, H8, W8);
-        else
-            hipLaunchKernelGGL((raft_corr_lookup_kernel<float, bf16_t>), lk_grid, dim3(256), 0, s, pyr, flow, (bf16_t*)corrf, M, H8, W8);
-        {
+        if (lk_fused) {
+            const dim3 g((unsigned)((M + LC_PX - 1) / LC_PX));
+            if (a->corr_f16)
+                hipLaunchKernelGGL(raft_lookup_convc1_kernel<_Float16>, g, dim3(512), LC_LDS, s, pyr, flow, (const bf16x8*)w1pk, F(w[1]), (bf16_t*)c1, M, H8, W8);
+            else
+                hipLaunchKernelGGL(raft_lookup_convc1_kernel<float>, g, dim3(512), LC_LDS, s, pyr, flow, (const bf16x8*)w1pk, F(w[1]), (bf16_t*)c1, M, H8, W8);
+        } else {
+            if (f32)
+                hipLaunchKernelGGL((raft_corr_lookup_kernel<float, float>), lk_grid, dim3(256), 0, s, pyr, flow, (float*)corrf, M, H8, W8);
+            else if (a->corr_f16)
+                hipLaunchKernelGGL((raft_corr_lookup_kernel<_Float16, bf16_t>), lk_grid, dim3(256), 0, s, pyr, flow, (bf16_t*)corrf, M, H8, W8);
+            else
+                hipLaunchKernelGGL((raft_corr_lookup_kernel<float, bf16_t>), lk_grid, dim3(256), 0, s, pyr, flow, (bf16_t*)corrf, M, H8, W8);
             GemmDesc d = conv_desc(dt, Mi, 256, H8, W8, 0, 0, 0, 0, corrf, 384, nullptr, 0, w[0], F(w[1]), VTGB_EPI_STORE, 1, c1, 256, zero);
             d.K = 384; d.ldw = 384;
             VTGB_TRY(launch_conv_gemm(d, s));
