@@ -251,7 +251,12 @@ __global__ __launch_bounds__(512, 2) void raft_lookup_convc1_kernel(const CorrPy
     const int HW = H8 * W8;
     const int64_t m_tile = (int64_t)blockIdx.x * LC_PX, m_first = m_tile + wave * LC_WPX;
     const int npx = (int)(M - m_first < LC_WPX ? (M - m_first > 0 ? M - m_first : 0) : LC_WPX);   // (a trailing wave may have none: its rows are never stored)
-    if (npx > 0) {
+#ifndef LC_ABL
+#define LC_ABL 0        // timing-only ablation builds (tools/exp/build_variant.sh -DLC_ABL=n): 1 no lookup phase, 2 no MFMA loop, 4 no output
+#endif                  // measured (1.38 ms whole): no lookup 0.44, no MFMA loop 0.99, no output 1.22, lookup alone 0.87 -- the phases ADD: the
+                        // gathers (8 scattered 2-byte loads per pixel) and the weight stream (176 KB per tile) share the CU's vector-memory
+                        // path, so a half-tile stagger of the CU's second workgroup changed nothing (1.37 vs 1.37 ms)
+    if (npx > 0 && !(LC_ABL & 1)) {
         const int p_first = (int)(m_first % HW);
         int sx0, sbase;
         float sqx, sqy;
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void raft_lookup_convc1_kernel(const CorrPy
         for (int j = 0; j < 4; j++) acc[i][j] = b;
     }
 #pragma unroll
-    for (int ks = 0; ks < LC_KS; ks++) {
+    for (int ks = 0; ks < ((LC_ABL & 2) ? 0 : LC_KS); ks++) {
         if (ks + 3 < LC_KS) {
 #pragma unroll
             for (int i = 0; i < 2; i++) wf[(ks + 3) & 3][i] = wp[((ks + 3) * 2 + i) * 64];
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void raft_lookup_convc1_kernel(const CorrPy
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int idx = it * 512 + threadIdx.x, px = idx >> 5, c = idx & 31;
-        if (m_tile + px < M)
+        if (m_tile + px < M && (!(LC_ABL & 4) || bias[0] == 12345.f))
             *reinterpret_cast<uint4*>(c1 + (m_tile + px) * 256 + c * 8) = *reinterpret_cast<const uint4*>(Ot + px * LC_LDO + c * 8);
     }
 }
