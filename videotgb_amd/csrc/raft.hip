@@ -392,10 +392,45 @@ __global__ __launch_bounds__(256) void raft_convf1_kernel(const float* __restric
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4, HW = H8 * W8;
     const int64_t n_groups = (M + 15) >> 4;
-    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < n_groups; g += (int64_t)gridDim.x * 4) {
+    // r4: the 14 tap loads of a group (2 per lane and k-step) used to sit behind bounds branches, each k-step waiting out its own loads
+    // (~5800 cycles per group for 900 cycles of MFMA).  They now go through a buffer descriptor of the flow field with an out-of-range
+    // offset for padding taps (the range check returns the zeros), are issued for the NEXT group before the current one is multiplied,
+    // and the per-pixel 64-bit modulo became one per wave.
+    const auto frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow), 0, (int)(M * 8), 0x00020000);
+    int tdy[7][2], tdx[7][2];                                            // this lane's taps: offsets from the pixel, or a row far outside for k >= 49
+#pragma unroll
+    for (int ks = 0; ks < 7; ks++)
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++) {
+            const int tap = ks * 8 + fg * 2 + tt, ky = tap / 7, kx = tap - ky * 7;
+            tdy[ks][tt] = tap < 49 ? ky - 3 : 1 << 20;
+            tdx[ks][tt] = kx - 3;
+        }
+    const float inv_w = 1.0f / (float)W8;
+    float2 cur[7][2], nxt[7][2];
+#define CF1_FETCH(gg, r)                                                                                                  \
+    {                                                                                                                      \
+        const int64_t g0 = (gg) * 16;                                                                                      \
+        const int p0 = __builtin_amdgcn_readfirstlane((int)(g0 % HW));                                                     \
+        int pix = p0 + fr;                                                                                                 \
+        pix = pix >= HW ? pix - HW : pix;                                                                                  \
+        const int y = (int)(((float)pix + 0.5f) * inv_w), x = pix - y * W8;                                                \
+        const unsigned mb = (unsigned)(g0 + fr);                                                                           \
+        const bool valid = g0 + fr < M;                                                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < 7; ks++) _Pragma("unroll") for (int tt = 0; tt < 2; tt++) {                \
+            const int yy = y + tdy[ks][tt], xx = x + tdx[ks][tt];                                                          \
+            const bool ok = valid && (unsigned)yy < (unsigned)H8 && (unsigned)xx < (unsigned)W8;                           \
+            const unsigned off = ok ? (mb + (unsigned)(tdy[ks][tt] * W8 + tdx[ks][tt])) * 8u : 0xFFFFFFF0u;                \
+            r[ks][tt] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(frs, off, 0, 0));                  \
+        }                                                                                                                  \
+    }
+    const int64_t g_first = (int64_t)blockIdx.x * 4 + wave, g_step = (int64_t)gridDim.x * 4;
+    if (g_first < n_groups) CF1_FETCH(g_first, cur)
+    for (int64_t g = g_first; g < n_groups; g += g_step) {
         const int64_t m = g * 16 + fr;
         const bool valid = m < M;
-        const int pix = (int)((valid ? m : 0) % HW), y = pix / W8, x = pix - y * W8;
+        const int64_t gn = g + g_step < n_groups ? g + g_step : g;      // (the last pass re-fetches its own group: no tail branch)
+        CF1_FETCH(gn, nxt)
         f32x4 acc[8];
 #pragma unroll
         for (int ct = 0; ct < 8; ct++) acc[ct] = *reinterpret_cast<const f32x4*>(b + ct * 16 + fg * 4);
@@ -404,11 +439,7 @@ __global__ __launch_bounds__(256) void raft_convf1_kernel(const float* __restric
             bf16x8 xf;
 #pragma unroll
             for (int tt = 0; tt < 2; tt++) {
-                const int tap = ks * 8 + fg * 2 + tt, ky = tap / 7, kx = tap - ky * 7;
-                const int yy = y + ky - 3, xx = x + kx - 3;
-                float2 f = make_float2(0.f, 0.f);
-                if (valid && tap < 49 && (unsigned)yy < (unsigned)H8 && (unsigned)xx < (unsigned)W8)
-                    f = *reinterpret_cast<const float2*>(flow + (m + (ky - 3) * W8 + (kx - 3)) * 2);      // (unconditional clamped loads measured slower: 398 vs 357 us)
+                const float2 f = cur[ks][tt];
                 const float hxf = bf16_round(f.x), hyf = bf16_round(f.y);      // (hi | lo split on the bits: common.h)
                 xf[tt * 4 + 0] = (bf16_t)hxf; xf[tt * 4 + 1] = (bf16_t)hyf;
                 xf[tt * 4 + 2] = (bf16_t)(f.x - hxf); xf[tt * 4 + 3] = (bf16_t)(f.y - hyf);
@@ -419,6 +450,8 @@ __global__ __launch_bounds__(256) void raft_convf1_kernel(const float* __restric
                 acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[ct], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int ks = 0; ks < 7; ks++) { cur[ks][0] = nxt[ks][0]; cur[ks][1] = nxt[ks][1]; }
         // D: column (lane & 15) = pixel, rows fg * 4 + reg = channel within the 16-channel tile
 #pragma unroll
         for (int ct = 0; ct < 8; ct++) {
@@ -441,6 +474,7 @@ __global__ __launch_bounds__(256) void raft_convf1_kernel(const float* __restric
             X[m * 256 + 255] = (bf16_t)flow[m * 2 + 1];
         }
     }
+#undef CF1_FETCH
 }
 
 // Exactness mode of convf1: the 7x7 convolution of the 2-channel flow as plain fp32 FMAs (98 taps per output); weights
@@ -611,7 +645,7 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     const size_t es = dtype_size(dt);
     const int H8 = a->H8, W8 = a->W8, HW = H8 * W8;
     const int64_t M = (int64_t)a->n_pairs * HW;
-    VTGB_REQUIRE(M < (1ll << 31), VTGB_EUNSUPPORTED, "raft_update: too many pixels");
+    VTGB_REQUIRE(M < (1ll << 28), VTGB_EUNSUPPORTED, "raft_update: too many pixels (the flow field is addressed through one 32-bit buffer range)");
     // activations: bf16 (VTGB_BF16) or fp32 (VTGB_F32); typed access through char* + element size
     // bf16 mode with the hoisted `inp` third and whole lines that fit a tile: the fused half-step kernel (hidden state hi | lo in bf16)
     const bool fused = !f32 && g_gru_fused && a->weights && a->weights[26] != nullptr && gru_fused_supported(a->n_pairs, H8, W8);
