@@ -183,11 +183,19 @@ __global__ __launch_bounds__(256) void llm_decode_attn_kernel(const T* __restric
     const float inv = 1.0f / sum;
     if constexpr (sizeof(T) == 2) {
         if ((hd & 1) == 0) {
-            // a lane owns two adjacent channels: one 4-byte load per key (a key row = one coalesced 2 hd-byte read), four keys in flight
+            // a lane owns two adjacent channels: one 4-byte load per key (a key row = one coalesced 2 hd-byte read), sixteen keys in flight
+            // (r4: four in flight made the ~68 keys of the bench seventeen dependent memory round trips: 38 us per launch), same summation order
             typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
             for (int d = lane * 2; d < hd; d += 128) {
                 float a0 = 0.f, a1 = 0.f;
                 int key = 0;
+                for (; key + 16 <= n_keys; key += 16) {
+                    bf16x2_t v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) v[u] = *reinterpret_cast<const bf16x2_t*>(vr + (int64_t)(key + u) * hd + d);
+#pragma unroll
+                    for (int u = 0; u < 16; u++) { a0 = fmaf(sc[key + u], (float)v[u][0], a0); a1 = fmaf(sc[key + u], (float)v[u][1], a1); }
+                }
                 for (; key + 4 <= n_keys; key += 4) {
                     bf16x2_t v[4];
 #pragma unroll
