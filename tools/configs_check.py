@@ -120,9 +120,9 @@ def c2(dev, tmp, B=32, reps=3, module=None):
     return dict(clips_per_s=B / dt, line=line)
 
 
-def sub(cmd):
+def sub(cmd, last=1):
     r = subprocess.run([sys.executable] + cmd, cwd=REPO, capture_output=True, text=True)
-    return (r.stdout.strip().splitlines() or [r.stderr.strip()[-300:]])[-1]
+    return "\n".join((r.stdout.strip().splitlines() or [r.stderr.strip()[-300:]])[-last:])
 
 
 def main():
@@ -144,7 +144,7 @@ def main():
                             "--warmup", "1"]))
         print(f"C4 same, T=256 -> 8 (per GPU; clips shard over the 8 GPUs with no collective): {d['value']} clips/s ({d['config']['clips_per_gpu_per_step']} clips per step)")
     if "c5" in which:
-        print("C5 " + sub(["tools/train_bench.py", "4"]))
+        print("C5 " + sub(["tools/train_bench.py", "4"], last=3))       # the step line, the device-time split, the prefix graph's GEMM rate
 
 
 if __name__ == "__main__":

@@ -22,5 +22,17 @@ for k in fe:
     f = sum(fe[k]) / len(fe[k]); w = sum(wr.get(k, [0])) / max(len(wr.get(k, [0])), 1)
     res[k] = {"launches": len(fe[k]), "FETCH_SIZE_KiB_avg": round(f, 1), "WRITE_SIZE_KiB_avg": round(w, 1),
               "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024)}
-json.dump({"note": "FETCH_SIZE doubled (gfx950 correction for 16 B/lane coalesced reads), WRITE_SIZE as read; KiB -> bytes", "kernels": res}, open(out, "w"), indent=1)
+# the update block's memory-side kernels beside the conv family (not read by bench.py): raw counters; the x2 read correction is established for wide
+# coalesced streams only, so the gather kernel's corrected figure is an upper bound
+mem = {}
+if want == "conv":
+    for k in fe:
+        if any(t in k for t in ("lookup_convc1", "raft_convf1", "norm_apply", "corr_lookup", "flow_head2")):
+            f = sum(fe[k]) / len(fe[k]); w = sum(wr.get(k, [0])) / max(len(wr.get(k, [0])), 1)
+            mem[k] = {"launches": len(fe[k]), "FETCH_SIZE_KiB_avg": round(f, 1), "WRITE_SIZE_KiB_avg": round(w, 1),
+                      "hbm_bytes_per_launch_raw": int((f + w) * 1024), "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024)}
+doc = {"note": "FETCH_SIZE doubled (gfx950 correction for 16 B/lane coalesced reads), WRITE_SIZE as read; KiB -> bytes", "kernels": res}
+if mem:
+    doc["memory_kernels"] = mem
+json.dump(doc, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -7,7 +7,7 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # an iteration starts at each lookup launch; take one from the middle of the last timed pass
-idx = [i for i, n in enumerate(names) if "raft_corr_lookup" in n]
+idx = [i for i, n in enumerate(names) if "raft_corr_lookup" in n or "raft_lookup_convc1" in n]
 a = idx[-10]; b = idx[-9]
 tot = 0
 for r in rows[a:b]:
