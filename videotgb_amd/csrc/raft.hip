@@ -71,6 +71,13 @@ constexpr int CL_PIX = 16;  // pixels per wave (the per-lane tables are built on
 // themselves, columns left / right get an out-of-range offset): no 64-bit address arithmetic, no validity bits carried to the
 // deposit; the bilinear form is P + wy (Q - P) on the packed pairs the LDS reads deliver, then one more lerp along x; only the last
 // 64 taps carry a guard.
+// timing-only ablation builds of the standalone lookup (tools/exp/build_variant.sh -DCL_ABL=n): 1 no window loads, 2 no interpolation, 4 no
+// output store.  Measured (0.90 ms whole): no loads 0.72, no interpolation 0.89, no store 0.73, no loads + no interpolation 0.35, none of the
+// three 0.32 -- the memory side (gathers + tap store) and the issue side (the interpolation: 33 LDS instructions per pixel, ~116 LDS cycles
+// per pixel and CU) bound it alternately; what is left with all three removed is addresses, deposit and the loop itself.
+#ifndef CL_ABL
+#define CL_ABL 0
+#endif
 typedef float lk_f32x2 __attribute__((ext_vector_type(2)));
 template <typename CT>
 __device__ __forceinline__ CT lk_load(__amdgpu_buffer_rsrc_t r, unsigned off);
@@ -147,8 +154,8 @@ __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr
             const int x0 = __builtin_amdgcn_readlane(sx0, (pi) * 4 + l), b0 = __builtin_amdgcn_readlane(sbase, (pi) * 4 + l); \
             const unsigned oa = (unsigned)(x0 + wx0) < (unsigned)pyr.w[l] ? (unsigned)(b0 + la[l]) : 0xFFFFFFF0u; \
             const unsigned ob = (unsigned)(x0 + wx1) < (unsigned)pyr.w[l] ? (unsigned)(b0 + lb[l]) : 0xFFFFFFF0u; \
-            r[2 * l] = lk_load<CT>(rs, oa);                                                             \
-            r[2 * l + 1] = lk_load<CT>(rs, ob);                                                         \
+            if (CL_ABL & 1) { r[2 * l] = (CT)(float)(oa & 7); r[2 * l + 1] = (CT)(float)(ob & 7); }     \
+            else { r[2 * l] = lk_load<CT>(rs, oa); r[2 * l + 1] = lk_load<CT>(rs, ob); }                \
         }                                                                                               \
     }
 #define CL_DEPOSIT(pi, r)                                                                               \
@@ -169,11 +176,11 @@ __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr
     // LDS into the other staging row | wait for the loads (the only vmcnt wait of the iteration: the store in front of them
     // has had the whole interpolation to complete) and deposit them
     for (int pi = 0; pi < npx; pi++) {
-        if (pi > 0) { CL_STORE(pi - 1) }
+        if (pi > 0 && !(CL_ABL & 4)) { CL_STORE(pi - 1) }
         const int pn = pi + 1 < npx ? pi + 1 : pi;                    // (the last iteration re-fetches its own pixel: no tail branch)
         CL_FETCH(pn, nxt)
 #pragma unroll
-        for (int kk = 0; kk < 6; kk++) {
+        for (int kk = 0; kk < ((CL_ABL & 2) ? 1 : 6); kk++) {
             const float wx = wv[frac_off[kk]], wy = wv[frac_off[kk] + 1];
             const float* q = wv + tap_off[kk];
             const lk_f32x2 top = {q[0], q[1]}, bot = {q[10], q[11]};
