@@ -178,13 +178,27 @@ __global__ __launch_bounds__(NKP <= 9 ? 576 : 256) void attn_bf16_kernel(const A
             // FMA) and one add instead of scale + mask, two causal selects, max, subtract, multiply, exp, add.  Only the tiles that
             // reach past s_kv (wave-uniform test) mask their padded keys.  (scale > 0: max and scale commute.)
             const float c = p.scale * 1.4426950408889634f;
+            // r4: hipcc turned the "tile reaches past s_kv" test into selects for ALL 72 scores of a lane and kept the 72 lane masks in SGPR
+            // pairs -- 131 of them spilled and came back through v_readlane: 144 + 131 of the ~800 vector-slot instructions of a query tile.
+            // When only the last key pair can be partial (s_kv > NK - 32: the ViT's 257 of 288) the selects exist for those two tiles only.
+            if (p.s_kv > (2 * NKP - 2) * 16) {
 #pragma unroll
-            for (int t = 0; t < 2 * NKP; t++) {
-                if (t * 16 + 16 > p.s_kv) {
+                for (int t = 0; t < 2 * NKP; t++) {
+                    if (t >= 2 * NKP - 2) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) s[t][r] = t * 16 + fg * 4 + r < p.s_kv ? s[t][r] : -INFINITY;
+                        for (int r = 0; r < 4; r++) s[t][r] = t * 16 + fg * 4 + r < p.s_kv ? s[t][r] : -INFINITY;
+                    }
+                    mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
                 }
-                mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2 * NKP; t++) {
+                    if (t * 16 + 16 > p.s_kv) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) s[t][r] = t * 16 + fg * 4 + r < p.s_kv ? s[t][r] : -INFINITY;
+                    }
+                    mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+                }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
