@@ -377,7 +377,9 @@ __global__ __launch_bounds__(256, 2) void gru_half_kernel(const GruHalfParams p)
         GF_W_DRAIN(qa, 2)                           // (vmcnt(0): the lo rows are here too -- the DMA pieces below must not sit in front of their wait)
         GF_W_DRAIN(qb, 2)
 #pragma unroll
-        for (int j = 0; j < GF_JF; j++) { asm volatile("" : "+v"(lo_t[j])); asm volatile("" : "+v"(sq_t[j])); asm volatile("" : "+v"(hpk[j])); }
+        for (int j = 0; j < GF_JF; j++) { asm volatile("" : "+v"(lo_t[j])); asm volatile("" : "+v"(sq_t[j])); asm volatile("" : "+v"(hpk[j])); asm volatile("" : "+v"(zpk[j])); }
+        // (z too: three of its seven entries are spilled across the q k-loop; un-pinned, hipcc reloaded them in the MIDDLE of the update phase with
+        //  vmcnt(0) -- i.e. behind the next tile's image DMA issued just above)
         if (next < p.n_tiles && !(GF_ABL & 64)) issue_images(next);
 #pragma unroll
         for (int j = 0; j < GF_JF; j++) {
