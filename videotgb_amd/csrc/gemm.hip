@@ -605,10 +605,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     f32x4 v = acc[i][j];
-                    if (p.act) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act);
-                    }
+                    if (p.act) apply_act4(v, p.act);
                     fdst[(j * 4 + i) * 64] = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                 }
             return;
@@ -631,10 +628,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                     if constexpr (EPI == EPI_GELU) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] = gelu_erf_fast(v[e]);
-                    } else if (p.act) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act);
-                    }
+                    } else if (p.act) apply_act4(v, p.act);
                     const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                     const int row = j * 16 + fr, c16 = (i * 2 + (fg >> 1)) ^ (row & 7);
                     *reinterpret_cast<bf16x4*>(cst + row * 128 + c16 * 16 + (fg & 1) * 8) = pk;

@@ -36,6 +36,16 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 2) return 1.0f / (1.0f + __expf(-v));
     return v;
 }
+// four values at a time: ONE scalar test per group (r4: per element, hipcc left a compare + branch per value in the unrolled epilogues --
+// ~650 scalar instructions and taken branches per 256 x 256 tile of the ReLU convolutions)
+__device__ __forceinline__ void apply_act4(f32x4& v, int act) {
+    if (act == 1) {
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    } else if (act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = 1.0f / (1.0f + __expf(-v[e]));
+    }
+}
 
 // Large-kernel epilogue split: bias (and the fp32 residual) are loaded INTO the accumulators before
 // the k-loop -- 32 independent 16-byte loads per lane in flight while the first LDS-DMA tiles

@@ -447,10 +447,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
 #pragma unroll
                         for (int i = 0; i < WF; i++) {
                             f32x4 v = acc[i][j];
-                            if (p.act) {
-#pragma unroll
-                                for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act);
-                            }
+                            if (p.act) apply_act4(v, p.act);
                             fdst[(j * 4 + i) * 64] = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                         }
                 }
@@ -469,10 +466,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         f32x4 v = acc[i][j];
-                        if (p.act) {
-#pragma unroll
-                            for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act);
-                        }
+                        if (p.act) apply_act4(v, p.act);
                         const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                         const int row = j * 16 + (lane_e & 15), c16 = (i * 2 + ((lane_e >> 4) >> 1)) ^ (row & 7);
                         *reinterpret_cast<bf16x4*>(cst + row * 128 + c16 * 16 + ((lane_e >> 4) & 1) * 8) = pk;
@@ -539,10 +533,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
                         if constexpr (EPI == EPI_GELU) {
 #pragma unroll
                             for (int e = 0; e < 4; e++) v[e] = gelu_erf_fast(v[e]);
-                        } else if (p.act) {
-#pragma unroll
-                            for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act);
-                        }
+                        } else if (p.act) apply_act4(v, p.act);
                         const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                         const int row = jj * 16 + (lane_e & 15), c16 = (i * 2 + ((lane_e >> 4) >> 1)) ^ (row & 7);
                         *reinterpret_cast<bf16x4*>(stage + row * 128 + c16 * 16 + ((lane_e >> 4) & 1) * 8) = pk;
