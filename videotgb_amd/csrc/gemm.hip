@@ -626,8 +626,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
                 for (int i = 0; i < 4; i++) {
                     f32x4 v = acc[i][j];
                     if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = gelu_erf_fast(v[e]);
+gelu_erf_fast4(v);
                     } else if (p.act) apply_act4(v, p.act);
                     const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                     const int row = j * 16 + fr, c16 = (i * 2 + (fg >> 1)) ^ (row & 7);

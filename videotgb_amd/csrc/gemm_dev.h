@@ -20,6 +20,26 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     q = fmaf(q, x2, -2.3011195660f);
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xc * q));
 }
+// two values at a time: the plain part on the packed fp32 pipe (v_pk_mul / v_pk_fma: r4 -- 128 values per lane in the fc1 epilogue), the
+// clamp and the two transcendentals per value as before; bit-identical to gelu_erf_fast per element
+typedef float gelu_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gelu_f32x2 gelu_erf_fast2(gelu_f32x2 x) {
+    const gelu_f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -8.0f, 8.0f), __builtin_amdgcn_fmed3f(x[1], -8.0f, 8.0f)};
+    const gelu_f32x2 x2 = xc * xc;
+    gelu_f32x2 q = __builtin_elementwise_fma(gelu_f32x2{1.0145391570e-3f, 1.0145391570e-3f}, x2, gelu_f32x2{-1.0677742213e-1f, -1.0677742213e-1f});
+    q = __builtin_elementwise_fma(q, x2, gelu_f32x2{-2.3011195660f, -2.3011195660f});
+    const gelu_f32x2 t = xc * q;
+    const gelu_f32x2 d = gelu_f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
+    return x * gelu_f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+__device__ __forceinline__ void gelu_erf_fast4(f32x4& v) {
+#ifdef VTGB_GELU_SCALAR      // (A/B builds)
+    v = f32x4{gelu_erf_fast(v[0]), gelu_erf_fast(v[1]), gelu_erf_fast(v[2]), gelu_erf_fast(v[3])};
+    return;
+#endif
+    const gelu_f32x2 a = gelu_erf_fast2(gelu_f32x2{v[0], v[1]}), b = gelu_erf_fast2(gelu_f32x2{v[2], v[3]});
+    v = f32x4{a[0], a[1], b[0], b[1]};
+}
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 

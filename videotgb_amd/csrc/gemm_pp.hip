@@ -534,8 +534,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
                     for (int i = 0; i < WF; i++) {
                         f32x4 v = acc[i][ps * JB + jj];
                         if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-                            for (int e = 0; e < 4; e++) v[e] = gelu_erf_fast(v[e]);
+gelu_erf_fast4(v);
                         } else if (p.act) apply_act4(v, p.act);
                         const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                         const int row = jj * 16 + (lane_e & 15), c16 = (i * 2 + ((lane_e >> 4) >> 1)) ^ (row & 7);
