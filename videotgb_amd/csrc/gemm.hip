@@ -372,11 +372,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
         const int cc2 = (first ? cv_c0 : cv_c0 - p.conv_split) * 2;                                     \
         const int dpix = (cv_ky - (p.conv_KH >> 1)) * cv_Wi + (cv_kx - (p.conv_KW >> 1));               \
         const int need = (1 << cv_ky) | (256 << cv_kx);                                                 \
+        const auto rs_ = first ? a_rsrc : a2_rsrc;      /* (as in gemm_pp.hip: one select per k-tile, 24-bit multiply-add + select per piece) */ \
         _Pragma("unroll") for (int i = 0; i < AI; i++) {                                                \
             const unsigned pix = (a_voff[i] & 0x00FFFFFFu) + (unsigned)dpix;                            \
-            const unsigned v = ((a_bits[i] & need) == need) ? pix * ldb + (a_voff[i] >> 28) * 16u : OOB; \
-            if (first) { __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(smem + (slot) * A_OP + (wave * (8 * AI) + i * 8) * 128), 16, v, cc2, 0, 0); } \
-            else { __builtin_amdgcn_raw_ptr_buffer_load_lds(a2_rsrc, (lptr_t)(smem + (slot) * A_OP + (wave * (8 * AI) + i * 8) * 128), 16, v, cc2, 0, 0); } \
+            const unsigned vin = __umul24(pix, ldb) + (a_voff[i] >> 28) * 16u;                          \
+            const unsigned v = ((a_bits[i] & need) == need) ? vin : OOB;                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lptr_t)(smem + (slot) * A_OP + (wave * (8 * AI) + i * 8) * 128), 16, v, cc2, 0, 0); \
         }                                                                                               \
         if (++cv_kx == p.conv_KW) { cv_kx = 0; if (++cv_ky == p.conv_KH) { cv_ky = 0; cv_c0 += L_BK; } } \
     } else {                                                                                            \
