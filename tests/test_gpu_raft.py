@@ -289,6 +289,22 @@ def test_raft_update_is_bit_reproducible(dev, n, h8, w8, iters):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("n,h8,w8", [(3, 28, 28), (2, 9, 13)])
+def test_raft_update_fp32_pyramid_equals_half_pyramid_at_bf16(dev, n, h8, w8):
+    """The bf16 update block reads its correlation pyramid as IEEE half (what vtgb_raft_corr writes at bf16) or as fp32: both instantiations of
+    the fused lookup + convc1 kernel on the SAME values (the half pyramid widened to fp32) must agree bit for bit."""
+    from videotgb_amd import ops, synth
+    sd = {k[len("of_extractor."):]: v.to(dev) for k, v in synth.synth_state_dict(synth.raft_shapes("of_extractor."), 0).items()}
+    w = ops.RaftWeights(sd, "update_block.", ops.BF16)
+    g = torch.Generator(device=dev).manual_seed(n * 31 + h8)
+    cnet = torch.randn(n, h8 * w8, 256, generator=g, device=dev)
+    pyr16 = [torch.randn(n * h8 * w8, 1, max(h8 >> l, 1), max(w8 >> l, 1), generator=g, device=dev).half() for l in range(4)]
+    pyr32 = [t.float() for t in pyr16]
+    a = ops.raft_update(w, None, None, pyr16, iters=4, cnet_nhwc=cnet, hw=(h8, w8)).clone()
+    b = ops.raft_update(w, None, None, pyr32, iters=4, cnet_nhwc=cnet, hw=(h8, w8)).clone()
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_raft_float_valued_frames(dev, tiny_sd):
     """The eval path feeds RAFT CLIP-normalised floats (eval/inference.py:68 -> eval/utils/model.py:79), not 0..255
     integers: after 2*(x/255)-1 the image is -1 +- 0.02.  Flow level, default weights, both modes (the encoder-level and
