@@ -52,7 +52,10 @@ __device__ __forceinline__ bf16x8 rope8(bf16x8 v, const float* tab_row, int d0, 
     return o;
 }
 
-template <int HD, int NKP, bool PLAIN>      // PLAIN: no key mask, not causal (the softmax does less per score)
+// PLAIN: no key mask, not causal (the softmax does less per score).  TAILONLY (PLAIN only): s_kv > NK - 32, i.e. only the last key pair can be
+// partial -- a launch-time fact, a template parameter so that the two forms of the padded-key selects do not meet in one function (as a
+// run-time branch they cost 63 register copies per query tile at the join).
+template <int HD, int NKP, bool PLAIN, bool TAILONLY = false>
 __global__ __launch_bounds__(NKP <= 9 ? 576 : 256) void attn_bf16_kernel(const AttnDesc p, const int tiles_per_split) {
     using C = AttnCfg<HD, NKP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(NKP <= 9 ? 576 : 256) void attn_bf16_kernel(const A
             // r4: hipcc turned the "tile reaches past s_kv" test into selects for ALL 72 scores of a lane and kept the 72 lane masks in SGPR
             // pairs -- 131 of them spilled and came back through v_readlane: 144 + 131 of the ~800 vector-slot instructions of a query tile.
             // When only the last key pair can be partial (s_kv > NK - 32: the ViT's 257 of 288) the selects exist for those two tiles only.
-            if (p.s_kv > (2 * NKP - 2) * 16) {
+            if constexpr (TAILONLY) {
 #pragma unroll
                 for (int t = 0; t < 2 * NKP; t++) {
                     if (t >= 2 * NKP - 2) {
@@ -347,11 +350,14 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnDesc p) {
     }
 }
 
-template <int HD, int NKP, bool PLAIN>
+template <int HD, int NKP, bool PLAIN, bool TAILONLY = false>
 static int launch_bf16_v(const AttnDesc& d, hipStream_t s) {
     using C = AttnCfg<HD, NKP>;
+    if constexpr (PLAIN && !TAILONLY) {
+        if (d.s_kv > (2 * NKP - 2) * 16) return launch_bf16_v<HD, NKP, true, true>(d, s);
+    }
     static DeviceOnce attr_set;
-    VTGB_FUNC_LDS_ONCE(attr_set, (attn_bf16_kernel<HD, NKP, PLAIN>), C::LDS);
+    VTGB_FUNC_LDS_ONCE(attr_set, (attn_bf16_kernel<HD, NKP, PLAIN, TAILONLY>), C::LDS);
     const int n_qt = (d.s_q + 15) / 16;
     int splits = 1;
     while ((int64_t)d.batch * d.heads * splits < 256 && splits * 2 <= n_qt && splits < 4) splits *= 2;
@@ -362,7 +368,7 @@ static int launch_bf16_v(const AttnDesc& d, hipStream_t s) {
     const int rounds = (tps + max_waves - 1) / max_waves;
     const int waves = (tps + rounds - 1) / rounds;
     ProfScope prof(VTGB_PROF_ATTN, 4.0 * d.batch * d.heads * (double)d.s_q * d.s_kv * d.head_dim, s);
-    hipLaunchKernelGGL((attn_bf16_kernel<HD, NKP, PLAIN>), dim3(splits, d.heads, d.batch), dim3(64 * waves), C::LDS, s, d, tps);
+    hipLaunchKernelGGL((attn_bf16_kernel<HD, NKP, PLAIN, TAILONLY>), dim3(splits, d.heads, d.batch), dim3(64 * waves), C::LDS, s, d, tps);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }
