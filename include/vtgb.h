@@ -329,7 +329,8 @@ int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream);
  * vtgb_raft_update replaces the refinement loop xraft.py:135-156: per iteration CorrBlock.__call__
  * (raft_utils/corr.py:29-50; the reference's optional `alt_cuda_corr`, corr.py:63-91, is the CUDA counterpart of the
  * lookup kernel), BasicUpdateBlock (raft_utils/update.py:123-144: BasicMotionEncoder :75-97, SepConvGRU :39-65,
- * FlowHead :6-18), then the mask head and upsample_flow (xraft.py:88-99) of the last iteration.
+ * FlowHead :6-18), then the mask head and upsample_flow (xraft.py:88-99) of the last iteration.  At VTGB_BF16 the lookup and
+ * convc1 are one launch (the 324 taps of a pixel never leave the CU).  n_pairs * H8 * W8 < 2^28 coarse pixels per call.
  * weights (host array of device pointers):
  *   [0] encoder.convc1.weight [256, 384] (324 input channels zero-padded to 384) [1] .bias
  *   [2] encoder.convc2.weight [192, 3,3,256] [3] .bias
