@@ -31,7 +31,13 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 template <int HD, int NKP>
 struct AttnCfg {
     static constexpr int NK = NKP * 32;       // padded key count
-    static constexpr int KS = HD * 2 + 16;    // K row stride (bytes)
+    // K row stride (bytes) and piece placement.  HD > 64 (r4): 256-byte rows, 16-byte piece c of row r at slot c ^ (r & 15) -- a
+    // ds_read_b128 is served in lane groups {0-3, 12-15, 20-27} (rows 0-3, 12-15 at piece c, rows 4-11 at piece c + 1), not in runs of 16
+    // lanes: with the padded stride HD * 2 + 16 of rounds 1-3 five row pairs of a group shared their banks (SQ_LDS_BANK_CONFLICT = a
+    // third of the kernel's LDS cycles, profiles/r04_pmc_attn.txt); with the XOR every group touches 16 different slots.
+    static constexpr bool KSWZ = HD > 64;
+    static constexpr int KS = KSWZ ? 256 : HD * 2 + 16;
+    static __device__ __forceinline__ int koff(int row, int piece) { return row * KS + ((KSWZ ? (piece ^ (row & 15)) : piece) << 4); }
     static constexpr int VS = HD * 2 + 32;    // V row stride (bytes): 8 consecutive rows x 32 bytes land on 64 distinct banks
     static constexpr int K_BYTES = NK * KS;
     static constexpr int V_BYTES = NK * VS;
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(NKP <= 9 ? 576 : 256) void attn_bf16_kernel(const A
             if (idx < C::NK * CH) {
                 bf16x8 val = kreg[i];
                 if (p.rope_k && key < p.s_kv && c * 8 < hd) val = rope8(val, p.rope_k + (int64_t)key * hd, c * 8, hd);
-                *reinterpret_cast<bf16x8*>(Ks + key * C::KS + c * 16) = val;
+                *reinterpret_cast<bf16x8*>(Ks + C::koff(key, c)) = val;
                 *reinterpret_cast<bf16x8*>(Vs + key * C::VS + c * 16) = vreg[i];
             }
         }
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(NKP <= 9 ? 576 : 256) void attn_bf16_kernel(const A
                 vv = *reinterpret_cast<const bf16x8*>(V + (int64_t)key * p.kv_tok + c * 8);
                 if (p.rope_k) val = rope8(val, p.rope_k + (int64_t)key * hd, c * 8, hd);
             }
-            *reinterpret_cast<bf16x8*>(Ks + key * C::KS + c * 16) = val;
+            *reinterpret_cast<bf16x8*>(Ks + C::koff(key, c)) = val;
             *reinterpret_cast<bf16x8*>(Vs + key * C::VS + c * 16) = vv;
         }
     }
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(NKP <= 9 ? 576 : 256) void attn_bf16_kernel(const A
         for (int tt = 0; tt < 2; tt++)
 #pragma unroll
             for (int ks = 0; ks < HD / 32; ks++)
-                kcur[tt][ks] = *reinterpret_cast<const bf16x8*>(Ks + (tt * 16 + fr) * C::KS + (ks * 4 + fg) * 16);
+                kcur[tt][ks] = *reinterpret_cast<const bf16x8*>(Ks + C::koff(tt * 16 + fr, ks * 4 + fg));
 #pragma unroll
         for (int u = 0; u < NKP; u++) {
             if (u + 1 < NKP) {
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(NKP <= 9 ? 576 : 256) void attn_bf16_kernel(const A
                 for (int tt = 0; tt < 2; tt++)
 #pragma unroll
                     for (int ks = 0; ks < HD / 32; ks++)
-                        knxt[tt][ks] = *reinterpret_cast<const bf16x8*>(Ks + ((2 * u + 2 + tt) * 16 + fr) * C::KS + (ks * 4 + fg) * 16);
+                        knxt[tt][ks] = *reinterpret_cast<const bf16x8*>(Ks + C::koff((2 * u + 2 + tt) * 16 + fr, ks * 4 + fg));
             }
 #pragma unroll
             for (int tt = 0; tt < 2; tt++) {
