@@ -48,6 +48,46 @@ __global__ void raft_init_kernel(const float* __restrict__ net, const float* __r
     }
 }
 
+// The bench's form of the state init (bf16, context features pixel-major, fused GRU: hidden state as a bf16 hi | lo pair): four channels
+// per thread with 16-byte loads, no per-thread 64-bit division (the image index is only needed for flow_init, by one thread per pixel),
+// tanh through the hardware exp / rcp (1e-6 relative: below the hi | lo pair's 2^-17).  The element-wise kernel above -- libm tanhf, two
+// 64-bit divisions and six 2- or 4-byte accesses per element -- was vector-instruction bound at 1.58 ms for 2.31 M pixels (its 4.7 GB at
+// HBM rate: 0.9 ms); it still serves the fp32 mode and NCHW inputs.
+__global__ __launch_bounds__(256) void raft_init_nhwc_bf16_kernel(const float* __restrict__ cnet, bf16_t* __restrict__ hb, bf16_t* __restrict__ hlo,
+                                                                  bf16_t* __restrict__ X, float* __restrict__ flow, const float* __restrict__ flow_init,
+                                                                  int64_t M, int HW) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (pixel, 4-channel group): 32 groups per pixel
+    if (i >= M * 32) return;
+    const int64_t m = i >> 5;
+    const int c = (int)(i & 31) * 4;
+    const f32x4 nv = *reinterpret_cast<const f32x4*>(cnet + m * 256 + c), iv = *reinterpret_cast<const f32x4*>(cnet + m * 256 + 128 + c);
+    bf16x4 hi4, lo4, x4;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const float ex = __expf(2.0f * nv[e]);                       // tanh = 1 - 2 / (exp(2 x) + 1); inf -> 1, 0 -> -1
+        const float hv = 1.0f - 2.0f * __builtin_amdgcn_rcpf(ex + 1.0f);
+        const float hi = bf16_round(hv);
+        hi4[e] = (bf16_t)hi;
+        lo4[e] = (bf16_t)(hv - hi);
+        x4[e] = (bf16_t)fmaxf(iv[e], 0.f);
+    }
+    *reinterpret_cast<bf16x4*>(hb + m * 128 + c) = hi4;
+    *reinterpret_cast<bf16x4*>(hlo + m * 128 + c) = lo4;
+    *reinterpret_cast<bf16x4*>(X + m * 256 + c) = x4;
+    if (c == 0) {                                                    // flow = coords1 - coords0: zero, or flow_init [n, 2, H8, W8] (xraft.py:131-132)
+        float f0 = 0.f, f1 = 0.f;
+        if (flow_init) {
+            const int64_t n = m / HW, pp = m - n * HW;
+            f0 = flow_init[(n * 2) * HW + pp];
+            f1 = flow_init[(n * 2 + 1) * HW + pp];
+        }
+        flow[m * 2] = f0;
+        flow[m * 2 + 1] = f1;
+        X[m * 256 + 254] = (bf16_t)f0;
+        X[m * 256 + 255] = (bf16_t)f1;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // correlation lookup: one wave per pixel, 4 levels x 9 x 9 bilinear taps (zero outside), bf16 out,
 // columns 324..383 zero (K padded to a multiple of 64 for the 1x1 convolution that follows).
@@ -715,6 +755,9 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     const dim3 init_grid((unsigned)((M * 128 + 255) / 256));
     if (f32)
         hipLaunchKernelGGL(raft_init_kernel<float>, init_grid, dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, h32, (float*)hb, (float*)nullptr, (float*)X, flow, a->flow_init, M, HW);
+    else if (a->cnet_nhwc && hlo && (((uintptr_t)a->cnet_nhwc) & 15) == 0)
+        hipLaunchKernelGGL(raft_init_nhwc_bf16_kernel, dim3((unsigned)((M * 32 + 255) / 256)), dim3(256), 0, s, a->cnet_nhwc, (bf16_t*)hb, (bf16_t*)hlo, (bf16_t*)X, flow,
+                           a->flow_init, M, HW);
     else
         hipLaunchKernelGGL(raft_init_kernel<bf16_t>, init_grid, dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, h32, (bf16_t*)hb, (bf16_t*)hlo, (bf16_t*)X, flow, a->flow_init, M, HW);
     const int Mi = (int)M;
