@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--llm", default="vicuna-7b")
     ap.add_argument("--decode", choices=["graph", "hf"], default="graph",
                     help="graph: videotgb_amd.decode.GreedyDecoder (one hipGraph replay per token); hf: HF generate, eager")
-    ap.add_argument("--raft-dtype", choices=["bf16", "f32"], default="bf16",
+    ap.add_argument("--raft-dtype", choices=["bf16", "bf16x3", "f32"], default="bf16",
                     help="arithmetic of RAFT in --flow raft mode: bf16 MFMA implicit-GEMM convolutions (default) or the fp32 exactness "
                          "mode (the reference's arithmetic; fp32 FMAs)")
     ap.add_argument("--raft-clips", type=int, default=31,

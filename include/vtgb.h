@@ -44,6 +44,7 @@ typedef struct ihipStream_t* vtgb_stream_t; /* == hipStream_t */
 
 #define VTGB_F32 0
 #define VTGB_BF16 1
+#define VTGB_BF16X3 2 /* RAFT entry points only: split-bf16 operands (hi | lo pairs, three bf16 MFMA products per fp32 product) */
 
 int vtgb_version(void);
 const char* vtgb_last_error(void);

@@ -36,11 +36,11 @@ def make(dev, tiny_sd, dtype):
     return r.to(dev)
 
 
-FLOW_TOL = {"f32": 1e-4, "bf16": 1e-2}
-ENC_TOL = {"f32": 1e-5, "bf16": 2e-2}
+FLOW_TOL = {"f32": 1e-4, "bf16": 1e-2, "bf16x3": 5e-4}
+ENC_TOL = {"f32": 1e-5, "bf16": 2e-2, "bf16x3": 2e-4}
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("iters", [5, 20])
 def test_raft_pairs_vs_reference(dev, tiny_sd, dtype, iters):
     """of_extractor(image1, image2) -- the reference-shaped entry (xraft.py:102) -- vs the reference's flows."""
@@ -53,7 +53,7 @@ def test_raft_pairs_vs_reference(dev, tiny_sd, dtype, iters):
     assert e <= FLOW_TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
 def test_raft_clip_path_vs_reference(dev, tiny_sd, dtype):
     """forward_clips (what LSTP.flow uses): fnet once per distinct frame; same flows as the pair entry."""
     g = load_golden("tiny_raft")
@@ -68,7 +68,7 @@ def test_raft_clip_path_vs_reference(dev, tiny_sd, dtype):
         assert (pair - flow).abs().max() <= 1e-5 * flow.abs().max()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
 def test_raft_single_iteration_and_flow_init(dev, tiny_sd, dtype):
     """One iteration isolates the kernels from the recurrence; flow_init = coords1 - coords0 offset (xraft.py:131-132)."""
     from oracle import vtgb_oracle as O
@@ -80,18 +80,18 @@ def test_raft_single_iteration_and_flow_init(dev, tiny_sd, dtype):
     got = r(fr[:-1].to(dev), fr[1:].to(dev), iters=1).cpu()
     e = rel_rms(got, ref)
     print(f"[raft {dtype} 1 iteration] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
-    assert e <= (1e-5 if dtype == "f32" else 2e-2)
+    assert e <= {"f32": 1e-5, "bf16": 2e-2, "bf16x3": 5e-4}[dtype]
     fi = torch.randn(2, 2, 16, 16, generator=torch.Generator().manual_seed(3)) * 0.5
     ref = O.raft_forward(sd, "of_extractor.", fr[:-1], fr[1:], iters=2, flow_init=fi)
     got = r(fr[:-1].to(dev), fr[1:].to(dev), iters=2, flow_init=fi.to(dev)).cpu()
     e = rel_rms(got, ref)
     print(f"[raft {dtype} flow_init] rel_rms={e:.3e}")
-    assert e <= (1e-5 if dtype == "f32" else 2e-2)
+    assert e <= {"f32": 1e-5, "bf16": 2e-2, "bf16x3": 5e-4}[dtype]
     flows = r(fr[:-1].to(dev), fr[1:].to(dev), iters=2, test_mode=False)      # (round 4: the all-iteration form exists; test_raft_all_iteration_flows checks it)
     assert isinstance(flows, list) and len(flows) == 2
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("net,kind", [("fnet.", "instance"), ("cnet.", "batch")])
 def test_raft_encoder_vs_oracle(dev, tiny_sd, net, kind, dtype):
     """BasicEncoder in HIP vs the fp32 oracle."""
@@ -102,14 +102,14 @@ def test_raft_encoder_vs_oracle(dev, tiny_sd, net, kind, dtype):
     fr = deq(g, "frames_q8")                                   # [3, 3, 128, 128]
     ref = O.raft_encoder(sd, "of_extractor." + net, 2 * (fr / 255.0) - 1.0, kind)       # [3, 256, 16, 16]
     rsd = {k[len("of_extractor."):]: v.to(dev) for k, v in sd.items() if k.startswith("of_extractor.")}
-    w = ops.RaftEncoderWeights(rsd, net, kind == "batch", ops.dtype_code(dtype))
+    w = ops.RaftEncoderWeights(rsd, net, kind == "batch", ops.raft_dtype_code(dtype))
     out = ops.raft_encoder(w, fr.to(dev)).cpu().view(3, 16, 16, 256).permute(0, 3, 1, 2)
     e = rel_rms(out, ref)
     print(f"[raft encoder {net} {dtype}] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
     assert e <= ENC_TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("size,n", [(224, 3), (96, 2)])
 def test_raft_context_encoder_image_sizes(dev, tiny_sd, size, n, dtype):
     """cnet (BatchNorm folded): ReLU, the skip connection and the cast live in the convolution epilogues (two
@@ -120,14 +120,14 @@ def test_raft_context_encoder_image_sizes(dev, tiny_sd, size, n, dtype):
     fr = torch.randint(0, 256, (n, 3, size, size), generator=torch.Generator().manual_seed(size + 1)).float()
     ref = O.raft_encoder(sd, "of_extractor.cnet.", 2 * (fr / 255.0) - 1.0, "batch")
     rsd = {k[len("of_extractor."):]: v.to(dev) for k, v in sd.items() if k.startswith("of_extractor.")}
-    w = ops.RaftEncoderWeights(rsd, "cnet.", True, ops.dtype_code(dtype))
+    w = ops.RaftEncoderWeights(rsd, "cnet.", True, ops.raft_dtype_code(dtype))
     out = ops.raft_encoder(w, fr.to(dev)).cpu().view(n, size // 8, size // 8, 256).permute(0, 3, 1, 2)
     e = rel_rms(out, ref)
     print(f"[raft cnet {size}x{size} {dtype}] rel_rms={e:.3e}")
-    assert e <= (1e-5 if dtype == "f32" else 1e-2)
+    assert e <= {"f32": 1e-5, "bf16": 1e-2, "bf16x3": 2e-4}[dtype]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("size,n", [(224, 5), (224, 1), (224, 2), (224, 3), (160, 1), (160, 2), (192, 1), (64, 3), (96, 2)])
 def test_raft_encoder_image_sizes(dev, tiny_sd, size, n, dtype):
     """InstanceNorm moments come from the convolution epilogue (bf16 mode): 224 -> 28x28 = 784-row images straddle the
@@ -141,7 +141,7 @@ def test_raft_encoder_image_sizes(dev, tiny_sd, size, n, dtype):
     fr = torch.randint(0, 256, (n, 3, size, size), generator=torch.Generator().manual_seed(size)).float()
     ref = O.raft_encoder(sd, "of_extractor.fnet.", 2 * (fr / 255.0) - 1.0, "instance")
     rsd = {k[len("of_extractor."):]: v.to(dev) for k, v in sd.items() if k.startswith("of_extractor.")}
-    w = ops.RaftEncoderWeights(rsd, "fnet.", False, ops.dtype_code(dtype))
+    w = ops.RaftEncoderWeights(rsd, "fnet.", False, ops.raft_dtype_code(dtype))
     out = ops.raft_encoder(w, fr.to(dev)).cpu().view(n, size // 8, size // 8, 256).permute(0, 3, 1, 2)
     e = rel_rms(out, ref)
     per = [rel_rms(out[i], ref[i]) for i in range(n)]
@@ -189,8 +189,8 @@ def float_frames(kind, n, size, seed):
 # fp32 mode on float-valued frames: the kernel packs the reference's own 2*(x/255)-1 (same roundings); what is left is the
 # summation order of the stem convolution, whose ~1e-7 relative noise sits on a -1 +- 0.008 image and is amplified ~128 x by
 # InstanceNorm (observed 1.1e-5 on fnet, cnet 1e-7): bound 1e-4 instead of the integer-frame 1e-5
-FLOAT_ENC_TOL = {"f32": 1e-4, "bf16": 2e-2}
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+FLOAT_ENC_TOL = {"f32": 1e-4, "bf16": 2e-2, "bf16x3": 5e-4}
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("weights", ["default", "sensitive"])
 @pytest.mark.parametrize("kind,size,n", [("randn", 128, 3), ("clip", 128, 3), ("randn", 224, 2), ("clip", 224, 2)])
 def test_raft_encoders_float_valued_frames(dev, tiny_sd, dtype, weights, kind, size, n):
@@ -204,17 +204,17 @@ def test_raft_encoders_float_valued_frames(dev, tiny_sd, dtype, weights, kind, s
     rsd = {k[len("of_extractor."):]: v.to(dev) for k, v in sd.items() if k.startswith("of_extractor.")}
     for net, okind in (("fnet.", "instance"), ("cnet.", "batch")):
         ref = O.raft_encoder(sd, "of_extractor." + net, 2 * (fr / 255.0) - 1.0, okind)
-        w = ops.RaftEncoderWeights(rsd, net, okind == "batch", ops.dtype_code(dtype))
+        w = ops.RaftEncoderWeights(rsd, net, okind == "batch", ops.raft_dtype_code(dtype))
         out = ops.raft_encoder(w, fr.to(dev)).cpu().view(n, size // 8, size // 8, 256).permute(0, 3, 1, 2)
         e = rel_rms(out, ref)
         print(f"[raft {net} float frames {kind} {size} {weights} {dtype}] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
         assert e <= FLOAT_ENC_TOL[dtype], (net, e)
 
 
-SENS_FLOW_TOL = {"f32": 2e-4, "bf16": 2e-2}
+SENS_FLOW_TOL = {"f32": 2e-4, "bf16": 2e-2, "bf16x3": 5e-4}
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
 def test_raft_sensitive_weights_vs_reference(dev, dtype):
     """The INPUT-SENSITIVE weight set (synth.raft_sensitive_state_dict: fan-in-scaled, the flow depends on the correlation
     features -- tests/test_oracle.py shows a 7 % fnet error moves it by > 1e-2) against the reference RAFT's own flows and fnet
@@ -232,14 +232,14 @@ def test_raft_sensitive_weights_vs_reference(dev, dtype):
         print(f"[raft sensitive {tag} {dtype}] flow rel_rms={e:.3e} max|ref|={g['flow_' + tag].abs().max():.3e}")
         assert e <= SENS_FLOW_TOL[dtype], (tag, e)
         if tag != "c":
-            w = ops.RaftEncoderWeights({k: v.to(dev) for k, v in sd.items()}, "fnet.", False, ops.dtype_code(dtype))
+            w = ops.RaftEncoderWeights({k: v.to(dev) for k, v in sd.items()}, "fnet.", False, ops.raft_dtype_code(dtype))
             fm = ops.raft_encoder(w, torch.cat([f[:-1], f[1:]], 0).to(dev)).cpu().view(4, 16, 16, 256).permute(0, 3, 1, 2)[:, ::4]
             ef = rel_rms(fm, g["fmap_" + tag])
             print(f"[raft sensitive {tag} {dtype}] fnet rel_rms vs the reference's feature maps={ef:.3e}")
             assert ef <= FLOAT_ENC_TOL[dtype], (tag, ef)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
 def test_raft_224_sensitive_weights_vs_reference(dev, dtype):
     """Full frame size (224 x 224 -> 28 x 28 coarse pixels: the geometry the fused GRU half-step, conv64 and the stem kernel run at in
     the bench), input-sensitive weights, 20 iterations, against the REFERENCE's own flow (tests/golden/raft224_sensitive.npz,
@@ -313,14 +313,14 @@ def test_raft_float_valued_frames(dev, tiny_sd):
     sd = tiny_sd["instructblip"][1]
     fr = torch.randn(3, 3, 128, 128, generator=torch.Generator().manual_seed(12))
     ref = O.raft_forward(sd, "of_extractor.", fr[:-1], fr[1:], iters=6)
-    for dtype, tol in (("f32", 1e-4), ("bf16", 2e-2)):
+    for dtype, tol in (("f32", 1e-4), ("bf16", 2e-2), ("bf16x3", 5e-4)):
         got = make(dev, tiny_sd, dtype)(fr[:-1].to(dev), fr[1:].to(dev), iters=6).cpu()
         e = rel_rms(got, ref)
         print(f"[raft normalised frames {dtype}] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
         assert e <= tol
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("h8,w8", [(28, 28), (16, 16), (9, 13)])
 def test_corr_pyramid_vs_oracle(dev, h8, w8, dtype):
     """CorrBlock.__init__ (corr.py:12-27, :52-60) in one kernel: all-pairs product / sqrt(dim) + three avg_pool2d, odd sizes
@@ -330,14 +330,14 @@ def test_corr_pyramid_vs_oracle(dev, h8, w8, dtype):
     g = torch.Generator().manual_seed(h8 * 31 + w8)
     b, t = 2, 3
     fm = torch.randn(b * t, h8 * w8, 256, generator=g) * 1.5
-    code = ops.dtype_code(dtype)
+    code = ops.raft_dtype_code(dtype)
     got = ops.raft_corr(fm.to(dev), b * (t - 1), h8, w8, t - 1, t, 0, 1, code)
     nchw = fm.view(b, t, h8, w8, 256).permute(0, 1, 4, 2, 3)
     f1, f2 = nchw[:, :-1].reshape(-1, 256, h8, w8), nchw[:, 1:].reshape(-1, 256, h8, w8)
     ref = O.raft_corr_pyramid(f1, f2)
-    tol = 1e-5 if dtype == "f32" else 3 * 2.0 ** -11
+    tol = 3 * 2.0 ** -11 if dtype == "bf16" else 1e-5
     for l in range(4):
-        assert got[l].shape == ref[l].shape and got[l].dtype == (torch.float32 if dtype == "f32" else torch.float16)
+        assert got[l].shape == ref[l].shape and got[l].dtype == (torch.float16 if dtype == "bf16" else torch.float32)
         err = (got[l].float().cpu() - ref[l]).abs().max().item()
         print(f"[corr {dtype} {h8}x{w8}] level {l}: max|diff|={err:.3e} max|ref|={ref[l].abs().max():.3e}")
         assert err <= tol * ref[l].abs().max().item()
@@ -360,7 +360,7 @@ def test_corr_large_features_do_not_overflow(dev):
     assert torch.isfinite(got[0].float()).all() and abs(got[0].float().mean().item() - 6400.0) < 4.0
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
 def test_raft_partial_last_tile(dev, tiny_sd, dtype):
     """2 frame pairs of 144 x 144: 2 x 324 = 648 coarse pixels, so the tiles of every update-block launch straddle the two images
     and the third one is partial -- fragment-order start maps, the fused flow-head tail, the gated and GRU epilogues and the
@@ -373,4 +373,4 @@ def test_raft_partial_last_tile(dev, tiny_sd, dtype):
     got = make(dev, tiny_sd, dtype)(fr[:-1].to(dev), fr[1:].to(dev), iters=4).cpu()
     e = rel_rms(got, ref)
     print(f"[raft 144x144 x 2 pairs {dtype}] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
-    assert torch.isfinite(got).all() and e <= (1e-4 if dtype == "f32" else 2e-2)
+    assert torch.isfinite(got).all() and e <= {"f32": 1e-4, "bf16": 2e-2, "bf16x3": 5e-4}[dtype]

@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTGB_LIB") or os.path.join(HERE, "libvtgb.so")
 
 F32, BF16 = 0, 1
+BF16X3 = 2      # RAFT entry points only: split-bf16 operands (include/vtgb.h)
 MAP_A, MAP_B = 0, 1
 POOL_MEAN, POOL_CONCAT = 0, 1
 TGB_MODE = {"text": 0, "vision": 0, "fusion": 1, "multi_modal": 2}

@@ -185,8 +185,18 @@ struct GemmDesc {
     const void* tail_w;
     float* tail_out;
     int64_t ldtail;
+    // ---- split-bf16 ("bf16x3") operands: an activation of C channels is stored as a bf16 PAIR row [hi(C) | lo(C)] (hi = bf16(x),
+    // lo = bf16(x - hi): 16 significant bits) and enters the contraction as the 3C channels [hi | lo | hi] against weights packed as
+    // [Wh | Wh | Wl] -- x.w ~ hi.Wh + lo.Wh + hi.Wl, fp32 accumulation (the lo.Wl term, 2^-16 of the product, is dropped).
+    // conv_wrap / conv_wrap2 (convolutions only; 0 = off): channel offsets >= wrap of the first / second source wrap around to
+    // offset - wrap, i.e. the third block reads the hi half again (wrap = 2C of that source; conv_Cin / conv_split count the 3C form).
+    int conv_wrap, conv_wrap2;
+    // EPI_SPLIT: out (bf16, row stride ldo) receives act(acc + bias) as such a pair: hi at column n, lo at column n + split_lo.
+    // N % 2 == 0, ldo % 4 == 0, split_lo % 4 == 0; persistent kernel only.
+    int split_lo;
 };
 #define VTGB_EPI_GRU 4
+#define VTGB_EPI_SPLIT 5
 int launch_gemm(const GemmDesc& d, hipStream_t s);
 int launch_conv_gemm(const GemmDesc& d, hipStream_t s);   // large kernel forced: implicit conv / activations / GRU
 
@@ -246,6 +256,9 @@ int launch_flow_assemble(const float* conv, const float* proj_b, const float* fc
 int launch_mean_pool_uniform(const float* q, float* out, int n_clips, int width, int64_t row_elems, hipStream_t s);
 int launch_pack_bf16(const float* src, void* dst, int64_t rows, int64_t cols, int64_t cols_pad, hipStream_t s);
 int launch_mrc_head(const float* x, const float* w, const float* b, float* logits, int B, int L, int hidden, hipStream_t s);
+
+// RAFT's correlation pyramid as the lookup kernels take it (raft.hip, raft_x3.hip)
+struct CorrPyr { const void* lvl[4]; int h[4], w[4]; };
 
 // launch timing (forward.hip): bracket a launch with events when profiling is enabled
 struct ProfScope {

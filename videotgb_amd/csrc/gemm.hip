@@ -369,7 +369,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_large_kernel(const GemmDesc 
     if constexpr (CONV) {                                                                               \
         const bool first = cv_c0 < p.conv_split;                                                        \
         const unsigned ldb = (unsigned)(first ? p.lda : p.lda2) * 2u;                                   \
-        const int cc2 = (first ? cv_c0 : cv_c0 - p.conv_split) * 2;                                     \
+        const int cs_ = first ? cv_c0 : cv_c0 - p.conv_split, wr_ = first ? p.conv_wrap : p.conv_wrap2;   /* (bf16x3 pairs: the third block is hi again) */ \
+        const int cc2 = ((wr_ > 0 && cs_ >= wr_) ? cs_ - wr_ : cs_) * 2;                                \
         const int dpix = (cv_ky - (p.conv_KH >> 1)) * cv_Wi + (cv_kx - (p.conv_KW >> 1));               \
         const int need = (1 << cv_ky) | (256 << cv_kx);                                                 \
         const auto rs_ = first ? a_rsrc : a2_rsrc;      /* (as in gemm_pp.hip: one select per k-tile, 24-bit multiply-add + select per piece) */ \
@@ -1143,6 +1144,16 @@ static int launch_large_forced(const GemmDesc& d, hipStream_t s) {
 
 int launch_conv_f32(const GemmDesc& d, hipStream_t s);   // conv_f32.hip: the exactness mode of this entry
 
+// bf16x3 pair store (EPI_SPLIT): persistent kernel only -- 256 x 128 tile up to 128 channels, 256 x 192 (48-column wave tiles) up to 192,
+// else 256 x 256
+static int launch_split(const GemmDesc& d, hipStream_t s) {
+    VTGB_REQUIRE(d.conv_KH > 0 && pp_supported(d), VTGB_EUNSUPPORTED, "conv gemm: pair store needs a convolution with N %% 2 == 0, 4-aligned rows and split_lo (N=%d ldo=%lld split_lo=%d)",
+                 d.N, (long long)d.ldo, d.split_lo);
+    if (d.N <= 128) return launch_large_pp<EPI_SPLIT, true, 2>(d, s);
+    if (d.N <= 192 && (d.N & 7) == 0) return launch_large_pp<EPI_SPLIT, true, 4, 3>(d, s);
+    return launch_large_pp<EPI_SPLIT, true, 4>(d, s);
+}
+
 // round-up magic for n / d, 0 <= n < 2^31, 1 <= d < 2^31: q = (umulhi(n, mul) + n) >> sh
 static void magic_div(uint32_t d, uint32_t* mul, uint32_t* sh) {
     uint32_t s = 0;
@@ -1165,6 +1176,8 @@ int launch_conv_gemm(const GemmDesc& d_in, hipStream_t s) {
                      VTGB_EINVAL, "conv gemm: inconsistent convolution geometry");
     }
     if (d.dtype == VTGB_F32) return launch_conv_f32(d, s);
+    VTGB_REQUIRE(d.conv_wrap >= 0 && d.conv_wrap2 >= 0 && (d.conv_wrap % L_BK) == 0 && (d.conv_wrap2 % L_BK) == 0 && (conv || (d.conv_wrap | d.conv_wrap2) == 0), VTGB_EINVAL,
+                 "conv gemm: pair wrap must be a multiple of 64 channels on a convolution");
     VTGB_REQUIRE((d.K % L_BK) == 0 && (d.lda % 8) == 0 && (d.ldw % 8) == 0, VTGB_EUNSUPPORTED, "conv gemm: K=%d must be a multiple of 64", d.K);
     VTGB_REQUIRE(large_kernel_addressable(d), VTGB_EUNSUPPORTED, "conv gemm: tile footprint beyond the 32-bit offsets of the LDS-DMA descriptors (%dx%d taps)", d.conv_KH, d.conv_KW);
     if (d.gate_from > 0)
@@ -1193,6 +1206,7 @@ int launch_conv_gemm(const GemmDesc& d_in, hipStream_t s) {
         case EPI_GRU:
             VTGB_REQUIRE(conv && d.resid && d.aux && d.out2, VTGB_EINVAL, "conv gemm: GRU epilogue needs h, z and both outputs");
             return launch_large_forced<EPI_GRU, true>(d, s);
+        case EPI_SPLIT: return launch_split(d, s);
     }
     vtgb_set_error("conv gemm: unsupported epilogue %d", d.epi);
     return VTGB_EINVAL;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
     constexpr int T_BM = 256, T_BN = WC * NWN;
     constexpr int A_OP = P_AOP, W_OP = T_BN * 128;
     constexpr int AI = 4, WI = T_BN / 64;      // LDS-DMA instructions per wave and k-tile
-    static_assert(WF == 4 || (WF == 3 && NWN == 4 && EPI == EPI_STORE && CONV && !TAIL && !PING), "48-column wave tiles: the plain bf16-store convolution only");
+    static_assert(WF == 4 || (WF == 3 && NWN == 4 && (EPI == EPI_STORE || EPI == EPI_SPLIT) && CONV && !TAIL && !PING), "48-column wave tiles: the plain bf16-store / pair-store convolution only");
     constexpr int A_SLOTS = 3;
     constexpr bool WHOLE = PING && NWN < 4;   // ping-pong on narrow tiles: one compute segment per k-tile (both halves), three weight slots
     constexpr int W_SLOTS = WHOLE ? 3 : 2;
@@ -138,7 +138,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
     if constexpr (CONV) {                                                                               \
         const bool first = cv_c0 < p.conv_split;                                                        \
         const unsigned ldb = (unsigned)(first ? p.lda : p.lda2) * 2u;                                   \
-        const int cc2 = (first ? cv_c0 : cv_c0 - p.conv_split) * 2;                                     \
+        const int cs_ = first ? cv_c0 : cv_c0 - p.conv_split, wr_ = first ? p.conv_wrap : p.conv_wrap2;   /* (bf16x3 pairs: the third block is hi again) */ \
+        const int cc2 = ((wr_ > 0 && cs_ >= wr_) ? cs_ - wr_ : cs_) * 2;                                \
         const int dpix = (cv_ky - (p.conv_KH >> 1)) * cv_Wi + (cv_kx - (p.conv_KW >> 1));               \
         const int need = (1 << cv_ky) | (256 << cv_kx);                                                 \
         /* r4: one descriptor select per k-tile (was a branch + four s_cselect per piece), the offset as a 24-bit multiply-add with a   \
@@ -681,6 +682,50 @@ gelu_erf_fast4(v);
                 }
             }
         }
+        if constexpr (EPI == EPI_SPLIT) {
+            // bf16x3 pair store (GemmDesc::split_lo): v = act(acc) goes through the staging region as fp32 (as in the fp32 path), is read back
+            // as whole row segments and leaves as hi = bf16(v) at column n and lo = bf16(v - hi) at column n + split_lo: 8 bytes per lane,
+            // 128 contiguous bytes per row and half, four rows per store instruction.  N % 4 == 2 (RAFT's 126-channel motion convolution, whose
+            // last two columns hold the flow written by another kernel): the group that straddles N is stored as 4 bytes.
+            constexpr int PR = SB / 256 < WROWS ? SB / 256 : WROWS, NP = WROWS / PR;
+            const int rl = lane_e >> 4, cl = lane_e & 15;
+            const int n = en0 + wn * WC + cl * 4;
+            const bool inw = cl * 4 < WC;
+            const auto o_rs = tile_rsrc(p.out, p.ldo, 2);
+            const unsigned o_off = (unsigned)((wm * WROWS + rl) * (int)p.ldo + n) * 2u;
+            const unsigned o_lane = (inw && n + 3 < p.N) ? o_off : OOB;
+            const unsigned o_part = (inw && n < p.N && n + 3 >= p.N) ? o_off : OOB;      // (N % 4 == 2: two columns)
+            const bool cut = (p.N & 3) != 0;
+            const unsigned lo_b = (unsigned)p.split_lo * 2u;
+            prefetch();
+#pragma unroll
+            for (int ps = 0; ps < NP; ps++) {
+#pragma unroll
+                for (int jj = 0; jj < PR / 16; jj++)
+#pragma unroll
+                    for (int i = 0; i < WF; i++) {
+                        const int row = jj * 16 + (lane_e & 15), chunk = i * 4 + (lane_e >> 4);
+                        *reinterpret_cast<f32x4*>(stage + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][ps * (PR / 16) + jj];
+                    }
+#pragma unroll
+                for (int rr = 0; rr < PR / 4; rr++) {
+                    const int row = rr * 4 + rl;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 256 + ((cl ^ (row & 15)) << 4));
+                    if (p.act) apply_act4(v, p.act);
+                    const f32x4 hf = {bf16_round(v[0]), bf16_round(v[1]), bf16_round(v[2]), bf16_round(v[3])};
+                    const bf16x4 hi = {(bf16_t)hf[0], (bf16_t)hf[1], (bf16_t)hf[2], (bf16_t)hf[3]};
+                    const bf16x4 lo = {(bf16_t)(v[0] - hf[0]), (bf16_t)(v[1] - hf[1]), (bf16_t)(v[2] - hf[2]), (bf16_t)(v[3] - hf[3])};
+                    const unsigned so = (unsigned)((ps * PR + rr * 4) * (int)p.ldo * 2);
+                    const u32x2_t hu = __builtin_bit_cast(u32x2_t, hi), lu = __builtin_bit_cast(u32x2_t, lo);
+                    P_STORE64(hu, o_rs, o_lane, so);
+                    P_STORE64(lu, o_rs, o_lane + lo_b, so);
+                    if (cut) {
+                        __builtin_amdgcn_raw_buffer_store_b32(hu[0], o_rs, o_part + so, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(lu[0], o_rs, o_part + lo_b + so, 0, 0);
+                    }
+                }
+            }
+        }
         if constexpr (EPI == EPI_GRU) {
             // h' = (1 - z) h + z tanh(acc): the accumulators go through the staging region as in the fp32 path so that h, z and both
             // outputs are touched as whole row segments.  h / z of pass h+1 are requested before pass h's stores (two register sets),
@@ -766,7 +811,7 @@ bool pp_supported(const GemmDesc& d) {
     if (d.o_map.seg_rows != 0 || d.r_map.seg_rows != 0) return false;
     if (d.init_bf16 && !d.init_frag) return false;
     if ((d.ldw & 63) != 0) return false;      // (the weight pieces' swizzle is applied as offset ^ 64: rows of whole 128 bytes)
-    if ((d.N & 3) != 0 && !(d.epi == EPI_STORE && !d.frag_out && (d.N & 1) == 0)) return false;
+    if ((d.N & 3) != 0 && !((d.epi == EPI_STORE || d.epi == EPI_SPLIT) && !d.frag_out && (d.N & 1) == 0)) return false;
     switch (d.epi) {
         case EPI_STORE:
         case EPI_GELU:
@@ -783,6 +828,8 @@ bool pp_supported(const GemmDesc& d) {
             return (d.ldo & 3) == 0 && d.act == 0 && d.out_scale == 0.f;
         case EPI_GRU:
             return ((d.ldo | d.ldr | d.ldaux | d.ldo2) & 3) == 0 && d.N <= 128;      // (RAFT's q convolutions: 128 channels)
+        case EPI_SPLIT:
+            return (d.N & 1) == 0 && (d.ldo & 3) == 0 && (d.split_lo & 3) == 0 && d.split_lo > 0 && d.out_scale == 0.f && d.conv_KH > 0;
     }
     return false;
 }
@@ -831,8 +878,10 @@ int launch_large_pp(const GemmDesc& d, hipStream_t s) {
 // explicit entry points used by gemm.hip (one per instantiation it dispatches to)
 #define PP_INST(EPI, CONV, NWN) template int launch_large_pp<EPI, CONV, NWN, 4>(const GemmDesc&, hipStream_t);
 template int launch_large_pp<EPI_STORE, true, 4, 3>(const GemmDesc&, hipStream_t);
+template int launch_large_pp<EPI_SPLIT, true, 4, 3>(const GemmDesc&, hipStream_t);
 PP_INST(EPI_STORE, false, 4) PP_INST(EPI_GELU, false, 4) PP_INST(EPI_RESID_F32, false, 4) PP_INST(EPI_STORE_F32, false, 4)
 PP_INST(EPI_STORE, false, 2) PP_INST(EPI_STORE_F32, false, 2)
 PP_INST(EPI_STORE, true, 4) PP_INST(EPI_STORE, true, 2)
 PP_INST(EPI_STORE_F32, true, 4) PP_INST(EPI_STORE_F32, true, 2)
 PP_INST(EPI_GRU, true, 2)
+PP_INST(EPI_SPLIT, true, 4) PP_INST(EPI_SPLIT, true, 2)

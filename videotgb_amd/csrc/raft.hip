@@ -97,7 +97,6 @@ __global__ __launch_bounds__(256) void raft_init_nhwc_bf16_kernel(const float* _
 // NB the reference adds stack(meshgrid(dy, dx)) to (x, y): the x coordinate receives the ROW offset of
 // the 9x9 window (corr.py:36-43) -- replicated as is.
 // ---------------------------------------------------------------------------------------
-struct CorrPyr { const void* lvl[4]; int h[4], w[4]; };
 
 constexpr int CL_PIX = 16;  // pixels per wave (the per-lane tables are built once and reused; 4 levels x 16 pixels = one lane each below)
 // Software-pipelined over the wave's pixels: the 8 window loads of pixel i + 1 are in flight while pixel i is interpolated out of
@@ -129,11 +128,13 @@ template <>
 __device__ __forceinline__ float lk_load<float>(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
-template <typename CT, typename OT>
+// PAIR (bf16x3 mode, OT = bf16): a pixel's row is [hi(384) | lo(384)], hi = bf16(v), lo = bf16(v - hi)
+template <typename CT, typename OT, bool PAIR = false>
 __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr, const float* __restrict__ flow, OT* __restrict__ out,
                                                                int64_t M, int H8, int W8) {
+    constexpr int OW = PAIR ? 768 : 384;   // elements per output row
     __shared__ float win[4][4][104];   // [wave][level][10 x 10 window | wx | wy | pad]
-    __shared__ __attribute__((aligned(16))) OT stage[4][2][384];
+    __shared__ __attribute__((aligned(16))) OT stage[4][2][OW];
     // (readfirstlane: the wave index -- and with it the pixel index and the level bases -- is wave-uniform; told so, hipcc keeps that
     // arithmetic on the scalar unit: r3)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -204,10 +205,10 @@ __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr
         if (lane < 36) wv[l * 104 + lane + 64] = (float)r[2 * l + 1];                                   \
     }                                                                                                   \
     if ((lane >> 2) == (pi)) { wv[(lane & 3) * 104 + 100] = sqx; wv[(lane & 3) * 104 + 101] = sqy; }
-    constexpr int CHUNKS = 384 * (int)sizeof(OT) / 16;
+    constexpr int CHUNKS = OW * (int)sizeof(OT) / 16;
 #define CL_STORE(pi)                                                                                    \
     _Pragma("unroll") for (int c = lane; c < CHUNKS; c += 64)                                           \
-        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out + (m_first + (pi)) * 384) + c * 16) =     \
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out + (m_first + (pi)) * OW) + c * 16) =      \
             *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(&stage[wave][(pi) & 1][0]) + c * 16);
     CL_FETCH(0, cur)
     CL_DEPOSIT(0, cur)
@@ -227,6 +228,11 @@ __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr
             const lk_f32x2 c = top + wy * (bot - top);                // both columns interpolated along y (packed)
             float v = c[0] + wx * (c[1] - c[0]);
             if (kk == 5) v = lane < 4 ? v : 0.f;                      // k >= 324: the zero padding of K
+            if constexpr (PAIR) {
+                const float hf = bf16_round(v);
+                stage[wave][pi & 1][kk * 64 + lane] = (OT)hf;
+                stage[wave][pi & 1][384 + kk * 64 + lane] = (OT)(v - hf);
+            } else
             stage[wave][pi & 1][kk * 64 + lane] = (OT)v;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // window reads done, staging row written
@@ -682,8 +688,10 @@ extern "C" void vtgb_debug_set_gru_fused(int v) { g_gru_fused = v; }
 extern "C" void vtgb_debug_set_lk_fused(int v) { g_lk_fused = v; }
 #endif
 
+int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s);   // raft_x3.hip: VTGB_BF16X3
 static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     VTGB_REQUIRE(a, VTGB_EINVAL, "raft_update: NULL args");
+    if (a->dtype == VTGB_BF16X3) return raft_x3_impl(a, ws, s);
     VTGB_REQUIRE(a->dtype == VTGB_BF16 || a->dtype == VTGB_F32, VTGB_EINVAL, "raft_update: bad dtype %d", a->dtype);
     VTGB_REQUIRE(a->n_pairs > 0 && a->H8 >= 8 && a->W8 >= 8 && a->iters > 0, VTGB_EINVAL, "raft_update: bad dims n=%d H8=%d W8=%d iters=%d",
                  a->n_pairs, a->H8, a->W8, a->iters);
@@ -882,6 +890,33 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
     return VTGB_OK;
 }
 
+// ---- launchers shared with the bf16x3 orchestration (raft_x3.hip)
+int raft_launch_lookup_pair(const CorrPyr& pyr, const float* flow, void* out_pair, int64_t M, int H8, int W8, hipStream_t s) {
+    const dim3 lk_grid((unsigned)((M + 4 * CL_PIX - 1) / (4 * CL_PIX)));
+    hipLaunchKernelGGL((raft_corr_lookup_kernel<float, bf16_t, true>), lk_grid, dim3(256), 0, s, pyr, flow, (bf16_t*)out_pair, M, H8, W8);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+int raft_launch_flow_head2(const float* P2, const float* bias, float* flow, int n_pairs, int H8, int W8, hipStream_t s) {
+    const int HW = H8 * W8;
+    const int64_t M = (int64_t)n_pairs * HW;
+    const size_t fh2_lds = (size_t)18 * HW * sizeof(float);
+    if (fh2_lds <= 160 * 1024) {
+        static DeviceOnce fh2_attr;
+        VTGB_FUNC_LDS_ONCE(fh2_attr, raft_flow_head2_kernel, 160 * 1024);
+        hipLaunchKernelGGL(raft_flow_head2_kernel, dim3((unsigned)n_pairs), dim3(256), fh2_lds, s, P2, bias, flow, M, H8, W8);
+    } else {
+        hipLaunchKernelGGL(raft_flow_head2_gather_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, P2, bias, flow, M, H8, W8);
+    }
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+int raft_launch_upsample(const float* flow, const float* mask, float* flow_up, int n_pairs, int H8, int W8, hipStream_t s) {
+    const int64_t npx = (int64_t)n_pairs * 64 * H8 * W8;
+    hipLaunchKernelGGL(raft_upsample_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, flow, mask, flow_up, (int64_t)n_pairs, H8, W8);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
 extern "C" size_t vtgb_raft_update_workspace_bytes(const vtgb_raft_update_args* a) {
     Workspace ws(nullptr, 0);
     if (raft_impl(a, ws, nullptr) != VTGB_OK) return 0;

@@ -173,25 +173,32 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
     }
 }
 
+// VTGB_BF16X3: the input is a pair row [hi(Cin) | lo(Cin)] contracted as [hi | lo | hi] against weights packed [Wh | Wh | Wl] (raft_x3.hip)
 static GemmDesc enc_conv(int dt, int Mo, int N, int Ho, int Wo, int K, int Cin, int stride, int Hi, int Wi, const void* A, const void* Wt, const float* bias,
                          float* out, int ldo, const void* zero, float* col_stats) {
     GemmDesc d;
     memset(&d, 0, sizeof(d));
-    d.dtype = dt; d.M = Mo; d.N = N; d.K = K * K * Cin; d.epi = VTGB_EPI_STORE_F32;
-    d.A = A; d.lda = Cin; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = out; d.ldo = ldo;
-    d.conv_H = Ho; d.conv_W = Wo; d.conv_KH = K; d.conv_KW = K; d.conv_Cin = Cin; d.conv_split = Cin;
+    const bool x3 = dt == VTGB_BF16X3;
+    const int Ce = x3 ? 3 * Cin : Cin;
+    d.dtype = x3 ? VTGB_BF16 : dt; d.M = Mo; d.N = N; d.K = K * K * Ce; d.epi = VTGB_EPI_STORE_F32;
+    d.A = A; d.lda = x3 ? 2 * Cin : Cin; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = out; d.ldo = ldo;
+    d.conv_H = Ho; d.conv_W = Wo; d.conv_KH = K; d.conv_KW = K; d.conv_Cin = Ce; d.conv_split = Ce; d.conv_wrap = x3 ? 2 * Cin : 0;
     d.conv_stride = stride; d.conv_Hi = Hi; d.conv_Wi = Wi; d.zero_page = zero;
     d.col_stats = col_stats; d.stats_rows = Ho * Wo;
+    if (x3) d.algo_flops = 2.0 * Mo * (double)N * (K * K * Cin);
     return d;
 }
+int launch_x3_pair_pass(const float* x, int64_t ldx, const float* stats, int HW, const void* resid, int64_t ldr, int r_lo, void* out, int64_t ldo, int o_lo,
+                        int C, int Cpad, int relu_in, int relu_out, int64_t M, hipStream_t s);   // raft_x3.hip
 
 static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t s) {
     VTGB_REQUIRE(a, VTGB_EINVAL, "raft_encoder: NULL args");
     VTGB_REQUIRE(a->n_images > 0 && a->H >= 64 && a->W >= 64 && (a->H % 8) == 0 && (a->W % 8) == 0 && (a->norm == 0 || a->norm == 1), VTGB_EINVAL,
                  "raft_encoder: bad dims n=%d H=%d W=%d", a->n_images, a->H, a->W);
-    VTGB_REQUIRE(a->dtype == VTGB_BF16 || a->dtype == VTGB_F32, VTGB_EINVAL, "raft_encoder: bad dtype %d", a->dtype);
+    VTGB_REQUIRE(a->dtype == VTGB_BF16 || a->dtype == VTGB_F32 || a->dtype == VTGB_BF16X3, VTGB_EINVAL, "raft_encoder: bad dtype %d", a->dtype);
     const int n = a->n_images, dt = a->dtype;
-    const size_t es = dtype_size(dt);
+    const bool x3 = dt == VTGB_BF16X3;                 // activations as bf16 pairs: 4 bytes per channel
+    const size_t es = x3 ? 4 : dtype_size(dt);
     const int H2 = a->H / 2, W2 = a->W / 2, H4 = a->H / 4, W4 = a->W / 4, H8 = a->H / 8, W8 = a->W / 8;
     const int64_t M2 = (int64_t)n * H2 * W2, M4 = (int64_t)n * H4 * W4, M8 = (int64_t)n * H8 * W8;
     VTGB_REQUIRE(M2 < (1ll << 31), VTGB_EUNSUPPORTED, "raft_encoder: too many pixels per call (chunk the images)");
@@ -221,6 +228,8 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
             const int splits = HW >= 4096 ? 16 : HW >= 1024 ? 4 : 1;
             hipLaunchKernelGGL(inorm_stats_kernel, dim3(n, splits), dim3(256), 0, s, x, st, HW, C, ldx);
         }
+        if (x3)
+            return launch_x3_pair_pass(x, ldx, inorm ? st : nullptr, HW, resid, 2 * Cpad, Cpad, out, 2 * Cpad, Cpad, C, Cpad, relu_in, relu_out, M, s);
         VTGB_REQUIRE(Cpad == 64 || Cpad == 128, VTGB_EUNSUPPORTED, "raft_encoder: normalisation pass over %d padded channels", Cpad);
         const int ppb = 256 / (Cpad / 4);
         const dim3 grid((unsigned)((HW + NA_PASS * ppb - 1) / (NA_PASS * ppb)), (unsigned)(M / HW));
@@ -236,7 +245,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     // moments for a convolution output: zero the buffer and hand it to the GEMM epilogue when the image is
     // large enough for the two-images-per-tile bookkeeping, else leave it to the separate pass
     auto stats_for = [&](float* st, int HW, int C) -> float* {
-        if (!inorm || HW < 256 || dt != VTGB_BF16) return nullptr;   // (the fp32 kernel leaves the moments to the separate pass)
+        if (!inorm || HW < 256 || dt == VTGB_F32) return nullptr;   // (the fp32 kernel leaves the moments to the separate pass)
         (void)hipMemsetAsync(st, 0, (size_t)n * C * 2 * sizeof(float), s);
         return st;
     };
@@ -255,7 +264,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
             VTGB_TRY(launch_stem7x7(a->images, w[0], F(w[1]), nullptr, nullptr, act0, n, a->H, a->W, 1, s));     // relu(bn1(conv1(x))) straight to bf16
         }
     } else {
-        if (dt == VTGB_BF16)
+        if (dt != VTGB_F32)
             hipLaunchKernelGGL(raft_stem_pack_kernel<bf16_t>, dim3((unsigned)((M2 * 4 + 255) / 256)), dim3(256), 0, s, a->images, (bf16_t*)act1, (bf16_t*)pad_page, M2,
                                a->H, a->W);
         else
@@ -263,12 +272,13 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
                                a->H, a->W);
         {
             float* sf = stats_for(stats, H2 * W2, 64);
-            const int cp = dt == VTGB_BF16 ? 128 : 64;            // bf16: hi | lo chunks (raft_stem_pack_kernel)
+            const int cp = dt == VTGB_BF16 ? 128 : 64;            // bf16: hi | lo chunks (raft_stem_pack_kernel); bf16x3: the same image read as a pair of 64
             GemmDesc d = enc_conv(dt, (int)M2, 64, H2, W2, 1, cp, 1, H2, W2, act1, w[0], F(w[1]), cf, 64, pad_page, sf);
-            d.conv_KH = 4; d.K = 4 * cp; d.ldw = 4 * cp;
-            if (!inorm) { d.epi = VTGB_EPI_STORE; d.act = 1; d.out = act0; }        // relu(bn1(conv1(x))) straight to bf16
+            d.conv_KH = 4; d.K = 4 * d.conv_Cin; d.ldw = d.K;
+            if (x3) d.algo_flops = 2.0 * (double)M2 * 64 * 147;
+            if (!inorm && !x3) { d.epi = VTGB_EPI_STORE; d.act = 1; d.out = act0; }        // relu(bn1(conv1(x))) straight to bf16
             VTGB_TRY(launch_conv_gemm(d, s));
-            if (inorm) VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, sf != nullptr));
+            if (inorm || x3) VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, sf != nullptr));
         }
     }
     // ---- six residual blocks
@@ -312,7 +322,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
             VTGB_TRY(launch_conv3x3_c64(t1, bw[2], F(bw[3]), cf, stats, nullptr, nullptr, n, g.Ho, g.Wo, 0, 0, s));
             outb = t1;
             VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, x, outb, 1, 1, stats, true));                                // relu(x + relu(norm2(conv2(y))))
-        } else if (!inorm) {
+        } else if (!inorm && !x3) {
             VTGB_TRY(conv_bn(Mo, g, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), 1, nullptr, 0, t1));        // y = relu(bn1(conv1(x)))
             const void* res = x;
             outb = t2;                                                                                          // conv2 reads t1: it cannot be the output
@@ -353,6 +363,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
         memset(&d, 0, sizeof(d));
         d.dtype = dt; d.M = (int)M8; d.N = 256; d.K = 128; d.epi = VTGB_EPI_STORE_F32;
         d.A = x; d.lda = 128; d.W = w[38]; d.ldw = 128; d.bias = F(w[39]); d.out = a->out; d.ldo = 256;
+        if (x3) d = enc_conv(dt, (int)M8, 256, H8, W8, 1, 128, 1, H8, W8, x, w[38], F(w[39]), a->out, 256, zero, nullptr);
         VTGB_TRY(launch_conv_gemm(d, s));
     }
     return VTGB_OK;

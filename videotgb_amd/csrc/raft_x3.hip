@@ -1,0 +1,287 @@
+// raft_x3.hip -- RAFT's refinement loop (xraft.py:135-156, raft_utils/update.py:39-144) at the reference's fp32 ACCURACY on the bf16
+// matrix cores: VTGB_BF16X3.  The reference runs RAFT in fp32 whatever the Lightning precision is (xraft.py:58,113-118); the bf16 mode of
+// raft.hip is 1.4e-2 off its flows under input-sensitive weights, the fp32 FMA mode (conv_f32.hip) is exact but runs on the vector ALUs.
+// Here every convolution operand is a bf16 PAIR -- hi = bf16(x), lo = bf16(x - hi), 16 significant bits -- and every product is formed as
+//     x . w  ~  hi . Wh + lo . Wh + hi . Wl            (three bf16 MFMA products, fp32 accumulation; the dropped lo . Wl is 2^-16 of it)
+// by the SAME implicit-GEMM kernels as the bf16 mode: an activation of C channels is stored as the row [hi(C) | lo(C)] and enters the
+// contraction as the 3C channels [hi | lo | hi] (GemmDesc::conv_wrap: the third block's LDS-DMA reads the hi half again) against weights
+// packed once as [Wh | Wh | Wl] (ops.py); the epilogue writes act(acc + bias) as a pair again (EPI_SPLIT).  Gates, the flow, the
+// correlation pyramid and its lookup stay fp32.  Cost: 3 x the bf16 mode's MFMA work.
+#include <math.h>
+#include <string.h>
+
+#include "common.h"
+
+int raft_launch_lookup_pair(const CorrPyr& pyr, const float* flow, void* out_pair, int64_t M, int H8, int W8, hipStream_t s);
+int raft_launch_flow_head2(const float* P2, const float* bias, float* flow, int n_pairs, int H8, int W8, hipStream_t s);
+int raft_launch_upsample(const float* flow, const float* mask, float* flow_up, int n_pairs, int H8, int W8, hipStream_t s);
+
+__device__ __forceinline__ void pair_split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const float hf = bf16_round(v[e]);
+        hi[e] = (bf16_t)hf;
+        lo[e] = (bf16_t)(v[e] - hf);
+    }
+}
+__device__ __forceinline__ f32x4 pair_join4(const bf16x4 hi, const bf16x4 lo) {
+    return f32x4{(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]};
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }   // (~1e-6 relative: far below the pair's 2^-17)
+
+// ---- fp32 rows -> pair rows with the element-wise tails of the encoders and of the 64-channel convolution:
+// y = [relu]((x - mean) * rstd) (InstanceNorm moments optional); out = [relu](resid + y); channels [C, Cpad) are written as zeros.
+// One thread per (pixel, 4 channels).
+struct PairPass {
+    const float* x; int64_t ldx;
+    const float* stats; int HW;                 // moments [(image * C + c) * 2 + {sum, sum of squares}] or NULL
+    const bf16_t* resid; int64_t ldr; int r_lo;
+    bf16_t* out; int64_t ldo; int o_lo;
+    int C, Cpad, relu_in, relu_out;
+    int64_t M;
+};
+__global__ __launch_bounds__(256) void x3_pair_pass_kernel(const PairPass p) {
+    const int g = p.Cpad >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.M * g) return;
+    const int64_t m = i / g;
+    const int c = (int)(i - m * g) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < p.C) {
+        v = *reinterpret_cast<const f32x4*>(p.x + m * p.ldx + c);
+        if (p.stats) {
+            const int64_t n = m / p.HW;
+            const float inv = 1.0f / (float)p.HW;
+            const f32x4 s01 = *reinterpret_cast<const f32x4*>(p.stats + (n * p.C + c) * 2), s23 = *reinterpret_cast<const f32x4*>(p.stats + (n * p.C + c) * 2 + 4);
+            const float sm[4] = {s01[0], s01[2], s23[0], s23[2]}, sq[4] = {s01[1], s01[3], s23[1], s23[3]};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float mean = sm[e] * inv;
+                const float rstd = rsqrtf(fmaxf(sq[e] * inv - mean * mean, 0.f) + 1e-5f);
+                v[e] = (v[e] - mean) * rstd;
+            }
+        }
+        if (p.relu_in) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.resid) {
+            const bf16_t* r = p.resid + m * p.ldr + c;
+            v += pair_join4(*reinterpret_cast<const bf16x4*>(r), *reinterpret_cast<const bf16x4*>(r + p.r_lo));
+        }
+        if (p.relu_out) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+        }
+    }
+    bf16x4 hi, lo;
+    pair_split4(v, hi, lo);
+    bf16_t* o = p.out + m * p.ldo + c;
+    *reinterpret_cast<bf16x4*>(o) = hi;
+    *reinterpret_cast<bf16x4*>(o + p.o_lo) = lo;
+}
+int launch_x3_pair_pass(const float* x, int64_t ldx, const float* stats, int HW, const void* resid, int64_t ldr, int r_lo, void* out, int64_t ldo, int o_lo,
+                        int C, int Cpad, int relu_in, int relu_out, int64_t M, hipStream_t s) {
+    VTGB_REQUIRE((C & 3) == 0 && (Cpad & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && (o_lo & 3) == 0 && (ldr & 3) == 0 && (r_lo & 3) == 0, VTGB_EINVAL,
+                 "pair pass: 4-aligned rows");
+    PairPass p{x, ldx, stats, HW, (const bf16_t*)resid, ldr, r_lo, (bf16_t*)out, ldo, o_lo, C, Cpad, relu_in, relu_out, M};
+    const int64_t n = M * (Cpad >> 2);
+    hipLaunchKernelGGL(x3_pair_pass_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+// ---- state init (xraft.py:126-132): h = tanh(cnet[:, :128]) -> hb pair [M, 256]; inp = relu(cnet[:, 128:]) -> X pair [M, 512] columns
+// [0, 128) | 256 + [0, 128); flow = flow_init or 0 -> flow fp32 and X columns 254, 255 (| + 256).  4 channels per thread.
+__global__ __launch_bounds__(256) void x3_init_kernel(const float* __restrict__ net, const float* __restrict__ inp, const float* __restrict__ cnet,
+                                                      bf16_t* __restrict__ hb, bf16_t* __restrict__ X, float* __restrict__ flow,
+                                                      const float* __restrict__ flow_init, int64_t M, int HW) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * 32) return;
+    const int64_t m = i >> 5;
+    const int c = (int)(i & 31) * 4;
+    f32x4 hv, iv;
+    if (cnet) {
+        const f32x4 nv = *reinterpret_cast<const f32x4*>(cnet + m * 256 + c);
+        iv = *reinterpret_cast<const f32x4*>(cnet + m * 256 + 128 + c);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { hv[e] = tanh_f(nv[e]); iv[e] = fmaxf(iv[e], 0.f); }
+    } else {      // NCHW, tanh / relu already applied by the caller
+        const int64_t n = m / HW, pp = m - n * HW;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { hv[e] = net[(n * 128 + c + e) * HW + pp]; iv[e] = inp[(n * 128 + c + e) * HW + pp]; }
+    }
+    bf16x4 hi, lo;
+    pair_split4(hv, hi, lo);
+    *reinterpret_cast<bf16x4*>(hb + m * 256 + c) = hi;
+    *reinterpret_cast<bf16x4*>(hb + m * 256 + 128 + c) = lo;
+    pair_split4(iv, hi, lo);
+    *reinterpret_cast<bf16x4*>(X + m * 512 + c) = hi;
+    *reinterpret_cast<bf16x4*>(X + m * 512 + 256 + c) = lo;
+    if (c == 0) {
+        float f0 = 0.f, f1 = 0.f;
+        if (flow_init) {
+            const int64_t n = m / HW, pp = m - n * HW;
+            f0 = flow_init[(n * 2) * HW + pp];
+            f1 = flow_init[(n * 2 + 1) * HW + pp];
+        }
+        flow[m * 2] = f0;
+        flow[m * 2 + 1] = f1;
+        const float h0 = bf16_round(f0), h1 = bf16_round(f1);
+        X[m * 512 + 254] = (bf16_t)h0; X[m * 512 + 255] = (bf16_t)h1;
+        X[m * 512 + 510] = (bf16_t)(f0 - h0); X[m * 512 + 511] = (bf16_t)(f1 - h1);
+    }
+}
+
+// ---- convf1 (update.py:81,92: 7x7, 2 -> 128, ReLU) as fp32 FMAs over the 98 taps in order (weights [98][128], k = c * 49 + ky * 7 + kx),
+// pair out; the flow itself goes to X columns 254, 255 (update.py:97).  Two pixels per workgroup, one thread per output channel.
+__global__ __launch_bounds__(256) void x3_convf1_kernel(const float* __restrict__ flow, const float* __restrict__ wt, const float* __restrict__ b,
+                                                        bf16_t* __restrict__ f1, bf16_t* __restrict__ X, int64_t M, int H8, int W8) {
+    __shared__ float win[2][100];
+    const int tid = threadIdx.x, HW = H8 * W8;
+    if (tid < 196) {
+        const int px = tid / 98, k = tid - px * 98, c = k / 49, t = k - c * 49, ky = t / 7, kx = t - ky * 7;
+        const int64_t m = (int64_t)blockIdx.x * 2 + px;
+        float v = 0.f;
+        if (m < M) {
+            const int pix = (int)(m % HW), y = pix / W8 + ky - 3, x = pix % W8 + kx - 3;
+            if ((unsigned)y < (unsigned)H8 && (unsigned)x < (unsigned)W8) v = flow[(m + (ky - 3) * W8 + (kx - 3)) * 2 + c];
+        }
+        win[px][k] = v;
+    }
+    __syncthreads();
+    const int px = tid >> 7, co = tid & 127;
+    const int64_t m = (int64_t)blockIdx.x * 2 + px;
+    if (m >= M) return;
+    float acc = b[co];
+    for (int k = 0; k < 98; k++) acc = fmaf(win[px][k], wt[k * 128 + co], acc);
+    acc = fmaxf(acc, 0.f);
+    const float hf = bf16_round(acc);
+    f1[m * 256 + co] = (bf16_t)hf;
+    f1[m * 256 + 128 + co] = (bf16_t)(acc - hf);
+    if (co < 2) {
+        const float f = flow[m * 2 + co], fh = bf16_round(f);
+        X[m * 512 + 254 + co] = (bf16_t)fh;
+        X[m * 512 + 510 + co] = (bf16_t)(f - fh);
+    }
+}
+
+// ---- SepConvGRU gates (update.py:52-55,59-62): zr fp32 [M, 256] = convz | convr pre-activations (bias included);
+// z = sigmoid(zr[:, :128]) stays fp32 in place, r * h -> RH pair [M, 256]
+__global__ __launch_bounds__(256) void x3_gru_gate_kernel(float* __restrict__ zr, const bf16_t* __restrict__ hb, bf16_t* __restrict__ RH, int64_t M) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * 32) return;
+    const int64_t m = i >> 5;
+    const int c = (int)(i & 31) * 4;
+    f32x4 z = *reinterpret_cast<const f32x4*>(zr + m * 256 + c);
+    const f32x4 r = *reinterpret_cast<const f32x4*>(zr + m * 256 + 128 + c);
+    const f32x4 h = pair_join4(*reinterpret_cast<const bf16x4*>(hb + m * 256 + c), *reinterpret_cast<const bf16x4*>(hb + m * 256 + 128 + c));
+    f32x4 rh;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { z[e] = sigmoid_f(z[e]); rh[e] = sigmoid_f(r[e]) * h[e]; }
+    *reinterpret_cast<f32x4*>(zr + m * 256 + c) = z;
+    bf16x4 hi, lo;
+    pair_split4(rh, hi, lo);
+    *reinterpret_cast<bf16x4*>(RH + m * 256 + c) = hi;
+    *reinterpret_cast<bf16x4*>(RH + m * 256 + 128 + c) = lo;
+}
+// h' = (1 - z) h + z tanh(q) (update.py:56-57,63-64): q fp32 [M, 128] pre-activation, z fp32 in zr[:, :128]; hb pair in place
+__global__ __launch_bounds__(256) void x3_gru_update_kernel(const float* __restrict__ zr, const float* __restrict__ q, bf16_t* __restrict__ hb, int64_t M) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * 32) return;
+    const int64_t m = i >> 5;
+    const int c = (int)(i & 31) * 4;
+    const f32x4 z = *reinterpret_cast<const f32x4*>(zr + m * 256 + c), qv = *reinterpret_cast<const f32x4*>(q + m * 128 + c);
+    const f32x4 h = pair_join4(*reinterpret_cast<const bf16x4*>(hb + m * 256 + c), *reinterpret_cast<const bf16x4*>(hb + m * 256 + 128 + c));
+    f32x4 hn;
+#pragma unroll
+    for (int e = 0; e < 4; e++) hn[e] = (1.0f - z[e]) * h[e] + z[e] * tanh_f(qv[e]);
+    bf16x4 hi, lo;
+    pair_split4(hn, hi, lo);
+    *reinterpret_cast<bf16x4*>(hb + m * 256 + c) = hi;
+    *reinterpret_cast<bf16x4*>(hb + m * 256 + 128 + c) = lo;
+}
+
+// a convolution over pair operands: C1 channels from A (row [hi(C1) | lo(C1)]), optionally C2 more from A2; K = taps * 3 (C1 + C2)
+static GemmDesc x3_conv(int M, int N, int H, int W, int KH, int KW, const void* A, int C1, const void* A2, int C2, const void* Wt, const float* bias, int epi,
+                        int act, void* out, int64_t ldo, int split_lo, const void* zero) {
+    GemmDesc d;
+    memset(&d, 0, sizeof(d));
+    const int Cin = 3 * (C1 + C2);
+    d.dtype = VTGB_BF16; d.M = M; d.N = N; d.K = KH * KW * Cin; d.epi = epi; d.act = act;
+    d.A = A; d.lda = 2 * C1; d.A2 = A2; d.lda2 = 2 * C2; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = out; d.ldo = ldo; d.split_lo = split_lo;
+    d.conv_H = H; d.conv_W = W; d.conv_KH = KH; d.conv_KW = KW; d.conv_Cin = Cin; d.conv_split = 3 * C1; d.conv_wrap = 2 * C1; d.conv_wrap2 = 2 * C2;
+    d.zero_page = zero;
+    d.algo_flops = 2.0 * M * (double)N * (KH * KW * (C1 + C2));      // the fp32 convolution this launch stands for (executed: 3 x)
+    return d;
+}
+
+int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
+    VTGB_REQUIRE(a->n_pairs > 0 && a->H8 >= 8 && a->W8 >= 8 && a->iters > 0, VTGB_EINVAL, "raft_update: bad dims n=%d H8=%d W8=%d iters=%d", a->n_pairs, a->H8,
+                 a->W8, a->iters);
+    const int H8 = a->H8, W8 = a->W8, HW = H8 * W8;
+    const int64_t M = (int64_t)a->n_pairs * HW;
+    VTGB_REQUIRE(M < (1ll << 28), VTGB_EUNSUPPORTED, "raft_update: too many pixels (the flow field is addressed through one 32-bit buffer range)");
+    // pair buffers (bf16 elements per pixel = 2 x channels)
+    bf16_t* hb = (bf16_t*)ws.take(M * 256 * 2);        // h
+    bf16_t* X = (bf16_t*)ws.take(M * 512 * 2);         // [inp(128) | motion(126) | flow(2)]
+    bf16_t* corrf = (bf16_t*)ws.take(M * 768 * 2);     // 324 taps, zero-padded to 384
+    bf16_t* c1 = (bf16_t*)ws.take(M * 512 * 2);
+    bf16_t* CF = (bf16_t*)ws.take(M * 512 * 2);        // [cor(192) | flo(64)]
+    bf16_t* f1 = (bf16_t*)ws.take(M * 256 * 2);
+    bf16_t* RH = (bf16_t*)ws.take(M * 256 * 2);
+    bf16_t* FH = (bf16_t*)ws.take(M * 512 * 2);
+    float* ZR = (float*)ws.take(M * 256 * 4);          // z | r pre-activations, then z
+    float* Q = (float*)ws.take(M * 128 * 4);           // q pre-activation; also convf2's fp32 output [M, 64]
+    float* flow = (float*)ws.take(M * 2 * 4);
+    float* mask = (float*)ws.take(M * 576 * 4);
+    float* P2 = mask;   // [M, 32] per-tap partial products of FlowHead.conv2 (the mask buffer is idle until the last iteration)
+    void* zero = ws.take(256);
+    if (ws.dry) return VTGB_OK;
+    VTGB_REQUIRE(ws.ok(), VTGB_EWORKSPACE, "raft_update: workspace %zu < %zu bytes", ws.size, ws.used);
+    VTGB_REQUIRE(((a->net && a->inp) || a->cnet_nhwc) && a->weights && a->flow_up, VTGB_EINVAL, "raft_update: NULL operand");
+    VTGB_REQUIRE(!a->corr_f16, VTGB_EINVAL, "raft_update: the bf16x3 mode takes an fp32 correlation pyramid");
+    const void* const* w = a->weights;
+    for (int i = 0; i < 26; i++) VTGB_REQUIRE(w[i], VTGB_EINVAL, "raft_update: weights[%d] is NULL", i);
+    CorrPyr pyr;
+    int hl = H8, wl = W8;
+    for (int l = 0; l < 4; l++) {
+        VTGB_REQUIRE(a->corr[l] && hl >= 1 && wl >= 1, VTGB_EINVAL, "raft_update: correlation level %d missing", l);
+        pyr.lvl[l] = a->corr[l]; pyr.h[l] = hl; pyr.w[l] = wl;
+        hl /= 2; wl /= 2;
+    }
+    VTGB_HIP(hipMemsetAsync(zero, 0, 256, s));
+    const int Mi = (int)M;
+    const dim3 g32((unsigned)((M * 32 + 255) / 256));
+    auto F = [](const void* p) { return (const float*)p; };
+    hipLaunchKernelGGL(x3_init_kernel, g32, dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, hb, X, flow, a->flow_init, M, HW);
+    for (int it = 0; it < a->iters; it++) {
+        // ---- BasicMotionEncoder (update.py:88-97)
+        VTGB_TRY(raft_launch_lookup_pair(pyr, flow, corrf, M, H8, W8, s));
+        VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 256, H8, W8, 1, 1, corrf, 384, nullptr, 0, w[0], F(w[1]), VTGB_EPI_SPLIT, 1, c1, 512, 256, zero), s));
+        VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 192, H8, W8, 3, 3, c1, 256, nullptr, 0, w[2], F(w[3]), VTGB_EPI_SPLIT, 1, CF, 512, 256, zero), s));
+        hipLaunchKernelGGL(x3_convf1_kernel, dim3((unsigned)((M + 1) / 2)), dim3(256), 0, s, flow, F(w[4]), F(w[5]), f1, X, M, H8, W8);
+        VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 64, H8, W8, 3, 3, f1, 128, nullptr, 0, w[6], F(w[7]), VTGB_EPI_STORE_F32, 0, Q, 64, 0, zero), s));
+        VTGB_TRY(launch_x3_pair_pass(Q, 64, nullptr, HW, nullptr, 0, 0, CF + 192, 512, 256, 64, 64, 1, 0, M, s));
+        VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 126, H8, W8, 3, 3, CF, 256, nullptr, 0, w[8], F(w[9]), VTGB_EPI_SPLIT, 1, X + 128, 512, 256, zero), s));
+        // ---- SepConvGRU (update.py:50-65): horizontal (1x5) then vertical (5x1); input channels [h(128) | inp(128) | motion(126) | flow(2)]
+        for (int half = 0; half < 2; half++) {
+            const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1, wi = 10 + 4 * half;
+            VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 256, H8, W8, kh, kw, hb, 128, X, 256, w[wi], F(w[wi + 1]), VTGB_EPI_STORE_F32, 0, ZR, 256, 0, zero), s));
+            hipLaunchKernelGGL(x3_gru_gate_kernel, g32, dim3(256), 0, s, ZR, hb, RH, M);
+            VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 128, H8, W8, kh, kw, RH, 128, X, 256, w[wi + 2], F(w[wi + 3]), VTGB_EPI_STORE_F32, 0, Q, 128, 0, zero), s));
+            hipLaunchKernelGGL(x3_gru_update_kernel, g32, dim3(256), 0, s, ZR, Q, hb, M);
+        }
+        // ---- FlowHead (update.py:10-18) and coords1 += delta_flow (xraft.py:145)
+        VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 256, H8, W8, 3, 3, hb, 128, nullptr, 0, w[18], F(w[19]), VTGB_EPI_SPLIT, 1, FH, 512, 256, zero), s));
+        VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 32, H8, W8, 1, 1, FH, 256, nullptr, 0, w[20], nullptr, VTGB_EPI_STORE_F32, 0, P2, 32, 0, zero), s));
+        VTGB_TRY(raft_launch_flow_head2(P2, F(w[21]), flow, a->n_pairs, H8, W8, s));
+    }
+    // ---- mask head of the last iteration (update.py:129-132,143; the 0.25 is folded into [24] / [25]) and convex upsample (xraft.py:88-99)
+    VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 256, H8, W8, 3, 3, hb, 128, nullptr, 0, w[22], F(w[23]), VTGB_EPI_SPLIT, 1, FH, 512, 256, zero), s));
+    VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 576, H8, W8, 1, 1, FH, 256, nullptr, 0, w[24], F(w[25]), VTGB_EPI_STORE_F32, 0, mask, 576, 0, zero), s));
+    VTGB_TRY(raft_launch_upsample(flow, mask, a->flow_up, a->n_pairs, H8, W8, s));
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}

@@ -271,7 +271,7 @@ class Raft(nn.Module):
         tree = ParamTree(synth.raft_shapes(""), "")
         for name, child in list(tree._modules.items()):
             self.add_module(name, child)
-        self.code = ops.dtype_code(compute_dtype)
+        self.code = ops.raft_dtype_code(compute_dtype)
         self._table = None
 
     def _apply(self, fn, *a, **k):
@@ -285,7 +285,7 @@ class Raft(nn.Module):
         return super().load_state_dict(state_dict, *a, **k)
 
     def set_compute_dtype(self, compute_dtype):
-        self.code = ops.dtype_code(compute_dtype)
+        self.code = ops.raft_dtype_code(compute_dtype)
         self._table = None
         return self
 

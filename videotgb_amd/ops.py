@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib as L
-from ._lib import BF16, F32
+from ._lib import BF16, BF16X3, F32
 
 Tensor = torch.Tensor
 
@@ -37,6 +37,14 @@ def dtype_code(dtype) -> int:
     if dtype in (F32, "f32", "fp32", torch.float32):
         return F32
     raise ValueError(f"unsupported compute dtype {dtype!r}")
+
+
+def raft_dtype_code(dtype) -> int:
+    """RAFT's modes: "bf16" (bf16 MFMA, a reduced-precision mode the reference does not have), "bf16x3" (split-bf16 operands: fp32
+    accuracy on the bf16 matrix cores) and "f32" (fp32 FMAs in the reference's order, the exactness mode)."""
+    if dtype in (BF16X3, "bf16x3", "x3"):
+        return BF16X3
+    return dtype_code(dtype)
 
 
 def act_dtype(code: int) -> torch.dtype:
@@ -69,6 +77,8 @@ def pack_weight(w: Tensor, code: int, cols_pad: Optional[int] = None) -> Tensor:
     w2 = w.reshape(w.shape[0], -1).contiguous().float()
     if code == F32:
         return w2
+    if code == BF16X3:
+        raise ValueError("pack_weight: bf16x3 weights are expanded per convolution (split3_k)")
     rows, cols = w2.shape
     if cols_pad is None and cols % 8:
         raise NotImplementedError(f"bf16 GEMM weights need in_features % 8 == 0 (got {cols})")
@@ -243,6 +253,8 @@ class _WeightTable:
     def add(self, t: Optional[Tensor], gemm_weight: bool = False, cols_pad: Optional[int] = None, force_f32: bool = False):
         if t is None:
             self.tensors.append(None)
+        elif gemm_weight and not force_f32 and self.code == BF16X3:
+            self.tensors.append(_bf16_exact(t.reshape(t.shape[0], -1).float()))      # (already split3: bf16 values)
         elif gemm_weight and not force_f32:
             self.tensors.append(pack_weight(t, self.code, cols_pad))
         else:
@@ -487,12 +499,39 @@ def conv_k_order(w: Tensor) -> Tensor:
     return w.reshape(co, kh * kw, ci // 64, 64).permute(0, 2, 1, 3).reshape(co, -1).contiguous()
 
 
+def _bf16_parts(w: Tensor) -> Tuple[Tensor, Tensor]:
+    """w fp32 -> (hi, lo) as fp32 tensors holding bf16 values: hi = bf16(w), lo = bf16(w - hi)."""
+    hi = w.to(torch.bfloat16).float()
+    return hi, (w - hi).to(torch.bfloat16).float()
+
+
+def split3(w: Tensor, sources: Optional[Sequence[int]] = None) -> Tensor:
+    """[co, kh, kw, ci] fp32 -> [co, kh, kw, 3 ci] for the bf16x3 contraction: per source of the (virtual) channel concatenation the
+    channel blocks [Wh | Wh | Wl], which meet the activation pair read as [hi | lo | hi] (GemmDesc::conv_wrap)."""
+    ci = w.shape[-1]
+    out, c0 = [], 0
+    for c in (sources or [ci]):
+        hi, lo = _bf16_parts(w[..., c0:c0 + c])
+        out += [hi, hi, lo]
+        c0 += c
+    assert c0 == ci
+    return torch.cat(out, -1)
+
+
+def _bf16_exact(w: Tensor) -> Tensor:
+    """fp32 holding bf16 values -> bf16 (exact)."""
+    return w.contiguous().to(torch.bfloat16)
+
+
 class RaftWeights(_WeightTable):
     """of_extractor.update_block.* -> the packed table of vtgb_raft_update ([C_out, KH, KW, C_in] in the compute dtype)."""
 
     def __init__(self, sd: Dict[str, Tensor], prefix: str = "update_block.", code: int = BF16, hoist_inp: Optional[bool] = None):
         super().__init__(code)
         p = prefix
+        if code == BF16X3:
+            self._init_x3(sd, p)
+            return
         # bf16 mode: split the loop-invariant `inp` channels (128..255) out of the GRU convolutions (include/vtgb.h [26..29])
         self.hoist_inp = (code == BF16) if hoist_inp is None else (hoist_inp and code == BF16)
 
@@ -546,6 +585,49 @@ class RaftWeights(_WeightTable):
         self.finish()
 
 
+def _raft_x3_table(self: RaftWeights, sd: Dict[str, Tensor], p: str) -> None:
+    """The bf16x3 table (raft_x3.hip): every MFMA convolution as [C_out, taps, 3 C_in] in the kernels' K order with the channel blocks
+    [Wh | Wh | Wl] per source; convf1 as in the fp32 mode; the mask head's 0.25 (update.py:143) folded into mask.2 (a power of two: exact)."""
+    self.hoist_inp = False
+
+    def conv(name, cin_pad=None, sources=None, scale=1.0):
+        w = sd[p + name + ".weight"].float() * scale
+        co, ci, kh, kw = w.shape
+        w = w.permute(0, 2, 3, 1)
+        if cin_pad and cin_pad != ci:
+            w = torch.nn.functional.pad(w, (0, cin_pad - ci))
+        return _bf16_exact(conv_k_order(split3(w, sources)))
+
+    def add_conv(name, cin_pad=None, scale=1.0):
+        self.tensors.append(conv(name, cin_pad, scale=scale))
+        self.add(sd[p + name + ".bias"].float() * scale)
+
+    add_conv("encoder.convc1", 384)
+    add_conv("encoder.convc2")
+    self.add(sd[p + "encoder.convf1.weight"].float().reshape(128, 98).t().contiguous())
+    self.add(sd[p + "encoder.convf1.bias"])
+    add_conv("encoder.convf2")
+    add_conv("encoder.conv")
+    for sfx in ("1", "2"):
+        self.tensors.append(torch.cat([conv("gru.convz" + sfx, sources=[128, 256]), conv("gru.convr" + sfx, sources=[128, 256])], 0).contiguous())
+        self.add(torch.cat([sd[p + "gru.convz" + sfx + ".bias"], sd[p + "gru.convr" + sfx + ".bias"]], 0))
+        self.tensors.append(conv("gru.convq" + sfx, sources=[128, 256]))
+        self.add(sd[p + "gru.convq" + sfx + ".bias"])
+    add_conv("flow_head.conv1")
+    w2 = sd[p + "flow_head.conv2.weight"].float().permute(2, 3, 0, 1).reshape(18, 256)
+    w2 = torch.nn.functional.pad(w2, (0, 0, 0, 14)).reshape(32, 1, 1, 256)
+    self.tensors.append(_bf16_exact(conv_k_order(split3(w2))))
+    self.add(sd[p + "flow_head.conv2.bias"])
+    add_conv("mask.0")
+    add_conv("mask.2", scale=0.25)
+    for _ in range(4):
+        self.add(None)
+    self.finish()
+
+
+RaftWeights._init_x3 = _raft_x3_table
+
+
 def raft_update(w: RaftWeights, net: Optional[Tensor], inp: Optional[Tensor], pyramid: Sequence[Tensor], iters: int = 20,
                 cnet_nhwc: Optional[Tensor] = None, hw: Optional[Tuple[int, int]] = None, flow_init: Optional[Tensor] = None) -> Tensor:
     """net/inp [n, 128, H8, W8] fp32 (tanh / relu applied) -- or ``cnet_nhwc`` [n, H8*W8, 256], the context encoder's
@@ -585,6 +667,8 @@ def raft_corr(fmap: Tensor, n_pairs: int, H8: int, W8: int, pairs_per_clip: int,
     _need_cuda(fmap)
     fmap = fmap.contiguous().float()
     n_images = fmap.numel() // (H8 * W8 * 256)
+    if code == BF16X3:
+        code = F32                       # the bf16x3 mode keeps the fp32 pyramid (include/vtgb.h)
     odt = torch.float16 if code == BF16 else torch.float32
     lv, h, w = [], H8, W8
     for _ in range(4):
@@ -629,12 +713,14 @@ class RaftEncoderWeights(_WeightTable):
                 b = (b - sd[p + bn + ".running_mean"].float()) * g + sd[p + bn + ".bias"].float()
             return w, b
 
+        x3 = code == BF16X3
+
         def packed(w, cin_pad, cout_pad=None):
             co, ci, kh, kw = w.shape
             w = w.permute(0, 2, 3, 1)
             if cin_pad != ci:
                 w = torch.nn.functional.pad(w, (0, cin_pad - ci))
-            w = conv_k_order(w)
+            w = conv_k_order(split3(w) if x3 else w)
             if batch_norm and cout_pad and cout_pad != co:        # cnet stores activations straight from the GEMM: padded channels = 0
                 w = torch.nn.functional.pad(w, (0, 0, 0, cout_pad - co))
             return w
@@ -646,7 +732,7 @@ class RaftEncoderWeights(_WeightTable):
         # ky = 2 tY + py - 1, kx = 2 dX + px - 1.  fp32 mode: the kernel packs 2*(x/255)-1 itself, weights as they are.
         # bf16 mode: the kernel packs x - 127.5 as a bf16 pair (hi | lo channel chunks), so w' = w * 2/255 in BOTH chunks, b' = b
         w, b = folded("conv1", "norm1")
-        if code == BF16:
+        if code != F32:
             w = w * (2.0 / 255.0)
         wp = torch.zeros(64, 4, 4, 2, 2, 3, dtype=torch.float32, device=w.device)
         for tY in range(4):
@@ -662,6 +748,8 @@ class RaftEncoderWeights(_WeightTable):
         wp = torch.nn.functional.pad(wp.reshape(64, 4, 48), (0, 16))                    # [co, tY, 64]
         if code == BF16:
             wp = torch.stack([wp, wp], 1)                                               # K order: 64-channel chunk major, tap minor
+        if x3:                                                                          # [co, tY, 1, 64] -> blocks [Wh | Wh | Wl], K order
+            wp = conv_k_order(split3(wp.reshape(64, 4, 1, 64)))
         self.add(wp.reshape(64, -1).contiguous(), True); self.add(b)
         cin_pad = 64
         for li, c, cpad in (("layer1", 64, 64), ("layer2", 96, 128), ("layer3", 128, 128)):
@@ -677,7 +765,8 @@ class RaftEncoderWeights(_WeightTable):
                 else:
                     self.add(None); self.add(None)
                 cin_pad = cpad
-        self.add(sd[p + "conv2.weight"].float().reshape(256, 128).contiguous(), True)
+        wh = sd[p + "conv2.weight"].float().reshape(256, 128)
+        self.add(conv_k_order(split3(wh.reshape(256, 1, 1, 128))) if x3 else wh.contiguous(), True)
         self.add(sd[p + "conv2.bias"])
         self.finish()
 
@@ -688,7 +777,7 @@ def raft_encoder(w: RaftEncoderWeights, images: Tensor, max_images: int = 384) -
     images = images.contiguous().float()
     n, _, H, W = images.shape
     out = torch.empty(n, (H // 8) * (W // 8), 256, dtype=torch.float32, device=images.device)
-    if w.code == F32:
+    if w.code != BF16:
         max_images = max(max_images // 2, 1)
     for i0 in range(0, n, max_images):
         chunk = images[i0:i0 + max_images]
