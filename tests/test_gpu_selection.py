@@ -35,15 +35,18 @@ def parts(dev):
     for k in list(sd):
         if ".downsample.1." in k:
             sd[k] = sd[k.replace(".downsample.1.", ".norm3.")]
-    tgb = models.TemporalEncoder(cfg.tgb, "bf16")
-    tgb.load_state_dict({k[len("temporal_encoder."):]: v for k, v in sd.items() if k.startswith("temporal_encoder.")}, strict=True)
+    tgbs = {}
+    for dt in ("bf16", "f32"):       # bf16: what bench.py runs; f32: isolates the flow's contribution to the logit difference (see below)
+        tgbs[dt] = models.TemporalEncoder(cfg.tgb, dt)
+        tgbs[dt].load_state_dict({k[len("temporal_encoder."):]: v for k, v in sd.items() if k.startswith("temporal_encoder.")}, strict=True)
+        tgbs[dt].to(dev)
     rafts = {}
     for wset, rsd in (("default", sd), ("sensitive", synth.raft_sensitive_state_dict(0))):
-        for dt in ("bf16", "f32"):
+        for dt in ("bf16", "bf16x3", "f32"):
             r = models.Raft(dt)
             r.load_state_dict({k[len("of_extractor."):]: v for k, v in rsd.items() if k.startswith("of_extractor.")}, strict=True)
             rafts[wset, dt] = r.to(dev)
-    return cfg, tgb.to(dev), rafts
+    return cfg, tgbs, rafts
 
 
 def make_clips(kind, n, T, gen, dev):
@@ -67,11 +70,13 @@ def make_clips(kind, n, T, gen, dev):
 @pytest.mark.parametrize("T,per_call", [(96, 8), (256, 4)])
 def test_cand_index_stable_under_bf16_raft(dev, parts, T, per_call, weights):
     from videotgb_amd import ops
-    cfg, tgb, rafts = parts
+    cfg, tgbs, rafts = parts
     gen = torch.Generator(device=dev).manual_seed(1000 + T)
     n_clips, N, nframe = 64, 32, 8
-    moved, differ, total_ep = 0, 0, 0
-    flow_rms, logit_err, logit_scale = 0.0, 0.0, 0.0
+    modes = ("bf16", "bf16x3")
+    keys = [(m, t) for m in modes for t in ("bf16", "f32")]
+    moved, differ, total_ep = {k: 0 for k in keys}, {k: 0 for k in keys}, 0
+    flow_rms, logit_err, logit_scale = {m: 0.0 for m in modes}, {k: 0.0 for k in keys}, {"bf16": 0.0, "f32": 0.0}
     for c0 in range(0, n_clips, per_call):
         kind = "randn" if (c0 // per_call) % 2 == 0 else "moving"
         frames = make_clips(kind, per_call, T, gen, dev)
@@ -79,26 +84,42 @@ def test_cand_index_stable_under_bf16_raft(dev, parts, T, per_call, weights):
                           torch.full((per_call, 1), 102, device=dev)], 1)
         noise = -torch.empty(2, 2 * per_call, T, device=dev).exponential_(generator=gen).log()
         res = {}
-        for dt in ("bf16", "f32"):
+        for dt in modes + ("f32",):
             fl = rafts[weights, dt].forward_clips(frames)
             of = torch.cat([fl, fl[:, -1:]], dim=1)                         # last flow repeated (eval/utils/model.py:81-82)
-            _, logits = tgb(encoder_embeds=of, attention_mask=torch.ones(per_call, T + 2, dtype=torch.long, device=dev),
-                            encoder_hidden_states=sids, encoder_attention_mask=torch.ones_like(sids), mode="multi_modal")
-            sel = ops.span_select(logits, noise, 0.5)
-            idx = ops.span_to_frames(sel, T, N, nframe, "A")
-            res[dt] = (of, logits, sel, idx)
+            res[dt] = {"of": of}
+            for tdt, tgb in tgbs.items():
+                _, logits = tgb(encoder_embeds=of, attention_mask=torch.ones(per_call, T + 2, dtype=torch.long, device=dev),
+                                encoder_hidden_states=sids, encoder_attention_mask=torch.ones_like(sids), mode="multi_modal")
+                sel = ops.span_select(logits, noise, 0.5)
+                res[dt][tdt] = (logits, sel, ops.span_to_frames(sel, T, N, nframe, "A"))
             del fl
-        a, b = res["bf16"], res["f32"]
-        flow_rms = max(flow_rms, float(((a[0] - b[0]).double().pow(2).mean().sqrt() / b[0].double().pow(2).mean().sqrt()).item()))
-        logit_err = max(logit_err, float((a[1] - b[1]).abs().max().item()))
-        logit_scale = max(logit_scale, float((b[1].max() - b[1].min()).item()))
-        moved += int((a[2] != b[2]).sum().item())
-        total_ep += a[2].numel()
-        differ += int((a[3] != b[3]).any(dim=1).sum().item())
+        b = res["f32"]
+        total_ep += b["f32"][1].numel()
+        for tdt in tgbs:
+            logit_scale[tdt] = max(logit_scale[tdt], float((b[tdt][0].max() - b[tdt][0].min()).item()))
+        for m in modes:
+            a = res[m]
+            flow_rms[m] = max(flow_rms[m], float(((a["of"] - b["of"]).double().pow(2).mean().sqrt() / b["of"].double().pow(2).mean().sqrt()).item()))
+            for tdt in tgbs:
+                logit_err[m, tdt] = max(logit_err[m, tdt], float((a[tdt][0] - b[tdt][0]).abs().max().item()))
+                moved[m, tdt] += int((a[tdt][1] != b[tdt][1]).sum().item())
+                differ[m, tdt] += int((a[tdt][2] != b[tdt][2]).any(dim=1).sum().item())
         del res, a, b, frames
-    print(f"[selection T={T} raft weights={weights}] {n_clips} clips: flow rel-RMS (bf16 vs fp32 RAFT) <= {flow_rms:.3e}; TGB logits max|diff| {logit_err:.3e} of range "
-          f"{logit_scale:.3e}; span endpoints moved {moved}/{total_ep}; clips with a different cand_index {differ}/{n_clips}")
-    # logits: default weights 2e-2 of their range (observed 9e-3); sensitive weights 1e-1 (observed 4.5e-2 ... 5.3e-2: the bf16 flow is
-    # 1.45e-2 off there and the flow reaches the logits) -- the assertion that matters is the selection itself
-    assert logit_err <= (2e-2 if weights == "default" else 1e-1) * logit_scale
-    assert differ <= 2
+    for m, tdt in keys:
+        print(f"[selection T={T} raft weights={weights} RAFT {m} vs fp32, TGB {tdt}] {n_clips} clips: flow rel-RMS <= {flow_rms[m]:.3e}; TGB logits max|diff| "
+              f"{logit_err[m, tdt]:.3e} = {logit_err[m, tdt] / logit_scale[tdt]:.2e} of their range {logit_scale[tdt]:.3e}; span endpoints moved "
+              f"{moved[m, tdt]}/{total_ep}; clips with a different cand_index {differ[m, tdt]}/{n_clips}")
+    # bf16 RAFT (a mode the reference does not have), TGB as bench.py runs it.  logits: default weights 2e-2 of their range (observed 9e-3);
+    # sensitive weights 1e-1 (observed 4.5e-2 ... 5.3e-2: the bf16 flow is 1.45e-2 off there and the flow reaches the logits); at most 2 of
+    # 64 clips may differ
+    assert logit_err["bf16", "bf16"] <= (2e-2 if weights == "default" else 1e-1) * logit_scale["bf16"]
+    assert differ["bf16", "bf16"] <= 2
+    # bf16x3 RAFT (split-bf16 operands: the reference's fp32 accuracy on the matrix cores): the SAME frames for every clip with either TGB,
+    # and the north star's 1e-3 on the logit tensor.  The 1e-3 is asserted through the fp32 TGB: the bf16 TGB rounds the flow to bf16 on
+    # entry, so ANY perturbation of the flow -- here 1e-5 relative -- flips a few of those roundings and re-draws the TGB's own bf16 noise
+    # (6e-3 ... 8e-3 of the logit range, the same size as the reference's bf16-vs-fp32 TGB difference): that number says
+    # nothing about RAFT and is printed, not asserted.
+    assert logit_err["bf16x3", "f32"] <= 1e-3 * logit_scale["f32"]
+    for tdt in tgbs:
+        assert differ["bf16x3", tdt] == 0 and moved["bf16x3", tdt] == 0, tdt

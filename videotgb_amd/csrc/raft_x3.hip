@@ -92,10 +92,10 @@ int launch_x3_pair_pass(const float* x, int64_t ldx, const float* stats, int HW,
     return VTGB_OK;
 }
 
-// ---- state init (xraft.py:126-132): h = tanh(cnet[:, :128]) -> hb pair [M, 256]; inp = relu(cnet[:, 128:]) -> X pair [M, 512] columns
-// [0, 128) | 256 + [0, 128); flow = flow_init or 0 -> flow fp32 and X columns 254, 255 (| + 256).  4 channels per thread.
+// ---- state init (xraft.py:126-132): h = tanh(cnet[:, :128]) -> hb pair [M, 256]; inp = relu(cnet[:, 128:]) -> INP pair [M, 256];
+// flow = flow_init or 0 -> flow fp32 and columns 126, 127 (| + 128) of the motion buffer X [M, 256].  4 channels per thread.
 __global__ __launch_bounds__(256) void x3_init_kernel(const float* __restrict__ net, const float* __restrict__ inp, const float* __restrict__ cnet,
-                                                      bf16_t* __restrict__ hb, bf16_t* __restrict__ X, float* __restrict__ flow,
+                                                      bf16_t* __restrict__ hb, bf16_t* __restrict__ INP, bf16_t* __restrict__ X, float* __restrict__ flow,
                                                       const float* __restrict__ flow_init, int64_t M, int HW) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M * 32) return;
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256) void x3_init_kernel(const float* __restrict__ 
     *reinterpret_cast<bf16x4*>(hb + m * 256 + c) = hi;
     *reinterpret_cast<bf16x4*>(hb + m * 256 + 128 + c) = lo;
     pair_split4(iv, hi, lo);
-    *reinterpret_cast<bf16x4*>(X + m * 512 + c) = hi;
-    *reinterpret_cast<bf16x4*>(X + m * 512 + 256 + c) = lo;
+    *reinterpret_cast<bf16x4*>(INP + m * 256 + c) = hi;
+    *reinterpret_cast<bf16x4*>(INP + m * 256 + 128 + c) = lo;
     if (c == 0) {
         float f0 = 0.f, f1 = 0.f;
         if (flow_init) {
@@ -129,53 +129,91 @@ __global__ __launch_bounds__(256) void x3_init_kernel(const float* __restrict__ 
         flow[m * 2] = f0;
         flow[m * 2 + 1] = f1;
         const float h0 = bf16_round(f0), h1 = bf16_round(f1);
-        X[m * 512 + 254] = (bf16_t)h0; X[m * 512 + 255] = (bf16_t)h1;
-        X[m * 512 + 510] = (bf16_t)(f0 - h0); X[m * 512 + 511] = (bf16_t)(f1 - h1);
+        X[m * 256 + 126] = (bf16_t)h0; X[m * 256 + 127] = (bf16_t)h1;
+        X[m * 256 + 254] = (bf16_t)(f0 - h0); X[m * 256 + 255] = (bf16_t)(f1 - h1);
     }
 }
 
-// ---- convf1 (update.py:81,92: 7x7, 2 -> 128, ReLU) as fp32 FMAs over the 98 taps in order (weights [98][128], k = c * 49 + ky * 7 + kx),
-// pair out; the flow itself goes to X columns 254, 255 (update.py:97).  Two pixels per workgroup, one thread per output channel.
+// ---- convf1 (update.py:81,92: 7x7, 2 -> 128, ReLU) as fp32 FMAs (weights [98][128], k = c * 49 + ky * 7 + kx), pair out; the flow
+// itself goes to columns 126, 127 of the motion buffer X (update.py:97).  A workgroup takes 64 consecutive pixels: their 98-tap windows
+// are staged tap-major in LDS (zero padded), thread (channel co, half) keeps its channel's 98 weights in registers and walks 32 pixels
+// four at a time -- one broadcast 16-byte LDS read and two packed FMAs per tap.  (The first form -- two pixels per workgroup, every
+// weight re-read from L2 per pixel -- took 3.8 ms per iteration of 40.)
+constexpr int CF1_PX = 64;
+typedef float x3_f32x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void x3_convf1_kernel(const float* __restrict__ flow, const float* __restrict__ wt, const float* __restrict__ b,
                                                         bf16_t* __restrict__ f1, bf16_t* __restrict__ X, int64_t M, int H8, int W8) {
-    __shared__ float win[2][100];
+    __shared__ __attribute__((aligned(16))) float win[98][CF1_PX];
     const int tid = threadIdx.x, HW = H8 * W8;
-    if (tid < 196) {
-        const int px = tid / 98, k = tid - px * 98, c = k / 49, t = k - c * 49, ky = t / 7, kx = t - ky * 7;
-        const int64_t m = (int64_t)blockIdx.x * 2 + px;
-        float v = 0.f;
-        if (m < M) {
-            const int pix = (int)(m % HW), y = pix / W8 + ky - 3, x = pix % W8 + kx - 3;
-            if ((unsigned)y < (unsigned)H8 && (unsigned)x < (unsigned)W8) v = flow[(m + (ky - 3) * W8 + (kx - 3)) * 2 + c];
+    const int64_t m0 = (int64_t)blockIdx.x * CF1_PX;
+    {
+        // thread -> (pixel, 25 taps): pixel = tid & 63 (consecutive lanes = consecutive pixels: coalesced-ish 8-byte gathers)
+        const int px = tid & 63, part = tid >> 6;
+        const int64_t m = m0 + px;
+        const bool live = m < M;
+        const int pix = live ? (int)(m % HW) : 0, y0 = pix / W8, x0 = pix - y0 * W8;
+        for (int t = part; t < 49; t += 4) {
+            const int ky = t / 7, kx = t - ky * 7, y = y0 + ky - 3, x = x0 + kx - 3;
+            float2 v = make_float2(0.f, 0.f);
+            if (live && (unsigned)y < (unsigned)H8 && (unsigned)x < (unsigned)W8) v = *reinterpret_cast<const float2*>(flow + (m + (ky - 3) * W8 + (kx - 3)) * 2);
+            win[t][px] = v.x;
+            win[49 + t][px] = v.y;
         }
-        win[px][k] = v;
     }
+    const int co = tid & 127, half = tid >> 7;
+    // the channel's weights as 49 register PAIRS (taps 2j, 2j + 1): the packed FMA takes the pixel pair from one source and BROADCASTS one
+    // half of the weight pair through op_sel (written as inline asm: left to the compiler, {w, w} was materialised per tap -- 470
+    // registers, one wave per SIMD, 4.0 ms per launch)
+    x3_f32x2 w2[49];
+#pragma unroll
+    for (int j = 0; j < 49; j++) w2[j] = x3_f32x2{wt[(2 * j) * 128 + co], wt[(2 * j + 1) * 128 + co]};
+    const float bias = b[co];
     __syncthreads();
-    const int px = tid >> 7, co = tid & 127;
-    const int64_t m = (int64_t)blockIdx.x * 2 + px;
-    if (m >= M) return;
-    float acc = b[co];
-    for (int k = 0; k < 98; k++) acc = fmaf(win[px][k], wt[k * 128 + co], acc);
-    acc = fmaxf(acc, 0.f);
-    const float hf = bf16_round(acc);
-    f1[m * 256 + co] = (bf16_t)hf;
-    f1[m * 256 + 128 + co] = (bf16_t)(acc - hf);
-    if (co < 2) {
-        const float f = flow[m * 2 + co], fh = bf16_round(f);
-        X[m * 512 + 254 + co] = (bf16_t)fh;
-        X[m * 512 + 510 + co] = (bf16_t)(f - fh);
+    for (int g = 0; g < 8; g++) {
+        const int p0 = half * 32 + g * 4;
+        if (m0 + p0 >= M) break;
+        x3_f32x2 a01 = {bias, bias}, a23 = {bias, bias};
+#pragma unroll
+        for (int j = 0; j < 49; j++) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(&win[2 * j][p0]), vb = *reinterpret_cast<const f32x4*>(&win[2 * j + 1][p0]);
+            const x3_f32x2 va01 = {va[0], va[1]}, va23 = {va[2], va[3]}, vb01 = {vb[0], vb[1]}, vb23 = {vb[2], vb[3]};
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a01) : "v"(va01), "v"(w2[j]));
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a23) : "v"(va23), "v"(w2[j]));
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a01) : "v"(vb01), "v"(w2[j]));
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a23) : "v"(vb23), "v"(w2[j]));
+        }
+        const float r[4] = {a01[0], a01[1], a23[0], a23[1]};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int64_t m = m0 + p0 + e;
+            if (m < M) {
+                const float v = fmaxf(r[e], 0.f), hf = bf16_round(v);
+                f1[m * 256 + co] = (bf16_t)hf;
+                f1[m * 256 + 128 + co] = (bf16_t)(v - hf);
+            }
+        }
+    }
+    if (tid < 2 * CF1_PX) {
+        const int64_t m = m0 + (tid >> 1);
+        if (m < M) {
+            const float f = flow[m * 2 + (tid & 1)], fh = bf16_round(f);
+            X[m * 256 + 126 + (tid & 1)] = (bf16_t)fh;
+            X[m * 256 + 254 + (tid & 1)] = (bf16_t)(f - fh);
+        }
     }
 }
 
-// ---- SepConvGRU gates (update.py:52-55,59-62): zr fp32 [M, 256] = convz | convr pre-activations (bias included);
-// z = sigmoid(zr[:, :128]) stays fp32 in place, r * h -> RH pair [M, 256]
-__global__ __launch_bounds__(256) void x3_gru_gate_kernel(float* __restrict__ zr, const bf16_t* __restrict__ hb, bf16_t* __restrict__ RH, int64_t M) {
+// ---- SepConvGRU gates (update.py:52-55,59-62): zr fp32 [M, 256] = the convz | convr sums over the [h | motion | flow] channels, zri the
+// loop-invariant `inp` third + bias (computed once per call); z = sigmoid(zr[:, :128] + zri[:, :128]) stays fp32 in place,
+// r * h -> RH pair [M, 256]
+__global__ __launch_bounds__(256) void x3_gru_gate_kernel(float* __restrict__ zr, const float* __restrict__ zri, const bf16_t* __restrict__ hb,
+                                                          bf16_t* __restrict__ RH, int64_t M) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M * 32) return;
     const int64_t m = i >> 5;
     const int c = (int)(i & 31) * 4;
-    f32x4 z = *reinterpret_cast<const f32x4*>(zr + m * 256 + c);
-    const f32x4 r = *reinterpret_cast<const f32x4*>(zr + m * 256 + 128 + c);
+    f32x4 z = *reinterpret_cast<const f32x4*>(zr + m * 256 + c) + *reinterpret_cast<const f32x4*>(zri + m * 256 + c);
+    const f32x4 r = *reinterpret_cast<const f32x4*>(zr + m * 256 + 128 + c) + *reinterpret_cast<const f32x4*>(zri + m * 256 + 128 + c);
     const f32x4 h = pair_join4(*reinterpret_cast<const bf16x4*>(hb + m * 256 + c), *reinterpret_cast<const bf16x4*>(hb + m * 256 + 128 + c));
     f32x4 rh;
 #pragma unroll
@@ -186,13 +224,16 @@ __global__ __launch_bounds__(256) void x3_gru_gate_kernel(float* __restrict__ zr
     *reinterpret_cast<bf16x4*>(RH + m * 256 + c) = hi;
     *reinterpret_cast<bf16x4*>(RH + m * 256 + 128 + c) = lo;
 }
-// h' = (1 - z) h + z tanh(q) (update.py:56-57,63-64): q fp32 [M, 128] pre-activation, z fp32 in zr[:, :128]; hb pair in place
-__global__ __launch_bounds__(256) void x3_gru_update_kernel(const float* __restrict__ zr, const float* __restrict__ q, bf16_t* __restrict__ hb, int64_t M) {
+// h' = (1 - z) h + z tanh(q + qi) (update.py:56-57,63-64): q fp32 [M, 128] the convq sum over [r h | motion | flow], qi its `inp` third + bias,
+// z fp32 in zr[:, :128]; hb pair in place
+__global__ __launch_bounds__(256) void x3_gru_update_kernel(const float* __restrict__ zr, const float* __restrict__ q, const float* __restrict__ qi,
+                                                            bf16_t* __restrict__ hb, int64_t M) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M * 32) return;
     const int64_t m = i >> 5;
     const int c = (int)(i & 31) * 4;
-    const f32x4 z = *reinterpret_cast<const f32x4*>(zr + m * 256 + c), qv = *reinterpret_cast<const f32x4*>(q + m * 128 + c);
+    const f32x4 z = *reinterpret_cast<const f32x4*>(zr + m * 256 + c);
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(q + m * 128 + c) + *reinterpret_cast<const f32x4*>(qi + m * 128 + c);
     const f32x4 h = pair_join4(*reinterpret_cast<const bf16x4*>(hb + m * 256 + c), *reinterpret_cast<const bf16x4*>(hb + m * 256 + 128 + c));
     f32x4 hn;
 #pragma unroll
@@ -225,7 +266,10 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     VTGB_REQUIRE(M < (1ll << 28), VTGB_EUNSUPPORTED, "raft_update: too many pixels (the flow field is addressed through one 32-bit buffer range)");
     // pair buffers (bf16 elements per pixel = 2 x channels)
     bf16_t* hb = (bf16_t*)ws.take(M * 256 * 2);        // h
-    bf16_t* X = (bf16_t*)ws.take(M * 512 * 2);         // [inp(128) | motion(126) | flow(2)]
+    bf16_t* X = (bf16_t*)ws.take(M * 256 * 2);         // [motion(126) | flow(2)]
+    bf16_t* INP = (bf16_t*)ws.take(M * 256 * 2);       // inp (128): read by the start-map convolutions only
+    float* ZRI[2] = {(float*)ws.take(M * 256 * 4), (float*)ws.take(M * 256 * 4)};   // per GRU half: bias + the convolution of `inp` (z | r), loop invariant
+    float* QI[2] = {(float*)ws.take(M * 128 * 4), (float*)ws.take(M * 128 * 4)};    // ... (q)
     bf16_t* corrf = (bf16_t*)ws.take(M * 768 * 2);     // 324 taps, zero-padded to 384
     bf16_t* c1 = (bf16_t*)ws.take(M * 512 * 2);
     bf16_t* CF = (bf16_t*)ws.take(M * 512 * 2);        // [cor(192) | flo(64)]
@@ -243,7 +287,7 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     VTGB_REQUIRE(((a->net && a->inp) || a->cnet_nhwc) && a->weights && a->flow_up, VTGB_EINVAL, "raft_update: NULL operand");
     VTGB_REQUIRE(!a->corr_f16, VTGB_EINVAL, "raft_update: the bf16x3 mode takes an fp32 correlation pyramid");
     const void* const* w = a->weights;
-    for (int i = 0; i < 26; i++) VTGB_REQUIRE(w[i], VTGB_EINVAL, "raft_update: weights[%d] is NULL", i);
+    for (int i = 0; i < VTGB_RAFT_NW; i++) VTGB_REQUIRE(w[i], VTGB_EINVAL, "raft_update: weights[%d] is NULL (the bf16x3 table always carries the inp split)", i);
     CorrPyr pyr;
     int hl = H8, wl = W8;
     for (int l = 0; l < 4; l++) {
@@ -255,23 +299,38 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     const int Mi = (int)M;
     const dim3 g32((unsigned)((M * 32 + 255) / 256));
     auto F = [](const void* p) { return (const float*)p; };
-    hipLaunchKernelGGL(x3_init_kernel, g32, dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, hb, X, flow, a->flow_init, M, HW);
+    hipLaunchKernelGGL(x3_init_kernel, g32, dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, hb, INP, X, flow, a->flow_init, M, HW);
+    // the GRU convolutions' contribution of `inp` (input channels 128..255: constant over the refinement iterations) + bias, once per call:
+    // the 80 GRU launches contract over [h | motion | flow] = 256 channels instead of 384 (as in the bf16 mode, here as fp32 maps
+    // that the gate kernels add)
+    for (int half = 0; half < 2; half++) {
+        const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1, wi = 10 + 4 * half;
+        GemmDesc mz = x3_conv(Mi, 256, H8, W8, kh, kw, INP, 128, nullptr, 0, w[26 + 2 * half], F(w[wi + 1]), VTGB_EPI_STORE_F32, 0, ZRI[half], 256, 0, zero);
+        GemmDesc mq = x3_conv(Mi, 128, H8, W8, kh, kw, INP, 128, nullptr, 0, w[27 + 2 * half], F(w[wi + 3]), VTGB_EPI_STORE_F32, 0, QI[half], 128, 0, zero);
+        mz.algo_flops = mq.algo_flops = -1.0;   // credited to the 20 per-iteration launches (the reference's form)
+        VTGB_TRY(launch_conv_gemm(mz, s));
+        VTGB_TRY(launch_conv_gemm(mq, s));
+    }
     for (int it = 0; it < a->iters; it++) {
         // ---- BasicMotionEncoder (update.py:88-97)
         VTGB_TRY(raft_launch_lookup_pair(pyr, flow, corrf, M, H8, W8, s));
         VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 256, H8, W8, 1, 1, corrf, 384, nullptr, 0, w[0], F(w[1]), VTGB_EPI_SPLIT, 1, c1, 512, 256, zero), s));
         VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 192, H8, W8, 3, 3, c1, 256, nullptr, 0, w[2], F(w[3]), VTGB_EPI_SPLIT, 1, CF, 512, 256, zero), s));
-        hipLaunchKernelGGL(x3_convf1_kernel, dim3((unsigned)((M + 1) / 2)), dim3(256), 0, s, flow, F(w[4]), F(w[5]), f1, X, M, H8, W8);
+        hipLaunchKernelGGL(x3_convf1_kernel, dim3((unsigned)((M + CF1_PX - 1) / CF1_PX)), dim3(256), 0, s, flow, F(w[4]), F(w[5]), f1, X, M, H8, W8);
         VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 64, H8, W8, 3, 3, f1, 128, nullptr, 0, w[6], F(w[7]), VTGB_EPI_STORE_F32, 0, Q, 64, 0, zero), s));
         VTGB_TRY(launch_x3_pair_pass(Q, 64, nullptr, HW, nullptr, 0, 0, CF + 192, 512, 256, 64, 64, 1, 0, M, s));
-        VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 126, H8, W8, 3, 3, CF, 256, nullptr, 0, w[8], F(w[9]), VTGB_EPI_SPLIT, 1, X + 128, 512, 256, zero), s));
-        // ---- SepConvGRU (update.py:50-65): horizontal (1x5) then vertical (5x1); input channels [h(128) | inp(128) | motion(126) | flow(2)]
+        VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 126, H8, W8, 3, 3, CF, 256, nullptr, 0, w[8], F(w[9]), VTGB_EPI_SPLIT, 1, X, 256, 128, zero), s));
+        // ---- SepConvGRU (update.py:50-65): horizontal (1x5) then vertical (5x1); input channels [h(128) | motion(126) | flow(2)], the inp third comes from the start maps
         for (int half = 0; half < 2; half++) {
             const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1, wi = 10 + 4 * half;
-            VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 256, H8, W8, kh, kw, hb, 128, X, 256, w[wi], F(w[wi + 1]), VTGB_EPI_STORE_F32, 0, ZR, 256, 0, zero), s));
-            hipLaunchKernelGGL(x3_gru_gate_kernel, g32, dim3(256), 0, s, ZR, hb, RH, M);
-            VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 128, H8, W8, kh, kw, RH, 128, X, 256, w[wi + 2], F(w[wi + 3]), VTGB_EPI_STORE_F32, 0, Q, 128, 0, zero), s));
-            hipLaunchKernelGGL(x3_gru_update_kernel, g32, dim3(256), 0, s, ZR, Q, hb, M);
+            GemmDesc zr = x3_conv(Mi, 256, H8, W8, kh, kw, hb, 128, X, 128, w[wi], nullptr, VTGB_EPI_STORE_F32, 0, ZR, 256, 0, zero);
+            zr.algo_flops = 2.0 * Mi * 256.0 * (5 * 384);
+            VTGB_TRY(launch_conv_gemm(zr, s));
+            hipLaunchKernelGGL(x3_gru_gate_kernel, g32, dim3(256), 0, s, ZR, ZRI[half], hb, RH, M);
+            GemmDesc q = x3_conv(Mi, 128, H8, W8, kh, kw, RH, 128, X, 128, w[wi + 2], nullptr, VTGB_EPI_STORE_F32, 0, Q, 128, 0, zero);
+            q.algo_flops = 2.0 * Mi * 128.0 * (5 * 384);
+            VTGB_TRY(launch_conv_gemm(q, s));
+            hipLaunchKernelGGL(x3_gru_update_kernel, g32, dim3(256), 0, s, ZR, Q, QI[half], hb, M);
         }
         // ---- FlowHead (update.py:10-18) and coords1 += delta_flow (xraft.py:145)
         VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 256, H8, W8, 3, 3, hb, 128, nullptr, 0, w[18], F(w[19]), VTGB_EPI_SPLIT, 1, FH, 512, 256, zero), s));

@@ -588,10 +588,12 @@ class RaftWeights(_WeightTable):
 def _raft_x3_table(self: RaftWeights, sd: Dict[str, Tensor], p: str) -> None:
     """The bf16x3 table (raft_x3.hip): every MFMA convolution as [C_out, taps, 3 C_in] in the kernels' K order with the channel blocks
     [Wh | Wh | Wl] per source; convf1 as in the fp32 mode; the mask head's 0.25 (update.py:143) folded into mask.2 (a power of two: exact)."""
-    self.hoist_inp = False
+    self.hoist_inp = True
 
-    def conv(name, cin_pad=None, sources=None, scale=1.0):
+    def conv(name, cin_pad=None, sources=None, scale=1.0, channels=None):
         w = sd[p + name + ".weight"].float() * scale
+        if channels is not None:
+            w = w[:, channels]
         co, ci, kh, kw = w.shape
         w = w.permute(0, 2, 3, 1)
         if cin_pad and cin_pad != ci:
@@ -608,10 +610,11 @@ def _raft_x3_table(self: RaftWeights, sd: Dict[str, Tensor], p: str) -> None:
     self.add(sd[p + "encoder.convf1.bias"])
     add_conv("encoder.convf2")
     add_conv("encoder.conv")
+    dyn = list(range(0, 128)) + list(range(256, 384))     # [h | motion + flow]: two pair sources of 128 channels
     for sfx in ("1", "2"):
-        self.tensors.append(torch.cat([conv("gru.convz" + sfx, sources=[128, 256]), conv("gru.convr" + sfx, sources=[128, 256])], 0).contiguous())
+        self.tensors.append(torch.cat([conv("gru.convz" + sfx, sources=[128, 128], channels=dyn), conv("gru.convr" + sfx, sources=[128, 128], channels=dyn)], 0).contiguous())
         self.add(torch.cat([sd[p + "gru.convz" + sfx + ".bias"], sd[p + "gru.convr" + sfx + ".bias"]], 0))
-        self.tensors.append(conv("gru.convq" + sfx, sources=[128, 256]))
+        self.tensors.append(conv("gru.convq" + sfx, sources=[128, 128], channels=dyn))
         self.add(sd[p + "gru.convq" + sfx + ".bias"])
     add_conv("flow_head.conv1")
     w2 = sd[p + "flow_head.conv2.weight"].float().permute(2, 3, 0, 1).reshape(18, 256)
@@ -620,8 +623,10 @@ def _raft_x3_table(self: RaftWeights, sd: Dict[str, Tensor], p: str) -> None:
     self.add(sd[p + "flow_head.conv2.bias"])
     add_conv("mask.0")
     add_conv("mask.2", scale=0.25)
-    for _ in range(4):
-        self.add(None)
+    inp = list(range(128, 256))                           # the loop-invariant third: start maps, once per call
+    for sfx in ("1", "2"):
+        self.tensors.append(torch.cat([conv("gru.convz" + sfx, channels=inp), conv("gru.convr" + sfx, channels=inp)], 0).contiguous())
+        self.tensors.append(conv("gru.convq" + sfx, channels=inp))
     self.finish()
 
 
