@@ -77,6 +77,7 @@ def test_cand_index_stable_under_bf16_raft(dev, parts, T, per_call, weights):
     keys = [(m, t) for m in modes for t in ("bf16", "f32")]
     moved, differ, total_ep = {k: 0 for k in keys}, {k: 0 for k in keys}, 0
     flow_rms, logit_err, logit_scale = {m: 0.0 for m in modes}, {k: 0.0 for k in keys}, {"bf16": 0.0, "f32": 0.0}
+    floor16, floor_moved = 0.0, 0
     for c0 in range(0, n_clips, per_call):
         kind = "randn" if (c0 // per_call) % 2 == 0 else "moving"
         frames = make_clips(kind, per_call, T, gen, dev)
@@ -95,6 +96,13 @@ def test_cand_index_stable_under_bf16_raft(dev, parts, T, per_call, weights):
                 res[dt][tdt] = (logits, sel, ops.span_to_frames(sel, T, N, nframe, "A"))
             del fl
         b = res["f32"]
+        # control: the bf16 TGB on the fp32-RAFT flow perturbed by 1e-5 relative noise (about the bf16x3 mode's distance from fp32)
+        pert = b["of"] * (1.0 + 1e-5 * torch.randn(b["of"].shape, generator=gen, device=dev))
+        _, lp = tgbs["bf16"](encoder_embeds=pert, attention_mask=torch.ones(per_call, T + 2, dtype=torch.long, device=dev),
+                             encoder_hidden_states=sids, encoder_attention_mask=torch.ones_like(sids), mode="multi_modal")
+        floor16 = max(floor16, float((lp - b["bf16"][0]).abs().max().item()))
+        floor_moved += int((ops.span_select(lp, noise, 0.5) != b["bf16"][1]).sum().item())
+        del pert, lp
         total_ep += b["f32"][1].numel()
         for tdt in tgbs:
             logit_scale[tdt] = max(logit_scale[tdt], float((b[tdt][0].max() - b[tdt][0].min()).item()))
@@ -110,16 +118,19 @@ def test_cand_index_stable_under_bf16_raft(dev, parts, T, per_call, weights):
         print(f"[selection T={T} raft weights={weights} RAFT {m} vs fp32, TGB {tdt}] {n_clips} clips: flow rel-RMS <= {flow_rms[m]:.3e}; TGB logits max|diff| "
               f"{logit_err[m, tdt]:.3e} = {logit_err[m, tdt] / logit_scale[tdt]:.2e} of their range {logit_scale[tdt]:.3e}; span endpoints moved "
               f"{moved[m, tdt]}/{total_ep}; clips with a different cand_index {differ[m, tdt]}/{n_clips}")
+    print(f"[selection T={T} raft weights={weights} control] the bf16 TGB on the fp32-RAFT flow x (1 + 1e-5 randn): logits max|diff| {floor16:.3e} = "
+          f"{floor16 / logit_scale['bf16']:.2e} of their range; span endpoints moved {floor_moved}/{total_ep}")
     # bf16 RAFT (a mode the reference does not have), TGB as bench.py runs it.  logits: default weights 2e-2 of their range (observed 9e-3);
     # sensitive weights 1e-1 (observed 4.5e-2 ... 5.3e-2: the bf16 flow is 1.45e-2 off there and the flow reaches the logits); at most 2 of
     # 64 clips may differ
     assert logit_err["bf16", "bf16"] <= (2e-2 if weights == "default" else 1e-1) * logit_scale["bf16"]
     assert differ["bf16", "bf16"] <= 2
-    # bf16x3 RAFT (split-bf16 operands: the reference's fp32 accuracy on the matrix cores): the SAME frames for every clip with either TGB,
-    # and the north star's 1e-3 on the logit tensor.  The 1e-3 is asserted through the fp32 TGB: the bf16 TGB rounds the flow to bf16 on
-    # entry, so ANY perturbation of the flow -- here 1e-5 relative -- flips a few of those roundings and re-draws the TGB's own bf16 noise
-    # (6e-3 ... 8e-3 of the logit range, the same size as the reference's bf16-vs-fp32 TGB difference): that number says
-    # nothing about RAFT and is printed, not asserted.
+    # bf16x3 RAFT (split-bf16 operands: the reference's fp32 accuracy on the matrix cores).  Through the fp32 TGB -- which isolates what the
+    # flow difference does -- the north star's 1e-3 on the logit tensor holds and EVERY clip selects the same frames.  Through the bf16 TGB any
+    # perturbation of the flow, however small, flips some of the bf16 roundings inside the TGB and re-draws part of ITS quantisation noise
+    # (~sqrt(perturbation x ulp) per rounding site): the control above -- 1e-5 relative noise on the fp32 flow -- moves the bf16 logits by the same
+    # 5e-3 ... 9e-3 of their range, the size of the reference's own bf16-vs-fp32 TGB difference.  That number is a property of
+    # the bf16 TGB, not of RAFT: printed, and bounded only by the selection (at most 2 of 64 clips, as for any flow source).
     assert logit_err["bf16x3", "f32"] <= 1e-3 * logit_scale["f32"]
-    for tdt in tgbs:
-        assert differ["bf16x3", tdt] == 0 and moved["bf16x3", tdt] == 0, tdt
+    assert differ["bf16x3", "f32"] == 0 and moved["bf16x3", "f32"] == 0
+    assert differ["bf16x3", "bf16"] <= 2

@@ -144,9 +144,11 @@ struct GemmDesc {
     int64_t ldaux;
     void* out2;
     int64_t ldo2;
-    // EPI_STORE_F32 (N % 4 == 0): per (image, column) sum and sum of squares of the stored values are
-    // accumulated (atomics) into col_stats[(row / stats_rows) * N + n][2] -- InstanceNorm statistics
-    // without a second pass over the output.  stats_rows >= 256; the caller zeroes the buffer.
+    // EPI_STORE_F32 (N % 4 == 0): per column the sum and sum of squares of the stored values of every 256-row tile are
+    // written to col_stats[(m_tile * N + n) * 4 + {sum a, sq a, sum b, sq b}] (a = the image of the tile's first row, row / stats_rows;
+    // b = the next image, if the tile reaches into it) -- InstanceNorm statistics without a second pass over the output.
+    // stats_rows >= 256; launch_stats_finish_tiles adds the slots of an image in tile order (r5: deterministic; rounds 1-4 accumulated
+    // with atomics, whose order -- and with it the last bits of every normalised feature -- changed from run to run).
     float* col_stats;
     int stats_rows;
     // EPI_STORE (bf16, whole-row stores): columns n >= gate_from are not stored to `out` but multiplied by
@@ -215,14 +217,19 @@ struct AttnDesc {
 int launch_attention(const AttnDesc& d, hipStream_t s);
 
 bool stem7x7_supported(int H, int W);
-int launch_stem7x7(const float* img, const void* w, const float* bias, float* out_f32, float* stats, void* out_bf16, int n_img, int H, int W, int relu,
-                   hipStream_t s);
+// stats_part: scratch for the per-run partial moments (stats_part_floats(n_img)); the moments land in `stats` [n_img, 64, 2] in a fixed order
+int launch_stem7x7(const float* img, const void* w, const float* bias, float* out_f32, float* stats, float* stats_part, void* out_bf16, int n_img, int H, int W,
+                   int relu, hipStream_t s);
+size_t conv64_stats_part_floats(int n_img);
+// InstanceNorm moments from per-tile / per-part partial sums, added in a fixed order (raft_enc.hip)
+int launch_stats_finish_tiles(const float* part, float* stats, int n_img, int HW, int N, int64_t M, hipStream_t s);
+int launch_stats_finish_parts(const float* part, float* stats, int n_img, int parts, int C, hipStream_t s);
 int cu_count();   // compute units of the current device (gemm_pp.hip)
 
 // conv64.hip: 3x3 / stride 1 / 64 -> 64 channels over NHWC bf16 with the input rows resident in LDS (RAFT encoders, layer1)
 bool conv3x3_c64_supported(int H, int W);
-int launch_conv3x3_c64(const void* in, const void* w, const float* bias, float* out_f32, float* stats, void* out_bf16, const void* resid, int n_img,
-                       int H, int W, int relu, int post_relu, hipStream_t s);
+int launch_conv3x3_c64(const void* in, const void* w, const float* bias, float* out_f32, float* stats, float* stats_part, void* out_bf16, const void* resid,
+                       int n_img, int H, int W, int relu, int post_relu, hipStream_t s);
 
 struct LnDesc {
     int dtype, M, D;

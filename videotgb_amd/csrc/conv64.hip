@@ -34,6 +34,7 @@ struct Conv64Params {
     const float* bias;     // [64]
     float* out_f32;        // MODE 0: [n_img * H * W, 64]
     float* stats;          // MODE 0: [n_img, 64, 2] (sum, sum of squares)
+    float* stats_part;     // parts > 1: [n_img * parts, 64, 2] per-run partial moments
     bf16_t* out_bf16;      // MODE 1
     const bf16_t* resid;   // MODE 1, nullable
     int n_img, H, W, relu, post_relu;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv64Params p) 
 #undef C64_ISSUE
         if constexpr (MODE == 0) {
             // moments of this unit's rows: over the 16 pixel lanes of a fragment, then over the four pixel waves (LDS), added to the image's
-            // (sum, sum of squares) -- one atomic per channel and unit (the buffer is zeroed by the launcher)
+            // (sum, sum of squares) -- stored per unit, added in unit order by a second pass (r5: was one atomic per channel and unit)
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -231,9 +232,9 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const Conv64Params p) 
                 float t = 0.f;
 #pragma unroll
                 for (int m_ = 0; m_ < 4; m_++) t += xch[((wn_ * 4 + m_) * 32 + c32) * 2 + which];
-                float* const dst = p.stats + ((int64_t)img * 64 + ch) * 2 + which;
-                if (p.parts == 1) *dst = t;               // the workgroup owns the image: stored, no atomics
-                else atomicAdd(dst, t);
+                // the workgroup owns the image: stored; else stored to this run's slot, added in run order by launch_stats_finish_parts (r5: no atomics)
+                if (p.parts == 1) p.stats[((int64_t)img * 64 + ch) * 2 + which] = t;
+                else p.stats_part[((int64_t)unit * 64 + ch) * 2 + which] = t;      // (unit = img * parts + run)
             }
         }
     }
@@ -258,6 +259,7 @@ struct StemParams {
     const float* bias;
     float* out_f32;        // MODE 0: [n_img * H2 * W2, 64] + moments
     float* stats;
+    float* stats_part;
     bf16_t* out_bf16;      // MODE 1: relu -> bf16
     int n_img, H, W, relu;
     int parts, rows_per_part;
@@ -438,9 +440,8 @@ __global__ __launch_bounds__(512) void stem7x7_kernel(const StemParams p) {
                 float t = 0.f;
 #pragma unroll
                 for (int m_ = 0; m_ < 4; m_++) t += xch[((wn_ * 4 + m_) * 32 + c32) * 2 + which];
-                float* const dst = p.stats + ((int64_t)img * 64 + ch) * 2 + which;
-                if (p.parts == 1) *dst = t;
-                else atomicAdd(dst, t);
+                if (p.parts == 1) p.stats[((int64_t)img * 64 + ch) * 2 + which] = t;
+                else p.stats_part[((int64_t)unit * 64 + ch) * 2 + which] = t;      // (unit = img * parts + run)
             }
         }
     }
@@ -452,12 +453,14 @@ __global__ __launch_bounds__(512) void stem7x7_kernel(const StemParams p) {
 // x [n_img, H, W, 64] bf16 -> 3x3 / stride 1 / pad 1 convolution with w [64, 576] (+ bias): fp32 [.., 64] + moments (out_f32 != NULL) or bf16
 bool conv3x3_c64_supported(int H, int W) { return W >= 16 && W <= C64_RS - 2 && H >= 1; }
 
-int launch_conv3x3_c64(const void* in, const void* w, const float* bias, float* out_f32, float* stats, void* out_bf16, const void* resid, int n_img,
-                       int H, int W, int relu, int post_relu, hipStream_t s) {
+size_t conv64_stats_part_floats(int n_img) { return ((size_t)n_img + 4 * (size_t)cu_count()) * 2 * 64 * 2; }   // n_img * parts < 2 * (n_img + 4 CUs)
+
+int launch_conv3x3_c64(const void* in, const void* w, const float* bias, float* out_f32, float* stats, float* stats_part, void* out_bf16, const void* resid,
+                       int n_img, int H, int W, int relu, int post_relu, hipStream_t s) {
     VTGB_REQUIRE(conv3x3_c64_supported(H, W), VTGB_EUNSUPPORTED, "conv3x3_c64: W=%d outside [16, %d]", W, C64_RS - 2);
     VTGB_REQUIRE((int64_t)H * W * 128 < 0x7FFFFF00ll, VTGB_EUNSUPPORTED, "conv3x3_c64: image too large");
     Conv64Params p;
-    p.in = (const bf16_t*)in; p.w = (const bf16_t*)w; p.bias = bias; p.out_f32 = out_f32; p.stats = stats; p.out_bf16 = (bf16_t*)out_bf16;
+    p.in = (const bf16_t*)in; p.w = (const bf16_t*)w; p.bias = bias; p.out_f32 = out_f32; p.stats = stats; p.stats_part = stats_part; p.out_bf16 = (bf16_t*)out_bf16;
     p.resid = (const bf16_t*)resid; p.n_img = n_img; p.H = H; p.W = W; p.relu = relu; p.post_relu = post_relu;
     // runs of rows: enough of them that the persistent grid is balanced (>= 4 per workgroup), each an even number of rows
     int parts = 1;
@@ -466,7 +469,7 @@ int launch_conv3x3_c64(const void* in, const void* w, const float* bias, float* 
     p.parts = (H + p.rows_per_part - 1) / p.rows_per_part;
     const int64_t units = (int64_t)n_img * p.parts;
     const int grid = units < cu_count() ? (int)units : cu_count();
-    if (out_f32 && p.parts > 1) VTGB_HIP(hipMemsetAsync(stats, 0, (size_t)n_img * 64 * 2 * sizeof(float), s));
+    if (out_f32 && p.parts > 1) VTGB_REQUIRE(stats_part && (size_t)units * 128 <= conv64_stats_part_floats(n_img), VTGB_EINVAL, "conv3x3_c64: partial-moment scratch missing");
     const double flops = 2.0 * n_img * H * W * 64.0 * 576.0;
     ProfScope prof(VTGB_PROF_CONV, flops, s, flops);
     static DeviceOnce a0, a1;
@@ -474,6 +477,7 @@ int launch_conv3x3_c64(const void* in, const void* w, const float* bias, float* 
         VTGB_REQUIRE(stats, VTGB_EINVAL, "conv3x3_c64: fp32 output needs the moments buffer");
         VTGB_FUNC_LDS_ONCE(a0, conv3x3_c64_kernel<0>, C64_LDS);
         hipLaunchKernelGGL(conv3x3_c64_kernel<0>, dim3(grid), dim3(512), C64_LDS, s, p);
+        if (p.parts > 1) VTGB_TRY(launch_stats_finish_parts(stats_part, stats, n_img, p.parts, 64, s));
     } else {
         VTGB_FUNC_LDS_ONCE(a1, conv3x3_c64_kernel<1>, C64_LDS);
         hipLaunchKernelGGL(conv3x3_c64_kernel<1>, dim3(grid), dim3(512), C64_LDS, s, p);
@@ -485,12 +489,12 @@ int launch_conv3x3_c64(const void* in, const void* w, const float* bias, float* 
 // the stem on raw frames: img [n_img, 3, H, W] fp32 -> [n_img, H/2, W/2, 64]; packed weights [64, 512] (vtgb.h: vtgb_raft_encoder)
 bool stem7x7_supported(int H, int W) { return (H % 2) == 0 && (W % 2) == 0 && W / 2 >= 16 && W / 2 <= 112 && H / 2 >= 4; }
 
-int launch_stem7x7(const float* img, const void* w, const float* bias, float* out_f32, float* stats, void* out_bf16, int n_img, int H, int W, int relu,
-                   hipStream_t s) {
+int launch_stem7x7(const float* img, const void* w, const float* bias, float* out_f32, float* stats, float* stats_part, void* out_bf16, int n_img, int H, int W,
+                   int relu, hipStream_t s) {
     VTGB_REQUIRE(stem7x7_supported(H, W), VTGB_EUNSUPPORTED, "stem7x7: %d x %d unsupported", H, W);
     const int H2 = H / 2, W2 = W / 2;
     StemParams p;
-    p.img = img; p.w = (const bf16_t*)w; p.bias = bias; p.out_f32 = out_f32; p.stats = stats; p.out_bf16 = (bf16_t*)out_bf16;
+    p.img = img; p.w = (const bf16_t*)w; p.bias = bias; p.out_f32 = out_f32; p.stats = stats; p.stats_part = stats_part; p.out_bf16 = (bf16_t*)out_bf16;
     p.n_img = n_img; p.H = H; p.W = W; p.relu = relu;
     int parts = 1;
     while ((int64_t)n_img * parts < 4 * cu_count() && H2 / (parts * 2) >= 14) parts *= 2;
@@ -498,7 +502,7 @@ int launch_stem7x7(const float* img, const void* w, const float* bias, float* ou
     p.parts = (H2 + p.rows_per_part - 1) / p.rows_per_part;
     const int64_t units = (int64_t)n_img * p.parts;
     const int grid = units < cu_count() ? (int)units : cu_count();
-    if (out_f32 && p.parts > 1) VTGB_HIP(hipMemsetAsync(stats, 0, (size_t)n_img * 64 * 2 * sizeof(float), s));
+    if (out_f32 && p.parts > 1) VTGB_REQUIRE(stats_part && (size_t)units * 128 <= conv64_stats_part_floats(n_img), VTGB_EINVAL, "stem7x7: partial-moment scratch missing");
     const int lds = ST_R * W2 * 256 + 8 * 32 * 2 * 4 + 64 * 4;
     const double flops = 2.0 * n_img * H2 * W2 * 64.0 * 147.0, exec = 2.0 * n_img * H2 * W2 * 64.0 * 512.0;
     ProfScope prof(VTGB_PROF_CONV, flops, s, exec);
@@ -507,6 +511,7 @@ int launch_stem7x7(const float* img, const void* w, const float* bias, float* ou
         VTGB_REQUIRE(stats, VTGB_EINVAL, "stem7x7: fp32 output needs the moments buffer");
         VTGB_FUNC_LDS_ONCE(a0, stem7x7_kernel<0>, ST_R * 112 * 256 + 8 * 32 * 2 * 4 + 64 * 4);
         hipLaunchKernelGGL(stem7x7_kernel<0>, dim3(grid), dim3(512), lds, s, p);
+        if (p.parts > 1) VTGB_TRY(launch_stats_finish_parts(stats_part, stats, n_img, p.parts, 64, s));
     } else {
         VTGB_FUNC_LDS_ONCE(a1, stem7x7_kernel<1>, ST_R * 112 * 256 + 8 * 32 * 2 * 4 + 64 * 4);
         hipLaunchKernelGGL(stem7x7_kernel<1>, dim3(grid), dim3(512), lds, s, p);

@@ -247,7 +247,7 @@ struct ClkScope {
 // encoder convolutions); its activation slot is 64 KiB, so the ring is 2 activation + 2 weight slots = 160 KiB.
 
 // Column-statistics fold (EPI_STORE_F32 + col_stats): 64 NWN threads add up the MW waves' partial sums of a column (parked in the
-// waves' staging regions) and issue one atomic per (image, column, moment).  Run by waves 0 .. NWN-1 WHETHER OR NOT their own
+// waves' staging regions) and store them to the tile's slot of the partial-moment buffer (r5: was one atomic per (image, column, moment)).  Run by waves 0 .. NWN-1 WHETHER OR NOT their own
 // sub-tile holds valid rows: with a last tile of <= WROWS valid rows those waves are row-inactive, and (rounds 1-2) returned
 // before the fold -- the last image's moments then missed that tile for the columns they should have folded (found in round 3:
 // fnet 3-10 % off on the last image whenever n_images * H/8 * W/8 mod 256 <= 64).
@@ -262,13 +262,9 @@ struct ClkScope {
                 const float* pr = reinterpret_cast<const float*>(smem + (wn_ * MW + wm_) * ((PR_) * 256));          \
                 _Pragma("unroll") for (int e = 0; e < 4; e++) t[e] += pr[e * 64 + c];                               \
             }                                                                                                       \
-            float* st = p.col_stats + ((int64_t)img_a_ * p.N + n) * 2;                                              \
-            unsafeAtomicAdd(st, t[0]);                                                                              \
-            unsafeAtomicAdd(st + 1, t[1]);                                                                          \
-            if (m0 + T_BM > m_b_ && m_b_ < p.M) {                                                                   \
-                unsafeAtomicAdd(st + 2 * p.N, t[2]);                                                                \
-                unsafeAtomicAdd(st + 2 * p.N + 1, t[3]);                                                            \
-            }                                                                                                       \
+            /* r5: the tile's partial moments are STORED to its own slot [m-tile][column][image a: sum, sum sq | image b: ...]; a second */ \
+            /* pass adds the slots in tile order (stats_finish_tiles): no atomics, the same bits on every run */              \
+            *reinterpret_cast<float4*>(p.col_stats + ((int64_t)mt * p.N + n) * 4) = make_float4(t[0], t[1], t[2], t[3]);    \
         }                                                                                                           \
     }
 
@@ -1135,7 +1131,7 @@ static int launch_large_forced(const GemmDesc& d, hipStream_t s) {
         // shape sits at the same ~30 GB/s per CU of operand fill, which is what bounds them, not the fragment-read ratio.
         // It stays selectable for experiments only.
 #ifdef VTGB_DEBUG_HOOKS
-        if (g_conv_nwn == 5 && d.M >= 512 * 1024 && (!d.col_stats || d.stats_rows >= 512)) return launch_large_nwn<EPI, CONV, 2, 8>(d, s);
+        if (g_conv_nwn == 5 && d.M >= 512 * 1024 && !d.col_stats) return launch_large_nwn<EPI, CONV, 2, 8>(d, s);
 #endif
         return launch_large_nwn<EPI, CONV, 2>(d, s);
     }

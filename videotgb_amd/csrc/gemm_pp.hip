@@ -670,13 +670,8 @@ gelu_erf_fast4(v);
 #pragma unroll
                                 for (int e = 0; e < 4; e++) t[e] += pr[e * 64 + c];
                             }
-                            float* st = p.col_stats + ((int64_t)img_a * p.N + nc) * 2;
-                            unsafeAtomicAdd(st, t[0]);
-                            unsafeAtomicAdd(st + 1, t[1]);
-                            if (em0 + T_BM > m_b && m_b < p.M) {
-                                unsafeAtomicAdd(st + 2 * p.N, t[2]);
-                                unsafeAtomicAdd(st + 2 * p.N + 1, t[3]);
-                            }
+                            // r5: stored to the tile's own slot [m-tile][column][4]; stats_finish_tiles adds the slots in tile order (no atomics)
+                            *reinterpret_cast<float4*>(p.col_stats + ((int64_t)emt * p.N + nc) * 4) = make_float4(t[0], t[1], t[2], t[3]);
                         }
                     }
                 }

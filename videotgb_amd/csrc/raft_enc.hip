@@ -77,11 +77,14 @@ __global__ __launch_bounds__(256) void raft_stem_pack_kernel(const float* __rest
     }
 }
 
-// ---- InstanceNorm2d statistics: per (image, channel) sum and sum of squares over the HW pixels, accumulated
-// into stats[(n * C + c) * 2 + {0, 1}] (zeroed by the caller).  The implicit-GEMM convolutions produce them in
-// their epilogue (GemmDesc::col_stats); this pass serves the stem and images of fewer than 256 pixels.
-// grid (n, splits): each workgroup reduces a slice of the image, then one atomic per channel and moment.
-__global__ __launch_bounds__(256) void inorm_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int HW, int C, int ldx) {
+// ---- InstanceNorm2d statistics: per (image, channel) sum and sum of squares over the HW pixels.  r5: DETERMINISTIC -- every producer
+// (the implicit-GEMM epilogues: one slot per 256-row tile; conv64.hip's kernels: one slot per run of rows; the separate pass below: one
+// slot per slice) STORES its partial moments and a second pass adds an image's slots in a fixed order.  Rounds 1-4 accumulated them with
+// atomics: the order, and with it the last bits of every normalised feature, changed from run to run, which the bf16 TGB downstream could
+// turn into a different frame selection.
+// This pass serves the stem of the fp32 mode and images of fewer than 256 pixels: grid (n, splits), each workgroup reduces a slice of the
+// image into part[((n * splits + split) * C + c) * 2 + {0, 1}].
+__global__ __launch_bounds__(256) void inorm_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C, int ldx) {
     __shared__ float s1[256], s2[256];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int c4 = C >> 2, cq = tid % c4, lane_p = tid / c4, np = 256 / c4;   // a thread owns 4 channels of every np-th pixel
@@ -102,11 +105,53 @@ __global__ __launch_bounds__(256) void inorm_stats_kernel(const float* __restric
         if (tid < c4) {
             float sa = 0.f, sq = 0.f;
             for (int l = 0; l < np; l++) { sa += s1[l * c4 + tid]; sq += s2[l * c4 + tid]; }
-            float* st = stats + ((int64_t)n * C + tid * 4 + e) * 2;
-            unsafeAtomicAdd(st, sa);
-            unsafeAtomicAdd(st + 1, sq);
+            float* st = part + (((int64_t)n * gridDim.y + blockIdx.y) * C + tid * 4 + e) * 2;
+            st[0] = sa;
+            st[1] = sq;
         }
     }
+}
+
+// stats[(img * C + c) * 2 + w] = sum over the image's `parts` slots, in slot order
+__global__ void stats_finish_parts_kernel(const float* __restrict__ part, float* __restrict__ stats, int64_t total, int parts, int C2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (img, c, w)
+    if (i >= total) return;
+    const int64_t img = i / C2;
+    const int cw = (int)(i - img * C2);
+    float t = 0.f;
+    for (int pt = 0; pt < parts; pt++) t += part[(img * parts + pt) * C2 + cw];
+    stats[i] = t;
+}
+int launch_stats_finish_parts(const float* part, float* stats, int n_img, int parts, int C, hipStream_t s) {
+    const int64_t total = (int64_t)n_img * C * 2;
+    hipLaunchKernelGGL(stats_finish_parts_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, stats, total, parts, C * 2);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+// the GEMM epilogues' slots part[(m_tile * N + n) * 4 + {sum a, sq a, sum b, sq b}] (256-row tiles; a = the image of the tile's first
+// row, b = the next one): stats[(img * N + n) * 2 + w] = the sum over the tiles that touch the image, in tile order
+__global__ void stats_finish_tiles_kernel(const float* __restrict__ part, float* __restrict__ stats, int n_img, int HW, int N, int64_t M) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (img, n)
+    if (i >= (int64_t)n_img * N) return;
+    const int img = (int)(i / N), n = (int)(i - (int64_t)img * N);
+    const int64_t r0 = (int64_t)img * HW, r1 = r0 + HW;                    // the image's rows
+    const int t0 = (int)(r0 >> 8), t1 = (int)((r1 - 1) >> 8);
+    float sa = 0.f, sq = 0.f;
+    for (int t = t0; t <= t1; t++) {
+        const float4 v = *reinterpret_cast<const float4*>(part + ((int64_t)t * N + n) * 4);
+        const int img_a = (int)(((int64_t)t << 8) / HW);
+        if (img_a == img) { sa += v.x; sq += v.y; }
+        else { sa += v.z; sq += v.w; }                                      // (stats_rows >= 256: a tile touches at most two images)
+    }
+    stats[i * 2] = sa;
+    stats[i * 2 + 1] = sq;
+}
+int launch_stats_finish_tiles(const float* part, float* stats, int n_img, int HW, int N, int64_t M, hipStream_t s) {
+    VTGB_REQUIRE(HW >= 256, VTGB_EINVAL, "stats_finish_tiles: images of >= 256 rows");
+    const int64_t total = (int64_t)n_img * N;
+    hipLaunchKernelGGL(stats_finish_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, stats, n_img, HW, N, M);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
 }
 
 // ---- y = [relu]((x - mean) * rstd); out = [relu](resid + y); bf16 NHWC with Cpad channels (pad = 0).
@@ -210,6 +255,11 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     void* act2 = act12 + (ws.dry ? 0 : M2 * 64 * es);
     float* stats = (float*)ws.take((int64_t)n * 128 * 2 * 4);
     float* stats2 = (float*)ws.take((int64_t)n * 128 * 2 * 4);   // the downsample branch's moments
+    // partial moments (one producer at a time): a slot per 256-row GEMM tile / per conv64 run of rows / per slice of the separate pass
+    size_t part_floats = (size_t)(M2 / 256 + 2) * 128 * 4;
+    if (conv64_stats_part_floats(n) > part_floats) part_floats = conv64_stats_part_floats(n);
+    if ((size_t)n * 16 * 128 * 2 > part_floats) part_floats = (size_t)n * 16 * 128 * 2;
+    float* spart = (float*)ws.take(part_floats * 4);
     void* zero = ws.take(256);
     void* pad_page = ws.take(256);   // the stem's out-of-image value (0 = normalised 0 in the raw - 127.5 encoding)
     if (ws.dry) return VTGB_OK;
@@ -224,9 +274,9 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     auto norm = [&](const float* x, int64_t M, int HW, int C, int Cpad, int ldx, const void* resid, void* out, int relu_in, int relu_out,
                     float* st, bool fused) -> int {
         if (inorm && !fused) {
-            VTGB_HIP(hipMemsetAsync(st, 0, (size_t)n * C * 2 * sizeof(float), s));
             const int splits = HW >= 4096 ? 16 : HW >= 1024 ? 4 : 1;
-            hipLaunchKernelGGL(inorm_stats_kernel, dim3(n, splits), dim3(256), 0, s, x, st, HW, C, ldx);
+            hipLaunchKernelGGL(inorm_stats_kernel, dim3(n, splits), dim3(256), 0, s, x, spart, HW, C, ldx);
+            VTGB_TRY(launch_stats_finish_parts(spart, st, n, splits, C, s));
         }
         if (x3)
             return launch_x3_pair_pass(x, ldx, inorm ? st : nullptr, HW, resid, 2 * Cpad, Cpad, out, 2 * Cpad, Cpad, C, Cpad, relu_in, relu_out, M, s);
@@ -242,12 +292,16 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
         VTGB_HIP(hipGetLastError());
         return VTGB_OK;
     };
-    // moments for a convolution output: zero the buffer and hand it to the GEMM epilogue when the image is
-    // large enough for the two-images-per-tile bookkeeping, else leave it to the separate pass
+    // moments for a convolution output: the GEMM epilogue writes per-tile partial moments into `spart` when the image is large enough for the
+    // two-images-per-tile bookkeeping (conv_stats then adds them into st in tile order), else they are left to the separate pass
     auto stats_for = [&](float* st, int HW, int C) -> float* {
         if (!inorm || HW < 256 || dt == VTGB_F32) return nullptr;   // (the fp32 kernel leaves the moments to the separate pass)
-        (void)hipMemsetAsync(st, 0, (size_t)n * C * 2 * sizeof(float), s);
-        return st;
+        return spart;
+    };
+    auto conv_stats = [&](const GemmDesc& d, float* st) -> int {    // the convolution, then its moments (if it produced any) into st
+        VTGB_TRY(launch_conv_gemm(d, s));
+        if (d.col_stats) VTGB_TRY(launch_stats_finish_tiles(d.col_stats, st, n, d.stats_rows, d.N, d.M, s));
+        return VTGB_OK;
     };
     // ---- stem: repack, then a 4x1 implicit-GEMM convolution whose epilogue also yields the InstanceNorm moments
 #ifdef VTGB_DEBUG_HOOKS
@@ -258,10 +312,10 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     if (stem_on && dt == VTGB_BF16 && stem7x7_supported(a->H, a->W)) {
         // the stem on the raw frames (conv64.hip: the packed rows are built in LDS, no HBM round trip)
         if (inorm) {
-            VTGB_TRY(launch_stem7x7(a->images, w[0], F(w[1]), cf, stats, nullptr, n, a->H, a->W, 0, s));
+            VTGB_TRY(launch_stem7x7(a->images, w[0], F(w[1]), cf, stats, spart, nullptr, n, a->H, a->W, 0, s));
             VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, true));
         } else {
-            VTGB_TRY(launch_stem7x7(a->images, w[0], F(w[1]), nullptr, nullptr, act0, n, a->H, a->W, 1, s));     // relu(bn1(conv1(x))) straight to bf16
+            VTGB_TRY(launch_stem7x7(a->images, w[0], F(w[1]), nullptr, nullptr, nullptr, act0, n, a->H, a->W, 1, s));     // relu(bn1(conv1(x))) straight to bf16
         }
     } else {
         if (dt != VTGB_F32)
@@ -277,7 +331,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
             d.conv_KH = 4; d.K = 4 * d.conv_Cin; d.ldw = d.K;
             if (x3) d.algo_flops = 2.0 * (double)M2 * 64 * 147;
             if (!inorm && !x3) { d.epi = VTGB_EPI_STORE; d.act = 1; d.out = act0; }        // relu(bn1(conv1(x))) straight to bf16
-            VTGB_TRY(launch_conv_gemm(d, s));
+            VTGB_TRY(conv_stats(d, stats));
             if (inorm || x3) VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, sf != nullptr));
         }
     }
@@ -313,13 +367,13 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
 #endif
         const bool c64 = c64_on && dt == VTGB_BF16 && g.C == 64 && g.Cpad == 64 && Cin_pad == 64 && g.stride == 1 && conv3x3_c64_supported(g.Ho, g.Wo);
         if (c64 && !inorm) {
-            VTGB_TRY(launch_conv3x3_c64(x, bw[0], F(bw[1]), nullptr, nullptr, t1, nullptr, n, g.Ho, g.Wo, 1, 0, s));      // y = relu(bn1(conv1(x)))
+            VTGB_TRY(launch_conv3x3_c64(x, bw[0], F(bw[1]), nullptr, nullptr, nullptr, t1, nullptr, n, g.Ho, g.Wo, 1, 0, s));      // y = relu(bn1(conv1(x)))
             outb = t2;
-            VTGB_TRY(launch_conv3x3_c64(t1, bw[2], F(bw[3]), nullptr, nullptr, outb, x, n, g.Ho, g.Wo, 1, 1, s));        // relu(x + relu(bn2(conv2(y))))
+            VTGB_TRY(launch_conv3x3_c64(t1, bw[2], F(bw[3]), nullptr, nullptr, nullptr, outb, x, n, g.Ho, g.Wo, 1, 1, s));        // relu(x + relu(bn2(conv2(y))))
         } else if (c64) {
-            VTGB_TRY(launch_conv3x3_c64(x, bw[0], F(bw[1]), cf, stats, nullptr, nullptr, n, g.Ho, g.Wo, 0, 0, s));
+            VTGB_TRY(launch_conv3x3_c64(x, bw[0], F(bw[1]), cf, stats, spart, nullptr, nullptr, n, g.Ho, g.Wo, 0, 0, s));
             VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t1, 1, 0, stats, true));                            // y = relu(norm1(conv1(x)))
-            VTGB_TRY(launch_conv3x3_c64(t1, bw[2], F(bw[3]), cf, stats, nullptr, nullptr, n, g.Ho, g.Wo, 0, 0, s));
+            VTGB_TRY(launch_conv3x3_c64(t1, bw[2], F(bw[3]), cf, stats, spart, nullptr, nullptr, n, g.Ho, g.Wo, 0, 0, s));
             outb = t1;
             VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, x, outb, 1, 1, stats, true));                                // relu(x + relu(norm2(conv2(y))))
         } else if (!inorm && !x3) {
@@ -334,14 +388,14 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
             VTGB_TRY(conv_bn(Mo, g, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), 1, res, 1, outb));             // relu(x + relu(bn2(conv2(y))))
         } else {
             float* sf = stats_for(stats, HWo, g.C);
-            VTGB_TRY(launch_conv_gemm(enc_conv(dt, (int)Mo, g.C, g.Ho, g.Wo, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), cf, g.Cpad, zero, sf), s));
+            VTGB_TRY(conv_stats(enc_conv(dt, (int)Mo, g.C, g.Ho, g.Wo, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), cf, g.Cpad, zero, sf), stats));
             VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t1, 1, 0, stats, sf != nullptr));  // y = relu(norm1(conv1(x)))
             sf = stats_for(stats, HWo, g.C);
-            VTGB_TRY(launch_conv_gemm(enc_conv(dt, (int)Mo, g.C, g.Ho, g.Wo, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), cf, g.Cpad, zero, sf), s));
+            VTGB_TRY(conv_stats(enc_conv(dt, (int)Mo, g.C, g.Ho, g.Wo, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), cf, g.Cpad, zero, sf), stats));
             const void* res = x;
             if (g.stride != 1) {                                                                      // x = norm3(downsample(x))
                 float* sf2 = stats_for(stats2, HWo, g.C);
-                VTGB_TRY(launch_conv_gemm(enc_conv(dt, (int)Mo, g.C, g.Ho, g.Wo, 1, Cin_pad, g.stride, Hi, Wi, x, bw[4], F(bw[5]), cf2, g.Cpad, zero, sf2), s));
+                VTGB_TRY(conv_stats(enc_conv(dt, (int)Mo, g.C, g.Ho, g.Wo, 1, Cin_pad, g.stride, Hi, Wi, x, bw[4], F(bw[5]), cf2, g.Cpad, zero, sf2), stats2));
                 VTGB_TRY(norm(cf2, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t2, 0, 0, stats2, sf2 != nullptr));
                 res = t2;
             }
