@@ -51,9 +51,12 @@ def pmc_traffic(family="gemm"):
     if not files:
         return None, None
     try:
-        ks = json.load(open(files[-1]))["kernels"]
+        import hashlib
+        raw = open(files[-1], "rb").read()
+        blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()      # = git hash-object: a stale or edited file is visible
+        ks = json.loads(raw)["kernels"]
         tot = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ks.values())
-        return int(tot / sum(v["launches"] for v in ks.values())), "profiles/" + os.path.basename(files[-1])
+        return int(tot / sum(v["launches"] for v in ks.values())), f"profiles/{os.path.basename(files[-1])} (git blob {blob[:12]})"
     except Exception:
         return None, None
 
@@ -185,8 +188,7 @@ def run_steps_overlapped(m, batches, steps, B, nframe, max_new_tokens, decoder, 
 def parity_probe(dev):
     """What the bf16 mode costs in accuracy, measured in THIS run on the tiny configuration of the golden fixtures (random seeded weights,
     12 flow frames, 8 candidate frames): the LLM prefix of the HIP bf16 path against the HIP fp32 exactness path (which the -m gpu suite
-    pins to the reference's fp32 tensors at <= 4e-6 of scale).  north_star asks for 1e-3 at bf16; the committed measurements against the
-    reference itself (tests/test_gpu_e2e.py / test_gpu_stages.py) are quoted next to the live number."""
+    pins to the reference's fp32 tensors at <= 4e-6 of scale).  Only numbers measured in this run are emitted."""
     from videotgb_amd import models, synth
     cfg = synth.tiny_cfg("instructblip")
     cfg.vit.image = 56
@@ -210,44 +212,44 @@ def parity_probe(dev):
     torch.cuda.synchronize()
     pf, pb = res["f32"][0], res["bf16"][0]
     lf, lb = res["f32"][1], res["bf16"][1]
-    return {"what": "tiny configuration, HIP bf16 vs HIP fp32 (fp32 is pinned to the reference at <= 4e-6 of scale by the -m gpu suite)",
+    return {"what": "tiny configuration, HIP bf16 vs HIP fp32, measured in this run (the -m gpu suite pins the fp32 mode to the reference's fp32 "
+                    "tensors; the reference-relative numbers live in the GPUTEST log and DESIGN.md section 2, not here)",
             "prefix_max_abs_diff": float((pb - pf).abs().max()), "prefix_scale": float(pf.abs().max()),
             "tgb_logits_max_abs_diff": float((lb - lf).abs().max()), "tgb_logits_scale": float(lf.abs().max()),
-            "frame_indices_equal": bool(torch.equal(res["f32"][2], res["bf16"][2])),
-            "north_star_bf16_1e-3": "met to 1.3-1.4e-3 on the tiny prefix / logits, NOT met at full depth (ViT-g 2.9e-2 abs on a 3.9 scale) -- the "
-                                    "reference's own bf16 autocast is 1.5e-3 / 2.9e-2 off its fp32 numbers on the same tensors; the tests bound "
-                                    "hip-bf16 by the reference's own bf16 error instead (DESIGN.md section 2)",
-            "committed_vs_reference": {"tiny_prefix_hip_bf16_vs_ref_fp32": 1.33e-3, "tiny_prefix_ref_bf16_vs_ref_fp32": 1.48e-3,
-                                       "full_vit_hip_bf16_vs_ref_fp32": 2.9e-2, "full_vit_ref_bf16_vs_ref_fp32": 2.9e-2,
-                                       "source": "tests/test_gpu_e2e.py, tests/test_gpu_stages.py (GPUTEST logs), DESIGN.md section 2"}}
+            "frame_indices_equal": bool(torch.equal(res["f32"][2], res["bf16"][2]))}
 
 
-def cpu_baseline(cfg, T, nframe, seed_sd, inline_raft=True, raft_pairs=4):
-    """Oracle (port of the reference's CPU path) on one clip, fp32: RAFT on a bounded sample of `raft_pairs` of the
-    clip's T-1 frame pairs (20 iterations each, extrapolated to T-1 pairs), then TGB -> select -> gather -> ViT-g ->
-    Q-Former -> mean-pool + projection on the whole clip.  The 7B LLM decode is left out of the sample (27 GB of
-    fp32 weights; third-party arithmetic on both sides)."""
+def cpu_baseline(cfg, T, nframe, seed_sd, inline_raft=True, raft_frames=None):
+    """Oracle (port of the reference's CPU path) on one clip, fp32: RAFT on a bounded sample of the clip's T-1 frame pairs -- the first
+    len(raft_frames) - 1 pairs of the SAME randn frames the GPU leg's first clip holds (20 iterations each, extrapolated to T-1 pairs) --
+    then TGB -> select -> gather -> ViT-g -> Q-Former -> mean-pool + projection on the whole clip.  The 7B LLM decode is left out of the
+    sample (27 GB of fp32 weights; third-party arithmetic on both sides).  Per-stage seconds are reported."""
     from oracle import vtgb_oracle as O
     from videotgb_amd import synth
     cores = torch.get_num_threads()
     clip = synth.synth_clip(0, T)
-    t_raft, raft_note = 0.0, "precomputed flow"
+    t_raft, raft_note, stages = 0.0, "precomputed flow", {}
     with torch.no_grad():
         if inline_raft:
-            g = torch.Generator().manual_seed(1)
-            fr = torch.randint(0, 256, (raft_pairs + 1, 3, 224, 224), generator=g).float()
+            fr = raft_frames.float()
+            raft_pairs = fr.shape[0] - 1
             t0 = time.time()
             O.raft_forward(seed_sd, "of_extractor.", fr[:-1], fr[1:], iters=20)
-            t_pair = (time.time() - t0) / raft_pairs
+            t_meas = time.time() - t0
+            t_pair = t_meas / raft_pairs
             t_raft = t_pair * (T - 1)
-            raft_note = f"RAFT on {raft_pairs} of {T - 1} frame pairs ({t_pair:.2f} s per pair, extrapolated to {t_raft:.1f} s)"
+            stages["raft_measured_s"] = round(t_meas, 2)
+            stages["raft_extrapolated_s"] = round(t_raft, 1)
+            raft_note = (f"RAFT on the first {raft_pairs} of the {T - 1} frame pairs of the GPU leg's first clip (randn frames; {t_meas:.1f} s measured, "
+                         f"{t_pair:.2f} s per pair, extrapolated to {t_raft:.1f} s)")
         t0 = time.time()
         O.lstp_prefix(seed_sd, arch="instructblip", frames=clip["frames"], nframe=nframe, sampler_ids=clip["sampler_ids"],
                       sampler_mask=clip["sampler_mask"], noise=clip["noise"], vit_heads=cfg.vit.heads,
                       qf_heads=cfg.qformer.heads, tgb_heads=cfg.tgb.heads, fusion_layer=cfg.tgb.fusion_layer, of=clip["of"],
                       qformer_ids=clip["qformer_ids"], qformer_mask=clip["qformer_mask"])
         dt = time.time() - t0
-    return {"value": round(1.0 / (dt + t_raft), 4), "unit": "clips/s", "cores": cores, "kind": "port",
+        stages["tgb_select_vit_qformer_projection_s"] = round(dt, 2)
+    return {"value": round(1.0 / (dt + t_raft), 4), "unit": "clips/s", "cores": cores, "kind": "port", "stages_s": stages,
             "sample": f"1 clip (T={T}->{nframe} of 32 frames): {raft_note}; TGB+select+gather+ViT-g+Q-Former+projection "
                       f"in fp32 on {cores} host threads, {dt:.1f} s; LLM decode excluded"}
 
@@ -267,16 +269,25 @@ def spawn_ranks(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def timed_steps(fn, steps, barrier, dev, world):
-    """K calls of fn(i) bracketed by barrier + synchronize on both sides; returns the MAX over ranks of the wall time."""
+def timed_steps(fn, steps, barrier, dev, world, per_rank=None):
+    """K calls of fn(i) bracketed by barrier + synchronize on both sides; returns the MAX over ranks of the wall time.  per_rank (a list):
+    receives every rank's own time to ITS last kernel (synchronize, before the closing barrier) -- stragglers show next to the MAX."""
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         fn(i)
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0
     barrier()
     t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if per_rank is not None:
+            g = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(dist.get_world_size())]
+            dist.all_gather(g, torch.tensor([own], device=dev, dtype=torch.float64))
+            per_rank[:] = [float(x.item()) for x in g]
+    elif per_rank is not None:
+        per_rank[:] = [own]
     return float(t.item())
 
 
@@ -355,6 +366,7 @@ def main():
     # streams the 13.5 GB of LLM weights once per token whatever the batch: 3.4 ms per clip at 32 clips, 1.6 at 124)
     B, T, nframe = (args.clips or (124 if args.flow == "raft" else 62)), args.T, args.nframe
     batches = [synth_batch(rank, i, B, T, args.flow, dev, cfg) for i in range(2)]
+    cpu_frames = batches[0]["flow_frames"][0, :17].cpu() if args.flow == "raft" else None      # cpu_baseline: 16 pairs of the GPU leg's first clip
     torch.cuda.synchronize()
     if rank == 0:
         print(f"[bench] setup {time.time() - t_setup:.1f}s, world={world}, clips/step/gpu={B}, flow={args.flow}", file=sys.stderr)
@@ -373,21 +385,21 @@ def main():
         run_step(m, batches[i % 2], B, nframe, args.max_new_tokens, None, decoder)
     # ---- the timed region: K steps, per-launch event recording OFF (it would add two hipEventRecord per GEMM launch)
     L.vtgb_prof_enable(0)
-    stage_ev = []
+    stage_ev, rank_times = [], []
     overlap = args.overlap and not args.stage_times
     side = torch.cuda.Stream(priority=-1) if overlap else None   # decode stream: high priority, short memory-bound kernels
     if overlap:   # one untimed overlapped pass so that both streams have their handles / graph ready
         run_steps_overlapped(m, batches, 2, B, nframe, args.max_new_tokens, decoder, side)
     if overlap:
         elapsed = timed_steps(lambda i: run_steps_overlapped(m, batches, args.steps, B, nframe, args.max_new_tokens, decoder, side) if i == 0 else None,
-                              1, barrier, dev, world)
+                              1, barrier, dev, world, rank_times)
     else:
         def one(i):
             ev = [] if args.stage_times else None
             run_step(m, batches[i % 2], B, nframe, args.max_new_tokens, ev, decoder)
             if ev:
                 stage_ev.append(ev)
-        elapsed = timed_steps(one, args.steps, barrier, dev, world)
+        elapsed = timed_steps(one, args.steps, barrier, dev, world, rank_times)
     total_clips = B * args.steps * world
     value = total_clips / elapsed
 
@@ -453,7 +465,26 @@ def main():
         del batches
         torch.cuda.empty_cache()
 
-        def leg(name, Bn, flow, steps, note, raft_dtype=None, tokens=None, T_leg=None, raft_clips=None):
+        def conv_roofline(run, steps=1):
+            """conv-family roofline of `steps` untimed passes (HIP events per launch, as in the headline's roofline pass)"""
+            L.vtgb_prof_reset()
+            L.vtgb_prof_enable(1)
+            for i in range(steps):
+                run(i)
+            torch.cuda.synchronize()
+            L.vtgb_prof_enable(0)
+            n, ms, fl = _lib.prof_summary(2)
+            if not n or ms <= 0:
+                return None
+            ex = _lib.prof_executed_flops(2)
+            return {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel<EPI,true,NWN> / gemm_bf16_large_kernel<EPI,0,true>: implicit-GEMM convolutions of RAFT",
+                    "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "executed_tflops": round(ex / (ms * 1e-3) / 1e12, 2),
+                    "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "ms_per_step": round(ms / steps, 3), "gflop_per_step": round(fl / steps / 1e9, 1),
+                    "flops_note": "achieved = ALGORITHMIC FLOPs (the fp32 convolutions the reference computes) / launch time; executed_tflops = the bf16 MFMA "
+                                  "work the launches execute (bf16x3: three products per fp32 product)"}
+
+        def leg(name, Bn, flow, steps, note, raft_dtype=None, tokens=None, T_leg=None, raft_clips=None, roof=False):
             if raft_dtype:
                 m.of_extractor.set_compute_dtype(raft_dtype)
             if raft_clips:
@@ -463,11 +494,14 @@ def main():
             for i in range(2):
                 run_step(m, bs[i % 2], Bn, nframe, ntok, None, decoder)
             el = timed_steps(lambda i: run_step(m, bs[i % 2], Bn, nframe, ntok, None, decoder), steps, barrier, dev, world)
+            rf = conv_roofline(lambda i: run_step(m, bs[i % 2], Bn, nframe, ntok, None, decoder)) if roof else None
             if raft_dtype:
                 m.of_extractor.set_compute_dtype(args.raft_dtype)
             m.flow_clips_per_call = args.raft_clips
             legs[name] = {"what": note, "clips_per_gpu_per_step": Bn, "steps": steps, "value": round(Bn * steps * world / el, 3),
                           "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 2)}
+            if rf:
+                legs[name]["roofline"] = rf
             del bs
             torch.cuda.empty_cache()
         # the same path with the flow precomputed (the training-time / LightningModule contract): RAFT is the only stage left out
@@ -477,8 +511,14 @@ def main():
                                        "latency of one clip")
         legs["single_clip"]["latency_ms_per_clip"] = legs["single_clip"]["ms_per_step"]
         if args.raft_dtype == "bf16":
-            leg("raft_fp32_exactness", 8, "raft", 1, "the headline path with RAFT in the fp32 exactness mode (the reference's RAFT arithmetic; "
-                                                     "tests/test_gpu_selection.py: the selected frames are identical for 64/64 clips at T=96)", raft_dtype="f32")
+            # RAFT at the reference's accuracy (the reference's RAFT is fp32 under every Lightning precision: xraft.py:58,113-118)
+            leg("raft_bf16x3", B, "raft", 3, "the headline path, same batch, with RAFT in the bf16x3 mode: split-bf16 operands (hi | lo pairs), three bf16 MFMA "
+                                             "products per fp32 product, fp32 accumulation / gates / flow / correlation pyramid -- the reference's fp32 "
+                                             "accuracy on the matrix cores (tests/test_gpu_raft.py: flows within 1e-4 rel-RMS of the reference's, input-sensitive "
+                                             "weights, 224 x 224; tests/test_gpu_selection.py: TGB logits within 4e-4 of their range and the same frames for "
+                                             "64/64 clips at T=96 and T=256)", raft_dtype="bf16x3", roof=True)
+            leg("raft_fp32_exactness", 8, "raft", 3, "the headline path with RAFT in the fp32 exactness mode (fp32 FMAs in the reference's summation order: the "
+                                                     "mode whose flows the -m gpu suite pins to the reference at <= 4e-6)", raft_dtype="f32")
         # BASELINE configs[3] (C4): the long-video shape, per GPU (the 8 GPUs shard clips with no collective)
         leg("c4_t256", 24, "raft", 2, "BASELINE configs[3]: InstructBLIP-Vicuna-7B + TGB, ActivityNet long-video shape T=256->8, per GPU (clip-parallel, no "
                                      "collective); RAFT on 255 frame pairs per clip, 12 clips per RAFT batch", T_leg=256, raft_clips=12)
@@ -489,13 +529,16 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"InstructBLIP-Vicuna-7B + TGB, T={T}->{nframe} of 32 frames, 224x224, greedy {args.max_new_tokens} new tokens "
                                       f"(BASELINE.json configs[2])", "flow": args.flow if args.flow == "precomputed" else (
-                              f"raft inline, all HIP ({'bf16 MFMA convolutions, fp32 state / accumulation' if args.raft_dtype == 'bf16' else 'fp32 exactness mode'}), "
+                              f"raft inline, all HIP ({ {'bf16': 'bf16 MFMA convolutions, fp32 state / accumulation', 'bf16x3': 'bf16x3: split-bf16 operands, fp32 accuracy on the MFMA', 'f32': 'fp32 exactness mode'}[args.raft_dtype]}), "
                               f"{args.raft_clips} clips per RAFT batch"),
                           "clips_per_gpu_per_step": B, "inputs": "resident in HBM when the timed region starts",
                           "global_batch": B * world, "parallelism": f"clip-parallel x{world} (no data-path collective)",
                           "llm": f"HF LlamaForCausalLM {args.llm} geometry, random init, KV cache, decode={args.decode}, no EOS stop (fixed work)",
                           "streams": "2 (prefix of batch i+1 over LLM decode of batch i)" if overlap else "1", "weights": "seeded N(0,0.02) random init"},
                "roofline": roofline}
+        out["per_rank_ms_per_step"] = [round(t / args.steps * 1e3, 2) for t in rank_times]      # each rank's own time to its last kernel
+        out["ranks"] = {"world_size": world, "backend": (dist.get_backend() + " (RCCL)") if use_dist else None,
+                        "comm_nranks": dist.get_world_size() if use_dist else 1}
         if vit_util is not None:
             out["vit_util"] = vit_util      # ViT-g FLOPs of the step / ViT stage time / dense bf16 peak (target >= 0.55)
             out["stages_ms"] = stages_ms    # one untimed step with an event per stage boundary (the first stage, RAFT, = ms_per_step - the rest)
@@ -504,10 +547,12 @@ def main():
         if legs:
             out["precomputed_flow"] = legs.pop("precomputed_flow", None)
             out["latency_ms_per_clip"] = legs["single_clip"]["latency_ms_per_clip"]
+            if "raft_bf16x3" in legs:
+                out["raft_fp32_accuracy"] = legs.pop("raft_bf16x3")      # first-class: the like-for-like number (RAFT at the reference's accuracy)
             out["companions"] = legs
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(cfg, T, nframe, sd, inline_raft=(args.flow == "raft"))
+            out["cpu_baseline"] = cpu_baseline(cfg, T, nframe, sd, inline_raft=(args.flow == "raft"), raft_frames=cpu_frames)
         # RCCL prints its version banner through C stdio, which (on a pipe) is flushed at exit -- AFTER Python's line: flush the
         # C buffers first so that the JSON line is the LAST line of stdout under multi-rank launches too
         try:

@@ -126,6 +126,70 @@ def test_flat_bucket_launches_segments_in_index_order_on_every_rank():
     assert n0 == n1 and n0 > 2 and o0 == o1 == list(range(n0))           # same sequence on both ranks, every segment exactly once
 
 
+def _ragged_worker(rank, world, port, q):
+    """world = 4, 5 clips: chunks of ceil(5 / 4) = 2 -> ranks 0, 1 hold 2 clips, rank 2 one, rank 3 NONE (get_chunk past the end).  Rank 3 runs no
+    forward / backward at all -- every segment of its bucket is still empty when all_reduce() is called -- and rank 2's single clip skips the last
+    layer (its last segment stays empty): both must issue the same collective sequence as the ranks whose hooks fired."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from videotgb_amd import dist as vd
+    clips = list(range(5))
+    mine = list(vd.get_chunk(clips, world, rank))
+    merged = vd.gather_results([(c, 10 * c) for c in mine])
+    torch.manual_seed(0)
+    make = lambda: torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 4))
+    net = make()
+    bucket = vd.FlatGradBucket(net.parameters(), segment_bytes=128)
+    order = []
+    orig = bucket._launch
+    bucket._launch = lambda si: (order.append(si), orig(si))[1]
+
+    def loss_of(model, r_, chunk):
+        if not chunk:
+            return None
+        x = torch.stack([torch.full((8,), float(c + 1)) for c in chunk])
+        return (model[1](model[0](x)) if r_ == 2 else model(x)).sum()
+    bucket.zero_()
+    bucket.arm(average=True)
+    l = loss_of(net, rank, mine)
+    if l is not None:
+        l.backward()
+    bucket.all_reduce(average=True)
+    ref = [torch.zeros_like(p) for p in net.parameters()]
+    for r_ in range(world):
+        n2 = make()
+        n2.load_state_dict(net.state_dict())
+        l2 = loss_of(n2, r_, list(vd.get_chunk(clips, world, r_)))
+        if l2 is not None:
+            l2.backward()
+        for g, p in zip(ref, n2.parameters()):
+            if p.grad is not None:
+                g += p.grad / world
+    ok = all(torch.allclose(p.grad, g, rtol=1e-6, atol=1e-6) for p, g in zip(net.parameters(), ref))
+    q.put((rank, mine, merged, ok, order, len(bucket.segments)))
+    dist.destroy_process_group()
+
+
+def test_four_ranks_ragged_clip_counts_and_empty_segments():
+    """SCALE readiness without hardware: 4 gloo ranks, more ranks than full chunks, a rank with nothing to do."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert [o[1] for o in out] == [[0, 1], [2, 3], [4], []]
+    n_seg = out[0][5]
+    for rank, mine, merged, ok, order, ns in out:
+        assert merged == [(c, 10 * c) for c in range(5)]                 # rank-order merge, the empty rank contributes nothing
+        assert ok                                                        # mean over the 4 ranks, zeros from the idle rank / the skipped layer
+        assert ns == n_seg and order == list(range(n_seg))               # the same collective sequence on every rank, each segment once
+
+
 def test_flat_bucket_rejects_non_fp32_parameters_and_disagreeing_average():
     from videotgb_amd import dist as vd
     lin = torch.nn.Linear(4, 4).to(torch.bfloat16)

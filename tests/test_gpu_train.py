@@ -416,3 +416,34 @@ def test_training_graph_issues_no_blas_and_no_torch_layernorm_kernel(dev, tiny_s
         assert any("ln_train_fwd_kernel" in n for n in names) and any("ln_train_bwd_kernel" in n for n in names) and any("gelu_bwd_kernel" in n for n in names)
         bad = [n for n in names if "Cijk_" in n or "layer_norm" in n.lower() or "GeluCUDAKernel" in n or "GeluBackward" in n]
         assert not bad, bad
+
+
+def test_training_ops_accept_what_the_torch_ops_accepted(dev):
+    """a row-broadcast gradient (strides (0, 1): a batch-1 linear output that was mean-reduced), empty inputs (a rank whose clips
+    all have width 0: dist.py) -- F.linear / F.layer_norm / torch.sum took them, so do the library-backed ops."""
+    from videotgb_amd import train
+    from videotgb_amd._lib import BF16, F32
+    g = torch.Generator(device=dev).manual_seed(3)
+    row = torch.randn(1, 24, generator=g, device=dev)
+    bc = row.expand(7, 24)                                           # strides (0, 1)
+    assert torch.allclose(train.col_sum(bc), bc.sum(0), rtol=1e-6, atol=1e-6)
+    assert torch.equal(train.col_sum(torch.empty(0, 24, device=dev)), torch.zeros(24, device=dev))
+    w = torch.randn(16, 24, generator=g, device=dev, requires_grad=True)
+    b = torch.randn(16, generator=g, device=dev, requires_grad=True)
+    for code in (F32, BF16):
+        x = torch.randn(1, 24, generator=g, device=dev, requires_grad=True)
+        y = train._HipLinear.apply(x, w, b, code)
+        y.mean().backward()                                          # dY is a broadcast of one value: strides (0, 0)
+        assert torch.isfinite(x.grad).all() and torch.allclose(b.grad, torch.full_like(b, 1.0 / 16), rtol=1e-5, atol=1e-6)
+        w.grad = b.grad = None
+        e = train._HipLinear.apply(torch.empty(0, 24, device=dev, requires_grad=True), w, b, code)      # widths = [0, 0]: no rows at all
+        assert tuple(e.shape) == (0, 16)
+        e.sum().backward()
+        assert torch.equal(w.grad, torch.zeros_like(w)) and torch.equal(b.grad, torch.zeros_like(b))
+        w.grad = b.grad = None
+    gam = torch.ones(24, device=dev, requires_grad=True)
+    bet = torch.zeros(24, device=dev, requires_grad=True)
+    z = train.layer_norm(torch.empty(0, 24, device=dev), gam, bet, 1e-12)
+    assert tuple(z.shape) == (0, 24)
+    z.sum().backward()
+    assert torch.equal(gam.grad, torch.zeros_like(gam))

@@ -282,6 +282,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
             return launch_x3_pair_pass(x, ldx, inorm ? st : nullptr, HW, resid, 2 * Cpad, Cpad, out, 2 * Cpad, Cpad, C, Cpad, relu_in, relu_out, M, s);
         VTGB_REQUIRE(Cpad == 64 || Cpad == 128, VTGB_EUNSUPPORTED, "raft_encoder: normalisation pass over %d padded channels", Cpad);
         const int ppb = 256 / (Cpad / 4);
+        VTGB_REQUIRE(M / HW <= 65535, VTGB_EUNSUPPORTED, "raft_encoder: %lld images per call exceed the normalisation pass's grid (chunk the images)", (long long)(M / HW));
         const dim3 grid((unsigned)((HW + NA_PASS * ppb - 1) / (NA_PASS * ppb)), (unsigned)(M / HW));
         if (dt == VTGB_BF16)
             hipLaunchKernelGGL(norm_apply_kernel<bf16_t>, grid, dim3(256), 0, s, x, inorm ? st : nullptr, (const bf16_t*)resid, (bf16_t*)out, HW, C, Cpad, ldx,

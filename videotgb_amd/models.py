@@ -317,7 +317,9 @@ class Raft(nn.Module):
         (InputPadder) -> flow_up [N, 2, H, W]; ``test_mode=False``: the list of every iteration's upsampled flow (:146-156; `upsample`
         is as unused as in the reference).  The update kernel keeps only the last iteration's mask head, so the per-iteration list
         re-runs the recurrence with 1, 2, ... iters iterations (identical states: iteration i never sees a later one) -- RAFT is
-        frozen in every module of the path, so this form exists for interface parity, not speed."""
+        frozen in every module of the path, so this form exists for interface parity, not speed.
+        COST of ``test_mode=False``: iters * (iters + 1) / 2 update iterations (210 for iters = 20) plus iters mask-head / upsample
+        passes, i.e. ~10 x the test-mode call; nothing on the inference or training path uses it."""
         upd, fw, cw = self._hip_tables()
         n, _, h, w = image1.shape
         h8, w8 = h // 8, w // 8

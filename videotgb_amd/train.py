@@ -112,6 +112,11 @@ def gemm_train(a: Tensor, a_kmajor: bool, b: Tensor, b_kmajor: bool, bias: Optio
     if K != Kb:
         raise ValueError(f"gemm_train: contraction lengths differ ({K} and {Kb})")
     bias = None if bias is None else bias.float().contiguous()
+    if M == 0 or N == 0:
+        return torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if K == 0:
+        z = torch.zeros(M, N, dtype=torch.float32, device=a.device)
+        return z if bias is None else z + bias
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     g = L.GemmTrainArgs(code, M, N, K, a.data_ptr(), a.stride(0), dtype_code(a.dtype), int(a_kmajor), b.data_ptr(), b.stride(0),
                         dtype_code(b.dtype), int(b_kmajor), None if bias is None else bias.data_ptr(), out.data_ptr(), out.stride(0), None, 0)
@@ -128,7 +133,9 @@ def col_sum(x: Tensor) -> Tensor:
     """Column sums of an fp32 matrix in a fixed order (vtgb_col_sum_f32): the bias gradient of a linear layer."""
     _need_cuda(x)
     x = x.float()
-    if x.stride(1) != 1:
+    if x.shape[0] == 0 or x.shape[1] == 0:          # (a rank whose clips all have width 0: torch's sum accepted it)
+        return torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    if x.stride(1) != 1 or x.stride(0) < x.shape[1]:      # a row-broadcast gradient (strides (0, 1)) is not a matrix the kernel can address
         x = x.contiguous()
     out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
     part = torch.empty(L.lib().vtgb_col_sum_parts(x.shape[0]), x.shape[1], dtype=torch.float32, device=x.device)
@@ -227,6 +234,8 @@ class _HipGelu(torch.autograd.Function):
 
 
 def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, resid: Optional[Tensor] = None, mask: Optional[Tensor] = None) -> Tensor:
+    if x.numel() == 0:      # no rows (F.layer_norm accepted them): nothing to normalise; keeps the graph connected with zero gradients
+        return x + 0.0 * (gamma.sum() + beta.sum())
     return _HipLayerNorm.apply(x, resid, mask, gamma, beta, eps)
 
 
