@@ -19,12 +19,12 @@
 
 // Store 4 consecutive n (n0..n0+3) of logical row m.  TAct is the activation type of
 // EPI_STORE / EPI_GELU outputs.
-template <int EPI, typename TAct, bool FAST_GELU = false>
+template <int EPI, typename TAct, bool FAST_GELU = false, bool ADD_BIAS = true>
 __device__ __forceinline__ void epilogue4(const GemmDesc& p, int m, int n0, float v0, float v1, float v2, float v3) {
     if (m >= p.M || n0 >= p.N) return;
     float v[4] = {v0, v1, v2, v3};
     const bool full = (n0 + 3 < p.N);
-    if (p.bias) {
+    if (ADD_BIAS && p.bias) {
         if (full) {
             const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
             v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -118,11 +118,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmDesc p) {
     *reinterpret_cast<uint4*>(Ws + (buf) * TILE_BYTES + lds_off##i) = RW;
 #define STAGE_WRITE(buf) STAGE_WRITE1(0, ra0, rw0, buf) STAGE_WRITE1(1, ra1, rw1, buf) STAGE_WRITE1(2, ra2, rw2, buf) STAGE_WRITE1(3, ra3, rw3, buf)
 
+    // the accumulators START at the bias, as in the large kernels (r5): bias + sum_k, then the residual -- the same association whichever
+    // kernel the problem size selects, so a row's result does not depend on how many rows the call holds (tests/test_gpu_scale.py)
     f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 4; i++) {
+        const int nb = n0 + (wave >> 1) * 64 + i * 16 + (lane >> 4) * 4;
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int e = 0; e < 4; e++) if (nb + e < p.N) b4[e] = p.bias[nb + e];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = b4;
+    }
 
     const int nk = (p.K + BK - 1) / BK;
     STAGE_LOAD(0)
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmDesc p) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int n = n0 + wn * 64 + i * 16 + fg * 4;
-            epilogue4<EPI, bf16_t, true>(p, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            epilogue4<EPI, bf16_t, true, false>(p, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
     }
 }
