@@ -199,6 +199,14 @@ struct GemmDesc {
 };
 #define VTGB_EPI_GRU 4
 #define VTGB_EPI_SPLIT 5
+// bf16x3 SepConvGRU epilogues (raft_x3.hip; persistent kernel only):
+// X3ZR (N = 256: z | r): v = acc + resid[m][n] (fp32 start map: the loop-invariant `inp` third + bias, ldr); columns [0, 128): out[m][n] (fp32, ldo) =
+//   sigmoid(v); columns [128, 256): out2[m][n - 128] (bf16 pair, ldo2, lo at + split_lo) = sigmoid(v) * h, h = aux[m][n - 128] + aux[m][n - 128 + split_lo]
+//   (bf16 pair, ldaux)
+// X3Q (N = 128): q = tanh(acc + resid[m][n]); z = aux[m][n] (fp32, ldaux); h = out[m][n] + out[m][n + split_lo] (bf16 pair, ldo);
+//   out <- (1 - z) h + z q as a pair, in place
+#define VTGB_EPI_X3ZR 6
+#define VTGB_EPI_X3Q 7
 int launch_gemm(const GemmDesc& d, hipStream_t s);
 int launch_conv_gemm(const GemmDesc& d, hipStream_t s);   // large kernel forced: implicit conv / activations / GRU
 

@@ -1212,6 +1212,12 @@ int launch_conv_gemm(const GemmDesc& d_in, hipStream_t s) {
             VTGB_REQUIRE(conv && d.resid && d.aux && d.out2, VTGB_EINVAL, "conv gemm: GRU epilogue needs h, z and both outputs");
             return launch_large_forced<EPI_GRU, true>(d, s);
         case EPI_SPLIT: return launch_split(d, s);
+        case EPI_X3ZR:
+            VTGB_REQUIRE(conv && pp_supported(d), VTGB_EUNSUPPORTED, "conv gemm: the bf16x3 z | r gate epilogue needs a 256-channel convolution with its start map, h and both outputs");
+            return launch_large_pp<EPI_X3ZR, true, 4>(d, s);
+        case EPI_X3Q:
+            VTGB_REQUIRE(conv && pp_supported(d), VTGB_EUNSUPPORTED, "conv gemm: the bf16x3 GRU update epilogue needs a 128-channel convolution with its start map and z");
+            return launch_large_pp<EPI_X3Q, true, 2>(d, s);
     }
     vtgb_set_error("conv gemm: unsupported epilogue %d", d.epi);
     return VTGB_EINVAL;

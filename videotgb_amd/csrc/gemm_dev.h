@@ -3,7 +3,7 @@
 #include "common.h"
 
 enum { EPI_STORE = VTGB_EPI_STORE, EPI_GELU = VTGB_EPI_GELU, EPI_RESID_F32 = VTGB_EPI_RESID_F32,
-       EPI_STORE_F32 = VTGB_EPI_STORE_F32, EPI_GRU = VTGB_EPI_GRU, EPI_SPLIT = VTGB_EPI_SPLIT };
+       EPI_STORE_F32 = VTGB_EPI_STORE_F32, EPI_GRU = VTGB_EPI_GRU, EPI_SPLIT = VTGB_EPI_SPLIT, EPI_X3ZR = VTGB_EPI_X3ZR, EPI_X3Q = VTGB_EPI_X3Q };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

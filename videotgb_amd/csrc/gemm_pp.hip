@@ -721,6 +721,103 @@ gelu_erf_fast4(v);
                 }
             }
         }
+        if constexpr (EPI == EPI_X3ZR || EPI == EPI_X3Q) {
+            // bf16x3 SepConvGRU gates in the convolution's epilogue (common.h): the accumulators go through the staging region as fp32, passes of 32
+            // rows in two sub-passes of 16; a lane holds four columns of four rows per sub-pass.  The operands (start map, h pair, z) of sub-pass
+            // s + 1 are requested after sub-pass s has consumed its own and before its stores; every wait is counted (the next tile's pieces /
+            // the previous sub-pass's stores stay in flight).  X3ZR: waves 0-3 hold z columns, waves 4-7 r columns (wave-uniform roles).
+            constexpr bool ZR = EPI == EPI_X3ZR;
+            constexpr int PR = SB / 256 < WROWS ? SB / 256 : WROWS, NP = WROWS / PR, NS = NP * (PR / 16);
+            static_assert(PR == 32, "two sub-passes of 16 rows per staged pass");
+            const int rl = lane_e >> 4, cl = lane_e & 15;
+            const int n = en0 + wn * 64 + cl * 4;
+            const bool is_r = ZR && n >= 128;                      // wave-uniform
+            const int c = is_r ? n - 128 : n;
+            const int rowl = wm * WROWS + rl;
+            const unsigned lo_b = (unsigned)p.split_lo * 2u;
+            const auto m_rs = tile_rsrc(p.resid, p.ldr, 4);                                      // fp32 start map
+            const auto h_rs = ZR ? tile_rsrc(p.aux, p.ldaux, 2) : tile_rsrc(p.out, p.ldo, 2);     // h pair
+            const auto z_rs = ZR ? tile_rsrc(p.out, p.ldo, 4) : tile_rsrc(p.aux, p.ldaux, 4);     // z fp32 (X3ZR: written; X3Q: read)
+            const auto o_rs = ZR ? tile_rsrc(p.out2, p.ldo2, 2) : tile_rsrc(p.out, p.ldo, 2);     // pair output (r h | h')
+            const int ld_h = ZR ? (int)p.ldaux : (int)p.ldo, ld_z = ZR ? (int)p.ldo : (int)p.ldaux, ld_o = ZR ? (int)p.ldo2 : (int)p.ldo;
+            const bool ok = n < p.N;
+            const unsigned m_lane = ok ? (unsigned)(rowl * (int)p.ldr + n) * 4u : OOB, h_lane = ok ? (unsigned)(rowl * ld_h + c) * 2u : OOB;
+            const unsigned z_lane = ok ? (unsigned)(rowl * ld_z + c) * 4u : OOB, o_lane = ok ? (unsigned)(rowl * ld_o + c) * 2u : OOB;
+            u32x4_t mq[4], zq[4];
+            u32x2_t hh[4], hl[4];
+#define P_X3_LOAD(sp)                                                                                                  \
+    _Pragma("unroll") for (int rr = 0; rr < 4; rr++) {                                                                 \
+        const int r0_ = (sp) * 16 + rr * 4;                                                                            \
+        mq[rr] = __builtin_amdgcn_raw_buffer_load_b128(m_rs, m_lane, r0_ * (int)p.ldr * 4, 0);                          \
+        if (!ZR) zq[rr] = __builtin_amdgcn_raw_buffer_load_b128(z_rs, z_lane, r0_ * ld_z * 4, 0);                        \
+        if (!ZR || is_r) {                                                                                             \
+            hh[rr] = __builtin_amdgcn_raw_buffer_load_b64(h_rs, h_lane, r0_ * ld_h * 2, 0);                             \
+            hl[rr] = __builtin_amdgcn_raw_buffer_load_b64(h_rs, h_lane + lo_b, r0_ * ld_h * 2, 0);                      \
+        }                                                                                                              \
+    }
+            P_X3_LOAD(0)
+            prefetch();
+#pragma unroll
+            for (int ps = 0; ps < NP; ps++) {
+#pragma unroll
+                for (int jj = 0; jj < PR / 16; jj++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int row = jj * 16 + (lane_e & 15), chunk = i * 4 + (lane_e >> 4);
+                        *reinterpret_cast<f32x4*>(stage + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][ps * (PR / 16) + jj];
+                    }
+#pragma unroll
+                for (int sub = 0; sub < 2; sub++) {
+                    const int sp = ps * 2 + sub;
+                    if (sp == 0) { P_WAIT_OPERANDS() }
+                    else if (!ZR || is_r) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);     // the previous sub-pass's 8 stores may still fly
+                    else __builtin_amdgcn_s_waitcnt(0x0F70 | 4);                     // (z waves: 4 stores)
+                    f32x4 res[4];
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        const int row = sub * 16 + rr * 4 + rl;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 256 + ((cl ^ (row & 15)) << 4));
+                        v += __builtin_bit_cast(f32x4, mq[rr]);
+                        if constexpr (ZR) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) v[e] = __frcp_rn(1.0f + __expf(-v[e]));
+                            if (is_r) {
+                                const bf16x4 a = __builtin_bit_cast(bf16x4, hh[rr]), b = __builtin_bit_cast(bf16x4, hl[rr]);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) v[e] *= (float)a[e] + (float)b[e];
+                            }
+                        } else {
+                            const f32x4 z = __builtin_bit_cast(f32x4, zq[rr]);
+                            const bf16x4 a = __builtin_bit_cast(bf16x4, hh[rr]), b = __builtin_bit_cast(bf16x4, hl[rr]);
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float q = 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v[e]) + 1.0f);
+                                v[e] = (1.0f - z[e]) * ((float)a[e] + (float)b[e]) + z[e] * q;
+                            }
+                        }
+                        res[rr] = v;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (sp + 1 < NS) { P_X3_LOAD(sp + 1) }       // the next sub-pass's operands (same registers), before this sub-pass's stores
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        const unsigned r0 = (unsigned)(sp * 16 + rr * 4);
+                        if (ZR && !is_r) {
+                            P_STORE128(__builtin_bit_cast(u32x4_t, res[rr]), z_rs, z_lane, r0 * (unsigned)ld_z * 4u);
+                        } else {
+                            const f32x4 v = res[rr];
+                            const f32x4 hf = {bf16_round(v[0]), bf16_round(v[1]), bf16_round(v[2]), bf16_round(v[3])};
+                            const bf16x4 hi = {(bf16_t)hf[0], (bf16_t)hf[1], (bf16_t)hf[2], (bf16_t)hf[3]};
+                            const bf16x4 lo = {(bf16_t)(v[0] - hf[0]), (bf16_t)(v[1] - hf[1]), (bf16_t)(v[2] - hf[2]), (bf16_t)(v[3] - hf[3])};
+                            P_STORE64(__builtin_bit_cast(u32x2_t, hi), o_rs, o_lane, r0 * (unsigned)ld_o * 2u);
+                            P_STORE64(__builtin_bit_cast(u32x2_t, lo), o_rs, o_lane + lo_b, r0 * (unsigned)ld_o * 2u);
+                        }
+                    }
+                }
+            }
+#undef P_X3_LOAD
+        }
         if constexpr (EPI == EPI_GRU) {
             // h' = (1 - z) h + z tanh(acc): the accumulators go through the staging region as in the fp32 path so that h, z and both
             // outputs are touched as whole row segments.  h / z of pass h+1 are requested before pass h's stores (two register sets),
@@ -823,6 +920,10 @@ bool pp_supported(const GemmDesc& d) {
             return (d.ldo & 3) == 0 && d.act == 0 && d.out_scale == 0.f;
         case EPI_GRU:
             return ((d.ldo | d.ldr | d.ldaux | d.ldo2) & 3) == 0 && d.N <= 128;      // (RAFT's q convolutions: 128 channels)
+        case EPI_X3ZR:
+            return d.N == 256 && d.conv_KH > 0 && d.resid && d.aux && d.out2 && ((d.ldr | d.ldaux | d.ldo | d.ldo2 | d.split_lo) & 3) == 0 && d.act == 0 && d.out_scale == 0.f && !d.bias;
+        case EPI_X3Q:
+            return d.N == 128 && d.conv_KH > 0 && d.resid && d.aux && ((d.ldr | d.ldaux | d.ldo | d.split_lo) & 3) == 0 && d.act == 0 && d.out_scale == 0.f && !d.bias;
         case EPI_SPLIT:
             return (d.N & 1) == 0 && (d.ldo & 3) == 0 && (d.split_lo & 3) == 0 && d.split_lo > 0 && d.out_scale == 0.f && d.conv_KH > 0;
     }
@@ -880,3 +981,4 @@ PP_INST(EPI_STORE, true, 4) PP_INST(EPI_STORE, true, 2)
 PP_INST(EPI_STORE_F32, true, 4) PP_INST(EPI_STORE_F32, true, 2)
 PP_INST(EPI_GRU, true, 2)
 PP_INST(EPI_SPLIT, true, 4) PP_INST(EPI_SPLIT, true, 2)
+PP_INST(EPI_X3ZR, true, 4) PP_INST(EPI_X3Q, true, 2)

@@ -18,6 +18,23 @@ typedef _Float16 half_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 half8;
 typedef __attribute__((ext_vector_type(4))) _Float16 half4;
 
+// bf16x3 mode: the features as a bf16 pair, hi = bf16(x) in y[0 .. n), lo = bf16(x - hi) in y[n .. 2n)
+__global__ void split_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    const float e[4] = {v.x, v.y, v.z, v.w};
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float hf = bf16_round(e[k]);
+        hi[k] = (bf16_t)hf;
+        lo[k] = (bf16_t)(e[k] - hf);
+    }
+    *reinterpret_cast<bf16x4*>(y + i * 4) = hi;
+    *reinterpret_cast<bf16x4*>(y + n4 * 4 + i * 4) = lo;
+}
+
 __global__ void cast_f16_kernel(const float* __restrict__ x, half_t* __restrict__ y, int64_t n4) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
@@ -32,7 +49,7 @@ constexpr int CORR_F1F_LD = CORR_D + 4;    // fp32 variant
 struct CorrLds { int ldS, n1, n2, n3, tp; size_t bytes; };
 // tp: image-1 rows per workgroup.  bf16 mode: 32 when the slice fits LDS (every workgroup streams ALL of image 2 from L2 -- 400 KB at
 // 28 x 28 -- so 32 rows halve the launch's L2 traffic: 58 GB per 2 945 pairs at 16 rows was what bound it), else 16; fp32 mode: 16.
-static inline CorrLds corr_lds_tp(int H8, int W8, bool f32, int tp) {
+static inline CorrLds corr_lds_tp(int H8, int W8, bool f32, int tp, bool split = false) {
     CorrLds c;
     const int HW = H8 * W8;
     c.ldS = (HW + 15) / 16 * 16 + 4;
@@ -40,7 +57,7 @@ static inline CorrLds corr_lds_tp(int H8, int W8, bool f32, int tp) {
     c.n2 = (H8 / 4) * (W8 / 4);
     c.n3 = (H8 / 8) * (W8 / 8);
     c.tp = tp;
-    c.bytes = (size_t)tp * (c.ldS + c.n1 + c.n2) * 4 + (f32 ? tp * CORR_F1F_LD * 4 : tp * CORR_F1H_LD * 2);
+    c.bytes = (size_t)tp * (c.ldS + c.n1 + c.n2) * 4 + (f32 ? tp * CORR_F1F_LD * 4 : tp * CORR_F1H_LD * 2 * (split ? 2 : 1));
     return c;
 }
 static inline CorrLds corr_lds(int H8, int W8, bool f32) {
@@ -51,7 +68,10 @@ static inline CorrLds corr_lds(int H8, int W8, bool f32) {
     return corr_lds_tp(H8, W8, f32, 16);
 }
 
-template <bool F32, typename OT, int TP>
+// SPLIT (VTGB_BF16X3): the features are bf16 pairs (fh = hi plane, then lo plane), S = f1h.f2h + f1h.f2l + f1l.f2h on the bf16 MFMA with
+// fp32 accumulation (the dropped lo.lo term is 2^-16 of a product), fp32 levels: the fp32 mode's accuracy at 3 x the bf16 mode's MFMA work
+// instead of fp32 FMAs (65 ms -> per 2 945 pairs)
+template <bool F32, typename OT, int TP, bool SPLIT = false>
 __global__ __launch_bounds__(TP * 16) void raft_corr_kernel(const vtgb_raft_corr_args a, const half_t* __restrict__ fh, const int ldS, const int n1,
                                                         const int n2) {
     extern __shared__ __attribute__((aligned(16))) char corr_sm[];
@@ -78,10 +98,13 @@ __global__ __launch_bounds__(TP * 16) void raft_corr_kernel(const vtgb_raft_corr
     } else {
         const half_t* f1 = fh + i1 * HW * CORR_D;
         half_t* dst = reinterpret_cast<half_t*>(f1s);
+        const int64_t plane = (int64_t)a.n_images * HW * CORR_D;      // SPLIT: the lo plane follows the hi plane (2-byte elements either way)
         for (int i = tid; i < TP * (CORR_D / 8); i += NT) {
             const int r = i / (CORR_D / 8), c = i - r * (CORR_D / 8);
             const int p = min(p0 + r, HW - 1);
             *reinterpret_cast<half8*>(dst + r * CORR_F1H_LD + c * 8) = *reinterpret_cast<const half8*>(f1 + (int64_t)p * CORR_D + c * 8);
+            if constexpr (SPLIT)
+                *reinterpret_cast<half8*>(dst + (TP + r) * CORR_F1H_LD + c * 8) = *reinterpret_cast<const half8*>(f1 + plane + (int64_t)p * CORR_D + c * 8);
         }
     }
     __syncthreads();
@@ -108,6 +131,50 @@ __global__ __launch_bounds__(TP * 16) void raft_corr_kernel(const vtgb_raft_corr
             }
 #pragma unroll
             for (int p = 0; p < 16; p++) S[p * ldS + q] = acc[p] * a.scale;
+        }
+    } else if constexpr (SPLIT) {
+        static_assert(!SPLIT || TP == 16, "the split path keeps one 16-row half");
+        const bf16_t* f2 = reinterpret_cast<const bf16_t*>(fh) + i2 * HW * CORR_D;
+        const int64_t plane = (int64_t)a.n_images * HW * CORR_D;
+        const bf16_t* f1l = reinterpret_cast<const bf16_t*>(f1s);
+        const int fr = lane & 15, fg = lane >> 4;
+        constexpr int NW = NT / 64, KS = CORR_D / 32;
+        bf16x8 bh[KS], bl[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            bh[ks] = *reinterpret_cast<const bf16x8*>(f1l + fr * CORR_F1H_LD + ks * 32 + fg * 8);
+            bl[ks] = *reinterpret_cast<const bf16x8*>(f1l + (TP + fr) * CORR_F1H_LD + ks * 32 + fg * 8);
+        }
+        const int n_qt = (HW + 15) >> 4;
+        bf16x8 ah[2][KS], al[2][KS];
+        auto load_a = [&](int qt, bf16x8 (&dh)[KS], bf16x8 (&dl)[KS]) {
+            const int q = min(qt * 16 + fr, HW - 1);
+            const bf16_t* row = f2 + (int64_t)q * CORR_D + fg * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                dh[ks] = *reinterpret_cast<const bf16x8*>(row + ks * 32);
+                dl[ks] = *reinterpret_cast<const bf16x8*>(row + plane + ks * 32);
+            }
+        };
+        auto compute = [&](int qt, const bf16x8 (&sh)[KS], const bf16x8 (&sl)[KS]) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc;      // the two small terms on their own accumulator: added last
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sl[ks], bh[ks], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh[ks], bl[ks], acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh[ks], bh[ks], acc, 0, 0, 0);
+            }
+            *reinterpret_cast<f32x4*>(S + fr * ldS + qt * 16 + fg * 4) = (acc + acc2) * a.scale;
+        };
+        int qt = wave;
+        if (qt < n_qt) load_a(qt, ah[0], al[0]);
+        for (; qt < n_qt; qt += 2 * NW) {
+            if (qt + NW < n_qt) load_a(qt + NW, ah[1], al[1]);
+            compute(qt, ah[0], al[0]);
+            if (qt + NW < n_qt) {
+                if (qt + 2 * NW < n_qt) load_a(qt + 2 * NW, ah[0], al[0]);
+                compute(qt + NW, ah[1], al[1]);
+            }
         }
     } else {
         const half_t* f2 = fh + i2 * HW * CORR_D;
@@ -199,14 +266,14 @@ __global__ __launch_bounds__(TP * 16) void raft_corr_kernel(const vtgb_raft_corr
 
 static int corr_check(const vtgb_raft_corr_args* a) {
     VTGB_REQUIRE(a, VTGB_EINVAL, "raft_corr: NULL args");
-    VTGB_REQUIRE(a->dtype == VTGB_BF16 || a->dtype == VTGB_F32, VTGB_EINVAL, "raft_corr: bad dtype %d", a->dtype);
+    VTGB_REQUIRE(a->dtype == VTGB_BF16 || a->dtype == VTGB_F32 || a->dtype == VTGB_BF16X3, VTGB_EINVAL, "raft_corr: bad dtype %d", a->dtype);
     VTGB_REQUIRE(a->n_pairs <= 65535, VTGB_EUNSUPPORTED, "raft_corr: at most 65535 pairs per call (got %d)", a->n_pairs);
     VTGB_REQUIRE(a->n_pairs > 0 && a->H8 >= 8 && a->W8 >= 8 && a->dim == CORR_D && a->pairs_per_clip > 0 && a->frames_per_clip > 0 && a->n_images > 0,
                  VTGB_EINVAL, "raft_corr: bad dims n_pairs=%d H8=%d W8=%d dim=%d", a->n_pairs, a->H8, a->W8, a->dim);
     const int64_t last = ((int64_t)(a->n_pairs - 1) / a->pairs_per_clip) * a->frames_per_clip + (a->n_pairs - 1) % a->pairs_per_clip;
     VTGB_REQUIRE(a->first_off >= 0 && a->second_off >= 0 && last + a->first_off < a->n_images && last + a->second_off < a->n_images, VTGB_EINVAL,
                  "raft_corr: pair -> image map leaves the %d feature maps", a->n_images);
-    const CorrLds c = corr_lds(a->H8, a->W8, a->dtype == VTGB_F32);
+    const CorrLds c = a->dtype == VTGB_BF16X3 ? corr_lds_tp(a->H8, a->W8, false, 16, true) : corr_lds(a->H8, a->W8, a->dtype == VTGB_F32);
     VTGB_REQUIRE(c.bytes <= 160 * 1024, VTGB_EUNSUPPORTED, "raft_corr: %d x %d maps exceed the LDS tile", a->H8, a->W8);
     return VTGB_OK;
 }
@@ -214,17 +281,25 @@ static int corr_check(const vtgb_raft_corr_args* a) {
 extern "C" size_t vtgb_raft_corr_workspace_bytes(const vtgb_raft_corr_args* a) {
     if (corr_check(a) != VTGB_OK) return 0;
     if (a->dtype == VTGB_F32) return 256;
-    return align_up((size_t)a->n_images * a->H8 * a->W8 * CORR_D * sizeof(half_t), 256);
+    return align_up((size_t)a->n_images * a->H8 * a->W8 * CORR_D * sizeof(half_t) * (a->dtype == VTGB_BF16X3 ? 2 : 1), 256);
 }
 
 extern "C" int vtgb_raft_corr(const vtgb_raft_corr_args* a, vtgb_stream_t stream) {
     VTGB_TRY(corr_check(a));
     VTGB_REQUIRE(a->fmap && a->levels[0] && a->levels[1] && a->levels[2] && a->levels[3], VTGB_EINVAL, "raft_corr: NULL operand");
-    const bool f32 = a->dtype == VTGB_F32;
-    const CorrLds c = corr_lds(a->H8, a->W8, f32);
+    const bool f32 = a->dtype == VTGB_F32, x3 = a->dtype == VTGB_BF16X3;
+    const CorrLds c = x3 ? corr_lds_tp(a->H8, a->W8, false, 16, true) : corr_lds(a->H8, a->W8, f32);
     const int HW = a->H8 * a->W8;
     const dim3 grid((unsigned)((HW + c.tp - 1) / c.tp), (unsigned)a->n_pairs);
-    if (f32) {
+    if (x3) {
+        const size_t need = vtgb_raft_corr_workspace_bytes(a);
+        VTGB_REQUIRE(a->workspace && a->workspace_bytes >= need, VTGB_EWORKSPACE, "raft_corr: workspace %zu < %zu bytes", a->workspace_bytes, need);
+        half_t* fh = reinterpret_cast<half_t*>(a->workspace);      // bf16 hi plane | lo plane
+        const int64_t n4 = (int64_t)a->n_images * HW * CORR_D / 4;
+        hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a->fmap, reinterpret_cast<bf16_t*>(fh), n4);
+        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_kernel<false, float, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.bytes));
+        hipLaunchKernelGGL((raft_corr_kernel<false, float, 16, true>), grid, dim3(256), c.bytes, stream, *a, fh, c.ldS, c.n1, c.n2);
+    } else if (f32) {
         VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_kernel<true, float, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.bytes));
         hipLaunchKernelGGL((raft_corr_kernel<true, float, 16>), grid, dim3(256), c.bytes, stream, *a, nullptr, c.ldS, c.n1, c.n2);
     } else {

@@ -5,8 +5,10 @@
 //     x . w  ~  hi . Wh + lo . Wh + hi . Wl            (three bf16 MFMA products, fp32 accumulation; the dropped lo . Wl is 2^-16 of it)
 // by the SAME implicit-GEMM kernels as the bf16 mode: an activation of C channels is stored as the row [hi(C) | lo(C)] and enters the
 // contraction as the 3C channels [hi | lo | hi] (GemmDesc::conv_wrap: the third block's LDS-DMA reads the hi half again) against weights
-// packed once as [Wh | Wh | Wl] (ops.py); the epilogue writes act(acc + bias) as a pair again (EPI_SPLIT).  Gates, the flow, the
-// correlation pyramid and its lookup stay fp32.  Cost: 3 x the bf16 mode's MFMA work.
+// packed once as [Wh | Wh | Wl] (ops.py); the epilogue writes act(acc + bias) as a pair again (EPI_SPLIT).  The SepConvGRU's gates are
+// evaluated in fp32 in the epilogues of its two convolutions (EPI_X3ZR: z, r * h; EPI_X3Q: h' = (1 - z) h + z tanh(q), in place on the h pair);
+// the loop-invariant `inp` third of the GRU convolutions is computed once per call into fp32 start maps.  The flow, the correlation pyramid
+// (split-bf16 products, raft_corr.hip) and its lookup stay fp32.  Cost: 3 x the bf16 mode's MFMA work.
 #include <math.h>
 #include <string.h>
 
@@ -27,7 +29,6 @@ __device__ __forceinline__ void pair_split4(const f32x4 v, bf16x4& hi, bf16x4& l
 __device__ __forceinline__ f32x4 pair_join4(const bf16x4 hi, const bf16x4 lo) {
     return f32x4{(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]};
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }   // (~1e-6 relative: far below the pair's 2^-17)
 
 // ---- fp32 rows -> pair rows with the element-wise tails of the encoders and of the 64-channel convolution:
@@ -203,47 +204,6 @@ __global__ __launch_bounds__(256) void x3_convf1_kernel(const float* __restrict_
     }
 }
 
-// ---- SepConvGRU gates (update.py:52-55,59-62): zr fp32 [M, 256] = the convz | convr sums over the [h | motion | flow] channels, zri the
-// loop-invariant `inp` third + bias (computed once per call); z = sigmoid(zr[:, :128] + zri[:, :128]) stays fp32 in place,
-// r * h -> RH pair [M, 256]
-__global__ __launch_bounds__(256) void x3_gru_gate_kernel(float* __restrict__ zr, const float* __restrict__ zri, const bf16_t* __restrict__ hb,
-                                                          bf16_t* __restrict__ RH, int64_t M) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= M * 32) return;
-    const int64_t m = i >> 5;
-    const int c = (int)(i & 31) * 4;
-    f32x4 z = *reinterpret_cast<const f32x4*>(zr + m * 256 + c) + *reinterpret_cast<const f32x4*>(zri + m * 256 + c);
-    const f32x4 r = *reinterpret_cast<const f32x4*>(zr + m * 256 + 128 + c) + *reinterpret_cast<const f32x4*>(zri + m * 256 + 128 + c);
-    const f32x4 h = pair_join4(*reinterpret_cast<const bf16x4*>(hb + m * 256 + c), *reinterpret_cast<const bf16x4*>(hb + m * 256 + 128 + c));
-    f32x4 rh;
-#pragma unroll
-    for (int e = 0; e < 4; e++) { z[e] = sigmoid_f(z[e]); rh[e] = sigmoid_f(r[e]) * h[e]; }
-    *reinterpret_cast<f32x4*>(zr + m * 256 + c) = z;
-    bf16x4 hi, lo;
-    pair_split4(rh, hi, lo);
-    *reinterpret_cast<bf16x4*>(RH + m * 256 + c) = hi;
-    *reinterpret_cast<bf16x4*>(RH + m * 256 + 128 + c) = lo;
-}
-// h' = (1 - z) h + z tanh(q + qi) (update.py:56-57,63-64): q fp32 [M, 128] the convq sum over [r h | motion | flow], qi its `inp` third + bias,
-// z fp32 in zr[:, :128]; hb pair in place
-__global__ __launch_bounds__(256) void x3_gru_update_kernel(const float* __restrict__ zr, const float* __restrict__ q, const float* __restrict__ qi,
-                                                            bf16_t* __restrict__ hb, int64_t M) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= M * 32) return;
-    const int64_t m = i >> 5;
-    const int c = (int)(i & 31) * 4;
-    const f32x4 z = *reinterpret_cast<const f32x4*>(zr + m * 256 + c);
-    const f32x4 qv = *reinterpret_cast<const f32x4*>(q + m * 128 + c) + *reinterpret_cast<const f32x4*>(qi + m * 128 + c);
-    const f32x4 h = pair_join4(*reinterpret_cast<const bf16x4*>(hb + m * 256 + c), *reinterpret_cast<const bf16x4*>(hb + m * 256 + 128 + c));
-    f32x4 hn;
-#pragma unroll
-    for (int e = 0; e < 4; e++) hn[e] = (1.0f - z[e]) * h[e] + z[e] * tanh_f(qv[e]);
-    bf16x4 hi, lo;
-    pair_split4(hn, hi, lo);
-    *reinterpret_cast<bf16x4*>(hb + m * 256 + c) = hi;
-    *reinterpret_cast<bf16x4*>(hb + m * 256 + 128 + c) = lo;
-}
-
 // a convolution over pair operands: C1 channels from A (row [hi(C1) | lo(C1)]), optionally C2 more from A2; K = taps * 3 (C1 + C2)
 static GemmDesc x3_conv(int M, int N, int H, int W, int KH, int KW, const void* A, int C1, const void* A2, int C2, const void* Wt, const float* bias, int epi,
                         int act, void* out, int64_t ldo, int split_lo, const void* zero) {
@@ -276,7 +236,7 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     bf16_t* f1 = (bf16_t*)ws.take(M * 256 * 2);
     bf16_t* RH = (bf16_t*)ws.take(M * 256 * 2);
     bf16_t* FH = (bf16_t*)ws.take(M * 512 * 2);
-    float* ZR = (float*)ws.take(M * 256 * 4);          // z | r pre-activations, then z
+    float* ZR = (float*)ws.take(M * 256 * 4);          // z (fp32 [M, 128]); the unfused form: z | r pre-activations [M, 256], then z
     float* Q = (float*)ws.take(M * 128 * 4);           // q pre-activation; also convf2's fp32 output [M, 64]
     float* flow = (float*)ws.take(M * 2 * 4);
     float* mask = (float*)ws.take(M * 576 * 4);
@@ -323,14 +283,16 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
         // ---- SepConvGRU (update.py:50-65): horizontal (1x5) then vertical (5x1); input channels [h(128) | motion(126) | flow(2)], the inp third comes from the start maps
         for (int half = 0; half < 2; half++) {
             const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1, wi = 10 + 4 * half;
-            GemmDesc zr = x3_conv(Mi, 256, H8, W8, kh, kw, hb, 128, X, 128, w[wi], nullptr, VTGB_EPI_STORE_F32, 0, ZR, 256, 0, zero);
+            // z | r convolution with the gates in its epilogue: z = sigmoid(. + start map) -> ZR [M, 128] fp32, r * h -> RH pair; then the q
+            // convolution over [r h | motion | flow] with the update h' = (1 - z) h + z tanh(. + start map) in ITS epilogue, in place on the h pair
+            GemmDesc zr = x3_conv(Mi, 256, H8, W8, kh, kw, hb, 128, X, 128, w[wi], nullptr, VTGB_EPI_X3ZR, 0, ZR, 128, 128, zero);
+            zr.resid = ZRI[half]; zr.ldr = 256; zr.aux = hb; zr.ldaux = 256; zr.out2 = RH; zr.ldo2 = 256;
             zr.algo_flops = 2.0 * Mi * 256.0 * (5 * 384);
             VTGB_TRY(launch_conv_gemm(zr, s));
-            hipLaunchKernelGGL(x3_gru_gate_kernel, g32, dim3(256), 0, s, ZR, ZRI[half], hb, RH, M);
-            GemmDesc q = x3_conv(Mi, 128, H8, W8, kh, kw, RH, 128, X, 128, w[wi + 2], nullptr, VTGB_EPI_STORE_F32, 0, Q, 128, 0, zero);
+            GemmDesc q = x3_conv(Mi, 128, H8, W8, kh, kw, RH, 128, X, 128, w[wi + 2], nullptr, VTGB_EPI_X3Q, 0, hb, 256, 128, zero);
+            q.resid = QI[half]; q.ldr = 128; q.aux = ZR; q.ldaux = 128;
             q.algo_flops = 2.0 * Mi * 128.0 * (5 * 384);
             VTGB_TRY(launch_conv_gemm(q, s));
-            hipLaunchKernelGGL(x3_gru_update_kernel, g32, dim3(256), 0, s, ZR, Q, QI[half], hb, M);
         }
         // ---- FlowHead (update.py:10-18) and coords1 += delta_flow (xraft.py:145)
         VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 256, H8, W8, 3, 3, hb, 128, nullptr, 0, w[18], F(w[19]), VTGB_EPI_SPLIT, 1, FH, 512, 256, zero), s));

@@ -672,9 +672,7 @@ def raft_corr(fmap: Tensor, n_pairs: int, H8: int, W8: int, pairs_per_clip: int,
     _need_cuda(fmap)
     fmap = fmap.contiguous().float()
     n_images = fmap.numel() // (H8 * W8 * 256)
-    if code == BF16X3:
-        code = F32                       # the bf16x3 mode keeps the fp32 pyramid (include/vtgb.h)
-    odt = torch.float16 if code == BF16 else torch.float32
+    odt = torch.float16 if code == BF16 else torch.float32      # (bf16x3: split-bf16 products, fp32 levels)
     lv, h, w = [], H8, W8
     for _ in range(4):
         lv.append(torch.empty(n_pairs * H8 * W8, 1, h, w, dtype=odt, device=fmap.device))
