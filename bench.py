@@ -219,6 +219,45 @@ def parity_probe(dev):
             "frame_indices_equal": bool(torch.equal(res["f32"][2], res["bf16"][2]))}
 
 
+def vit_gemm_baseline(dev, frames):
+    """hipBLASLt (torch F.linear) and libvtgb.so's own GEMM on the four GEMM shapes of an EVA-ViT-g layer at the step's frame count, same box, same
+    run: a BASELINE for the ViT stage's GEMM rate -- hipBLASLt never enters the product path (tests/test_decode.py and the rocprof stats
+    show no Cijk_* kernel in a step)."""
+    import torch.nn.functional as F
+    from videotgb_amd import ops
+    M = frames * 257
+    g = torch.Generator(device=dev).manual_seed(7)
+    out = {"rows": M, "unit": "TFLOP/s", "shapes": {}}
+
+    def rate(fn, flops):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return round(flops * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+    tot = {"hipblaslt": 0.0, "own": 0.0}
+    for name, K, N in (("qkv", 1408, 4224), ("proj", 1408, 1408), ("fc1", 1408, 6144), ("fc2", 6144, 1408)):
+        x = (torch.randn(M, K, generator=g, device=dev) * 0.5).to(torch.bfloat16)
+        w = (torch.randn(N, K, generator=g, device=dev) * 0.03).to(torch.bfloat16)
+        b = torch.randn(N, generator=g, device=dev)
+        bb = b.to(torch.bfloat16)
+        fl = 2.0 * M * N * K
+        r_lt, r_own = rate(lambda: F.linear(x, w, bb), fl), rate(lambda: ops.gemm(x, w, b), fl)
+        out["shapes"][name] = {"K": K, "N": N, "hipblaslt": r_lt, "own": r_own}
+        tot["hipblaslt"] += fl / r_lt
+        tot["own"] += fl / r_own
+        del x, w
+    fl_all = sum(2.0 * M * v["N"] * v["K"] for v in out["shapes"].values())
+    out["layer_mean"] = {k: round(fl_all / v, 1) for k, v in tot.items()}      # FLOP-weighted over the four shapes (plain bias epilogue on both sides)
+    out["note"] = "plain bias epilogue on both sides (the product path fuses GELU / the fp32 residual into its epilogues); baseline only"
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(cfg, T, nframe, seed_sd, inline_raft=True, raft_frames=None):
     """Oracle (port of the reference's CPU path) on one clip, fp32: RAFT on a bounded sample of the clip's T-1 frame pairs -- the first
     len(raft_frames) - 1 pairs of the SAME randn frames the GPU leg's first clip holds (20 iterations each, extrapolated to T-1 pairs) --
@@ -544,6 +583,7 @@ def main():
             out["stages_ms"] = stages_ms    # one untimed step with an event per stage boundary (the first stage, RAFT, = ms_per_step - the rest)
         if world == 1 and not args.no_prof:
             out["parity"] = parity_probe(dev)
+            out["vit_gemm_baseline"] = vit_gemm_baseline(dev, B * nframe)
         if legs:
             out["precomputed_flow"] = legs.pop("precomputed_flow", None)
             out["latency_ms_per_clip"] = legs["single_clip"]["latency_ms_per_clip"]

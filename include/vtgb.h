@@ -31,7 +31,8 @@ extern "C" {
 
 typedef struct ihipStream_t* vtgb_stream_t; /* == hipStream_t */
 
-#define VTGB_VERSION 401 /* 401: vtgb_gemm_train / vtgb_col_sum_f32 / vtgb_layernorm_train_* / vtgb_gelu_* (the training graph without operand copies or torch
+#define VTGB_VERSION 500 /* 500: VTGB_BF16X3 (RAFT at fp32 accuracy on the bf16 MFMA), deterministic InstanceNorm moments, vtgb_gemm_skinny defer_reduce +
+                            vtgb_llm_rmsnorm_parts / vtgb_llm_rope_cache_parts.  401: vtgb_gemm_train / vtgb_col_sum_f32 / vtgb_layernorm_train_* / vtgb_gelu_* (the training graph without operand copies or torch
                             elementwise passes); 400 = round 4: vtgb_llm_attention_rows / vtgb_llm_gated_act (the T5 language model of the BLIP-2 flavours on own kernels:
                             eval/utils/model.py:427-437), vtgb_llm_rope_cache with NULL tables = plain cache append; 300 = round 3: stem weight hi|lo layout; vtgb_attention_args.causal; vtgb_gemm_skinny without workspace when unsplit;
                             vtgb_llm_rope_cache_prefill; vtgb_attn_train_forward / backward; vtgb_comm_* / vtgb_allreduce_f32 */
@@ -473,7 +474,18 @@ typedef struct {
                                             eight 128-byte row segments a DRAM page apart */
     void* workspace;
     size_t workspace_bytes;
+    int32_t defer_reduce;                /* 1 (with a K split): skip the second launch -- `out` is not written; the consumer adds the fragments
+                                            workspace[(tile * n_splits + split) * M + m][128] in split order and rounds once itself
+                                            (vtgb_llm_rmsnorm_parts, vtgb_llm_rope_cache_parts; vtgb_gemm_skinny_splits tells n_splits) */
 } vtgb_gemm_skinny_args;
+int32_t vtgb_gemm_skinny_splits(const vtgb_gemm_skinny_args* a);   /* the K split the call will use (1: `out` is written directly) */
+/* The decode step's consumers of a deferred split (bf16; rows = the GEMM's M <= 128): x += sum of the fragments (rounded once, as the reduce
+ * launch would have stored it), h = rmsnorm(x) * w;  and rotary + cache append reading q | k | v from the fragments.  Same values as the two-launch
+ * form, bit for bit (tests/test_decode.py). */
+int vtgb_llm_rmsnorm_parts(int dtype, void* x, const float* part, int32_t n_splits, const void* w, void* h, int64_t rows, int32_t H, float eps,
+                           vtgb_stream_t stream);
+int vtgb_llm_rope_cache_parts(int dtype, const float* part, int32_t n_splits, void* q_out, void* kc, void* vc, const void* cos_t, const void* sin_t,
+                              const int64_t* pos, int32_t B, int32_t nq, int32_t nkv, int32_t hd, int32_t tmax, vtgb_stream_t stream);
 size_t vtgb_pack_skinny_weight_bytes(int32_t N, int32_t K);
 int vtgb_pack_skinny_weight(const void* w, int64_t ldw, int32_t N, int32_t K, void* dst, vtgb_stream_t stream);
 size_t vtgb_gemm_skinny_workspace_bytes(const vtgb_gemm_skinny_args* a);

@@ -63,3 +63,50 @@ def test_skinny_shared_workspace(dev):
             assert torch.equal(ops.gemm_skinny(x, w, n_splits=S, workspace=ws), ref)
     for (x, w, S), ref in zip(ops_in, first):
         assert (ref.float() - x.float() @ w.float().t()).abs().max().item() <= 2 ** -7 * ref.float().abs().max().item()
+
+
+@pytest.mark.parametrize("M", [1, 124])
+def test_deferred_split_consumers_equal_the_two_launch_form_bit_for_bit(dev, M):
+    """r5: the decode step's split-K projections leave their fp32 fragments to the consumer (vtgb_llm_rmsnorm_parts: residual add + RMSNorm;
+    vtgb_llm_rope_cache_parts: rotary + cache append), which adds them in split order and rounds once -- exactly what the separate reduce
+    launch stored.  Vicuna-7B shapes: o / down -> RMSNorm, qkv -> rotary."""
+    import ctypes as C
+    from videotgb_amd import _lib as L, ops
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device=dev).manual_seed(M)
+    H, nq, hd, tmax = 4096, 32, 128, 64
+    for K in (4096, 11008):                                          # o (S = 4) and down (S = 7)
+        a = torch.randn(M, K, generator=g, device=dev).bfloat16()
+        w = ops.SkinnyWeight((torch.randn(H, K, generator=g, device=dev) * K ** -0.5).bfloat16())
+        gam = torch.randn(H, generator=g, device=dev).bfloat16()
+        x0 = torch.randn(M, H, generator=g, device=dev).bfloat16()
+        delta = ops.gemm_skinny(a, w)
+        xa, ha = x0.clone(), torch.empty_like(x0)
+        L.check(lib.vtgb_llm_rmsnorm(L.BF16, xa.data_ptr(), delta.data_ptr(), gam.data_ptr(), ha.data_ptr(), M, H, 1e-6, st))
+        out, S, ws = ops.gemm_skinny(a, w, defer_reduce=True)
+        assert S > 1
+        xb, hb = x0.clone(), torch.empty_like(x0)
+        L.check(lib.vtgb_llm_rmsnorm_parts(L.BF16, xb.data_ptr(), ws.data_ptr(), S, gam.data_ptr(), hb.data_ptr(), M, H, 1e-6, st))
+        assert torch.equal(xa, xb) and torch.equal(ha, hb), K
+    a = torch.randn(M, H, generator=g, device=dev).bfloat16()
+    w = ops.SkinnyWeight((torch.randn(3 * H, H, generator=g, device=dev) * H ** -0.5).bfloat16())
+    cos, sin = torch.randn(tmax, hd, generator=g, device=dev).bfloat16(), torch.randn(tmax, hd, generator=g, device=dev).bfloat16()
+    pos = torch.tensor([5], device=dev)
+    res = []
+    for deferred in (False, True):
+        q = torch.zeros(M, nq * hd, dtype=torch.bfloat16, device=dev)
+        kc = torch.zeros(M, nq, tmax, hd, dtype=torch.bfloat16, device=dev)
+        vc = torch.zeros_like(kc)
+        if deferred:
+            _, S, ws = ops.gemm_skinny(a, w, defer_reduce=True)
+            assert S > 1
+            L.check(lib.vtgb_llm_rope_cache_parts(L.BF16, ws.data_ptr(), S, q.data_ptr(), kc.data_ptr(), vc.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                                  pos.data_ptr(), M, nq, nq, hd, tmax, st))
+        else:
+            qkv = ops.gemm_skinny(a, w)
+            L.check(lib.vtgb_llm_rope_cache(L.BF16, qkv.data_ptr(), q.data_ptr(), kc.data_ptr(), vc.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                            pos.data_ptr(), M, nq, nq, hd, tmax, st))
+        res.append((q, kc, vc))
+    for t0, t1 in zip(*res):
+        assert torch.equal(t0, t1) and t0.abs().sum() > 0

@@ -29,7 +29,7 @@ EXPORTS = [
     "vtgb_pool_project", "vtgb_tgb_workspace_bytes", "vtgb_tgb_forward", "vtgb_gemm", "vtgb_attention",
     "vtgb_layernorm", "vtgb_prof_enable", "vtgb_prof_reset", "vtgb_prof_summary", "vtgb_prof_executed_flops",
     "vtgb_llm_rmsnorm", "vtgb_llm_rope_cache", "vtgb_llm_rope_cache_prefill", "vtgb_llm_decode_attention", "vtgb_llm_silu_mul",
-    "vtgb_llm_attention_rows", "vtgb_llm_gated_act",
+    "vtgb_llm_attention_rows", "vtgb_llm_gated_act", "vtgb_llm_rmsnorm_parts", "vtgb_llm_rope_cache_parts", "vtgb_gemm_skinny_splits",
     "vtgb_gemm_skinny_workspace_bytes", "vtgb_gemm_skinny", "vtgb_pack_skinny_weight_bytes", "vtgb_pack_skinny_weight",
     "vtgb_raft_update_workspace_bytes", "vtgb_raft_update", "vtgb_raft_encoder_workspace_bytes", "vtgb_raft_encoder",
     "vtgb_raft_corr_workspace_bytes", "vtgb_raft_corr", "vtgb_preprocess_frames", "vtgb_concat_text_io", "vtgb_shifted_ce_forward", "vtgb_shifted_ce_backward",
@@ -138,7 +138,7 @@ class RaftEncoderArgs(C.Structure):
 
 class GemmSkinnyArgs(C.Structure):
     _fields_ = [("M", i32), ("N", i32), ("K", i32), ("n_splits", i32), ("x", vp), ("ldx", i64), ("w", vp), ("ldw", i64), ("out", vp), ("ldo", i64),
-                ("out_dtype", i32), ("w_tiled", i32), ("workspace", vp), ("workspace_bytes", sz)]
+                ("out_dtype", i32), ("w_tiled", i32), ("workspace", vp), ("workspace_bytes", sz), ("defer_reduce", i32)]
 
 
 class GemmArgs(C.Structure):
@@ -213,6 +213,12 @@ def lib() -> C.CDLL:
     L.vtgb_llm_attention_rows.restype = C.c_int
     L.vtgb_llm_gated_act.argtypes = [C.c_int, vp, vp, i64, i32, i32, i32, vp]
     L.vtgb_llm_gated_act.restype = C.c_int
+    L.vtgb_llm_rmsnorm_parts.argtypes = [C.c_int, vp, vp, i32, vp, vp, i64, i32, f32, vp]
+    L.vtgb_llm_rmsnorm_parts.restype = C.c_int
+    L.vtgb_llm_rope_cache_parts.argtypes = [C.c_int, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.vtgb_llm_rope_cache_parts.restype = C.c_int
+    L.vtgb_gemm_skinny_splits.argtypes = [C.POINTER(GemmSkinnyArgs)]
+    L.vtgb_gemm_skinny_splits.restype = i32
     L.vtgb_gemm_skinny.argtypes = [C.POINTER(GemmSkinnyArgs), vp]
     L.vtgb_gemm_skinny.restype = C.c_int
     L.vtgb_gemm_skinny_workspace_bytes.argtypes = [C.POINTER(GemmSkinnyArgs)]

@@ -29,6 +29,27 @@ template <> struct Cvt<bf16_t> {
     }
 };
 
+// The decode step's split-K projections leave fp32 fragments part[(tile b * S + split) * M + row][128] (gemm_skinny_kernel); their consumers add a
+// tile's fragments in split order and round once to the activation type themselves (r5: the separate reduce launch -- three per layer -- is gone:
+// same sums, same rounding, 96 launches fewer per token).  V consecutive columns starting at column i (i % V == 0, V <= 8) of row `row`:
+template <typename T, int V>
+__device__ __forceinline__ void parts_sum(const float* __restrict__ part, int S, int M, int64_t row, int i, float (&out)[V]) {
+    const int b = i >> 7, c = i & 127;
+#pragma unroll
+    for (int e = 0; e < V; e++) out[e] = 0.f;
+    for (int sp = 0; sp < S; sp++) {
+        const float* p = part + ((int64_t)(b * S + sp) * M + row) * 128 + c;
+#pragma unroll
+        for (int q = 0; q < V; q += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p + q);
+#pragma unroll
+            for (int e = 0; e < 4; e++) out[q + e] += t[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < V; e++) out[e] = Cvt<T>::rnd(out[e]);
+}
+
 // ---- x (+= delta) ; h = rmsnorm(x) * w.   One workgroup per row.
 template <typename T>
 __global__ __launch_bounds__(256) void llm_rmsnorm_kernel(T* __restrict__ x, const T* __restrict__ delta, const T* __restrict__ w,
@@ -61,7 +82,8 @@ __global__ __launch_bounds__(256) void llm_rmsnorm_kernel(T* __restrict__ x, con
 // dependent 2-byte round trips per pass; 65 launches per decoded token).  NV 16-byte vectors per thread: H == 256 * NV * (16 / sizeof(T)).
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void llm_rmsnorm_vec_kernel(T* __restrict__ x, const T* __restrict__ delta, const T* __restrict__ w,
-                                                              T* __restrict__ h, int H, float eps) {
+                                                              T* __restrict__ h, int H, float eps, const float* __restrict__ part = nullptr, int S = 0,
+                                                              int M = 0) {
     constexpr int V = 16 / (int)sizeof(T);
     typedef T TV __attribute__((ext_vector_type(V)));
     __shared__ float red[4];
@@ -75,7 +97,17 @@ __global__ __launch_bounds__(256) void llm_rmsnorm_vec_kernel(T* __restrict__ x,
         const TV xv = *reinterpret_cast<const TV*>(xr + i);
 #pragma unroll
         for (int e = 0; e < V; e++) v[c][e] = (float)xv[e];
-        if (delta) {
+        if (part) {            // delta = the sum of the K-split fragments, rounded once (what the reduce launch stored)
+            float dv[V];
+            parts_sum<T, V>(part, S, M, row, i, dv);
+            TV o;
+#pragma unroll
+            for (int e = 0; e < V; e++) {
+                v[c][e] = Cvt<T>::rnd(v[c][e] + dv[e]);
+                o[e] = Cvt<T>::to(v[c][e]);
+            }
+            *reinterpret_cast<TV*>(xr + i) = o;
+        } else if (delta) {
             const TV dv = *reinterpret_cast<const TV*>(delta + row * H + i);
             TV o;
 #pragma unroll
@@ -108,18 +140,27 @@ __global__ __launch_bounds__(256) void llm_rmsnorm_vec_kernel(T* __restrict__ x,
 template <typename T>
 __global__ __launch_bounds__(128) void llm_rope_cache_kernel(const T* __restrict__ qkv, T* __restrict__ q_out, T* __restrict__ kc,
                                                              T* __restrict__ vc, const T* __restrict__ cos_t, const T* __restrict__ sin_t,
-                                                             const int64_t* __restrict__ pos_p, int nq, int nkv, int hd, int tmax) {
+                                                             const int64_t* __restrict__ pos_p, int nq, int nkv, int hd, int tmax,
+                                                             const float* __restrict__ part = nullptr, int S = 0, int M = 0) {
 #pragma clang fp contract(off)      // fp32: mul, mul, add are three roundings in the reference -- no FMA
     const int b = blockIdx.y, head = blockIdx.x;   // head in [0, nq + 2 nkv)
     const int64_t pos = *pos_p;
     const T* src = qkv + ((int64_t)b * (nq + 2 * nkv) + head) * hd;
     const int half = hd >> 1;
+    // part != NULL: qkv is still the projection's K-split fragments -- element (b, col) = the fragments' sum in split order, rounded once
+    auto at = [&](int d) -> float {
+        if (!part) return (float)src[d];
+        const int col = head * hd + d;
+        float t = 0.f;
+        for (int sp = 0; sp < S; sp++) t += part[((int64_t)((col >> 7) * S + sp) * M + b) * 128 + (col & 127)];
+        return Cvt<T>::rnd(t);
+    };
     for (int d = threadIdx.x; d < hd; d += blockDim.x) {
-        const float v = (float)src[d];
+        const float v = at(d);
         float outv = v;
         if (head < nq + nkv && cos_t) {      // (cos_t == NULL: no rotary -- T5's decoder: q passed through, k / v appended)
             const float c = (float)cos_t[pos * hd + d], sn = (float)sin_t[pos * hd + d];
-            const float rot = d < half ? -(float)src[d + half] : (float)src[d - half];
+            const float rot = d < half ? -at(d + half) : at(d - half);
             const float pa = Cvt<T>::rnd(v * c), pb = Cvt<T>::rnd(rot * sn);      // (contract(off): the reference's three roundings, no FMA)
             outv = Cvt<T>::rnd(pa + pb);
         }
@@ -265,6 +306,33 @@ extern "C" int vtgb_llm_rmsnorm(int dtype, void* x, const void* delta, const voi
         hipLaunchKernelGGL(llm_rmsnorm_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, s, (bf16_t*)x, (const bf16_t*)delta, (const bf16_t*)w, (bf16_t*)h, H, eps);
     else
         hipLaunchKernelGGL(llm_rmsnorm_kernel<float>, dim3((unsigned)rows), dim3(256), 0, s, (float*)x, (const float*)delta, (const float*)w, (float*)h, H, eps);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+// delta = the K-split fragments of a vtgb_gemm_skinny call with defer_reduce (bf16 activations; M = rows)
+extern "C" int vtgb_llm_rmsnorm_parts(int dtype, void* x, const float* part, int32_t S, const void* w, void* h, int64_t rows, int32_t H, float eps,
+                                      vtgb_stream_t s) {
+    VTGB_REQUIRE(x && part && w && h && rows > 0 && rows <= 128 && S > 1 && dtype == VTGB_BF16, VTGB_EINVAL, "llm_rmsnorm_parts: bad argument");
+    VTGB_REQUIRE((((uintptr_t)x | (uintptr_t)part | (uintptr_t)w | (uintptr_t)h) & 15) == 0 && (H == 4096 || H == 2048), VTGB_EUNSUPPORTED,
+                 "llm_rmsnorm_parts: hidden size %d (4096 or 2048, 16-byte aligned operands)", H);
+    if (H == 4096)
+        hipLaunchKernelGGL((llm_rmsnorm_vec_kernel<bf16_t, 2>), dim3((unsigned)rows), dim3(256), 0, s, (bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)w, (bf16_t*)h, H, eps,
+                           part, S, (int)rows);
+    else
+        hipLaunchKernelGGL((llm_rmsnorm_vec_kernel<bf16_t, 1>), dim3((unsigned)rows), dim3(256), 0, s, (bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)w, (bf16_t*)h, H, eps,
+                           part, S, (int)rows);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+extern "C" int vtgb_llm_rope_cache_parts(int dtype, const float* part, int32_t S, void* q_out, void* kc, void* vc, const void* cos_t, const void* sin_t,
+                                         const int64_t* pos, int32_t B, int32_t nq, int32_t nkv, int32_t hd, int32_t tmax, vtgb_stream_t s) {
+    VTGB_REQUIRE(part && S > 1 && q_out && kc && vc && ((cos_t == nullptr) == (sin_t == nullptr)) && pos && B > 0 && B <= 128 && nq > 0 && nkv > 0 && (hd % 2) == 0 &&
+                     dtype == VTGB_BF16,
+                 VTGB_EINVAL, "llm_rope_cache_parts: bad argument");
+    hipLaunchKernelGGL(llm_rope_cache_kernel<bf16_t>, dim3(nq + 2 * nkv, B), dim3(128), 0, s, (const bf16_t*)nullptr, (bf16_t*)q_out, (bf16_t*)kc, (bf16_t*)vc,
+                       (const bf16_t*)cos_t, (const bf16_t*)sin_t, pos, nq, nkv, hd, tmax, part, S, B);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }
@@ -746,6 +814,11 @@ static int skinny_check(const vtgb_gemm_skinny_args* a) {
     return VTGB_OK;
 }
 
+extern "C" int32_t vtgb_gemm_skinny_splits(const vtgb_gemm_skinny_args* a) {
+    if (skinny_check(a) != VTGB_OK) return 0;
+    return skinny_splits(a);
+}
+
 extern "C" size_t vtgb_gemm_skinny_workspace_bytes(const vtgb_gemm_skinny_args* a) {
     if (skinny_check(a) != VTGB_OK) return 0;
     const int S = skinny_splits(a);
@@ -766,7 +839,7 @@ extern "C" int vtgb_gemm_skinny(const vtgb_gemm_skinny_args* a, vtgb_stream_t s)
         hipLaunchKernelGGL(gemm_skinny_kernel, dim3(n_tiles, S), dim3(SK_THREADS), LDS, s, (const bf16_t*)a->x, a->M, (int)a->ldx, (const bf16_t*)a->w, a->N,
                            (int)a->ldw, nk, (float*)a->workspace, a->w_tiled, a->out, a->ldo, a->out_dtype == VTGB_F32 ? 1 : 0);
     }
-    if (S > 1) {
+    if (S > 1 && !a->defer_reduce) {      // (defer_reduce: the consumer adds the fragments -- vtgb_llm_rmsnorm_parts / vtgb_llm_rope_cache_parts)
         const dim3 rgrid(n_tiles, (a->M + 7) / 8 < 4 ? (a->M + 7) / 8 : 4);
         if (a->out_dtype == VTGB_BF16)
             hipLaunchKernelGGL(gemm_skinny_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, s, (const float*)a->workspace, a->M, a->N, S, (bf16_t*)a->out, a->ldo);

@@ -261,21 +261,40 @@ class GreedyDecoder:
         else:
             def lin(xin, li, which, buf):
                 return F.linear(xin, self.layers[li][(1, 2, 4, 5)[which]])
+        # skinny path (bf16, batch <= 128): the split-K projections (qkv, o, down) leave their fp32 fragments in the workspace and the kernel that
+        # consumes them (rotary + cache / RMSNorm + residual) adds them itself: 10 launches per layer instead of 13, the same values bit for bit
+        defer = skinny and H in (2048, 4096)
+
+        def lin_d(xin, li, which, buf):        # -> (tensor, n_splits): n_splits > 1 means "fragments in ws, tensor not written"
+            if not defer:
+                return lin(xin, li, which, buf), 1
+            o_, S_, _ = ops.gemm_skinny(xin, sw[li][which], out=st[buf], workspace=ws, defer_reduce=True)
+            return o_, S_
+
+        def norm(delta_t, delta_S, wt):
+            if delta_t is not None and delta_S > 1:
+                L.check(lib.vtgb_llm_rmsnorm_parts(code, x.data_ptr(), ws.data_ptr(), delta_S, wt.data_ptr(), h.data_ptr(), B, H, self.eps, stream))
+            else:
+                L.check(lib.vtgb_llm_rmsnorm(code, x.data_ptr(), None if delta_t is None else delta_t.data_ptr(), wt.data_ptr(), h.data_ptr(),
+                                             B, H, self.eps, stream))
+        dS = 1
         for li, (ln1, wqkv, wo, ln2, wgu, wd) in enumerate(self.layers):
-            L.check(lib.vtgb_llm_rmsnorm(code, x.data_ptr(), None if delta is None else delta.data_ptr(), ln1.data_ptr(), h.data_ptr(),
-                                         B, H, self.eps, stream))
-            qkv = lin(h, li, 0, "sk_qkv")
-            L.check(lib.vtgb_llm_rope_cache(code, qkv.data_ptr(), q.data_ptr(), st["kc"][li].data_ptr(), st["vc"][li].data_ptr(),
-                                            st["cos"].data_ptr(), st["sin"].data_ptr(), pos.data_ptr(), B, nq, nkv, hd, tmax, stream))
+            norm(delta, dS, ln1)
+            qkv, qS = lin_d(h, li, 0, "sk_qkv")
+            if qS > 1:
+                L.check(lib.vtgb_llm_rope_cache_parts(code, ws.data_ptr(), qS, q.data_ptr(), st["kc"][li].data_ptr(), st["vc"][li].data_ptr(),
+                                                      st["cos"].data_ptr(), st["sin"].data_ptr(), pos.data_ptr(), B, nq, nkv, hd, tmax, stream))
+            else:
+                L.check(lib.vtgb_llm_rope_cache(code, qkv.data_ptr(), q.data_ptr(), st["kc"][li].data_ptr(), st["vc"][li].data_ptr(),
+                                                st["cos"].data_ptr(), st["sin"].data_ptr(), pos.data_ptr(), B, nq, nkv, hd, tmax, stream))
             L.check(lib.vtgb_llm_decode_attention(code, q.data_ptr(), st["kc"][li].data_ptr(), st["vc"][li].data_ptr(), a.data_ptr(),
                                                   pos.data_ptr(), B, nq, nkv, hd, tmax, float(hd) ** -0.5, stream))
-            o = lin(a, li, 1, "sk_o")
-            L.check(lib.vtgb_llm_rmsnorm(code, x.data_ptr(), o.data_ptr(), ln2.data_ptr(), h.data_ptr(), B, H, self.eps, stream))
+            o, oS = lin_d(a, li, 1, "sk_o")
+            norm(o, oS, ln2)
             gu = lin(h, li, 2, "sk_gu")
             L.check(lib.vtgb_llm_silu_mul(code, gu.data_ptr(), act.data_ptr(), B, self.inter, stream))
-            delta = lin(act, li, 3, "sk_d")
-        L.check(lib.vtgb_llm_rmsnorm(code, x.data_ptr(), delta.data_ptr(), self.lm.model.norm.weight.data_ptr(), h.data_ptr(), B, H,
-                                     self.eps, stream))
+            delta, dS = lin_d(act, li, 3, "sk_d")
+        norm(delta, dS, self.lm.model.norm.weight)
         if skinny:
             self._emit(st, ops.gemm_skinny(h, sw[-1], out=st["sk_logits"], workspace=ws))
         elif self._gemm_ok(x.dtype):

@@ -191,8 +191,9 @@ def gemm_skinny_workspace_bytes(M: int, N: int, K: int, n_splits: int = 0) -> in
 
 
 def gemm_skinny(x: Tensor, w: Tensor, out: Optional[Tensor] = None, n_splits: int = 0, out_dtype: Optional[torch.dtype] = None,
-                workspace: Optional[Tensor] = None) -> Tensor:
-    """x [M <= 128, K] bf16, w [N, K] bf16 (nn.Linear.weight, or its SkinnyWeight) -> x @ w.T [M, N]: the decode step's projections (vtgb_gemm_skinny:
+                workspace: Optional[Tensor] = None, defer_reduce: bool = False):
+    """``defer_reduce``: returns (out, n_splits, workspace) and leaves the K-split fragments to the consumer (see below).
+    x [M <= 128, K] bf16, w [N, K] bf16 (nn.Linear.weight, or its SkinnyWeight) -> x @ w.T [M, N]: the decode step's projections (vtgb_gemm_skinny:
     the weights stream once, K split over workgroups, fp32 partials added in a fixed order).  ``out`` may be a preallocated
     [M, N] tensor and ``workspace`` a preallocated uint8 scratch (hipGraph capture: fixed addresses, no allocation)."""
     tiled = isinstance(w, SkinnyWeight)
@@ -204,12 +205,17 @@ def gemm_skinny(x: Tensor, w: Tensor, out: Optional[Tensor] = None, n_splits: in
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype or x.dtype, device=x.device)
     a = L.GemmSkinnyArgs(M, N, K, n_splits, x.data_ptr(), x.stride(0), w.data.data_ptr() if tiled else w.data_ptr(), K if tiled else w.stride(0),
-                         out.data_ptr(), out.stride(0), dtype_code(out.dtype), 1 if tiled else 0, None, 0)
+                         out.data_ptr(), out.stride(0), dtype_code(out.dtype), 1 if tiled else 0, None, 0, 1 if defer_reduce else 0)
     need = L.lib().vtgb_gemm_skinny_workspace_bytes(C.byref(a))      # 0: no K split (or bad arguments, which the call reports)
     if need:
         ws = workspace if workspace is not None else _ws.get(need, x.device)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     L.check(L.lib().vtgb_gemm_skinny(C.byref(a), _stream()))
+    if defer_reduce:
+        # (out, n_splits, fragments): n_splits > 1 -> `out` is NOT written; the consumer (vtgb_llm_rmsnorm_parts / vtgb_llm_rope_cache_parts) adds the
+        # fragments left in the workspace
+        S = int(L.lib().vtgb_gemm_skinny_splits(C.byref(a))) if need else 1
+        return out, S, (ws if need else None)
     return out
 
 
