@@ -155,13 +155,19 @@ int vtgb_shifted_ce_backward(const vtgb_shifted_ce_args* a, vtgb_stream_t stream
  *   [0] patch_embedding.weight  `dtype` [hidden, kpad]   (kpad: see vtgb_vit_patch_kpad)
  *   [1] patch_embedding.bias  [2] class_embedding  [3] position_embedding [tokens, hidden]
  *   [4] post_layernorm.weight [5] post_layernorm.bias
- *   then per layer l, at 6 + 12*l:
+ *   then per layer l, at 6 + 18*l:
  *   +0 layer_norm1.weight +1 layer_norm1.bias +2 self_attn.qkv.weight `dtype` [3h, h]
  *   +3 self_attn.qkv.bias +4 self_attn.projection.weight `dtype` +5 .bias
  *   +6 layer_norm2.weight +7 layer_norm2.bias +8 mlp.fc1.weight `dtype` +9 .bias
- *   +10 mlp.fc2.weight `dtype` +11 .bias                                              */
+ *   +10 mlp.fc2.weight `dtype` +11 .bias
+ *   +12 .. +17 optional, VTGB_BF16 only (all six or none; NULL = the LayerNorms run as their own passes): the two LayerNorms FOLDED into the
+ *   GEMMs that follow them -- LN(x) W^T + b = rstd (x W'^T - mean cs) + c with
+ *   +12 W'_qkv = bf16(qkv.weight * layer_norm1.weight[None, :]) [3h, h]   +13 cs = row sums of W'_qkv (of the bf16 values), fp32 [3h]
+ *   +14 c = qkv.weight @ layer_norm1.bias + qkv.bias, fp32 [3h]           +15 / +16 / +17 the same for mlp.fc1 with layer_norm2 [mlp]:
+ *   the producer of the residual stream (projection / fc2 epilogue) then also writes bf16(x) and the rows' moments, and no stand-alone
+ *   LayerNorm pass is left between the GEMMs of a layer (version 500) */
 #define VTGB_VIT_NW_GLOBAL 6
-#define VTGB_VIT_NW_LAYER 12
+#define VTGB_VIT_NW_LAYER 18
 typedef struct {
     int32_t dtype, n_frames, image, patch, hidden, heads, mlp, layers;
     float eps;

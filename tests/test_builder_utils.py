@@ -53,3 +53,32 @@ def test_module_flavour_table_matches_the_reference_variants():
     assert f["src.models.LSTP_Vicuna_IVT_module.LSTPModule"][6:] == (True, "CAUSAL_LM")
     assert f["src.models.LSTP_Blip2_IVT_module.LSTPModule"][6:] == (True, "SEQ_2_SEQ_LM")
     assert f["src.models.LSTP_Vicuna_IV_module.LSTPModule"][6:] == (True, None)
+
+
+def test_pack_decoded_accepts_any_decoder_output():
+    """row f3's decode feed: arrays, CPU tensors, iterables of frames and PyAV-like frame objects all become one uint8 [T, H, W, 3] clip."""
+    import numpy as np
+    import pytest
+    import torch
+    from videotgb_amd import video
+    rng = np.random.default_rng(0)
+    clip = rng.integers(0, 256, (5, 12, 16, 3), dtype=np.uint8)
+
+    class AvFrame:                                                 # what av.VideoFrame offers
+        def __init__(self, a):
+            self.a = a
+
+        def to_ndarray(self, format="rgb24"):
+            assert format == "rgb24"
+            return self.a
+    for src in (clip, torch.from_numpy(clip), list(clip), (torch.from_numpy(f) for f in clip), [AvFrame(f) for f in clip]):
+        assert np.array_equal(video.pack_decoded(src), clip)
+    slot = np.zeros((8, 12, 16, 3), dtype=np.uint8)
+    out = video.pack_decoded(iter(clip), slot)
+    assert out.shape == clip.shape and np.array_equal(slot[:5], clip) and out.base is slot or np.shares_memory(out, slot)
+    with pytest.raises(ValueError):
+        video.pack_decoded(clip, np.zeros((4, 12, 16, 3), dtype=np.uint8))           # more frames than the slot holds
+    with pytest.raises(TypeError):
+        video.pack_decoded(clip.astype(np.float32))
+    with pytest.raises(ValueError):
+        video.pack_decoded([])

@@ -254,3 +254,23 @@ def test_preprocess_frames_vs_reference_and_oracle(dev):
         assert a.shape == b.shape and d.max() <= level and (d > 0).float().mean() <= 1e-4
     with pytest.raises(TypeError):
         ops.preprocess_frames(raw.float().to(dev))
+
+
+@pytest.mark.gpu
+def test_frame_stager_overlapped_uploads_equal_the_direct_path(dev):
+    """row f3's decode feed (video.FrameStager): clips written by an external decoder into pinned slots and uploaded on a copy stream give the
+    same tensors as preprocessing the clip directly; slots are reused across more clips than there are slots."""
+    import numpy as np
+    from videotgb_amd import builder_utils, video
+    rng = np.random.default_rng(1)
+    st = video.FrameStager(dev, max_frames=40, height=90, width=160, slots=2)
+    clips = [rng.integers(0, 256, (t, 90, 160, 3), dtype=np.uint8) for t in (40, 17, 33, 40, 9)]
+    tickets = [st.stage(clips[0]), st.stage(iter(clips[1]))]
+    for i, c in enumerate(clips):
+        frames, flow = st.frames(tickets[i])
+        rf, rff = video.get_frames(torch.from_numpy(c).to(dev))
+        assert torch.equal(frames, rf) and torch.equal(flow, rff) and tuple(flow.shape) == (c.shape[0], 3, 224, 224)
+        bf, bff = builder_utils.get_frames(c, device=dev)                      # the reference-shaped entry with a host-side clip
+        assert torch.equal(bf, rf) and torch.equal(bff, rff)
+        if i + 2 < len(clips):
+            tickets.append(st.stage(clips[i + 2]))                             # reuses the slot of clip i

@@ -18,7 +18,7 @@ MAP_A, MAP_B = 0, 1
 POOL_MEAN, POOL_CONCAT = 0, 1
 TGB_MODE = {"text": 0, "vision": 0, "fusion": 1, "multi_modal": 2}
 EPI_STORE, EPI_GELU, EPI_RESID_F32, EPI_STORE_F32 = 0, 1, 2, 3
-VIT_NW_GLOBAL, VIT_NW_LAYER = 6, 12
+VIT_NW_GLOBAL, VIT_NW_LAYER = 6, 18
 QF_NW_GLOBAL, QF_NW_LAYER = 4, 32
 TGB_NW_GLOBAL, TGB_NW_LAYER = 17, 26
 

@@ -59,11 +59,17 @@ def read_video_frames(video_path: str, fps=2) -> torch.Tensor:
 
 def get_frames(video_path, target_size=224, keyframe=False, start_ratio=0.0, end_ratio=1.0, fps=None, device="cuda"):
     """eval/utils/builder_utils.py:117-144 -> ``(frames [32, 3, S, S], flow_frames [T, 3, S, S])`` fp32, here on ``device``
-    (the reference returns CPU tensors and the driver moves them, eval/inference.py:70-71).  ``video_path``: a file path, or
-    decoded frames [T, H, W, 3] uint8.  ``keyframe`` / ``start_ratio`` / ``end_ratio`` are accepted and, as in the
-    reference's live code, unused."""
+    (the reference returns CPU tensors and the driver moves them, eval/inference.py:70-71).  ``video_path``: a file path (decoded with
+    PyAV, as the reference does -- if it is installed), or the output of ANY decoder: a [T, H, W, 3] uint8 tensor / numpy array, or an
+    iterable of [H, W, 3] RGB frames (``video.pack_decoded``).  Host-side clips go through pinned memory (``video.FrameStager`` keeps
+    the slots and overlaps the upload with the previous clip).  ``keyframe`` / ``start_ratio`` / ``end_ratio`` are accepted and, as in
+    the reference's live code, unused."""
     raw = read_video_frames(video_path, fps) if isinstance(video_path, str) else video_path
-    return video.get_frames(raw.to(device), target_size)
+    if not (isinstance(raw, torch.Tensor) and raw.is_cuda):
+        raw = torch.from_numpy(video.pack_decoded(raw))
+        if torch.device(device).type == "cuda":
+            raw = raw.pin_memory()
+    return video.get_frames(raw.to(device, non_blocking=True), target_size)
 
 
 class KeywordsStoppingCriteria:

@@ -196,7 +196,21 @@ struct GemmDesc {
     // EPI_SPLIT: out (bf16, row stride ldo) receives act(acc + bias) as such a pair: hi at column n, lo at column n + split_lo.
     // N % 2 == 0, ldo % 4 == 0, split_lo % 4 == 0; persistent kernel only.
     int split_lo;
+    // ---- LayerNorm folded into the GEMMs around it (bf16 ViT path, r5: the 79 stand-alone LayerNorm passes of EVA-ViT-g are gone).
+    // y = LN(x) W^T + b = rstd_m (x_m . W'_n - mean_m cs_n) + c_n   with W' = W diag(gamma), cs_n = sum_k W'_nk, c_n = sum_k beta_k W_nk + b_n.
+    // PRODUCER (EPI_RESID_F32: the GEMM that writes the residual stream x): ln_xb (bf16 [M, ldxb]) also receives bf16(x) -- the next GEMM's
+    // operand -- and ln_part [M][ceil(N / 64)][2] the (sum, sum of squares) of every 64-column block of the row (launch_ln_fold_stats turns
+    // them into (mean, rstd) per row, in block order).
+    void* ln_xb;
+    int64_t ldxb;
+    float* ln_part;
+    // CONSUMER (EPI_STORE / EPI_GELU, bias == NULL, N % 4 == 0): out = act(rstd_m (acc - mean_m cs_n) + c_n); ln_stats [M][2] = (mean, rstd).
+    const float* ln_stats;
+    const float* ln_cs;
+    const float* ln_c;
 };
+int launch_ln_fold_stats(const float* part, int nblk, int D, float eps, float* stats, int64_t M, hipStream_t s);
+int launch_ln_fold_prepare(const float* x, int64_t ldx, int D, float eps, void* xb, float* stats, int64_t M, hipStream_t s);
 #define VTGB_EPI_GRU 4
 #define VTGB_EPI_SPLIT 5
 // bf16x3 SepConvGRU epilogues (raft_x3.hip; persistent kernel only):

@@ -349,3 +349,55 @@ int launch_pack_bf16(const float* src, void* dst, int64_t rows, int64_t cols, in
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm folded into the GEMMs around it (GemmDesc::ln_*, r5)
+// ---------------------------------------------------------------------------------------
+// (mean, rstd) of every row from the (sum, sum of squares) of its 64-column blocks, added in block order
+__global__ void ln_fold_stats_kernel(const float* __restrict__ part, int nblk, float inv_d, float eps, float* __restrict__ stats, int64_t M) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float s = 0.f, q = 0.f;
+    for (int b = 0; b < nblk; b++) {
+        const float2 v = *reinterpret_cast<const float2*>(part + (m * nblk + b) * 2);
+        s += v.x; q += v.y;
+    }
+    const float mean = s * inv_d;
+    const float var = fmaxf(fmaf(-mean, mean, q * inv_d), 0.f);
+    *reinterpret_cast<float2*>(stats + m * 2) = make_float2(mean, rsqrtf(var + eps));
+}
+int launch_ln_fold_stats(const float* part, int nblk, int D, float eps, float* stats, int64_t M, hipStream_t s) {
+    hipLaunchKernelGGL(ln_fold_stats_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, part, nblk, 1.0f / (float)D, eps, stats, M);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+// the first LayerNorm of a stack (its input comes from the embedding, not from a residual GEMM): bf16 copy of x and the rows' block moments, in the
+// SAME association as the GEMM epilogues produce them (four columns per lane, a 16-lane butterfly per 64-column block: gemm_dev.h ln_part4)
+__global__ __launch_bounds__(256) void ln_fold_prepare_kernel(const float* __restrict__ x, int64_t ldx, int D, bf16_t* __restrict__ xb, float* __restrict__ part, int64_t M) {
+    const int lane = threadIdx.x & 63, cl = lane & 15, sub = lane >> 4;
+    const int64_t m = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub;      // a wave: four rows, sixteen lanes each
+    const int nblk = (D + 63) >> 6;
+    for (int b = 0; b < nblk; b++) {
+        const int n = b * 64 + cl * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < M && n < D) {
+            v = *reinterpret_cast<const f32x4*>(x + m * ldx + n);
+            *reinterpret_cast<bf16x4*>(xb + m * D + n) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        }
+        float s_ = (v[0] + v[1]) + (v[2] + v[3]);
+        float q_ = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { s_ += __shfl_xor(s_, off); q_ += __shfl_xor(q_, off); }
+        if (m < M && cl == 0) *reinterpret_cast<float2*>(part + (m * nblk + b) * 2) = make_float2(s_, q_);
+    }
+}
+int launch_ln_fold_prepare(const float* x, int64_t ldx, int D, float eps, void* xb, float* stats, int64_t M, hipStream_t s) {
+    // stats doubles as the partial buffer's owner: the caller passes part = stats + 2 M ... (see vit_impl); here `stats` IS the partial buffer
+    (void)eps;
+    VTGB_REQUIRE((D & 3) == 0 && (ldx & 3) == 0, VTGB_EINVAL, "ln_fold_prepare: 4-aligned rows");
+    hipLaunchKernelGGL(ln_fold_prepare_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s, x, ldx, D, (bf16_t*)xb, stats, M);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}

@@ -130,12 +130,20 @@ static int vit_impl(const vtgb_vit_args* a, Workspace& ws, hipStream_t s) {
     void* qkv = ws.take(M * 3 * D * es);
     void* ctx = ws.take(M * D * es);
     void* mlp = ws.take(M * a->mlp * es);
+    const int ln_nblk = (D + 63) / 64;
+    float* ln_part = (float*)ws.take(M * ln_nblk * 2 * 4);      // folded LayerNorms: per (row, 64-column block) moments; (mean, rstd) per row
+    float* ln_stats = (float*)ws.take(M * 2 * 4);
     if (ws.dry) return VTGB_OK;
     VTGB_REQUIRE(ws.ok(), VTGB_EWORKSPACE, "vit: workspace %zu < %zu bytes", ws.size, ws.used);
     VTGB_REQUIRE(a->pixel_values && a->weights && (a->out_f32 || a->out_act), VTGB_EINVAL, "vit: You have to specify pixel_values");
     const void* const* w = a->weights;
-    for (int i = 0; i < VTGB_VIT_NW_GLOBAL + VTGB_VIT_NW_LAYER * a->layers; i++)
+    // bf16: the LayerNorms folded into the qkv / fc1 GEMMs when the table carries the folded weights (+12 .. +17 of every layer)
+    bool fold = dt == VTGB_BF16 && a->layers > 0 && (D % 4) == 0;
+    for (int i = 0; i < VTGB_VIT_NW_GLOBAL + VTGB_VIT_NW_LAYER * a->layers; i++) {
+        const int li = i < VTGB_VIT_NW_GLOBAL ? -1 : (i - VTGB_VIT_NW_GLOBAL) % VTGB_VIT_NW_LAYER;
+        if (li >= 12) { fold = fold && w[i] != nullptr; continue; }
         VTGB_REQUIRE(w[i], VTGB_EINVAL, "vit: weights[%d] is NULL", i);
+    }
 
     // embeddings (xinstructblip.py:113-122): patch GEMM writes rows 1.. with + position_embedding fused
     VTGB_TRY(launch_im2col(dt, a->pixel_values, col, n, 3, a->image, a->patch, kpad, s));
@@ -147,10 +155,28 @@ static int vit_impl(const vtgb_vit_args* a, Workspace& ws, hipStream_t s) {
     }
     VTGB_TRY(launch_vit_cls_rows((const float*)w[2], (const float*)w[3], x, n, tokens, D, s));
     const float scale = (float)pow((double)hd, -0.5);   // :140
+    // folded LayerNorms (GemmDesc::ln_*): h holds bf16(x), written with the rows' block moments by whoever produced x -- the embedding (one
+    // pass below) or the projection / fc2 epilogue -- and the GEMM that follows applies rstd (acc - mean cs) + c in ITS epilogue
+    auto ln_consumer = [&](GemmDesc d, const void* wf, const void* cs, const void* c) {
+        d.W = wf; d.bias = nullptr; d.ln_stats = ln_stats; d.ln_cs = (const float*)cs; d.ln_c = (const float*)c;
+        return d;
+    };
+    auto ln_producer = [&](GemmDesc d, bool on) {
+        if (on) { d.ln_xb = h; d.ldxb = D; d.ln_part = ln_part; }
+        return d;
+    };
+    if (fold) {
+        VTGB_TRY(launch_ln_fold_prepare(x, D, D, a->eps, h, ln_part, M, s));
+        VTGB_TRY(launch_ln_fold_stats(ln_part, ln_nblk, D, a->eps, ln_stats, M, s));
+    }
     for (int l = 0; l < a->layers; l++) {
         const void* const* lw = w + VTGB_VIT_NW_GLOBAL + VTGB_VIT_NW_LAYER * l;
+        if (fold) {
+            VTGB_TRY(launch_gemm(ln_consumer(gemm(dt, (int)M, 3 * D, D, VTGB_EPI_STORE, h, D, lw[12], D, nullptr, qkv, 3 * D), lw[12], lw[13], lw[14]), s));
+        } else {
         VTGB_TRY(launch_layernorm(ln(dt, (int)M, D, a->eps, x, (const float*)lw[0], (const float*)lw[1], nullptr, h), s));
         VTGB_TRY(launch_gemm(gemm(dt, (int)M, 3 * D, D, VTGB_EPI_STORE, h, D, lw[2], D, (const float*)lw[3], qkv, 3 * D), s));
+        }
         AttnDesc at;
         memset(&at, 0, sizeof(at));
         at.dtype = dt; at.batch = n; at.heads = a->heads; at.head_dim = hd; at.s_q = tokens; at.s_kv = tokens;
@@ -158,12 +184,19 @@ static int vit_impl(const vtgb_vit_args* a, Workspace& ws, hipStream_t s) {
         at.q_tok = at.kv_tok = 3 * D; at.q_batch = at.kv_batch = (int64_t)tokens * 3 * D;
         at.scale = scale; at.out = ctx; at.o_tok = D; at.o_batch = (int64_t)tokens * D;
         VTGB_TRY(launch_attention(at, s));
-        VTGB_TRY(launch_gemm(with_resid(gemm(dt, (int)M, D, D, VTGB_EPI_RESID_F32, ctx, D, lw[4], D, (const float*)lw[5], x, D), x, D,
-                                        rowmap_identity()), s));
+        VTGB_TRY(launch_gemm(ln_producer(with_resid(gemm(dt, (int)M, D, D, VTGB_EPI_RESID_F32, ctx, D, lw[4], D, (const float*)lw[5], x, D), x, D,
+                                                    rowmap_identity()), fold), s));
+        if (fold) {
+            VTGB_TRY(launch_ln_fold_stats(ln_part, ln_nblk, D, a->eps, ln_stats, M, s));
+            VTGB_TRY(launch_gemm(ln_consumer(gemm(dt, (int)M, a->mlp, D, VTGB_EPI_GELU, h, D, lw[15], D, nullptr, mlp, a->mlp), lw[15], lw[16], lw[17]), s));
+        } else {
         VTGB_TRY(launch_layernorm(ln(dt, (int)M, D, a->eps, x, (const float*)lw[6], (const float*)lw[7], nullptr, h), s));
         VTGB_TRY(launch_gemm(gemm(dt, (int)M, a->mlp, D, VTGB_EPI_GELU, h, D, lw[8], D, (const float*)lw[9], mlp, a->mlp), s));
-        VTGB_TRY(launch_gemm(with_resid(gemm(dt, (int)M, D, a->mlp, VTGB_EPI_RESID_F32, mlp, a->mlp, lw[10], a->mlp, (const float*)lw[11], x, D),
-                                        x, D, rowmap_identity()), s));
+        }
+        const bool more = fold && l + 1 < a->layers;      // (the last layer's output goes to post_layernorm, a pass of its own: it has two outputs)
+        VTGB_TRY(launch_gemm(ln_producer(with_resid(gemm(dt, (int)M, D, a->mlp, VTGB_EPI_RESID_F32, mlp, a->mlp, lw[10], a->mlp, (const float*)lw[11], x, D),
+                                                    x, D, rowmap_identity()), more), s));
+        if (more) VTGB_TRY(launch_ln_fold_stats(ln_part, ln_nblk, D, a->eps, ln_stats, M, s));
     }
     VTGB_TRY(launch_layernorm(ln(dt, (int)M, D, a->eps, x, (const float*)w[4], (const float*)w[5], a->out_f32, a->out_act), s));
     return VTGB_OK;

@@ -167,6 +167,52 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmDesc p) {
 #undef STAGE_WRITE
 #undef STAGE_WRITE1
     // D layout: column (lane & 15) <- X row (m), rows (lane >> 4) * 4 + reg <- W row (n)
+    // LayerNorm folded into the GEMM (GemmDesc::ln_*; gemm_dev.h): the same arithmetic as the persistent kernel's epilogues
+    if constexpr (EPI == EPI_STORE || EPI == EPI_GELU) {
+        if (p.ln_stats) {
+            f32x4 cs4[4], c4[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int nc = min(n0 + wn * 64 + i * 16 + fg * 4, p.N - 4);
+                cs4[i] = *reinterpret_cast<const f32x4*>(p.ln_cs + nc);
+                c4[i] = *reinterpret_cast<const f32x4*>(p.ln_c + nc);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int mr = min(m0 + wm * 64 + j * 16 + fr, p.M - 1);
+                const float2 st = *reinterpret_cast<const float2*>(p.ln_stats + (int64_t)mr * 2);
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[i][j] = ln_fold4(acc[i][j], st.x, st.y, cs4[i], c4[i]);
+            }
+        }
+    }
+    if constexpr (EPI == EPI_RESID_F32) {
+        if (p.ln_xb) {      // producer: x = acc + resid -> fp32 out, bf16 copy, (sum, sum of squares) of the row's 64-column block
+            const int nblk = (p.N + 63) >> 6, blk = (n0 + wn * 64) >> 6;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int m = m0 + wm * 64 + j * 16 + fr;
+                const bool mok = m < p.M;
+                float s4[4], q4[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int n = n0 + wn * 64 + i * 16 + fg * 4;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (mok && n < p.N) {
+                        v = acc[i][j] + *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n) = v;
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.ln_xb) + (int64_t)m * p.ldxb + n) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    }
+                    ln_part4(v, s4[i], q4[i]);
+                    s4[i] += __shfl_xor(s4[i], 16); q4[i] += __shfl_xor(q4[i], 16);      // column groups cl = 4 i + fg: cl ^ 1, cl ^ 2 are lanes, cl ^ 4, cl ^ 8 registers
+                    s4[i] += __shfl_xor(s4[i], 32); q4[i] += __shfl_xor(q4[i], 32);
+                }
+                const float S = (s4[0] + s4[1]) + (s4[2] + s4[3]), Q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+                if (mok && fg == 0 && blk < nblk) *reinterpret_cast<float2*>(p.ln_part + ((int64_t)m * nblk + blk) * 2) = make_float2(S, Q);
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int m = m0 + wm * 64 + j * 16 + fr;
@@ -1055,6 +1101,7 @@ static int launch_epi(const GemmDesc& d, hipStream_t s) {
             const int mx = (m_tiles + 7) / 8, groups = (mx + G - 1) / G;
             const dim3 grid(8 * groups * G * n_tiles);
             if (!use_old_large() && !g_ablate && pp_supported(d) && pp_class_enabled(EPI, false, 4, false)) return launch_large_pp<EPI, false, 4>(d, s);
+            VTGB_REQUIRE(!d.ln_xb && !d.ln_stats, VTGB_EUNSUPPORTED, "gemm: the folded LayerNorm needs the persistent or the 128 x 128 kernel (row maps / alignment)");
             ProfScope prof(VTGB_PROF_GEMM, 2.0 * d.M * d.N * d.K, s);
 #ifdef VTGB_DEBUG_HOOKS
             if (g_ablate && (EPI == EPI_STORE || EPI == EPI_RESID_F32)) {
@@ -1233,6 +1280,11 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
         VTGB_REQUIRE(((uintptr_t)d.A % 16) == 0 && ((uintptr_t)d.W % 16) == 0, VTGB_EINVAL, "gemm bf16: operands must be 16-byte aligned");
     }
     if (d.epi == EPI_RESID_F32) VTGB_REQUIRE(d.resid != nullptr, VTGB_EINVAL, "gemm: residual epilogue without resid");
+    if (d.ln_xb || d.ln_stats)
+        VTGB_REQUIRE(d.dtype == VTGB_BF16 && (d.N & 3) == 0 && (d.ldo & 3) == 0 && d.o_map.seg_rows == 0 && d.r_map.seg_rows == 0 && d.a_map.seg_rows == 0 &&
+                         (d.ln_xb ? (d.epi == EPI_RESID_F32 && d.ln_part && (d.ldxb & 3) == 0 && (d.ldr & 3) == 0)
+                                  : ((d.epi == EPI_STORE || d.epi == EPI_GELU) && !d.bias && d.ln_cs && d.ln_c)),
+                     VTGB_EINVAL, "gemm: folded LayerNorm needs bf16, identity row maps, 4-aligned rows and (producer) the partial buffer / (consumer) no bias");
     switch (d.epi) {
         case EPI_STORE: return launch_epi<EPI_STORE>(d, s);
         case EPI_GELU: return launch_epi<EPI_GELU>(d, s);

@@ -147,3 +147,18 @@ __device__ __forceinline__ void store4(const GemmDesc& p, int m, int n0, f32x4 v
     }
 }
 
+
+// ---- LayerNorm folded into the GEMMs around it (GemmDesc::ln_*): the SAME functions in every kernel that produces or consumes the
+// statistics, so that a row's numbers do not depend on the kernel its batch size selects.
+// sum and sum of squares of four consecutive values, fixed association
+__device__ __forceinline__ void ln_part4(const f32x4 v, float& s, float& q) {
+    s = (v[0] + v[1]) + (v[2] + v[3]);
+    q = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+}
+// rstd (acc - mean cs) + c, element-wise
+__device__ __forceinline__ f32x4 ln_fold4(const f32x4 acc, float mean, float rstd, const f32x4 cs, const f32x4 c) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e] = fmaf(rstd, fmaf(-mean, cs[e], acc[e]), c[e]);
+    return o;
+}

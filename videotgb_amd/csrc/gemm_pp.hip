@@ -38,7 +38,9 @@ constexpr int P_AOP = 256 * P_BK * 2;   // 32 KiB activation slot (256 rows)
 // WF = 16-column weight fragments per wave: 4 (64-column wave tiles: every instantiation but one) or 3 -- the 256 x 192 tile of RAFT's convc2
 // (3x3, 256 -> 192 channels; update.py:79): on the 256-wide tile two of its eight waves held only padding, and since waves w and w + 4
 // share a SIMD two SIMDs carried twice the MFMA work of the other two; with 48-column wave tiles all eight waves multiply (round 4).
-template <int EPI, bool CONV, int NWN, bool TAIL = false, bool PING = !CONV, int WF = 4>
+// LNF: the LayerNorm-folded forms of the plain GEMMs (GemmDesc::ln_*) are their own instantiations -- the extra epilogue state (column sums, row
+// statistics / the bf16 copy and the row moments) pushed the shared ones past 256 registers
+template <int EPI, bool CONV, int NWN, bool TAIL = false, bool PING = !CONV, int WF = 4, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G, const int total_blocks) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NX = 2 * NWN;          // activation fragments per wave: wave tile = (16 NX) x 64
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
             // per lane_e, 8 whole 128-byte row segments per store instruction.  The operands of the fused elementwise tails (r * h gate,
             // ResidualBlock skip) of ALL passes are requested first, then the next tile's first k-tile; one counted wait.
             constexpr int RP = SB / 128 < WROWS ? SB / 128 : WROWS, NP = WROWS / RP, JB = RP / 16;
-            const bool gated = EPI == EPI_STORE && p.gate_from > 0, resd = EPI == EPI_STORE && !gated && p.resid_bf16 != nullptr;
+            const bool gated = !LNF && EPI == EPI_STORE && p.gate_from > 0, resd = !LNF && EPI == EPI_STORE && !gated && p.resid_bf16 != nullptr;
             const int ch0 = lane_e & 7, nn = ch0 * 8 < WC ? en0 + wn * WC + ch0 * 8 : 0x40000000;      // (48-column wave tiles: chunks 6, 7 of a staged row do not exist)
             const bool to_out2 = gated && (en0 + wn * WC) >= p.gate_from;     // wave-uniform (gate_from % 64 == 0): this wave's columns are r -> r * h
             const int col = to_out2 ? nn - p.gate_from : nn;
@@ -526,7 +528,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
             const unsigned g_lane = nn < p.N ? (unsigned)((wm * WROWS + (lane_e >> 3)) * (int)ld_g + col) * 2u : OOB;
 #define P_OPND_LOAD(h) _Pragma("unroll") for (int rr = 0; rr < RP / 8; rr++) opnd[rr] = __builtin_amdgcn_raw_buffer_load_b128(g_rs, g_lane, ((h) * RP + rr * 8) * (int)ld_g * 2, 0);
             if (has_opnd) { P_OPND_LOAD(0) }
+            // LayerNorm folded into this GEMM (GemmDesc::ln_stats; plain GEMMs): the lane's column sums / constants and its rows' (mean, rstd),
+            // requested in front of the next tile's pieces like every other epilogue operand
+            constexpr bool lnf = LNF && !CONV;
+            f32x4 ln_cs4[WF], ln_c4[WF];
+            float ln_m[NX], ln_r[NX];
+            if (lnf) {
+#pragma unroll
+                for (int i = 0; i < WF; i++) {
+                    const int nc = min(en0 + wn * WC + i * 16 + (lane_e >> 4) * 4, p.N - 4);      // (columns beyond N are never stored)
+                    ln_cs4[i] = *reinterpret_cast<const f32x4*>(p.ln_cs + nc);
+                    ln_c4[i] = *reinterpret_cast<const f32x4*>(p.ln_c + nc);
+                }
+#pragma unroll
+                for (int j = 0; j < NX; j++) {
+                    const int mr = min(em0 + wm * WROWS + j * 16 + (lane_e & 15), p.M - 1);
+                    const float2 st_ = *reinterpret_cast<const float2*>(p.ln_stats + (int64_t)mr * 2);
+                    ln_m[j] = st_.x; ln_r[j] = st_.y;
+                }
+            }
             prefetch();
+            if (lnf) { P_WAIT_OPERANDS() }
 #pragma unroll
             for (int ps = 0; ps < NP; ps++) {
 #pragma unroll
@@ -534,6 +556,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmDesc p, 
 #pragma unroll
                     for (int i = 0; i < WF; i++) {
                         f32x4 v = acc[i][ps * JB + jj];
+                        if (lnf) v = ln_fold4(v, ln_m[ps * JB + jj], ln_r[ps * JB + jj], ln_cs4[i], ln_c4[i]);
                         if constexpr (EPI == EPI_GELU) {
 gelu_erf_fast4(v);
                         } else if (p.act) apply_act4(v, p.act);
@@ -600,6 +623,13 @@ gelu_erf_fast4(v);
             const unsigned o_lane = n < p.N ? (unsigned)((wm * WROWS + rl) * (int)p.ldo + n) * 4u : OOB;
             const auto r_rs = tile_rsrc(EPI == EPI_RESID_F32 ? (const void*)p.resid : (const void*)p.out, EPI == EPI_RESID_F32 ? p.ldr : p.ldo, 4);
             const unsigned r_lane = n < p.N ? (unsigned)((wm * WROWS + rl) * (int)(EPI == EPI_RESID_F32 ? p.ldr : p.ldo) + n) * 4u : OOB;
+            // LayerNorm fold, producer side (GemmDesc::ln_xb): bf16 copy of the rows + per (row, 64-column block) moments
+            constexpr bool lnp = LNF && EPI == EPI_RESID_F32 && !CONV;
+            const int ln_nblk = (p.N + 63) >> 6;
+            const auto xb_rs = tile_rsrc(lnp ? p.ln_xb : p.out, lnp ? p.ldxb : p.ldo, 2);
+            const auto pt_rs = tile_rsrc(lnp ? (const void*)p.ln_part : (const void*)p.out, lnp ? ln_nblk * 2 : p.ldo, 4);
+            const unsigned xb_lane = (lnp && n < p.N) ? (unsigned)((wm * WROWS + rl) * (int)p.ldxb + n) * 2u : OOB;
+            const unsigned pt_lane = (lnp && cl == 0 && n < p.N) ? (unsigned)((wm * WROWS + rl) * ln_nblk * 2 + (n >> 6) * 2) * 4u : OOB;
             u32x4_t rq[PR / 4];
 #define P_RESID_LOAD(h)                                                                                             \
     _Pragma("unroll") for (int rr = 0; rr < PR / 4; rr++) rq[rr] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, r_lane, ((h) * PR + rr * 4) * (int)p.ldr * 4, 0);
@@ -616,6 +646,7 @@ gelu_erf_fast4(v);
                     }
                 if constexpr (EPI == EPI_RESID_F32) {
                     if (ps == 0) { P_WAIT_OPERANDS() }
+                    else if (lnp) __builtin_amdgcn_s_waitcnt(0x4F78);     // (LayerNorm fold: 3 stores per row group -- vmcnt(24))
                     else __builtin_amdgcn_s_waitcnt(0x0F70 | (PR / 4));   // this pass's rows; the previous pass's PR / 4 stores may still fly
                 }
                 f32x4 vv[PR / 4];
@@ -631,6 +662,19 @@ gelu_erf_fast4(v);
 #pragma unroll
                 for (int rr = 0; rr < PR / 4; rr++) {
                     P_STORE128(__builtin_bit_cast(u32x4_t, vv[rr]), o_rs, o_lane, (ps * PR + rr * 4) * (int)p.ldo * 4);
+                    if constexpr (EPI == EPI_RESID_F32) {
+                        if (lnp) {
+                            const f32x4 v = vv[rr];
+                            const bf16x4 xb4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                            P_STORE64(__builtin_bit_cast(u32x2_t, xb4), xb_rs, xb_lane, (ps * PR + rr * 4) * (int)p.ldxb * 2);
+                            float s_, q_;
+                            ln_part4(v, s_, q_);
+#pragma unroll
+                            for (int off = 1; off < 16; off <<= 1) { s_ += __shfl_xor(s_, off); q_ += __shfl_xor(q_, off); }
+                            const u32x2_t sq = {__float_as_uint(s_), __float_as_uint(q_)};
+                            P_STORE64(sq, pt_rs, pt_lane, (ps * PR + rr * 4) * ln_nblk * 2 * 4);
+                        }
+                    }
                     if constexpr (EPI == EPI_STORE_F32) {
                         if (do_stats) {
                             const int m = em0 + wm * WROWS + ps * PR + rr * 4 + rl;
@@ -901,6 +945,10 @@ int cu_count() {
 // whole-vector rows for its staged epilogues, fragment-order start maps, wave-aligned gates.
 bool pp_supported(const GemmDesc& d) {
     if (d.o_map.seg_rows != 0 || d.r_map.seg_rows != 0) return false;
+    if (d.ln_xb && (d.epi != EPI_RESID_F32 || d.conv_KH > 0 || (d.ldxb & 3) != 0 || !d.ln_part || (d.N & 3) != 0)) return false;
+    if (d.ln_stats && (!(d.epi == EPI_STORE || d.epi == EPI_GELU) || d.conv_KH > 0 || d.bias || !d.ln_cs || !d.ln_c || (d.N & 3) != 0 || d.frag_out || d.gate_from > 0 ||
+                       d.resid_bf16 || d.tail_w))
+        return false;
     if (d.init_bf16 && !d.init_frag) return false;
     if ((d.ldw & 63) != 0) return false;      // (the weight pieces' swizzle is applied as offset ^ 64: rows of whole 128 bytes)
     if ((d.N & 3) != 0 && !((d.epi == EPI_STORE || d.epi == EPI_SPLIT) && !d.frag_out && (d.N & 1) == 0)) return false;
@@ -959,6 +1007,15 @@ int launch_large_pp(const GemmDesc& d, hipStream_t s) {
             static DeviceOnce attr_t;
             VTGB_FUNC_LDS_ONCE(attr_t, (gemm_bf16_pp_kernel<EPI, CONV, NWN, true>), LDS);
             hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, CONV, NWN, true>), dim3(grid), dim3(512), LDS, s, d, m_tiles, n_tiles, G, total);
+            VTGB_HIP(hipGetLastError());
+            return VTGB_OK;
+        }
+    }
+    if constexpr (!CONV && NWN == 4 && (EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_RESID_F32)) {
+        if (d.ln_stats || d.ln_xb) {      // LayerNorm folded into the GEMM: its own instantiation
+            static DeviceOnce attr_ln;
+            VTGB_FUNC_LDS_ONCE(attr_ln, (gemm_bf16_pp_kernel<EPI, CONV, NWN, false, PING, 4, true>), LDS);
+            hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, CONV, NWN, false, PING, 4, true>), dim3(grid), dim3(512), LDS, s, d, m_tiles, n_tiles, G, total);
             VTGB_HIP(hipGetLastError());
             return VTGB_OK;
         }

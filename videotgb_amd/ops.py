@@ -277,7 +277,7 @@ class _WeightTable:
 class VitWeights(_WeightTable):
     """model.vision_model.* -> the pointer table of vtgb_vit_forward (include/vtgb.h)."""
 
-    def __init__(self, sd: Dict[str, Tensor], prefix: str, code: int, heads: int, eps: float = 1e-6):
+    def __init__(self, sd: Dict[str, Tensor], prefix: str, code: int, heads: int, eps: float = 1e-6, fold_ln: bool = True):
         super().__init__(code)
         p = prefix
         pw = sd[p + "embeddings.patch_embedding.weight"]
@@ -302,6 +302,17 @@ class VitWeights(_WeightTable):
             self.add(sd[lp + "layer_norm2.weight"]); self.add(sd[lp + "layer_norm2.bias"])
             self.add(sd[lp + "mlp.fc1.weight"], True); self.add(sd[lp + "mlp.fc1.bias"])
             self.add(sd[lp + "mlp.fc2.weight"], True); self.add(sd[lp + "mlp.fc2.bias"])
+            # bf16 mode: the two LayerNorms folded into the GEMMs that follow them (include/vtgb.h: +12 .. +17)
+            for lnn, lin in (("layer_norm1", "self_attn.qkv"), ("layer_norm2", "mlp.fc1")):
+                if code == BF16 and fold_ln:
+                    wl, bl = sd[lp + lin + ".weight"].float(), sd[lp + lin + ".bias"].float()
+                    gam, bet = sd[lp + lnn + ".weight"].float(), sd[lp + lnn + ".bias"].float()
+                    wf = (wl * gam[None, :]).to(torch.bfloat16)
+                    self.tensors.append(wf.contiguous())
+                    self.add(wf.float().sum(1))
+                    self.add((wl.double() @ bet.double() + bl.double()).float())
+                else:
+                    self.add(None); self.add(None); self.add(None)
             self.mlp = sd[lp + "mlp.fc1.weight"].shape[0]
             self.layers += 1
         self.finish()

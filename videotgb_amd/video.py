@@ -48,3 +48,90 @@ def get_frames(raw: Tensor, target_size: int = 224, n_cand: int = 32) -> Tuple[T
     idx = torch.tensor(candidate_frame_ids(raw.shape[0], n_cand), dtype=torch.int64, device=raw.device)
     frames = ops.preprocess_frames(raw, idx, target_size)
     return frames, flow_frames
+
+
+def pack_decoded(frames, out: np.ndarray = None) -> np.ndarray:
+    """Any decoder's output -> one contiguous uint8 array [T, H, W, 3] (written into ``out[:T]`` if given): a [T, H, W, 3] array /
+    CPU tensor, or an iterable of [H, W, 3] RGB frames (numpy arrays, CPU tensors, or objects with ``to_ndarray(format="rgb24")``
+    such as PyAV's VideoFrame -- what eval/utils/builder_utils.py:117-128 collects)."""
+    def one(f):
+        if hasattr(f, "to_ndarray"):
+            f = f.to_ndarray(format="rgb24")
+        if isinstance(f, Tensor):
+            f = f.numpy()
+        f = np.asarray(f)
+        if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] != 3:
+            raise TypeError(f"decoded frames must be uint8 [H, W, 3] RGB (got {f.dtype} {f.shape})")
+        return f
+    if isinstance(frames, Tensor):
+        frames = frames.numpy()
+    if isinstance(frames, np.ndarray):
+        if frames.dtype != np.uint8 or frames.ndim != 4 or frames.shape[3] != 3:
+            raise TypeError(f"decoded clip must be uint8 [T, H, W, 3] (got {frames.dtype} {frames.shape})")
+        if out is None:
+            return np.ascontiguousarray(frames)
+        if frames.shape[0] > out.shape[0] or frames.shape[1:] != out.shape[1:]:
+            raise ValueError(f"clip {frames.shape} does not fit the staging slot {out.shape}")
+        out[:frames.shape[0]] = frames
+        return out[:frames.shape[0]]
+    t = 0
+    rows = []
+    for f in frames:
+        f = one(f)
+        if out is None:
+            rows.append(f)
+        else:
+            if t >= out.shape[0] or f.shape != out.shape[1:]:
+                raise ValueError(f"frame {t} {f.shape} does not fit the staging slot {out.shape}")
+            out[t] = f
+        t += 1
+    if t == 0:
+        raise ValueError("empty clip")
+    return np.stack(rows) if out is None else out[:t]
+
+
+class FrameStager:
+    """Decode feed of row f3 (eval/utils/builder_utils.py:117-144) for an EXTERNAL decoder: the decoder (PyAV, a hardware decoder's host
+    copy, a dataloader worker) writes RGB frames into pinned host slots, a copy stream uploads a slot while the previous clip computes,
+    and ``frames()`` hands the device-side preprocessing (resize / crop-free squash, /255, CLIP normalise, candidate pick: one kernel each
+    for the 32 candidate frames and the T flow frames) a tensor that is already in HBM.
+
+        st = FrameStager("cuda", max_frames=96, height=360, width=640)        # two slots by default
+        t0 = st.stage(decoded_clip_0)                                          # async H2D; returns a ticket
+        t1 = st.stage(decoded_clip_1)                                          # overlaps clip 0's compute
+        frames, flow_frames = st.frames(t0)                                    # == builder_utils.get_frames(...) of the reference
+    A slot is reused once the clip staged ``slots`` calls earlier has been consumed by ``frames()`` (stream-ordered: an event guards it)."""
+
+    def __init__(self, device="cuda", max_frames: int = 256, height: int = 360, width: int = 640, slots: int = 2):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("FrameStager stages into HBM: it needs a cuda device")
+        self.shape = (max_frames, height, width, 3)
+        self.host = [torch.empty(self.shape, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.dev = [torch.empty(self.shape, dtype=torch.uint8, device=self.device) for _ in range(slots)]
+        self.uploaded = [torch.cuda.Event() for _ in range(slots)]
+        self.consumed = [None] * slots
+        self.copy = torch.cuda.Stream(device=self.device)
+        self.n = 0
+
+    def stage(self, decoded) -> Tuple[int, int]:
+        i = self.n % len(self.host)
+        self.n += 1
+        if self.consumed[i] is not None:
+            self.consumed[i].synchronize()                      # the clip that used this slot has been preprocessed (host buffer AND device buffer free)
+        t = pack_decoded(decoded, self.host[i].numpy()).shape[0]
+        with torch.cuda.stream(self.copy):
+            self.dev[i][:t].copy_(self.host[i][:t], non_blocking=True)
+            self.uploaded[i].record(self.copy)
+        return i, t
+
+    @torch.no_grad()
+    def frames(self, ticket: Tuple[int, int], target_size: int = 224, n_cand: int = 32) -> Tuple[Tensor, Tensor]:
+        i, t = ticket
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self.uploaded[i])
+        out = get_frames(self.dev[i][:t], target_size, n_cand)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.consumed[i] = ev
+        return out
