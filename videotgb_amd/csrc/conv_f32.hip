@@ -4,7 +4,7 @@
 // activation layout, same K order (64-channel chunk major, tap minor) and the same epilogues as the bf16
 // MFMA kernel of gemm.hip, so raft.hip / raft_enc.hip drive both modes with one launch sequence; every
 // buffer the bf16 mode keeps in bf16 is fp32 here (GemmDesc::aux, out2, resid_bf16 point at floats).
-// 64 x 64 output tile, 16-deep k-slabs through LDS, 4 x 4 outputs per thread.
+// 128 x 64 output tile, 16-deep k-slabs through LDS, fp32-input MFMA (r5; rounds 2-4: 4 x 4 outputs per thread, scalar FMAs).
 #include <string.h>
 
 #include "common.h"
@@ -17,96 +17,109 @@ __device__ __forceinline__ float f32_act(float v, int act) {
     return v;
 }
 
+// r5: the products run on the fp32-input matrix instruction v_mfma_f32_32x32x2_f32 -- bit for bit a k-ordered fmaf chain (one rounding per
+// product, no wider accumulation: cdna_hip_programming.md, "FP32-input MFMA"), i.e. the SAME numbers as the scalar-FMA loop of rounds 2-4, at
+// the packed-FMA rate instead of the plain-FMA rate that loop was pinned to (78 TFLOP/s: RAFT's exactness mode ran at 81).
+// Workgroup tile 128 pixels x 64 channels, 16-deep k-slabs through LDS (k-major), four waves of 64 x 32: the weight slab is the A operand
+// (rows = output channels), the activation slab the B operand, so a lane ends up with four runs of four consecutive channels of ONE pixel;
+// the next slab's global loads are in flight while the current one is multiplied.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int CF_BM = 128, CF_BN = 64;
+
 template <bool CONV, bool GRU>
 __global__ __launch_bounds__(256) void conv_f32_kernel(const GemmDesc p) {
-    __shared__ float As[16][68];
-    __shared__ float Ws[16][68];
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    __shared__ float As[16][CF_BM + 4];
+    __shared__ float Ws[16][CF_BN + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;                      // wave tile: pixels [wm * 64, +64), channels [wn * 32, +32)
+    const int m0 = blockIdx.x * CF_BM, n0 = blockIdx.y * CF_BN;
     const float* __restrict__ A = reinterpret_cast<const float*>(p.A);
     const float* __restrict__ A2 = reinterpret_cast<const float*>(p.A2);
     const float* __restrict__ W = reinterpret_cast<const float*>(p.W);
     const float* __restrict__ pad = reinterpret_cast<const float*>(p.zero_page);
-    const int lrow = tid >> 2, lk = (tid & 3) * 4;
-    int am = m0 + lrow; am = am < p.M ? am : p.M - 1;
+    const int lrow = tid >> 2, lk = (tid & 3) * 4;              // staged rows lrow, lrow + 64 (activations) / lrow (weights); k offset lk
     int wr = n0 + lrow; wr = wr < p.N ? wr : p.N - 1;
     const float* wp = W + (int64_t)wr * p.ldw;
-    // staged row: plain GEMM -> its base pointer; convolution -> image base pixel and output (y, x)
-    const float* ap = nullptr;
-    int img_px = 0, oy = 0, ox = 0;
+    const float* ap[2] = {nullptr, nullptr};
+    int img_px[2] = {0, 0}, oy[2] = {0, 0}, ox[2] = {0, 0};
     const int taps = CONV ? p.conv_KH * p.conv_KW : 1;
     const int cst = p.conv_stride ? p.conv_stride : 1;
     const int Hi = p.conv_Hi ? p.conv_Hi : p.conv_H, Wi = p.conv_Wi ? p.conv_Wi : p.conv_W;
-    if constexpr (CONV) {
-        const int hw = p.conv_H * p.conv_W, img = am / hw, rem = am - img * hw;
-        img_px = img * Hi * Wi;
-        oy = rem / p.conv_W;
-        ox = rem - oy * p.conv_W;
-    } else {
-        ap = A + map_row(p.a_map, am) * p.lda;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        int am = m0 + lrow + h * 64; am = am < p.M ? am : p.M - 1;
+        if constexpr (CONV) {
+            const int hw = p.conv_H * p.conv_W, img = am / hw, rem = am - img * hw;
+            img_px[h] = img * Hi * Wi;
+            oy[h] = rem / p.conv_W;
+            ox[h] = rem - oy[h] * p.conv_W;
+        } else {
+            ap[h] = A + map_row(p.a_map, am) * p.lda;
+        }
     }
-    float acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = 0.f;
-    for (int k0 = 0; k0 < p.K; k0 += 16) {
+    auto fetch = [&](int k0, float4 (&av)[2], float4& wv) {
         const int k = k0 + lk;
-        float4 av = make_float4(0.f, 0.f, 0.f, 0.f), wv = av;
+        av[0] = av[1] = wv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < p.K) {
             wv = *reinterpret_cast<const float4*>(wp + k);
             if constexpr (CONV) {
                 const int blk = k >> 6, c = k & 63, chunk = blk / taps, tap = blk - chunk * taps;
                 const int dy = tap / p.conv_KW - (p.conv_KH >> 1), dx = tap % p.conv_KW - (p.conv_KW >> 1);
-                const int y = oy * cst + dy, x = ox * cst + dx;
                 int ch = chunk * 64 + c;
                 const bool first = ch < p.conv_split;
                 const float* base = first ? A : A2;
                 const int64_t ld = first ? p.lda : p.lda2;
                 if (!first) ch -= p.conv_split;
-                if ((unsigned)y < (unsigned)Hi && (unsigned)x < (unsigned)Wi)
-                    av = *reinterpret_cast<const float4*>(base + (int64_t)(img_px + y * Wi + x) * ld + ch);
-                else
-                    av = *reinterpret_cast<const float4*>(pad + c);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int y = oy[h] * cst + dy, x = ox[h] * cst + dx;
+                    if ((unsigned)y < (unsigned)Hi && (unsigned)x < (unsigned)Wi)
+                        av[h] = *reinterpret_cast<const float4*>(base + (int64_t)(img_px[h] + y * Wi + x) * ld + ch);
+                    else
+                        av[h] = *reinterpret_cast<const float4*>(pad + c);
+                }
             } else {
-                av = *reinterpret_cast<const float4*>(ap + k);
+                av[0] = *reinterpret_cast<const float4*>(ap[0] + k);
+                av[1] = *reinterpret_cast<const float4*>(ap[1] + k);
             }
         }
-        As[lk + 0][lrow] = av.x; As[lk + 1][lrow] = av.y; As[lk + 2][lrow] = av.z; As[lk + 3][lrow] = av.w;
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
+    float4 av[2], wv;
+    fetch(0, av, wv);
+    const int l31 = lane & 31, kh = lane >> 5;
+    for (int k0 = 0; k0 < p.K; k0 += 16) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            As[lk + 0][lrow + h * 64] = av[h].x; As[lk + 1][lrow + h * 64] = av[h].y; As[lk + 2][lrow + h * 64] = av[h].z; As[lk + 3][lrow + h * 64] = av[h].w;
+        }
         Ws[lk + 0][lrow] = wv.x; Ws[lk + 1][lrow] = wv.y; Ws[lk + 2][lrow] = wv.z; Ws[lk + 3][lrow] = wv.w;
         __syncthreads();
+        if (k0 + 16 < p.K) fetch(k0 + 16, av, wv);                // the next slab's loads fly under this slab's products
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) {
-            const float4 a = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
-            const float4 w = *reinterpret_cast<const float4*>(&Ws[kk][tx * 4]);
-            const float a4[4] = {a.x, a.y, a.z, a.w}, w4[4] = {w.x, w.y, w.z, w.w};
+        for (int kk = 0; kk < 8; kk++) {                           // k = k0 + 2 kk + {0, 1}: ascending inside the instruction and across them
+            const float wf = Ws[2 * kk + kh][wn * 32 + l31];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = fmaf(a4[i], w4[j], acc[i][j]);
+            for (int j = 0; j < 2; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf, As[2 * kk + kh][wm * 64 + j * 32 + l31], acc[j], 0, 0, 0);
         }
         __syncthreads();
     }
-    // ---- epilogue: 4 rows x 4 consecutive columns per thread
-    const int nb = n0 + tx * 4;
-    if (nb >= p.N) return;
-    float bias[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) if (nb + j < p.N) bias[j] = p.bias[nb + j];
-    }
+    // ---- epilogue.  D[i][j]: column j = lane & 31 -> pixel, rows i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> channel
     const float sc = p.out_scale != 0.f ? p.out_scale : 1.0f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int m = m0 + ty * 4 + i;
+    for (int j = 0; j < 2; j++) {
+        const int m = m0 + wm * 64 + j * 32 + l31;
         if (m >= p.M) continue;
         const int64_t orow = map_row(p.o_map, m);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int n = nb + j;
+        for (int reg = 0; reg < 16; reg++) {
+            const int n = n0 + wn * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
             if (n >= p.N) continue;
-            float v = acc[i][j] + bias[j];
+            float v = acc[j][reg] + (p.bias ? p.bias[n] : 0.f);
             if constexpr (GRU) {
                 // h' = (1 - z) h + z tanh(acc + bias) (update.py:57-58, :64-65)
                 const float h = p.resid[map_row(p.r_map, m) * p.ldr + n];
@@ -136,7 +149,7 @@ int launch_conv_f32(const GemmDesc& d, hipStream_t s) {
     VTGB_REQUIRE((d.K % 4) == 0 && (d.lda % 4) == 0 && (d.ldw % 4) == 0 && (!d.A2 || (d.lda2 % 4) == 0), VTGB_EUNSUPPORTED,
                  "conv gemm fp32: K=%d and the row strides must be multiples of 4", d.K);
     VTGB_REQUIRE(!d.col_stats, VTGB_EUNSUPPORTED, "conv gemm fp32: column statistics are taken by the separate pass in this mode");
-    const dim3 grid((unsigned)((d.M + 63) / 64), (unsigned)((d.N + 63) / 64));
+    const dim3 grid((unsigned)((d.M + CF_BM - 1) / CF_BM), (unsigned)((d.N + CF_BN - 1) / CF_BN));
     ProfScope prof(conv ? VTGB_PROF_CONV : VTGB_PROF_GEMM, 2.0 * d.M * d.N * d.K, s);
     if (d.epi == F_EPI_GRU) {
         VTGB_REQUIRE(conv && d.resid && d.aux && d.out2, VTGB_EINVAL, "conv gemm: GRU epilogue needs h, z and both outputs");

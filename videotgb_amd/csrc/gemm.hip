@@ -983,48 +983,82 @@ gelu_erf_fast4(v);
 // ---------------------------------------------------------------------------------------
 // fp32 kernel (exactness mode; also the on-GPU cross-check for the MFMA kernel)
 // ---------------------------------------------------------------------------------------
+// r5: the products run on v_mfma_f32_32x32x2_f32, bit for bit a k-ordered fmaf chain (cdna_hip_programming.md, "FP32-input MFMA"): the same
+// numbers as the scalar-FMA loop of rounds 1-4 at twice its rate.  128 x 64 tile, 16-deep k-slabs through LDS (k-major), four waves of
+// 64 x 32; the weight slab is the A operand, so a lane holds four runs of four consecutive columns of one row; the next slab's loads fly
+// under the current slab's products.
+typedef float gf_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int GF_BM = 128, GF_BN = 64;
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc p) {
-    __shared__ float As[16][68];
-    __shared__ float Ws[16][68];
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    __shared__ float As[16][GF_BM + 4];
+    __shared__ float Ws[16][GF_BN + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int m0 = blockIdx.y * GF_BM, n0 = blockIdx.x * GF_BN;
     const float* __restrict__ A = reinterpret_cast<const float*>(p.A);
     const float* __restrict__ W = reinterpret_cast<const float*>(p.W);
     const int lrow = tid >> 2, lk = (tid & 3) * 4;
-    int am = m0 + lrow; am = am < p.M ? am : p.M - 1;
     int wr = n0 + lrow; wr = wr < p.N ? wr : p.N - 1;
-    const float* ap = A + map_row(p.a_map, am) * p.lda;
     const float* wp = W + (int64_t)wr * p.ldw;
-    float acc[4][4];
+    const float* ap[2];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int h = 0; h < 2; h++) {
+        int am = m0 + lrow + h * 64; am = am < p.M ? am : p.M - 1;
+        ap[h] = A + map_row(p.a_map, am) * p.lda;
+    }
+    // 16-byte loads when every row start and the contraction length allow them (wave-uniform)
+    const bool vec = ((p.K | (int)p.lda | (int)p.ldw) & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
+    float av[2][4], wv[4];
+    auto fetch = [&](int k0) {
+        const int k = k0 + lk;
+        if (vec) {
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, w4 = a0;
+            if (k < p.K) { a0 = *reinterpret_cast<const float4*>(ap[0] + k); a1 = *reinterpret_cast<const float4*>(ap[1] + k); w4 = *reinterpret_cast<const float4*>(wp + k); }
+            av[0][0] = a0.x; av[0][1] = a0.y; av[0][2] = a0.z; av[0][3] = a0.w;
+            av[1][0] = a1.x; av[1][1] = a1.y; av[1][2] = a1.z; av[1][3] = a1.w;
+            wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = 0.f;
+            for (int i = 0; i < 4; i++) {
+                av[0][i] = k + i < p.K ? ap[0][k + i] : 0.f;
+                av[1][i] = k + i < p.K ? ap[1][k + i] : 0.f;
+                wv[i] = k + i < p.K ? wp[k + i] : 0.f;
+            }
+        }
+    };
+    gf_f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
+    fetch(0);
+    const int l31 = lane & 31, kh = lane >> 5;
     for (int k0 = 0; k0 < p.K; k0 += 16) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int k = k0 + lk + i;
-            As[lk + i][lrow] = k < p.K ? ap[k] : 0.f;
-            Ws[lk + i][lrow] = k < p.K ? wp[k] : 0.f;
+            As[lk + i][lrow] = av[0][i];
+            As[lk + i][lrow + 64] = av[1][i];
+            Ws[lk + i][lrow] = wv[i];
         }
         __syncthreads();
+        if (k0 + 16 < p.K) fetch(k0 + 16);
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const float4 a = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
-            const float4 w = *reinterpret_cast<const float4*>(&Ws[k][tx * 4]);
-            const float av[4] = {a.x, a.y, a.z, a.w}, wv[4] = {w.x, w.y, w.z, w.w};
+        for (int kk = 0; kk < 8; kk++) {
+            const float wf = Ws[2 * kk + kh][wn * 32 + l31];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = fmaf(av[i], wv[j], acc[i][j]);
+            for (int j = 0; j < 2; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf, As[2 * kk + kh][wm * 64 + j * 32 + l31], acc[j], 0, 0, 0);
         }
         __syncthreads();
     }
+    // D[i][j]: column j = lane & 31 -> row m, rows i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> column n: four consecutive n per reg >> 2
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-        epilogue4<EPI, float>(p, m0 + ty * 4 + i, n0 + tx * 4, acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    for (int j = 0; j < 2; j++) {
+        const int m = m0 + wm * 64 + j * 32 + l31;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++)
+            epilogue4<EPI, float>(p, m, n0 + wn * 32 + 8 * g4 + 4 * kh, acc[j][4 * g4], acc[j][4 * g4 + 1], acc[j][4 * g4 + 2], acc[j][4 * g4 + 3]);
+    }
 }
 
 // round 3: the persistent ping-pong form of the large kernel (gemm_pp.hip); VTGB_GEMM_OLD=1 keeps the one-tile-per-workgroup kernel
@@ -1130,7 +1164,7 @@ static int launch_epi(const GemmDesc& d, hipStream_t s) {
         ProfScope prof(VTGB_PROF_GEMM, 2.0 * d.M * d.N * d.K, s);
         hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(256), lds, s, d);
     } else {
-        dim3 grid((d.N + 63) / 64, (d.M + 63) / 64);
+        dim3 grid((d.N + GF_BN - 1) / GF_BN, (d.M + GF_BM - 1) / GF_BM);
         hipLaunchKernelGGL(gemm_f32_kernel<EPI>, grid, dim3(256), 0, s, d);
     }
     VTGB_HIP(hipGetLastError());
