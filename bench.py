@@ -516,7 +516,10 @@ def main():
             if not n or ms <= 0:
                 return None
             ex = _lib.prof_executed_flops(2)
+            traffic, src = pmc_traffic("convx3")
             return {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel<EPI,true,NWN> / gemm_bf16_large_kernel<EPI,0,true>: implicit-GEMM convolutions of RAFT",
+                    "traffic": traffic, "traffic_source": (f"{src} (committed rocprofv3 --pmc passes of one bf16x3 RAFT call at the bench's 31-clip batch; not "
+                                                            f"collected in this run)") if src else None,
                     "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "executed_tflops": round(ex / (ms * 1e-3) / 1e12, 2),
                     "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "ms_per_step": round(ms / steps, 3), "gflop_per_step": round(fl / steps / 1e9, 1),
