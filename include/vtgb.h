@@ -331,7 +331,17 @@ int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream);
  * three: VTGB_BF16 = bf16 MFMA implicit-GEMM convolutions over NHWC bf16 activations, fp32 accumulation, fp32
  * hidden state / flow / norms, IEEE-half correlation pyramid (a reduced-precision mode the reference does not have);
  * VTGB_F32 = fp32 operands and FMAs everywhere, k summed in order -- the exactness mode, which is how the reference
- * runs RAFT (xraft.py:118-119).  Convolution weights are packed [C_out, K] in `dtype` with K running 64-channel chunk
+ * runs RAFT (xraft.py:118-119; since version 500 on the fp32-input matrix instruction, the same fmaf chain bit for bit).
+ * VTGB_BF16X3 (version 500) = the reference's fp32 ACCURACY on the bf16 matrix cores: every convolution operand is a bf16 pair
+ * (hi = bf16(x), lo = bf16(x - hi): 16 significant bits), x . w ~ hi . Wh + lo . Wh + hi . Wl with fp32 accumulation; activations
+ * are stored as rows [hi(C) | lo(C)], gates / flow / correlation pyramid / lookup stay fp32 (the pyramid from split-bf16 products).
+ * Flows within 1e-4 relative RMS of the reference's under input-sensitive weights (tests/test_gpu_raft.py), 3 x the MFMA work of VTGB_BF16.
+ * Weight tables at VTGB_BF16X3: every MFMA convolution [C_out, taps, 3 C_in] in the K order below with the channel blocks
+ * [Wh | Wh | Wl] per source of the (virtual) input concatenation (bf16; built by ops.split3); vtgb_raft_update: [4] convf1 as at VTGB_F32,
+ * [10] .. [17] the GRU convolutions over [h(128) | motion(126) | flow(2)] and [26] .. [29] their `inp` parts (always present: the loop-invariant
+ * third is computed once per call into fp32 start maps), [24] / [25] mask.2 with its 0.25 folded in; vtgb_raft_encoder: [0] the stem
+ * [64, 4 (tY), 3 x 64] scaled by 2/255, the 1x1 head [256, 3 x 128].
+ * Convolution weights are packed [C_out, K] in `dtype` with K running 64-channel chunk
  * major, tap minor, channel-in-chunk innermost (written [C_out, KH,KW,C_in] below for the shapes only).
  *
  * vtgb_raft_update replaces the refinement loop xraft.py:135-156: per iteration CorrBlock.__call__
@@ -380,13 +390,14 @@ int vtgb_raft_update(const vtgb_raft_update_args* a, vtgb_stream_t stream);
  * (n / pairs_per_clip) * frames_per_clip + n % pairs_per_clip + {first_off, second_off}: consecutive frames of whole
  * clips are (T-1, T, 0, 1); separate image1 / image2 batches of N encoded as cat([image1, image2]) are (N, N, 0, N).
  * VTGB_BF16: half-precision MFMA on an fp16 copy of the features (made in the workspace), fp32 accumulate and scale,
- * levels IEEE half; VTGB_F32: fp32 FMAs, levels fp32. */
+ * levels IEEE half; VTGB_F32: fp32 FMAs, levels fp32; VTGB_BF16X3: the features as bf16 pairs (hi | lo planes in the workspace),
+ * three bf16 MFMA products per fp32 product, fp32 accumulate, levels fp32. */
 typedef struct {
     int32_t dtype, n_pairs, H8, W8, dim;
     int32_t pairs_per_clip, frames_per_clip, first_off, second_off, n_images;
     float scale;                /* 1 / sqrt(dim) = 1/16                                                            */
     const float* fmap;          /* [n_images, H8*W8, dim] fp32 (vtgb_raft_encoder output)                           */
-    void* levels[4];            /* level l: [n_pairs*H8*W8, H8>>l, W8>>l] half (VTGB_BF16) or fp32 (VTGB_F32)       */
+    void* levels[4];            /* level l: [n_pairs*H8*W8, H8>>l, W8>>l] half (VTGB_BF16) or fp32 (VTGB_F32, VTGB_BF16X3) */
     void* workspace;
     size_t workspace_bytes;
 } vtgb_raft_corr_args;
