@@ -89,6 +89,32 @@ def test_c3_c4_instructblip_vicuna7b_raft_inline(dev, vicuna, T, clips):
     assert torch.equal(idx, idx2) and torch.equal(ids, ids2)
 
 
+def test_c3_with_raft_at_fp32_accuracy(dev, vicuna):
+    """C3 with RAFT in the bf16x3 mode (split-bf16 operands: the reference's fp32 RAFT accuracy on the matrix cores; bench.py's `raft_fp32_accuracy` leg):
+    the whole step runs, is bit-reproducible, and its flows agree with the fp32 FMA mode's to 1e-4 (the bf16 mode: 2.5e-3 on these weights)."""
+    import bench
+    from videotgb_amd.decode import GreedyDecoder
+    m, cfg = vicuna
+    T, clips = 96, 2
+    m.flow_clips_per_call = clips
+    d = bench.synth_batch(0, 7, clips, T, "raft", dev, cfg)
+    flows = {}
+    for mode in ("f32", "bf16x3", "bf16"):
+        m.of_extractor.set_compute_dtype(mode)
+        flows[mode] = m.flow(d["flow_frames"]).clone()
+    rel = lambda a, b: float(((a - b).double().pow(2).mean().sqrt() / b.double().pow(2).mean().sqrt()).item())
+    e3, e1 = rel(flows["bf16x3"], flows["f32"]), rel(flows["bf16"], flows["f32"])
+    print(f"[C3 flows vs fp32 RAFT] bf16x3 {e3:.3e}, bf16 {e1:.3e}")
+    assert e3 <= 1e-4 and e3 < e1 / 20
+    m.of_extractor.set_compute_dtype("bf16x3")
+    dec = GreedyDecoder(m.model.language_model)
+    ids, idx = bench.run_step(m, d, clips, 8, 16, None, dec)
+    ids2, idx2 = bench.run_step(m, d, clips, 8, 16, None, dec)
+    m.of_extractor.set_compute_dtype("bf16")
+    assert tuple(ids.shape) == (clips, 16) and bool((idx[:, 1:] >= idx[:, :-1]).all()) and int(idx.min()) >= 0 and int(idx.max()) < 32
+    assert torch.equal(idx, idx2) and torch.equal(ids, ids2)
+
+
 def test_c5_vicuna7b_lora_qformer_micro_step(dev, vicuna):
     from videotgb_amd import train
     m, cfg = vicuna

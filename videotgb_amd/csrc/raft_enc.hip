@@ -387,6 +387,24 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
                 outb = x;                                                                                       // the block input is dead from here on
             }
             VTGB_TRY(conv_bn(Mo, g, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), 1, res, 1, outb));             // relu(x + relu(bn2(conv2(y))))
+        } else if (x3 && !inorm && g.Cpad == 128) {
+            // cnet at bf16x3, 128-channel stages: no statistics are needed, so conv1 (+ ReLU) and the downsample branch leave the convolution as pairs
+            // (EPI_SPLIT; the packed weights carry C_pad output rows, the padded ones zero); conv2 needs the skip operand: fp32 + the pair pass
+            auto split_conv = [&](int K, int Cin, int stride, int Hi_, int Wi_, const void* A, const void* Wt, const float* bias, int relu, void* out) -> int {
+                GemmDesc d = enc_conv(dt, (int)Mo, g.Cpad, g.Ho, g.Wo, K, Cin, stride, Hi_, Wi_, A, Wt, bias, nullptr, 2 * g.Cpad, zero, nullptr);
+                d.epi = VTGB_EPI_SPLIT; d.act = relu; d.out = out; d.split_lo = g.Cpad;
+                d.algo_flops = 2.0 * Mo * (double)g.C * (K * K * Cin);
+                return launch_conv_gemm(d, s);
+            };
+            VTGB_TRY(split_conv(3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), 1, t1));                                 // y = relu(bn1(conv1(x)))
+            VTGB_TRY(launch_conv_gemm(enc_conv(dt, (int)Mo, g.C, g.Ho, g.Wo, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), cf, g.Cpad, zero, nullptr), s));
+            const void* res = x;
+            outb = t1;
+            if (g.stride != 1) {                                                                                          // x = bn3(downsample(x))
+                VTGB_TRY(split_conv(1, Cin_pad, g.stride, Hi, Wi, x, bw[4], F(bw[5]), 0, t2));
+                res = t2;
+            }
+            VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, res, outb, 1, 1, stats, false));                                // relu(x + relu(bn2(conv2(y))))
         } else {
             float* sf = stats_for(stats, HWo, g.C);
             VTGB_TRY(conv_stats(enc_conv(dt, (int)Mo, g.C, g.Ho, g.Wo, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), cf, g.Cpad, zero, sf), stats));

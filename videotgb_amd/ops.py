@@ -797,7 +797,7 @@ def raft_encoder(w: RaftEncoderWeights, images: Tensor, max_images: int = 384) -
     images = images.contiguous().float()
     n, _, H, W = images.shape
     out = torch.empty(n, (H // 8) * (W // 8), 256, dtype=torch.float32, device=images.device)
-    if w.code != BF16:
+    if w.code == F32:
         max_images = max(max_images // 2, 1)
     for i0 in range(0, n, max_images):
         chunk = images[i0:i0 + max_images]
