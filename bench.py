@@ -564,6 +564,8 @@ def main():
         # BASELINE configs[3] (C4): the long-video shape, per GPU (the 8 GPUs shard clips with no collective)
         leg("c4_t256", 24, "raft", 2, "BASELINE configs[3]: InstructBLIP-Vicuna-7B + TGB, ActivityNet long-video shape T=256->8, per GPU (clip-parallel, no "
                                      "collective); RAFT on 255 frame pairs per clip, 12 clips per RAFT batch", T_leg=256, raft_clips=12)
+        if args.raft_dtype == "bf16":
+            leg("c4_t256_raft_bf16x3", 24, "raft", 2, "the C4 shape with RAFT in the bf16x3 mode (fp32 accuracy): per GPU", T_leg=256, raft_clips=12, raft_dtype="bf16x3")
         legs["host_resident_inputs"] = host_resident_leg(m, rank, 32, T, nframe, args.max_new_tokens, decoder, dev, 3, barrier, world)
     if rank == 0:
         out = {"metric": "clips/sec end-to-end VideoQA (96->8 frames)", "value": round(value, 3), "unit": "clips/s",
