@@ -254,3 +254,30 @@ def test_preprocess_and_frame_pick_match_the_reference_functions():
         vlen, n, fix = row[:3]
         want = [x for x in row[3:] if x >= 0]
         assert video.sample_frames(n, vlen, "uniform", float(fix)) == want
+
+
+def test_split_bf16_weight_layout_and_accuracy():
+    """The bf16x3 RAFT mode's weight preparation (ops.split3; CPU): per source of the channel concatenation the blocks [Wh | Wh | Wl] with
+    Wh = bf16(w), Wl = bf16(w - Wh); the pair carries 16 significant bits, and the three-product form x.w ~ xh.Wh + xl.Wh + xh.Wl is within
+    2^-15 of the fp32 product summed over a 1152-deep contraction (the dropped xl.Wl term is 2^-16 of a product)."""
+    from videotgb_amd import ops
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(8, 1, 5, 384, generator=g) * 0.05
+    e = ops.split3(w, [128, 256])
+    assert tuple(e.shape) == (8, 1, 5, 3 * 384)
+    wh = w.to(torch.bfloat16).float()
+    wl = (w - wh).to(torch.bfloat16).float()
+    assert torch.equal(e[..., 0:128], wh[..., :128]) and torch.equal(e[..., 128:256], wh[..., :128]) and torch.equal(e[..., 256:384], wl[..., :128])
+    assert torch.equal(e[..., 384:640], wh[..., 128:]) and torch.equal(e[..., 640:896], wh[..., 128:]) and torch.equal(e[..., 896:], wl[..., 128:])
+    assert torch.equal(e, e.to(torch.bfloat16).float())                          # every entry is a bf16 value: the device table is exact
+    assert ((wh + wl) - w).abs().max() <= 2.0 ** -16 * w.abs().max()             # 16 significant bits
+    x = torch.randn(64, 384, generator=g)
+    xh = x.to(torch.bfloat16).float()
+    xl = (x - xh).to(torch.bfloat16).float()
+    w2 = w[:, 0, 2, :]                                                           # one tap: [8, 384]
+    exact = x.double() @ w2.double().t()
+    three = (xh.double() @ wh[:, 0, 2].double().t()) + (xl.double() @ wh[:, 0, 2].double().t()) + (xh.double() @ wl[:, 0, 2].double().t())
+    one = xh.double() @ wh[:, 0, 2].double().t()
+    scale = (x.abs().double() @ w2.abs().double().t()).max()
+    assert (three - exact).abs().max() <= 2.0 ** -15 * scale
+    assert (one - exact).abs().max() > 50 * (three - exact).abs().max()          # the plain bf16 product is two orders of magnitude further off
