@@ -22,7 +22,7 @@ B = int(args[0]) if args else 4                            # per-GPU micro-batch
 lora_only = "--lora-only" in sys.argv
 cfg = synth.full_cfg("instructblip")
 lm = llm.build_llama("vicuna-7b", torch.bfloat16, dev)
-m = models.LSTP(cfg, dev, language_model=lm, compute_dtype="bf16")
+m = models.LSTP(cfg, dev, language_model=lm, compute_dtype="bf16", raft_dtype="bf16")
 sd = synth.path_state_dict(cfg, 0, with_raft=False)
 m.load_state_dict(sd, strict=False); m.to(dev); lm.to(torch.bfloat16)
 step = train.LoraTrainStep(m, pad_token_id=0, lr=1e-4, accumulate_grad_batches=4, train_prefix=not lora_only)

@@ -419,7 +419,8 @@ class _LSTPBase(nn.Module):
         HF config in ``base_model_path`` sizes the vision tower, Q-Former and language model (random init, the checkpoint
         fills them), the TGB is BERT-base with fusion_layer 6, RAFT is RAFT-large.  ``base_model_path`` may also be a
         ``synth.PathCfg`` (``from_cfg``): then ``language_model`` is the caller's.  Keyword extensions: ``compute_dtype``
-        ("bf16" / "f32") of the HIP stages, ``raft_dtype`` to run RAFT in another mode, ``lm_dtype`` of the built LLM
+        ("bf16" / "f32") of the HIP stages, ``raft_dtype`` ("bf16x3" by default next to bf16 stages: the reference's fp32 RAFT accuracy; "bf16" = the
+        fast reduced-precision RAFT; "f32" = the fp32 FMA chain), ``lm_dtype`` of the built LLM
         (default: bf16 with compute_dtype "bf16", else fp32), ``tgb_cfg`` to size the TGB differently from BERT-base (tests)."""
         super().__init__()
         hf_config = None
@@ -437,7 +438,10 @@ class _LSTPBase(nn.Module):
         self.cfg = cfg
         self.model = PathModel(cfg, language_model, compute_dtype, hf_config=hf_config)
         self.temporal_encoder = TemporalEncoder(cfg.tgb, compute_dtype)
-        self.of_extractor = Raft(raft_dtype or compute_dtype)      # raft_dtype: run RAFT in another mode than the rest
+        # RAFT's mode.  The reference keeps RAFT in fp32 under EVERY Lightning precision (xraft.py:58,113-118: mixed_precision = False), so the
+        # default follows that contract: "bf16x3" (fp32 accuracy on the bf16 matrix cores) next to bf16 stages, "f32" next to fp32 stages.
+        # ``raft_dtype="bf16"`` opts into the faster reduced-precision RAFT the reference does not have (bench.py's headline does, and says so).
+        self.of_extractor = Raft(raft_dtype or self._default_raft_dtype(compute_dtype))
         self._raft_follows = raft_dtype is None
         self.device = device
         self.fell_back = False
@@ -448,6 +452,10 @@ class _LSTPBase(nn.Module):
             from .train import apply_lora
             apply_lora(self.model.language_model, r=8, lora_alpha=32, lora_dropout=0.1)
             self.model.language_model.eval()
+
+    @staticmethod
+    def _default_raft_dtype(compute_dtype):
+        return "bf16x3" if ops.dtype_code(compute_dtype) == ops.BF16 else "f32"
 
     @classmethod
     def from_cfg(cls, cfg: synth.PathCfg, device="cuda", language_model: Optional[nn.Module] = None, compute_dtype="bf16", raft_dtype=None):
@@ -467,7 +475,7 @@ class _LSTPBase(nn.Module):
         self.model.language_projection.code = ops.dtype_code(compute_dtype)
         self.model.language_projection._packed = None
         if self._raft_follows:
-            self.of_extractor.set_compute_dtype(compute_dtype)
+            self.of_extractor.set_compute_dtype(self._default_raft_dtype(compute_dtype))
         return self
 
     # ---- stages -------------------------------------------------------------------------------
