@@ -559,6 +559,8 @@ def main():
                                              "accuracy on the matrix cores (tests/test_gpu_raft.py: flows within 1e-4 rel-RMS of the reference's, input-sensitive "
                                              "weights, 224 x 224; tests/test_gpu_selection.py: TGB logits within 4e-4 of their range and the same frames for "
                                              "64/64 clips at T=96 and T=256)", raft_dtype="bf16x3", roof=True)
+            leg("single_clip_raft_bf16x3", 1, "raft", 5, "one clip at a time with the module's DEFAULT RAFT mode (bf16x3: the reference's fp32 RAFT accuracy): the latency "
+                                                         "a drop-in user of eval/inference.py sees without opting into bf16 RAFT", raft_dtype="bf16x3")
             leg("raft_fp32_exactness", 8, "raft", 3, "the headline path with RAFT in the fp32 exactness mode (fp32 FMAs in the reference's summation order: the "
                                                      "mode whose flows the -m gpu suite pins to the reference at <= 4e-6)", raft_dtype="f32")
         # BASELINE configs[3] (C4): the long-video shape, per GPU (the 8 GPUs shard clips with no collective)
