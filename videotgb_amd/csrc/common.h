@@ -210,7 +210,7 @@ struct GemmDesc {
     const float* ln_c;
 };
 int launch_ln_fold_stats(const float* part, int nblk, int D, float eps, float* stats, int64_t M, hipStream_t s);
-int launch_ln_fold_prepare(const float* x, int64_t ldx, int D, float eps, void* xb, float* stats, int64_t M, hipStream_t s);
+int launch_ln_fold_prepare(const float* x, int64_t ldx, int D, void* xb, float* part, int64_t M, hipStream_t s);   // bf16(x) -> xb [M, D], block moments -> part
 #define VTGB_EPI_GRU 4
 #define VTGB_EPI_SPLIT 5
 // bf16x3 SepConvGRU epilogues (raft_x3.hip; persistent kernel only):

@@ -393,11 +393,9 @@ __global__ __launch_bounds__(256) void ln_fold_prepare_kernel(const float* __res
         if (m < M && cl == 0) *reinterpret_cast<float2*>(part + (m * nblk + b) * 2) = make_float2(s_, q_);
     }
 }
-int launch_ln_fold_prepare(const float* x, int64_t ldx, int D, float eps, void* xb, float* stats, int64_t M, hipStream_t s) {
-    // stats doubles as the partial buffer's owner: the caller passes part = stats + 2 M ... (see vit_impl); here `stats` IS the partial buffer
-    (void)eps;
+int launch_ln_fold_prepare(const float* x, int64_t ldx, int D, void* xb, float* part, int64_t M, hipStream_t s) {
     VTGB_REQUIRE((D & 3) == 0 && (ldx & 3) == 0, VTGB_EINVAL, "ln_fold_prepare: 4-aligned rows");
-    hipLaunchKernelGGL(ln_fold_prepare_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s, x, ldx, D, (bf16_t*)xb, stats, M);
+    hipLaunchKernelGGL(ln_fold_prepare_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s, x, ldx, D, (bf16_t*)xb, part, M);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }

@@ -166,7 +166,7 @@ static int vit_impl(const vtgb_vit_args* a, Workspace& ws, hipStream_t s) {
         return d;
     };
     if (fold) {
-        VTGB_TRY(launch_ln_fold_prepare(x, D, D, a->eps, h, ln_part, M, s));
+        VTGB_TRY(launch_ln_fold_prepare(x, D, D, h, ln_part, M, s));
         VTGB_TRY(launch_ln_fold_stats(ln_part, ln_nblk, D, a->eps, ln_stats, M, s));
     }
     for (int l = 0; l < a->layers; l++) {

@@ -601,53 +601,49 @@ class RaftWeights(_WeightTable):
                 self.add(None); self.add(None)
         self.finish()
 
+    def _init_x3(self, sd: Dict[str, Tensor], p: str) -> None:
+        """The bf16x3 table (raft_x3.hip): every MFMA convolution as [C_out, taps, 3 C_in] in the kernels' K order with the channel blocks
+        [Wh | Wh | Wl] per source; convf1 as in the fp32 mode; the mask head's 0.25 (update.py:143) folded into mask.2 (a power of two: exact)."""
+        self.hoist_inp = True
 
-def _raft_x3_table(self: RaftWeights, sd: Dict[str, Tensor], p: str) -> None:
-    """The bf16x3 table (raft_x3.hip): every MFMA convolution as [C_out, taps, 3 C_in] in the kernels' K order with the channel blocks
-    [Wh | Wh | Wl] per source; convf1 as in the fp32 mode; the mask head's 0.25 (update.py:143) folded into mask.2 (a power of two: exact)."""
-    self.hoist_inp = True
+        def conv(name, cin_pad=None, sources=None, scale=1.0, channels=None):
+            w = sd[p + name + ".weight"].float() * scale
+            if channels is not None:
+                w = w[:, channels]
+            co, ci, kh, kw = w.shape
+            w = w.permute(0, 2, 3, 1)
+            if cin_pad and cin_pad != ci:
+                w = torch.nn.functional.pad(w, (0, cin_pad - ci))
+            return _bf16_exact(conv_k_order(split3(w, sources)))
 
-    def conv(name, cin_pad=None, sources=None, scale=1.0, channels=None):
-        w = sd[p + name + ".weight"].float() * scale
-        if channels is not None:
-            w = w[:, channels]
-        co, ci, kh, kw = w.shape
-        w = w.permute(0, 2, 3, 1)
-        if cin_pad and cin_pad != ci:
-            w = torch.nn.functional.pad(w, (0, cin_pad - ci))
-        return _bf16_exact(conv_k_order(split3(w, sources)))
+        def add_conv(name, cin_pad=None, scale=1.0):
+            self.tensors.append(conv(name, cin_pad, scale=scale))
+            self.add(sd[p + name + ".bias"].float() * scale)
 
-    def add_conv(name, cin_pad=None, scale=1.0):
-        self.tensors.append(conv(name, cin_pad, scale=scale))
-        self.add(sd[p + name + ".bias"].float() * scale)
-
-    add_conv("encoder.convc1", 384)
-    add_conv("encoder.convc2")
-    self.add(sd[p + "encoder.convf1.weight"].float().reshape(128, 98).t().contiguous())
-    self.add(sd[p + "encoder.convf1.bias"])
-    add_conv("encoder.convf2")
-    add_conv("encoder.conv")
-    dyn = list(range(0, 128)) + list(range(256, 384))     # [h | motion + flow]: two pair sources of 128 channels
-    for sfx in ("1", "2"):
-        self.tensors.append(torch.cat([conv("gru.convz" + sfx, sources=[128, 128], channels=dyn), conv("gru.convr" + sfx, sources=[128, 128], channels=dyn)], 0).contiguous())
-        self.add(torch.cat([sd[p + "gru.convz" + sfx + ".bias"], sd[p + "gru.convr" + sfx + ".bias"]], 0))
-        self.tensors.append(conv("gru.convq" + sfx, sources=[128, 128], channels=dyn))
-        self.add(sd[p + "gru.convq" + sfx + ".bias"])
-    add_conv("flow_head.conv1")
-    w2 = sd[p + "flow_head.conv2.weight"].float().permute(2, 3, 0, 1).reshape(18, 256)
-    w2 = torch.nn.functional.pad(w2, (0, 0, 0, 14)).reshape(32, 1, 1, 256)
-    self.tensors.append(_bf16_exact(conv_k_order(split3(w2))))
-    self.add(sd[p + "flow_head.conv2.bias"])
-    add_conv("mask.0")
-    add_conv("mask.2", scale=0.25)
-    inp = list(range(128, 256))                           # the loop-invariant third: start maps, once per call
-    for sfx in ("1", "2"):
-        self.tensors.append(torch.cat([conv("gru.convz" + sfx, channels=inp), conv("gru.convr" + sfx, channels=inp)], 0).contiguous())
-        self.tensors.append(conv("gru.convq" + sfx, channels=inp))
-    self.finish()
-
-
-RaftWeights._init_x3 = _raft_x3_table
+        add_conv("encoder.convc1", 384)
+        add_conv("encoder.convc2")
+        self.add(sd[p + "encoder.convf1.weight"].float().reshape(128, 98).t().contiguous())
+        self.add(sd[p + "encoder.convf1.bias"])
+        add_conv("encoder.convf2")
+        add_conv("encoder.conv")
+        dyn = list(range(0, 128)) + list(range(256, 384))     # [h | motion + flow]: two pair sources of 128 channels
+        for sfx in ("1", "2"):
+            self.tensors.append(torch.cat([conv("gru.convz" + sfx, sources=[128, 128], channels=dyn), conv("gru.convr" + sfx, sources=[128, 128], channels=dyn)], 0).contiguous())
+            self.add(torch.cat([sd[p + "gru.convz" + sfx + ".bias"], sd[p + "gru.convr" + sfx + ".bias"]], 0))
+            self.tensors.append(conv("gru.convq" + sfx, sources=[128, 128], channels=dyn))
+            self.add(sd[p + "gru.convq" + sfx + ".bias"])
+        add_conv("flow_head.conv1")
+        w2 = sd[p + "flow_head.conv2.weight"].float().permute(2, 3, 0, 1).reshape(18, 256)
+        w2 = torch.nn.functional.pad(w2, (0, 0, 0, 14)).reshape(32, 1, 1, 256)
+        self.tensors.append(_bf16_exact(conv_k_order(split3(w2))))
+        self.add(sd[p + "flow_head.conv2.bias"])
+        add_conv("mask.0")
+        add_conv("mask.2", scale=0.25)
+        inp = list(range(128, 256))                           # the loop-invariant third: start maps, once per call
+        for sfx in ("1", "2"):
+            self.tensors.append(torch.cat([conv("gru.convz" + sfx, channels=inp), conv("gru.convr" + sfx, channels=inp)], 0).contiguous())
+            self.tensors.append(conv("gru.convq" + sfx, channels=inp))
+        self.finish()
 
 
 def raft_update(w: RaftWeights, net: Optional[Tensor], inp: Optional[Tensor], pyramid: Sequence[Tensor], iters: int = 20,
