@@ -390,3 +390,17 @@ def test_raft_partial_last_tile(dev, tiny_sd, dtype):
     e = rel_rms(got, ref)
     print(f"[raft 144x144 x 2 pairs {dtype}] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
     assert torch.isfinite(got).all() and e <= {"f32": 1e-4, "bf16": 2e-2, "bf16x3": 5e-4}[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
+def test_raft_non_square_frames(dev, tiny_sd, dtype):
+    """128 x 208 frames (16 x 26 coarse pixels, 416-pixel images: rows of a 256-row tile straddle image lines and images; the vertical GRU half has
+    lines of 16, the horizontal one of 26) vs the fp32 oracle, 6 iterations, 3 pairs."""
+    from oracle import vtgb_oracle as O
+    sd = tiny_sd["instructblip"][1]
+    fr = torch.randn(4, 3, 128, 208, generator=torch.Generator().manual_seed(33))
+    ref = O.raft_forward(sd, "of_extractor.", fr[:-1], fr[1:], iters=6)
+    got = make(dev, tiny_sd, dtype)(fr[:-1].to(dev), fr[1:].to(dev), iters=6).cpu()
+    e = rel_rms(got, ref)
+    print(f"[raft 128x208 {dtype}] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
+    assert tuple(got.shape) == (3, 2, 128, 208) and torch.isfinite(got).all() and e <= {"f32": 1e-4, "bf16": 2e-2, "bf16x3": 5e-4}[dtype]
