@@ -241,7 +241,6 @@ __global__ __launch_bounds__(256) void tg_f32_kernel(const TgF32Params p) {
     __shared__ float As[16][68];
     __shared__ float Bs[16][68];
     const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const TA* __restrict__ A = reinterpret_cast<const TA*>(p.a);
     const TB* __restrict__ B = reinterpret_cast<const TB*>(p.b);
@@ -252,11 +251,14 @@ __global__ __launch_bounds__(256) void tg_f32_kernel(const TgF32Params p) {
     int bn = n0 + brow; bn = bn < p.N ? bn : p.N - 1;
     const TA* ap = A + (int64_t)am * p.a_rs;
     const TB* bp = B + (int64_t)bn * p.b_rs;
-    float acc[4][4];
+    // r5: the products run on v_mfma_f32_32x32x2_f32 -- bit for bit the k-ordered fmaf chain of the scalar loop it replaces (cdna_hip_programming.md,
+    // "FP32-input MFMA").  Four waves of 32 x 32; the b slab is the A operand (rows = n), so a lane holds runs of four consecutive n of one row m.
+    typedef float tg_f32x16 __attribute__((ext_vector_type(16)));
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    tg_f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = 0.f;
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
     for (int k0 = 0; k0 < p.K; k0 += 16) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -266,24 +268,16 @@ __global__ __launch_bounds__(256) void tg_f32_kernel(const TgF32Params p) {
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[k][ty * 4]);
-            const f32x4 w = *reinterpret_cast<const f32x4*>(&Bs[k][tx * 4]);
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = fmaf(a[i], w[j], acc[i][j]);
-        }
+        for (int kk = 0; kk < 8; kk++)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Bs[2 * kk + kh][wn * 32 + l31], As[2 * kk + kh][wm * 32 + l31], acc, 0, 0, 0);
         __syncthreads();
     }
+    const int m = m0 + wm * 32 + l31;
+    if (m < p.M) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int m = m0 + ty * 4 + i;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int n = n0 + tx * 4 + j;
-            if (n < p.N) p.out[(int64_t)m * p.ldo + n] = acc[i][j] + (p.bias ? p.bias[n] : 0.f);
+        for (int reg = 0; reg < 16; reg++) {
+            const int n = n0 + wn * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            if (n < p.N) p.out[(int64_t)m * p.ldo + n] = acc[reg] + (p.bias ? p.bias[n] : 0.f);
         }
     }
 }
