@@ -305,6 +305,21 @@ def test_raft_update_is_bit_reproducible(dev, n, h8, w8, iters):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("n,h8,w8,iters", [(300, 28, 28, 4), (7, 16, 16, 12), (5, 9, 13, 8)])
+def test_raft_update_bf16x3_is_bit_reproducible(dev, n, h8, w8, iters):
+    """The bf16x3 refinement loop (pair-store, gate and GRU-update epilogues with hand-counted waits, in-place h update) on the same inputs three
+    times: the same bits -- a guard against races; (300, 28, 28) = 918 m-tiles on the persistent grid, (5, 9, 13): tiles that straddle images."""
+    from videotgb_amd import ops, synth
+    sd = {k[len("of_extractor."):]: v.to(dev) for k, v in synth.raft_sensitive_state_dict(0).items()}
+    w = ops.RaftWeights(sd, "update_block.", ops.BF16X3)
+    g = torch.Generator(device=dev).manual_seed(n + 1)
+    cnet = torch.randn(n, h8 * w8, 256, generator=g, device=dev)
+    pyr = [torch.randn(n * h8 * w8, 1, max(h8 >> l, 1), max(w8 >> l, 1), generator=g, device=dev) for l in range(4)]
+    outs = [ops.raft_update(w, None, None, pyr, iters=iters, cnet_nhwc=cnet, hw=(h8, w8)).clone() for _ in range(3)]
+    assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("n,h8,w8", [(3, 28, 28), (2, 9, 13)])
 def test_raft_update_fp32_pyramid_equals_half_pyramid_at_bf16(dev, n, h8, w8):
     """The bf16 update block reads its correlation pyramid as IEEE half (what vtgb_raft_corr writes at bf16) or as fp32: both instantiations of
