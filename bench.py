@@ -79,9 +79,10 @@ def parse():
     ap.add_argument("--llm", default="vicuna-7b")
     ap.add_argument("--decode", choices=["graph", "hf"], default="graph",
                     help="graph: videotgb_amd.decode.GreedyDecoder (one hipGraph replay per token); hf: HF generate, eager")
-    ap.add_argument("--raft-dtype", choices=["bf16", "bf16x3", "f32"], default="bf16",
-                    help="arithmetic of RAFT in --flow raft mode: bf16 MFMA implicit-GEMM convolutions (default) or the fp32 exactness "
-                         "mode (the reference's arithmetic; fp32 FMAs)")
+    ap.add_argument("--raft-dtype", choices=["bf16", "bf16x3", "f32"], default="bf16x3",
+                    help="arithmetic of RAFT in --flow raft mode.  bf16x3 (default, the module's default too): the reference's fp32 RAFT accuracy on "
+                         "the matrix cores (split operands, fp32 accumulation); f32: the exactness mode (fp32 FMAs in the reference's order); bf16: a "
+                         "REDUCED-PRECISION opt-in the reference does not have (reported as the `raft_bf16_fast` companion of the default run)")
     ap.add_argument("--raft-clips", type=int, default=31,
                     help="clips per RAFT call (pairs of that many clips form one batch; 31 clips = 249 ViT m-tiles / 9020 RAFT m-tiles: "
                          "few idle CUs in the last round of 256-row tiles)")

@@ -31,7 +31,7 @@ extern "C" {
 
 typedef struct ihipStream_t* vtgb_stream_t; /* == hipStream_t */
 
-#define VTGB_VERSION 500 /* 500: VTGB_BF16X3 (RAFT at fp32 accuracy on the bf16 MFMA), deterministic InstanceNorm moments, vtgb_gemm_skinny defer_reduce +
+#define VTGB_VERSION 600 /* 600: VTGB_F16C8 (vtgb_raft_update: the update block over fp16 + fp8-correction operands, weights[30] = scale bytes).  500: VTGB_BF16X3 (RAFT at fp32 accuracy on the bf16 MFMA), deterministic InstanceNorm moments, vtgb_gemm_skinny defer_reduce +
                             vtgb_llm_rmsnorm_parts / vtgb_llm_rope_cache_parts.  401: vtgb_gemm_train / vtgb_col_sum_f32 / vtgb_layernorm_train_* / vtgb_gelu_* (the training graph without operand copies or torch
                             elementwise passes); 400 = round 4: vtgb_llm_attention_rows / vtgb_llm_gated_act (the T5 language model of the BLIP-2 flavours on own kernels:
                             eval/utils/model.py:427-437), vtgb_llm_rope_cache with NULL tables = plain cache append; 300 = round 3: stem weight hi|lo layout; vtgb_attention_args.causal; vtgb_gemm_skinny without workspace when unsplit;
@@ -46,6 +46,7 @@ typedef struct ihipStream_t* vtgb_stream_t; /* == hipStream_t */
 #define VTGB_F32 0
 #define VTGB_BF16 1
 #define VTGB_BF16X3 2 /* RAFT entry points only: split-bf16 operands (hi | lo pairs, three bf16 MFMA products per fp32 product) */
+#define VTGB_F16C8 3  /* vtgb_raft_update only: fp16 main product + two OCP-fp8 correction products (fp32 accuracy class at 2/3 of VTGB_BF16X3's matrix work) */
 
 int vtgb_version(void);
 const char* vtgb_last_error(void);
@@ -341,6 +342,15 @@ int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream);
  * [10] .. [17] the GRU convolutions over [h(128) | motion(126) | flow(2)] and [26] .. [29] their `inp` parts (always present: the loop-invariant
  * third is computed once per call into fp32 start maps), [24] / [25] mask.2 with its 0.25 folded in; vtgb_raft_encoder: [0] the stem
  * [64, 4 (tY), 3 x 64] scaled by 2/255, the 1x1 head [256, 3 x 128].
+ * VTGB_F16C8 (version 600; vtgb_raft_update only -- the encoders and the correlation volume of that mode run at VTGB_BF16X3): the nine large
+ * convolutions of the update block ([0] convc1, [2] convc2, [8] conv, [10] / [12] / [14] / [16] the GRU's, [18] flow_head.conv1, [22] mask.0) take
+ * their operands as  x . w ~ xh . Wh  (fp16 x fp16)  +  2^-11/sw (xl' . Wh8 + xh8 . Wl')  (OCP fp8 on the block-scaled matrix instruction, twice the
+ * fp16 rate), xh = fp16(x), xl' = e5m2((x - xh) 2^11), xh8 = e5m2(x), Wh = fp16(w), Wh8 = e4m3(w sw), Wl' = e4m3((w - Wh) sw 2^11), sw a power of two
+ * per layer: the corrections are 2^-11 of the product, so 3-4 significant bits on each side leave ~2^-16 -- the bf16 pair's level (tests/
+ * test_gpu_raft.py holds this mode to the bf16x3 mode's bounds).  Their weights are [C_out, K] 16-bit units with K = per source (fp16 [taps, C] |
+ * correction bytes [taps, C / 4 groups of (Wh8 x 4, Wl' x 4)]), each half in the 64-channel-chunk-major K order below (ops.h8_conv_pack);
+ * weights[30] = DEVICE int32 [9]: the E8M0 byte of 2^-11 / sw of those nine convolutions in the order above.  Everything else in the table is as
+ * at VTGB_BF16X3.  Activations beyond +-57344 saturate (e5m2's range; RAFT's are normalised features, gates and correlations of unit-scale features).
  * Convolution weights are packed [C_out, K] in `dtype` with K running 64-channel chunk
  * major, tap minor, channel-in-chunk innermost (written [C_out, KH,KW,C_in] below for the shapes only).
  *
@@ -383,6 +393,27 @@ typedef struct {
 } vtgb_raft_update_args;
 size_t vtgb_raft_update_workspace_bytes(const vtgb_raft_update_args* a);
 int vtgb_raft_update(const vtgb_raft_update_args* a, vtgb_stream_t stream);
+
+/* Unit-level surface of the VTGB_F16C8 operand format (version 600; what tests/test_gpu_h8.py checks piece by piece -- vtgb_raft_update is built from
+ * these): vtgb_pair_pack writes fp32 rows [M, C] (C % 4 == 0) as pair rows [M, 2 * ld_pair 16-bit units] -- fmt VTGB_F16C8: fp16 values at unit c, the
+ * eight correction bytes of channels 4g .. 4g+3 at unit ld_pair + 4g (csrc/pair_h8.h); fmt VTGB_BF16X3: bf16 hi at unit c, bf16 lo at unit ld_pair + c.
+ * Channels [C, ld_pair) are written as zeros.  vtgb_pair_conv: one stride-1 "same" convolution (RAFT update block, raft_utils/update.py:75-97) over
+ * f16c8 pair rows: out = act(conv(x) + bias) as a pair row again (out_fmt VTGB_F16C8 or VTGB_BF16X3), x = C1 channels from `a` (+ C1 more from `a2`:
+ * a virtual concatenation), weights / scale as vtgb_raft_update's table holds them (ops.h8_conv_pack; scale = device int32: the E8M0 byte). */
+int vtgb_pair_pack(int32_t fmt, const float* x, void* out, int64_t M, int32_t C, int32_t ld_pair, vtgb_stream_t stream);
+typedef struct {
+    int32_t M, N, H, W, KH, KW, C1;   /* M = images * H * W output pixels; N output channels (even); C1 % 64 == 0 input channels per source */
+    const void* a;                    /* pair rows [M, 2 * C1 units] */
+    const void* a2;                   /* optional second source, same width */
+    const void* weights;              /* [N, taps * 2 * C1 * sources] 16-bit units */
+    const int32_t* scale;             /* device: E8M0 byte of 2^-11 / sw */
+    const float* bias;                /* optional [N] */
+    int32_t act;                      /* 0 none, 1 relu */
+    int32_t out_fmt;                  /* VTGB_F16C8 or VTGB_BF16X3 */
+    void* out;                        /* pair rows [M, 2 * ld_out units], second half at unit ld_out */
+    int32_t ld_out;                   /* >= N, % 4 == 0 */
+} vtgb_pair_conv_args;
+int vtgb_pair_conv(const vtgb_pair_conv_args* a, vtgb_stream_t stream);
 
 /* CorrBlock.__init__ (raft_utils/corr.py:12-27; the all-pairs product :52-60): for every pair the correlation of each
  * pixel of image 1 with every pixel of image 2 over the `dim` = 256 features, divided by sqrt(dim), and its three

@@ -36,11 +36,11 @@ def make(dev, tiny_sd, dtype):
     return r.to(dev)
 
 
-FLOW_TOL = {"f32": 1e-4, "bf16": 1e-2, "bf16x3": 5e-4}
+FLOW_TOL = {"f32": 1e-4, "bf16": 1e-2, "bf16x3": 5e-4, "f16c8": 5e-4}      # (f16c8, round 6: held to the bf16x3 mode's bounds everywhere)
 ENC_TOL = {"f32": 1e-5, "bf16": 2e-2, "bf16x3": 2e-4}
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3", "f16c8"])
 @pytest.mark.parametrize("iters", [5, 20])
 def test_raft_pairs_vs_reference(dev, tiny_sd, dtype, iters):
     """of_extractor(image1, image2) -- the reference-shaped entry (xraft.py:102) -- vs the reference's flows."""
@@ -53,7 +53,7 @@ def test_raft_pairs_vs_reference(dev, tiny_sd, dtype, iters):
     assert e <= FLOW_TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3", "f16c8"])
 def test_raft_clip_path_vs_reference(dev, tiny_sd, dtype):
     """forward_clips (what LSTP.flow uses): fnet once per distinct frame; same flows as the pair entry."""
     g = load_golden("tiny_raft")
@@ -68,7 +68,7 @@ def test_raft_clip_path_vs_reference(dev, tiny_sd, dtype):
         assert (pair - flow).abs().max() <= 1e-5 * flow.abs().max()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3", "f16c8"])
 def test_raft_single_iteration_and_flow_init(dev, tiny_sd, dtype):
     """One iteration isolates the kernels from the recurrence; flow_init = coords1 - coords0 offset (xraft.py:131-132)."""
     from oracle import vtgb_oracle as O
@@ -80,13 +80,13 @@ def test_raft_single_iteration_and_flow_init(dev, tiny_sd, dtype):
     got = r(fr[:-1].to(dev), fr[1:].to(dev), iters=1).cpu()
     e = rel_rms(got, ref)
     print(f"[raft {dtype} 1 iteration] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
-    assert e <= {"f32": 1e-5, "bf16": 2e-2, "bf16x3": 5e-4}[dtype]
+    assert e <= {"f32": 1e-5, "bf16": 2e-2, "bf16x3": 5e-4, "f16c8": 5e-4}[dtype]
     fi = torch.randn(2, 2, 16, 16, generator=torch.Generator().manual_seed(3)) * 0.5
     ref = O.raft_forward(sd, "of_extractor.", fr[:-1], fr[1:], iters=2, flow_init=fi)
     got = r(fr[:-1].to(dev), fr[1:].to(dev), iters=2, flow_init=fi.to(dev)).cpu()
     e = rel_rms(got, ref)
     print(f"[raft {dtype} flow_init] rel_rms={e:.3e}")
-    assert e <= {"f32": 1e-5, "bf16": 2e-2, "bf16x3": 5e-4}[dtype]
+    assert e <= {"f32": 1e-5, "bf16": 2e-2, "bf16x3": 5e-4, "f16c8": 5e-4}[dtype]
     flows = r(fr[:-1].to(dev), fr[1:].to(dev), iters=2, test_mode=False)      # (round 4: the all-iteration form exists; test_raft_all_iteration_flows checks it)
     assert isinstance(flows, list) and len(flows) == 2
 
@@ -205,7 +205,7 @@ def float_frames(kind, n, size, seed):
 # fp32 mode on float-valued frames: the kernel packs the reference's own 2*(x/255)-1 (same roundings); what is left is the
 # summation order of the stem convolution, whose ~1e-7 relative noise sits on a -1 +- 0.008 image and is amplified ~128 x by
 # InstanceNorm (observed 1.1e-5 on fnet, cnet 1e-7): bound 1e-4 instead of the integer-frame 1e-5
-FLOAT_ENC_TOL = {"f32": 1e-4, "bf16": 2e-2, "bf16x3": 5e-4}
+FLOAT_ENC_TOL = {"f32": 1e-4, "bf16": 2e-2, "bf16x3": 5e-4, "f16c8": 5e-4}      # (f16c8: its encoders ARE the bf16x3 ones)
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("weights", ["default", "sensitive"])
 @pytest.mark.parametrize("kind,size,n", [("randn", 128, 3), ("clip", 128, 3), ("randn", 224, 2), ("clip", 224, 2)])
@@ -227,10 +227,10 @@ def test_raft_encoders_float_valued_frames(dev, tiny_sd, dtype, weights, kind, s
         assert e <= FLOAT_ENC_TOL[dtype], (net, e)
 
 
-SENS_FLOW_TOL = {"f32": 2e-4, "bf16": 2e-2, "bf16x3": 5e-4}
+SENS_FLOW_TOL = {"f32": 2e-4, "bf16": 2e-2, "bf16x3": 5e-4, "f16c8": 5e-4}
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3", "f16c8"])
 def test_raft_sensitive_weights_vs_reference(dev, dtype):
     """The INPUT-SENSITIVE weight set (synth.raft_sensitive_state_dict: fan-in-scaled, the flow depends on the correlation
     features -- tests/test_oracle.py shows a 7 % fnet error moves it by > 1e-2) against the reference RAFT's own flows and fnet
@@ -248,14 +248,14 @@ def test_raft_sensitive_weights_vs_reference(dev, dtype):
         print(f"[raft sensitive {tag} {dtype}] flow rel_rms={e:.3e} max|ref|={g['flow_' + tag].abs().max():.3e}")
         assert e <= SENS_FLOW_TOL[dtype], (tag, e)
         if tag != "c":
-            w = ops.RaftEncoderWeights({k: v.to(dev) for k, v in sd.items()}, "fnet.", False, ops.raft_dtype_code(dtype))
+            w = ops.RaftEncoderWeights({k: v.to(dev) for k, v in sd.items()}, "fnet.", False, ops.raft_stage_code(ops.raft_dtype_code(dtype)))
             fm = ops.raft_encoder(w, torch.cat([f[:-1], f[1:]], 0).to(dev)).cpu().view(4, 16, 16, 256).permute(0, 3, 1, 2)[:, ::4]
             ef = rel_rms(fm, g["fmap_" + tag])
             print(f"[raft sensitive {tag} {dtype}] fnet rel_rms vs the reference's feature maps={ef:.3e}")
             assert ef <= FLOAT_ENC_TOL[dtype], (tag, ef)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3", "f16c8"])
 def test_raft_224_sensitive_weights_vs_reference(dev, dtype):
     """Full frame size (224 x 224 -> 28 x 28 coarse pixels: the geometry the fused GRU half-step, conv64 and the stem kernel run at in
     the bench), input-sensitive weights, 20 iterations, against the REFERENCE's own flow (tests/golden/raft224_sensitive.npz,
@@ -305,13 +305,14 @@ def test_raft_update_is_bit_reproducible(dev, n, h8, w8, iters):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f16c8"])
 @pytest.mark.parametrize("n,h8,w8,iters", [(300, 28, 28, 4), (7, 16, 16, 12), (5, 9, 13, 8)])
-def test_raft_update_bf16x3_is_bit_reproducible(dev, n, h8, w8, iters):
+def test_raft_update_bf16x3_is_bit_reproducible(dev, n, h8, w8, iters, mode):
     """The bf16x3 refinement loop (pair-store, gate and GRU-update epilogues with hand-counted waits, in-place h update) on the same inputs three
     times: the same bits -- a guard against races; (300, 28, 28) = 918 m-tiles on the persistent grid, (5, 9, 13): tiles that straddle images."""
     from videotgb_amd import ops, synth
     sd = {k[len("of_extractor."):]: v.to(dev) for k, v in synth.raft_sensitive_state_dict(0).items()}
-    w = ops.RaftWeights(sd, "update_block.", ops.BF16X3)
+    w = ops.RaftWeights(sd, "update_block.", ops.raft_dtype_code(mode))      # (f16c8: gemm_h8.hip's four-phase k-loop and its pair epilogues)
     g = torch.Generator(device=dev).manual_seed(n + 1)
     cnet = torch.randn(n, h8 * w8, 256, generator=g, device=dev)
     pyr = [torch.randn(n * h8 * w8, 1, max(h8 >> l, 1), max(w8 >> l, 1), generator=g, device=dev) for l in range(4)]
@@ -344,7 +345,7 @@ def test_raft_float_valued_frames(dev, tiny_sd):
     sd = tiny_sd["instructblip"][1]
     fr = torch.randn(3, 3, 128, 128, generator=torch.Generator().manual_seed(12))
     ref = O.raft_forward(sd, "of_extractor.", fr[:-1], fr[1:], iters=6)
-    for dtype, tol in (("f32", 1e-4), ("bf16", 2e-2), ("bf16x3", 5e-4)):
+    for dtype, tol in (("f32", 1e-4), ("bf16", 2e-2), ("bf16x3", 5e-4), ("f16c8", 5e-4)):
         got = make(dev, tiny_sd, dtype)(fr[:-1].to(dev), fr[1:].to(dev), iters=6).cpu()
         e = rel_rms(got, ref)
         print(f"[raft normalised frames {dtype}] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
@@ -391,7 +392,7 @@ def test_corr_large_features_do_not_overflow(dev):
     assert torch.isfinite(got[0].float()).all() and abs(got[0].float().mean().item() - 6400.0) < 4.0
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3", "f16c8"])
 def test_raft_partial_last_tile(dev, tiny_sd, dtype):
     """2 frame pairs of 144 x 144: 2 x 324 = 648 coarse pixels, so the tiles of every update-block launch straddle the two images
     and the third one is partial -- fragment-order start maps, the fused flow-head tail, the gated and GRU epilogues and the
@@ -404,10 +405,10 @@ def test_raft_partial_last_tile(dev, tiny_sd, dtype):
     got = make(dev, tiny_sd, dtype)(fr[:-1].to(dev), fr[1:].to(dev), iters=4).cpu()
     e = rel_rms(got, ref)
     print(f"[raft 144x144 x 2 pairs {dtype}] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
-    assert torch.isfinite(got).all() and e <= {"f32": 1e-4, "bf16": 2e-2, "bf16x3": 5e-4}[dtype]
+    assert torch.isfinite(got).all() and e <= {"f32": 1e-4, "bf16": 2e-2, "bf16x3": 5e-4, "f16c8": 5e-4}[dtype]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3", "f16c8"])
 def test_raft_non_square_frames(dev, tiny_sd, dtype):
     """128 x 208 frames (16 x 26 coarse pixels, 416-pixel images: rows of a 256-row tile straddle image lines and images; the vertical GRU half has
     lines of 16, the horizontal one of 26) vs the fp32 oracle, 6 iterations, 3 pairs."""
@@ -418,4 +419,4 @@ def test_raft_non_square_frames(dev, tiny_sd, dtype):
     got = make(dev, tiny_sd, dtype)(fr[:-1].to(dev), fr[1:].to(dev), iters=6).cpu()
     e = rel_rms(got, ref)
     print(f"[raft 128x208 {dtype}] rel_rms={e:.3e} max|ref|={ref.abs().max():.3e}")
-    assert tuple(got.shape) == (3, 2, 128, 208) and torch.isfinite(got).all() and e <= {"f32": 1e-4, "bf16": 2e-2, "bf16x3": 5e-4}[dtype]
+    assert tuple(got.shape) == (3, 2, 128, 208) and torch.isfinite(got).all() and e <= {"f32": 1e-4, "bf16": 2e-2, "bf16x3": 5e-4, "f16c8": 5e-4}[dtype]

@@ -281,3 +281,60 @@ def test_split_bf16_weight_layout_and_accuracy():
     scale = (x.abs().double() @ w2.abs().double().t()).max()
     assert (three - exact).abs().max() <= 2.0 ** -15 * scale
     assert (one - exact).abs().max() > 50 * (three - exact).abs().max()          # the plain bf16 product is two orders of magnitude further off
+
+
+def _h8_pack_rows(x):
+    """CPU statement of csrc/pair_h8.h's activation row: x [M, C] fp32 -> uint8 [M, 4 C] = [fp16(x) x C | per 4 channels: e5m2((x - xh) 2^11) x 4,
+    e5m2(x) x 4]."""
+    M, Cc = x.shape
+    x = x.clamp(-57344.0, 57344.0)
+    xh = x.to(torch.float16)
+    r8 = ((x - xh.float()) * 2048.0).to(torch.float8_e5m2).view(torch.uint8).reshape(M, Cc // 4, 4)
+    v8 = x.to(torch.float8_e5m2).view(torch.uint8).reshape(M, Cc // 4, 4)
+    return torch.cat([xh.view(torch.uint8).reshape(M, 2 * Cc), torch.stack([r8, v8], 2).reshape(M, 2 * Cc)], 1)
+
+
+def test_f16c8_weight_layout_and_accuracy():
+    """The f16c8 RAFT mode's operand format (csrc/pair_h8.h, ops.h8_conv_pack; CPU): the contraction is walked exactly as gemm_h8.hip walks it -- per
+    source `run` fp16 k-tiles (64 channels of one tap: fp16 x fp16) then `run` fp8 k-tiles (the 128 correction bytes of the same 64 channels:
+    activation byte p as e5m2 times weight byte p as e4m3, scaled by 2^(byte - 127)) -- over a two-source 1x5 convolution's packed weights and
+    packed activation rows, and must agree with the fp64 product to ~2^-15 of its scale, where the fp16-only product is > 20 x further off."""
+    from videotgb_amd import ops
+    g = torch.Generator().manual_seed(1)
+    co, taps, C1 = 8, 5, 128
+    w = torch.randn(co, 1, taps, 2 * C1, generator=g) * 0.05
+    sw, byte = ops.h8_weight_scale(w)
+    assert sw * float(w.abs().max()) <= 448.0 < 2 * sw * float(w.abs().max()) and byte == 127 - 11 - int(round(torch.log2(torch.tensor(sw)).item()))
+    packed = ops.h8_conv_pack(w, sw, [C1, C1]).view(torch.int16)                 # [co, K] 16-bit units, K = taps * 2 * (C1 + C1)
+    assert tuple(packed.shape) == (co, taps * 4 * C1)
+    wb = packed.contiguous().view(torch.uint8).reshape(co, -1, 128)               # k-tiles of 128 bytes
+    M = 32
+    xs = [torch.randn(M, taps, C1, generator=g) * torch.rand(M, 1, 1, generator=g) * 40.0 for _ in range(2)]      # per tap the row the tap reads
+    rows = [[_h8_pack_rows(x[:, t]) for t in range(taps)] for x in xs]           # [source][tap] -> uint8 [M, 4 C1]
+    run, kt = taps * (C1 // 64), 0
+    acc = torch.zeros(M, co, dtype=torch.float64)
+    only16 = torch.zeros(M, co, dtype=torch.float64)
+    scale = 2.0 ** (byte - 127)
+    for src in range(2):
+        for kind in range(2):                                                    # fp16 run, then fp8 run
+            for chunk in range(C1 // 64):
+                for t in range(taps):
+                    a = rows[src][t][:, kind * 2 * C1 + chunk * 128: kind * 2 * C1 + (chunk + 1) * 128]      # [M, 128] bytes
+                    b = wb[:, kt]                                                                             # [co, 128] bytes
+                    if kind == 0:
+                        p = a.contiguous().view(torch.float16).double() @ b.contiguous().view(torch.float16).double().t()
+                        only16 += p
+                    else:
+                        p = (a.contiguous().view(torch.float8_e5m2).double() @ b.contiguous().view(torch.float8_e4m3fn).double().t()) * scale
+                    acc += p
+                    kt += 1
+    assert kt == 2 * 2 * run == wb.shape[1]
+    exact = sum(torch.einsum("mtc,otc->mo", xs[s].double(), w[:, 0, :, s * C1:(s + 1) * C1].double()) for s in range(2))
+    bound = sum(torch.einsum("mtc,otc->mo", xs[s].abs().double(), w[:, 0, :, s * C1:(s + 1) * C1].abs().double()) for s in range(2))
+    err, err16 = ((acc - exact).abs() / bound).max(), ((only16 - exact).abs() / bound).max()
+    assert err <= 2.0 ** -15 and err16 > 20 * err, (float(err), float(err16))
+    # the pair read back element-wise (the GRU's h): xh + xl' 2^-11 carries ~15 bits
+    h = torch.randn(64, 128, generator=g).tanh()
+    r = _h8_pack_rows(h)
+    back = r[:, :256].contiguous().view(torch.float16).float() + r[:, 256:].reshape(64, 32, 2, 4)[:, :, 0].reshape(64, 128).contiguous().view(torch.float8_e5m2).float() / 2048.0
+    assert (back - h).abs().max() <= 2.0 ** -14 * h.abs().max()

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("VTGB_LIB") or os.path.join(HERE, "libvtgb.so")
 
 F32, BF16 = 0, 1
 BF16X3 = 2      # RAFT entry points only: split-bf16 operands (include/vtgb.h)
+F16C8 = 3       # vtgb_raft_update only: fp16 main product + two fp8 correction products (include/vtgb.h)
 MAP_A, MAP_B = 0, 1
 POOL_MEAN, POOL_CONCAT = 0, 1
 TGB_MODE = {"text": 0, "vision": 0, "fusion": 1, "multi_modal": 2}
@@ -37,6 +38,7 @@ EXPORTS = [
     "vtgb_attn_train_forward", "vtgb_attn_train_backward",
     "vtgb_gemm_train", "vtgb_gemm_train_workspace_bytes", "vtgb_col_sum_parts", "vtgb_col_sum_f32", "vtgb_layernorm_train_partials", "vtgb_layernorm_train_forward", "vtgb_layernorm_train_backward",
     "vtgb_gelu_forward", "vtgb_gelu_backward",
+    "vtgb_pair_pack", "vtgb_pair_conv",
 ]
 COMM_ID_BYTES = 128
 
@@ -125,6 +127,11 @@ class RaftUpdateArgs(C.Structure):
                 ("flow_init", vp)]
 
 
+class PairConvArgs(C.Structure):
+    _fields_ = [("M", i32), ("N", i32), ("H", i32), ("W", i32), ("KH", i32), ("KW", i32), ("C1", i32), ("a", vp), ("a2", vp), ("weights", vp), ("scale", vp),
+                ("bias", vp), ("act", i32), ("out_fmt", i32), ("out", vp), ("ld_out", i32)]
+
+
 class RaftCorrArgs(C.Structure):
     _fields_ = [("dtype", i32), ("n_pairs", i32), ("H8", i32), ("W8", i32), ("dim", i32), ("pairs_per_clip", i32), ("frames_per_clip", i32),
                 ("first_off", i32), ("second_off", i32), ("n_images", i32), ("scale", f32), ("fmap", vp), ("levels", vp * 4),
@@ -192,6 +199,10 @@ def lib() -> C.CDLL:
         fn = getattr(L, f"vtgb_{name}_workspace_bytes")
         fn.argtypes = [C.POINTER(st)]
         fn.restype = sz
+    L.vtgb_pair_pack.argtypes = [i32, vp, vp, i64, i32, i32, vp]
+    L.vtgb_pair_pack.restype = C.c_int
+    L.vtgb_pair_conv.argtypes = [C.POINTER(PairConvArgs), vp]
+    L.vtgb_pair_conv.restype = C.c_int
     L.vtgb_raft_update.argtypes = [C.POINTER(RaftUpdateArgs), vp]
     L.vtgb_raft_update.restype = C.c_int
     L.vtgb_raft_update_workspace_bytes.argtypes = [C.POINTER(RaftUpdateArgs)]

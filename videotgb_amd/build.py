@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvtgb.so")
-SOURCES = ["gemm.hip", "gemm_pp.hip", "conv64.hip", "conv_f32.hip", "attn.hip", "elementwise.hip", "select.hip", "forward.hip", "llm.hip", "raft.hip", "raft_x3.hip", "gru_fused.hip", "raft_corr.hip", "raft_enc.hip", "train.hip", "train_attn.hip", "train_ops.hip", "comm.hip"]
+SOURCES = ["gemm.hip", "gemm_pp.hip", "gemm_h8.hip", "conv64.hip", "conv_f32.hip", "attn.hip", "elementwise.hip", "select.hip", "forward.hip", "llm.hip", "raft.hip", "raft_x3.hip", "gru_fused.hip", "raft_corr.hip", "raft_enc.hip", "train.hip", "train_attn.hip", "train_ops.hip", "comm.hip"]
 
 
 FLAGS_STAMP = os.path.join(HERE, "build", "flags")

@@ -208,7 +208,15 @@ struct GemmDesc {
     const float* ln_stats;
     const float* ln_cs;
     const float* ln_c;
+    // ---- VTGB_F16C8 operands (pair_h8.h; launch_conv_h8 only): the activation row of a C-channel source is [xh fp16 x C | 8 correction bytes per 4
+    // channels] = 2 C 16-bit units (conv_Cin / conv_split / lda count those), K = taps x conv_Cin runs per source `h8_run` fp16 k-tiles then
+    // `h8_run` fp8 k-tiles (h8_run = taps x C / 64).  h8_scale: DEVICE pointer to the E8M0 byte (as an int) of 2^-11 / sw, sw = the layer's
+    // power-of-two weight scale (ops.py h8_pack).  h8_out_bf16 (EPI_SPLIT): the output pair is written as a bf16 pair [hi | lo] instead.
+    int h8_run;
+    const int* h8_scale;
+    int h8_out_bf16;
 };
+int launch_conv_h8(const GemmDesc& d, hipStream_t s);   // gemm_h8.hip
 int launch_ln_fold_stats(const float* part, int nblk, int D, float eps, float* stats, int64_t M, hipStream_t s);
 int launch_ln_fold_prepare(const float* x, int64_t ldx, int D, void* xb, float* part, int64_t M, hipStream_t s);   // bf16(x) -> xb [M, D], block moments -> part
 #define VTGB_EPI_GRU 4

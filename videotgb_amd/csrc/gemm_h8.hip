@@ -1,0 +1,530 @@
+// gemm_h8.hip -- the implicit-GEMM convolution of RAFT's update block in the VTGB_F16C8 operand format (pair_h8.h; xraft.py:135-152,
+// raft_utils/update.py:39-144): the persistent 256-row tile kernel of gemm_pp.hip (same LDS image, same LDS-DMA staging, same tile walk,
+// same accumulator layout, same epilogue structure) with a k-loop that alternates RUNS of two kinds of k-tile:
+//   * fp16 k-tiles  -- 64 channels of xh against Wh: 2 x v_mfma_f32_16x16x32_f16 per 16 x 16 block (as the bf16 kernels);
+//   * fp8 k-tiles   -- the 128 correction bytes of the same 64 channels ([xl' x 4 | xh8 x 4] per group of four channels) against
+//                      [Wh8 x 4 | Wl' x 4]: ONE v_mfma_scale_f32_16x16x128_f8f6f4 per block (weights e4m3, activations e5m2, the power-of-two
+//                      scale 2^-11 / sw in the weight operand's E8M0 scale) -- the same 128 bytes per row and the same matrix-pipe cycles as an
+//                      fp16 k-tile, for BOTH corrections (tools/exp/f8_mfma_probe.hip: operand bytes pair up position by position whatever
+//                      the instruction's k order is, so the fragment reads of the fp16 tiles serve as they are).
+// A C-channel source therefore costs 2 C / 64 k-tiles per tap where the bf16x3 form ([hi | lo | hi] against [Wh | Wh | Wl]) costs 3 C / 64.
+// K order (weights packed by ops.py h8_conv_pack): per source, `run` = taps x C / 64 fp16 k-tiles, then `run` fp8 k-tiles (chunk major, tap
+// minor inside each); all sources of a launch have the same C.
+//
+// The fp8 instruction needs BOTH 64-byte halves of its operands at once, so the fp16 loop's "multiply one half while the other is being
+// read" does not carry over.  An fp8 k-tile is multiplied in four phases over quarters of the (weight fragment, activation fragment) grid,
+// ordered so that fragments die early and are re-read from the NEXT k-tile under the remaining phases:
+//     1a (w lo, x lo)   1b (w hi, x lo)   -- barrier: next k-tile landed --   2a (w lo, x hi) + read x lo'   2b (w hi, x hi) + read w lo'
+//     tail: read w hi', x hi' (they land under the next tile's phase 1a)
+// with no more registers than the two fragment sets of the fp16 loop.
+#include "common.h"
+#include "gemm_dev.h"
+#include "pair_h8.h"
+
+constexpr int H_BK = 64;
+constexpr int H_AOP = 256 * H_BK * 2;   // 32 KiB activation slot (256 rows x 128 bytes)
+
+typedef int h8_i32x4 __attribute__((ext_vector_type(4)));
+typedef int h8_i32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h8_f16x8 __attribute__((ext_vector_type(8)));
+
+#define H_STORE128(data, rs, lane_off, soff) __builtin_amdgcn_raw_buffer_store_b128(data, rs, (lane_off) + (unsigned)(soff), 0, 0)
+#define H_STORE64(data, rs, lane_off, soff) __builtin_amdgcn_raw_buffer_store_b64(data, rs, (lane_off) + (unsigned)(soff), 0, 0)
+#define H_PHASE_BARRIER() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+
+// OFMT: what the pair-writing epilogues store -- 1 the f16c8 pair (pair_h8.h), 0 the bf16 pair [hi | lo] of the bf16x3 kernels (FlowHead.conv1 /
+// mask.0, whose 1x1 successors stay on the bf16x3 kernels)
+template <int EPI, int NWN, int WF, int OFMT>
+__global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G, const int total_blocks) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NX = 2 * NWN;          // activation fragments per wave: wave tile = (16 NX) x (16 WF)
+    constexpr int WROWS = 16 * NX;
+    constexpr int MW = 8 / NWN;
+    constexpr int WC = 16 * WF;
+    constexpr int T_BM = 256, T_BN = WC * NWN;
+    constexpr int A_OP = H_AOP, W_OP = T_BN * 128;
+    constexpr int AI = 4, WI = T_BN / 64;
+    constexpr int A_SLOTS = 3;
+    constexpr int SB = (A_SLOTS - 1) * A_OP / 8;   // epilogue staging bytes per wave (A slots 1, 2)
+    constexpr int NPRE = AI + WI;
+    constexpr int WH = WF / 2, XH = NX / 2;        // the quarters of the fragment grid (WF = 3: 1 + 2 weight fragments)
+    static_assert(WF == 4 || (WF == 3 && NWN == 4 && EPI == EPI_SPLIT), "48-column wave tiles: the pair-store convolution (convc2) only");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const smem_w = smem + A_SLOTS * A_OP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % MW, wn = wave / MW;
+    const int nk = p.K / H_BK;
+    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);      // (16-bit units: the fp8 half of a row is addressed as 64 "channels" per 128 bytes)
+    const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
+    char* const stage = smem + A_OP + wave * SB;
+    const int sc_w = *p.h8_scale;        // E8M0 byte of 2^-11 / sw (the activations' own scale is 1: byte 127)
+
+    const int Gn = G * n_tiles;
+    auto decode = [&](int q, int& mt_, int& nt_) {
+        const int g = q / Gn, r = q - g * Gn;
+        const int Gc = min(G, m_tiles - g * G);
+        nt_ = r / Gc;
+        mt_ = g * G + (r - nt_ * Gc);
+    };
+    auto next_valid = [&](int q, int& mt_, int& nt_) -> int {
+        if (q >= total_blocks) return -1;
+        decode(q, mt_, nt_);
+        return q;
+    };
+    const int grid_ = (int)gridDim.x;
+    const int first_q = (grid_ & 7) == 0 ? (grid_ >> 3) * ((int)blockIdx.x & 7) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+
+    // ---- per-tile LDS-DMA state (gemm_pp.hip: tile descriptors + loop-invariant lane offsets)
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int RANGE = 0x7FFFFF00;
+    unsigned w_voff, a_voff[AI];
+    int a_bits[AI];
+    int m0 = 0, n0 = 0, mt = 0, nt = 0;
+    bool wave_active = false;
+    auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, RANGE, 0x00020000);
+    auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, RANGE, 0x00020000);
+    auto a2_rsrc = a_rsrc;
+    const int cv_hw = p.conv_H * p.conv_W, cv_Wi = p.conv_W;
+    int cv_ky = 0, cv_kx = 0, cv_c0 = 0;
+#define H_TILE_SETUP()                                                                                                       \
+    {                                                                                                                        \
+        m0 = mt * T_BM; n0 = nt * T_BN;                                                                                      \
+        wave_active = (n0 + wn * WC < p.N) && (m0 + wm * WROWS < p.M);                                                       \
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W + (int64_t)n0 * p.ldw), 0, (int)(min(T_BN, p.N - n0) * p.ldw * 2), 0x00020000); \
+        {                                                                                                                    \
+            const int row = wave * (8 * WI) + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);                     \
+            w_voff = (unsigned)(row * (int)p.ldw + c * 8) * 2u;                                                              \
+        }                                                                                                                    \
+        const int cv_img0 = m0 / cv_hw;                                                                                      \
+        const int64_t a_row0 = (int64_t)cv_img0 * cv_hw;                                                                     \
+        a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + a_row0 * p.lda), 0, RANGE, 0x00020000);           \
+        a2_rsrc = __builtin_amdgcn_make_buffer_rsrc(                                                                         \
+            const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.A2 ? p.A2 : p.A) + a_row0 * (p.A2 ? p.lda2 : p.lda)), 0, RANGE, 0x00020000); \
+        _Pragma("unroll") for (int i = 0; i < AI; i++) {                                                                     \
+            const int row = wave * (8 * AI) + i * 8 + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);             \
+            const int am = (m0 + row) < p.M ? (m0 + row) : p.M - 1;                                                          \
+            const int img = (int)((__umulhi((unsigned)am, p.div_hw_mul) + (unsigned)am) >> p.div_hw_sh), rem = am - img * cv_hw; \
+            const int y = (int)((__umulhi((unsigned)rem, p.div_w_mul) + (unsigned)rem) >> p.div_w_sh), x = rem - y * p.conv_W; \
+            a_voff[i] = (unsigned)((img - cv_img0) * cv_hw + y * cv_Wi + x) | ((unsigned)c << 28);                           \
+            const int py = p.conv_KH >> 1, px = p.conv_KW >> 1;                                                              \
+            const int ylo = max(0, py - y), yhi = min(p.conv_KH - 1, p.conv_H - 1 - y + py), xlo = max(0, px - x), xhi = min(p.conv_KW - 1, cv_Wi - 1 - x + px); \
+            const int yb = yhi >= ylo ? ((2 << yhi) - 1) & ~((1 << ylo) - 1) : 0, xb = xhi >= xlo ? ((2 << xhi) - 1) & ~((1 << xlo) - 1) : 0; \
+            a_bits[i] = yb | (xb << 8);                                                                                      \
+        }                                                                                                                    \
+        cv_ky = 0; cv_kx = 0; cv_c0 = 0;                                                                                     \
+    }
+#define H_ISSUE_A(slot)                                                                                 \
+    {                                                                                                   \
+        const bool first = cv_c0 < p.conv_split;                                                        \
+        const unsigned ldb = (unsigned)(first ? p.lda : p.lda2) * 2u;                                   \
+        const int cc2 = (first ? cv_c0 : cv_c0 - p.conv_split) * 2;                                     \
+        const int dpix = (cv_ky - (p.conv_KH >> 1)) * cv_Wi + (cv_kx - (p.conv_KW >> 1));               \
+        const int need = (1 << cv_ky) | (256 << cv_kx);                                                 \
+        const auto rs_ = first ? a_rsrc : a2_rsrc;                                                      \
+        _Pragma("unroll") for (int i = 0; i < AI; i++) {                                                \
+            const unsigned pix = (a_voff[i] & 0x00FFFFFFu) + (unsigned)dpix;                            \
+            const unsigned vin = __umul24(pix, ldb) + (a_voff[i] >> 28) * 16u;                          \
+            const unsigned v = ((a_bits[i] & need) == need) ? vin : OOB;                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lptr_t)(smem + (slot) * A_OP + (wave * (8 * AI) + i * 8) * 128), 16, v, cc2, 0, 0); \
+        }                                                                                               \
+        if (++cv_kx == p.conv_KW) { cv_kx = 0; if (++cv_ky == p.conv_KH) { cv_ky = 0; cv_c0 += H_BK; } } \
+    }
+#define H_ISSUE_W(slot, k0)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < WI; i++)                                                      \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(smem_w + (slot) * W_OP + (wave * (8 * WI) + i * 8) * 128), 16, w_voff ^ ((i & 1) * 64), (k0) * 2 + i * 8 * (int)p.ldw * 2, 0, 0);
+
+    // fragments: 32 bytes per (16-row block, lane) = the two 64-byte halves' 16-byte pieces, as ONE register tuple (the fp8 instruction's operand);
+    // the fp16 instruction takes either half of it
+    h8_i32x8 wfr[WF], xfr[NX];
+#define H_LW(i, H, ws_)                                                                                                   \
+    {                                                                                                                     \
+        const h8_i32x4 t_ = *reinterpret_cast<const h8_i32x4*>((ws_) + (w_off0 ^ ((H) * 64)) + (i) * 2048);               \
+        if ((H) == 0) wfr[i].lo = t_; else wfr[i].hi = t_;                                                                \
+    }
+#define H_LX(j, H, as_)                                                                                                   \
+    {                                                                                                                     \
+        const h8_i32x4 t_ = *reinterpret_cast<const h8_i32x4*>((as_) + (x_off0 ^ ((H) * 64)) + (j) * 2048);               \
+        if ((H) == 0) xfr[j].lo = t_; else xfr[j].hi = t_;                                                                \
+    }
+#define H_MF16(i, j, H)                                                                                                   \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_f16x8, (H) == 0 ? wfr[i].lo : wfr[i].hi),    \
+                                                       __builtin_bit_cast(h8_f16x8, (H) == 0 ? xfr[j].lo : xfr[j].hi), acc[i][j], 0, 0, 0);
+#define H_MF8(i, j) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wfr[i], xfr[j], acc[i][j], 0, 1, 0, sc_w, 0, 127);
+#define H_MF8_BLOCK(i0, i1, j0, j1)                                                                      \
+    _Pragma("unroll") for (int i = (i0); i < (i1); i++)                                                  \
+        _Pragma("unroll") for (int j = (j0); j < (j1); j++) { H_MF8(i, j) }
+#define H_SCHED_IL(PIECES, NMF)                                                                          \
+    if constexpr ((PIECES) > 0 && (NMF) % (PIECES) == 0) {                                               \
+        _Pragma("unroll") for (int g_ = 0; g_ < (PIECES); g_++) {                                        \
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                                           \
+            __builtin_amdgcn_sched_group_barrier(0x008, (NMF) / (PIECES), 0);                            \
+        }                                                                                                \
+    }
+
+    int b = next_valid(first_q, mt, nt);
+    if (b < 0) return;
+    H_TILE_SETUP()
+    H_ISSUE_A(0)
+    H_ISSUE_W(0, 0)
+    while (true) {
+        int lane_k = lane;
+        asm volatile("" : "+v"(lane_k));
+        const int w_off0 = swz(wn * WC + (lane_k & 15), lane_k >> 4), x_off0 = swz(wm * WROWS + (lane_k & 15), lane_k >> 4);
+        const int fg = lane_k >> 4;
+        f32x4 acc[WF][NX];
+        {
+            f32x4 b4[WF];
+#pragma unroll
+            for (int i = 0; i < WF; i++) {
+                const int n = n0 + wn * WC + i * 16 + fg * 4;
+                b4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias && n + 3 < p.N) b4[i] = *reinterpret_cast<const f32x4*>(p.bias + n);
+                else if (p.bias && n < p.N) {
+                    for (int e = 0; e < 4 && n + e < p.N; e++) b4[i][e] = p.bias[n + e];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NX; j++)
+#pragma unroll
+                for (int i = 0; i < WF; i++) acc[i][j] = b4[i];
+        }
+        // ---------- k-loop (nk >= 4, runs of >= 2 k-tiles; the first run is fp16, the last fp8).  A(g) in slot g % 3, W(g) in slot g % 2
+        H_ISSUE_A(1) H_ISSUE_W(1, H_BK)
+        H_ISSUE_A(2)
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * AI + WI));
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        int a_slot = 0;
+        if (!wave_active) {
+            for (int kt = 0; kt + 1 < nk; kt++) {
+                if (kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | AI);
+                else __builtin_amdgcn_s_waitcnt(0x0F70);
+                __builtin_amdgcn_s_barrier();
+                if (kt + 2 < nk) { H_ISSUE_W(kt & 1, (kt + 2) * H_BK) }
+                if (kt + 3 < nk) { H_ISSUE_A(a_slot) }
+                a_slot = a_slot == 2 ? 0 : a_slot + 1;
+            }
+        } else {
+            // One k-tile of either kind, multiplied in four phases over the quarters of the fragment grid (file header); KIND 0: fp16 (two
+            // 32-deep MFMAs per block, the eight first halves of a quarter before its eight second halves), KIND 1: fp8 (one 128-deep MFMA).
+            // The fragments of the whole k-tile are in registers (or on their way) at the top; the next k-tile's are read under phases 2a / 2b
+            // and behind them.  Every LDS read of a k-tile is complete at the NEXT k-tile's barrier (lgkmcnt(0) in front of it), after which its
+            // slots are re-armed (W(t+2) right there, A(t+3) at the top of the k-tile after).
+#define H_MF_BLOCK(KIND, i0, i1, j0, j1)                                                                 \
+    if constexpr ((KIND) == 1) {                                                                         \
+        H_MF8_BLOCK(i0, i1, j0, j1)                                                                      \
+    } else {                                                                                             \
+        _Pragma("unroll") for (int i = (i0); i < (i1); i++)                                              \
+            _Pragma("unroll") for (int j = (j0); j < (j1); j++) { H_MF16(i, j, 0) }                      \
+        _Pragma("unroll") for (int i = (i0); i < (i1); i++)                                              \
+            _Pragma("unroll") for (int j = (j0); j < (j1); j++) { H_MF16(i, j, 1) }                      \
+    }
+#define H_ITER(KIND, DEFER, WCOND, WAIT4)                                                                \
+    {                                                                                                    \
+        constexpr int MPB = (KIND) == 1 ? 1 : 2;      /* MFMAs per block */                              \
+        const int a_nxt = a_slot == 2 ? 0 : a_slot + 1;                                                  \
+        const int a_prv = a_slot == 0 ? 2 : a_slot - 1;                                                  \
+        if (DEFER) { H_ISSUE_A(a_prv) }                                                                  \
+        H_MF_BLOCK(KIND, 0, WH, 0, XH)                                                                   \
+        H_MF_BLOCK(KIND, WH, WF, 0, XH)                                                                  \
+        H_SCHED_IL(AI, WF * XH * MPB)                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (WAIT4) __builtin_amdgcn_s_waitcnt(0x0070 | AI);                                              \
+        else __builtin_amdgcn_s_waitcnt(0x0070);                                                         \
+        __builtin_amdgcn_s_barrier();                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (WCOND) { H_ISSUE_W(kt & 1, (kt + 2) * H_BK) }                                                \
+        {                                                                                                \
+            const char* an = smem + a_nxt * A_OP;                                                        \
+            const char* wn_ = smem_w + ((kt + 1) & 1) * W_OP;                                            \
+            _Pragma("unroll") for (int j = 0; j < XH; j++) { H_LX(j, 0, an) H_LX(j, 1, an) }             \
+            H_MF_BLOCK(KIND, 0, WH, XH, NX)                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            _Pragma("unroll") for (int i = 0; i < WH; i++) { H_LW(i, 0, wn_) H_LW(i, 1, wn_) }           \
+            H_MF_BLOCK(KIND, WH, WF, XH, NX)                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            _Pragma("unroll") for (int i = WH; i < WF; i++) { H_LW(i, 0, wn_) H_LW(i, 1, wn_) }          \
+            _Pragma("unroll") for (int j = XH; j < NX; j++) { H_LX(j, 0, an) H_LX(j, 1, an) }            \
+        }                                                                                                \
+        a_slot = a_nxt;                                                                                  \
+    }
+            {
+                _Pragma("unroll") for (int i = 0; i < WF; i++) { H_LW(i, 0, smem_w) H_LW(i, 1, smem_w) }
+                _Pragma("unroll") for (int j = 0; j < NX; j++) { H_LX(j, 0, smem) H_LX(j, 1, smem) }
+            }
+            int kt = 0;
+            { H_ITER(0, false, true, true) kt = 1; }
+            // runs: [fp16 x run | fp8 x run] per source, as straight-line inner loops (a two-way branch per k-tile between two bodies made hipcc
+            // spill ~800 registers); the last two k-tiles (fp8) are peeled: nothing is left to issue there
+            const int run = p.h8_run, npair = nk / (2 * run);
+            for (int pr = 0; pr < npair; pr++) {
+                for (int r = pr == 0 ? 1 : 0; r < run; r++, kt++) { H_ITER(0, true, true, true) }
+                const int n8 = pr == npair - 1 ? run - 2 : run;
+                for (int r = 0; r < n8; r++, kt++) { H_ITER(1, true, true, true) }
+            }
+            { H_ITER(1, false, false, false) kt++; }      // k-tile nk - 2 (fp8): nothing left to issue
+            {   // last k-tile (fp8; its fragments were read by the tile before)
+                H_MF8_BLOCK(0, WF, 0, NX)
+            }
+#undef H_ITER
+#undef H_MF_BLOCK
+        }
+        H_PHASE_BARRIER()                      // every wave's LDS reads and DMAs of this tile are done: the ring is free
+
+        // ================= the next tile: its setup replaces this tile's DMA state, its first k-tile is issued by the epilogue
+        const int em0 = m0, en0 = n0;
+        const bool eactive = wave_active;
+        (void)eactive;
+        const int b2 = next_valid(b + (int)gridDim.x, mt, nt);
+        const bool has_next = b2 >= 0;
+        if (has_next) H_TILE_SETUP()
+        constexpr bool PARK = NWN == 4;
+        uint4* const park = reinterpret_cast<uint4*>(smem_w + W_OP) + tid;
+        auto prefetch = [&]() {
+            if (has_next) {
+                H_ISSUE_A(0)
+                H_ISSUE_W(0, 0)
+                if constexpr (PARK) {
+                    park[0] = make_uint4(a_voff[0], a_voff[1], a_voff[2], a_voff[3]);
+                    park[512] = make_uint4((unsigned)a_bits[0], (unsigned)a_bits[1], (unsigned)a_bits[2], (unsigned)a_bits[3]);
+                    park[1024] = make_uint4(w_voff, 0u, 0u, 0u);
+                }
+            }
+        };
+#define H_WAIT_OPERANDS() if (has_next) __builtin_amdgcn_s_waitcnt(0x0F70 | NPRE); else __builtin_amdgcn_s_waitcnt(0x0F70);
+
+        // ================= epilogue of tile (em0, en0): gemm_pp.hip's pair epilogues with the pair written / read in the f16c8 format
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int rows_here = min(T_BM, p.M - em0);
+        auto tile_rsrc = [&](const void* base, int64_t ld, int es) {
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + (int64_t)em0 * ld * es, 0, (int)(rows_here * ld * es), 0x00020000);
+        };
+        typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+        typedef h8_u32x2 u32x2_t;
+        // v -> the pair's two 8-byte words
+        auto encode = [&](const f32x4 v, u32x2_t& hu, u32x2_t& lu) {
+            if constexpr (OFMT == 1) {
+                h8_split4(v, hu, lu);
+            } else {
+                const f32x4 hf = {bf16_round(v[0]), bf16_round(v[1]), bf16_round(v[2]), bf16_round(v[3])};
+                const bf16x4 hi = {(bf16_t)hf[0], (bf16_t)hf[1], (bf16_t)hf[2], (bf16_t)hf[3]};
+                const bf16x4 lo = {(bf16_t)(v[0] - hf[0]), (bf16_t)(v[1] - hf[1]), (bf16_t)(v[2] - hf[2]), (bf16_t)(v[3] - hf[3])};
+                hu = __builtin_bit_cast(u32x2_t, hi); lu = __builtin_bit_cast(u32x2_t, lo);
+            }
+        };
+        if constexpr (EPI == EPI_SPLIT) {
+            constexpr int PR = SB / 256 < WROWS ? SB / 256 : WROWS, NP = WROWS / PR;
+            const int rl = lane_e >> 4, cl = lane_e & 15;
+            const int n = en0 + wn * WC + cl * 4;
+            const bool inw = cl * 4 < WC;
+            const auto o_rs = tile_rsrc(p.out, p.ldo, 2);
+            const unsigned o_off = (unsigned)((wm * WROWS + rl) * (int)p.ldo + n) * 2u;
+            const unsigned o_lane = (inw && n + 3 < p.N) ? o_off : OOB;
+            const unsigned o_part = (inw && n < p.N && n + 3 >= p.N) ? o_off : OOB;      // (N % 4 == 2: two columns)
+            const bool cut = (p.N & 3) != 0;
+            const unsigned lo_b = (unsigned)p.split_lo * 2u;
+            prefetch();
+#pragma unroll
+            for (int ps = 0; ps < NP; ps++) {
+#pragma unroll
+                for (int jj = 0; jj < PR / 16; jj++)
+#pragma unroll
+                    for (int i = 0; i < WF; i++) {
+                        const int row = jj * 16 + (lane_e & 15), chunk = i * 4 + (lane_e >> 4);
+                        *reinterpret_cast<f32x4*>(stage + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][ps * (PR / 16) + jj];
+                    }
+#pragma unroll
+                for (int rr = 0; rr < PR / 4; rr++) {
+                    const int row = rr * 4 + rl;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 256 + ((cl ^ (row & 15)) << 4));
+                    if (p.act) apply_act4(v, p.act);
+                    u32x2_t hu, lu;
+                    encode(v, hu, lu);
+                    const unsigned so = (unsigned)((ps * PR + rr * 4) * (int)p.ldo * 2);
+                    H_STORE64(hu, o_rs, o_lane, so);
+                    H_STORE64(lu, o_rs, o_lane + lo_b, so);
+                    if (cut) {      // the group that straddles N: its first two columns
+                        __builtin_amdgcn_raw_buffer_store_b32(hu[0], o_rs, o_part + so, 0, 0);
+                        if constexpr (OFMT == 1) {
+                            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(lu[0] & 0xFFFFu), o_rs, o_part + lo_b + so, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(lu[1] & 0xFFFFu), o_rs, o_part + lo_b + 4u + so, 0, 0);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b32(lu[0], o_rs, o_part + lo_b + so, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (EPI == EPI_X3ZR || EPI == EPI_X3Q) {
+            // SepConvGRU gates in the convolution's epilogue (common.h: VTGB_EPI_X3ZR / X3Q), h / r h / h' as f16c8 pairs
+            static_assert(EPI == EPI_SPLIT || OFMT == 1, "the GRU's pairs are f16c8 pairs");
+            constexpr bool ZR = EPI == EPI_X3ZR;
+            constexpr int PR = SB / 256 < WROWS ? SB / 256 : WROWS, NP = WROWS / PR, NS = NP * (PR / 16);
+            static_assert(EPI == EPI_SPLIT || PR == 32, "two sub-passes of 16 rows per staged pass");
+            const int rl = lane_e >> 4, cl = lane_e & 15;
+            const int n = en0 + wn * 64 + cl * 4;
+            const bool is_r = ZR && n >= 128;                      // wave-uniform
+            const int c = is_r ? n - 128 : n;
+            const int rowl = wm * WROWS + rl;
+            const unsigned lo_b = (unsigned)p.split_lo * 2u;
+            const auto m_rs = tile_rsrc(p.resid, p.ldr, 4);                                      // fp32 start map
+            const auto h_rs = ZR ? tile_rsrc(p.aux, p.ldaux, 2) : tile_rsrc(p.out, p.ldo, 2);     // h pair
+            const auto z_rs = ZR ? tile_rsrc(p.out, p.ldo, 4) : tile_rsrc(p.aux, p.ldaux, 4);     // z fp32 (X3ZR: written; X3Q: read)
+            const auto o_rs = ZR ? tile_rsrc(p.out2, p.ldo2, 2) : tile_rsrc(p.out, p.ldo, 2);     // pair output (r h | h')
+            const int ld_h = ZR ? (int)p.ldaux : (int)p.ldo, ld_z = ZR ? (int)p.ldo : (int)p.ldaux, ld_o = ZR ? (int)p.ldo2 : (int)p.ldo;
+            const bool ok = n < p.N;
+            const unsigned m_lane = ok ? (unsigned)(rowl * (int)p.ldr + n) * 4u : OOB, h_lane = ok ? (unsigned)(rowl * ld_h + c) * 2u : OOB;
+            const unsigned z_lane = ok ? (unsigned)(rowl * ld_z + c) * 4u : OOB, o_lane = ok ? (unsigned)(rowl * ld_o + c) * 2u : OOB;
+            u32x4_t mq[4], zq[4];
+            u32x2_t hh[4], hl[4];
+#define H_X3_LOAD(sp)                                                                                                  \
+    _Pragma("unroll") for (int rr = 0; rr < 4; rr++) {                                                                 \
+        const int r0_ = (sp) * 16 + rr * 4;                                                                            \
+        mq[rr] = __builtin_amdgcn_raw_buffer_load_b128(m_rs, m_lane, r0_ * (int)p.ldr * 4, 0);                          \
+        if (!ZR) zq[rr] = __builtin_amdgcn_raw_buffer_load_b128(z_rs, z_lane, r0_ * ld_z * 4, 0);                        \
+        if (!ZR || is_r) {                                                                                             \
+            hh[rr] = __builtin_amdgcn_raw_buffer_load_b64(h_rs, h_lane, r0_ * ld_h * 2, 0);                             \
+            hl[rr] = __builtin_amdgcn_raw_buffer_load_b64(h_rs, h_lane + lo_b, r0_ * ld_h * 2, 0);                      \
+        }                                                                                                              \
+    }
+            H_X3_LOAD(0)
+            prefetch();
+#pragma unroll
+            for (int ps = 0; ps < NP; ps++) {
+#pragma unroll
+                for (int jj = 0; jj < PR / 16; jj++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int row = jj * 16 + (lane_e & 15), chunk = i * 4 + (lane_e >> 4);
+                        *reinterpret_cast<f32x4*>(stage + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][ps * (PR / 16) + jj];
+                    }
+#pragma unroll
+                for (int sub = 0; sub < 2; sub++) {
+                    const int sp = ps * 2 + sub;
+                    if (sp == 0) { H_WAIT_OPERANDS() }
+                    else if (!ZR || is_r) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);     // the previous sub-pass's 8 stores may still fly
+                    else __builtin_amdgcn_s_waitcnt(0x0F70 | 4);                     // (z waves: 4 stores)
+                    f32x4 res[4];
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        const int row = sub * 16 + rr * 4 + rl;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 256 + ((cl ^ (row & 15)) << 4));
+                        v += __builtin_bit_cast(f32x4, mq[rr]);
+                        if constexpr (ZR) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) v[e] = __frcp_rn(1.0f + __expf(-v[e]));
+                            if (is_r) v *= h8_join4(hh[rr], hl[rr]);
+                        } else {
+                            const f32x4 z = __builtin_bit_cast(f32x4, zq[rr]);
+                            const f32x4 h = h8_join4(hh[rr], hl[rr]);
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float q = 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v[e]) + 1.0f);
+                                v[e] = (1.0f - z[e]) * h[e] + z[e] * q;
+                            }
+                        }
+                        res[rr] = v;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (sp + 1 < NS) { H_X3_LOAD(sp + 1) }       // the next sub-pass's operands (same registers), before this sub-pass's stores
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        const unsigned r0 = (unsigned)(sp * 16 + rr * 4);
+                        if (ZR && !is_r) {
+                            H_STORE128(__builtin_bit_cast(u32x4_t, res[rr]), z_rs, z_lane, r0 * (unsigned)ld_z * 4u);
+                        } else {
+                            u32x2_t hu, lu;
+                            encode(res[rr], hu, lu);
+                            H_STORE64(hu, o_rs, o_lane, r0 * (unsigned)ld_o * 2u);
+                            H_STORE64(lu, o_rs, o_lane + lo_b, r0 * (unsigned)ld_o * 2u);
+                        }
+                    }
+                }
+            }
+#undef H_X3_LOAD
+        }
+        if (!has_next) break;
+        b = b2;
+        if constexpr (PARK) {
+            const uint4 t0 = park[0], t1 = park[512], t2 = park[1024];
+            a_voff[0] = t0.x; a_voff[1] = t0.y; a_voff[2] = t0.z; a_voff[3] = t0.w;
+            a_bits[0] = (int)t1.x; a_bits[1] = (int)t1.y; a_bits[2] = (int)t1.z; a_bits[3] = (int)t1.w;
+            w_voff = t2.x;
+        }
+        H_PHASE_BARRIER()                 // every wave is done with its staging region (and its parked state): A'(1) / W'(1) may land
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------
+template <int EPI, int NWN, int WF, int OFMT>
+static int launch_h8(const GemmDesc& d, hipStream_t s) {
+    constexpr int T_BM = 256, T_BN = 16 * WF * NWN;
+    constexpr int LDS = 3 * H_AOP + 2 * T_BN * 128;
+    static DeviceOnce attr;
+    VTGB_FUNC_LDS_ONCE(attr, (conv_h8_kernel<EPI, NWN, WF, OFMT>), LDS);
+    const int m_tiles = (d.M + T_BM - 1) / T_BM, n_tiles = (d.N + T_BN - 1) / T_BN, total = m_tiles * n_tiles;
+    const int grid = total < cu_count() ? total : cu_count();
+    const double exec_flops = 2.0 * d.M * d.N * d.K;      // in fp16-MFMA units: an fp8 k-tile takes the matrix-pipe cycles of an fp16 one
+    ProfScope prof(VTGB_PROF_CONV, d.algo_flops > 0 ? d.algo_flops : d.algo_flops < 0 ? 0.0 : exec_flops, s, exec_flops);
+    hipLaunchKernelGGL((conv_h8_kernel<EPI, NWN, WF, OFMT>), dim3(grid), dim3(512), LDS, s, d, m_tiles, n_tiles, 8, total);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+// Convolution over f16c8 operands (GemmDesc::h8_run > 0).  epi: EPI_SPLIT (pair store; d.h8_out_bf16: as a bf16 pair), EPI_X3ZR, EPI_X3Q.
+int launch_conv_h8(const GemmDesc& d_in, hipStream_t s) {
+    GemmDesc d = d_in;
+    VTGB_REQUIRE(d.conv_KH > 0 && d.conv_H > 0 && d.conv_W > 0 && d.A && d.W && d.out && d.M > 0 && d.N > 0 && d.zero_page, VTGB_EINVAL, "conv h8: bad argument");
+    {
+        auto magic = [](uint32_t dv, uint32_t* mul, uint32_t* sh) {
+            uint32_t q = 0;
+            while ((1ull << q) < dv) q++;
+            *mul = (uint32_t)((((1ull << q) - dv) << 32) / dv + 1);
+            *sh = q;
+        };
+        magic((uint32_t)(d.conv_H * d.conv_W), &d.div_hw_mul, &d.div_hw_sh);
+        magic((uint32_t)d.conv_W, &d.div_w_mul, &d.div_w_sh);
+    }
+    const int nk = d.K / H_BK;
+    VTGB_REQUIRE(d.dtype == VTGB_BF16 && (d.K % H_BK) == 0 && d.K == d.conv_KH * d.conv_KW * d.conv_Cin && (d.conv_Cin % 128) == 0 && (d.conv_split % 128) == 0 &&
+                     (d.conv_split == d.conv_Cin || (d.A2 && d.conv_split * 2 == d.conv_Cin)) && (d.M % (d.conv_H * d.conv_W)) == 0 && d.conv_stride <= 1 && d.conv_Hi == 0 &&
+                     d.conv_Wi == 0 && d.conv_wrap == 0 && d.conv_wrap2 == 0,
+                 VTGB_EINVAL, "conv h8: inconsistent geometry (sources of equal width, stride 1)");
+    const int src_c = d.conv_split / 2;      // channels per source; its fp16 half = src_c / 64 chunks
+    VTGB_REQUIRE(d.h8_run == d.conv_KH * d.conv_KW * (src_c / 64) && d.h8_run >= 3 && nk >= 6 && nk % (2 * d.h8_run) == 0, VTGB_EINVAL,
+                 "conv h8: run %d does not match taps x channels / 64 = %d (K = %d)", d.h8_run, d.conv_KH * d.conv_KW * (src_c / 64), d.K);
+    VTGB_REQUIRE(d.h8_scale != nullptr, VTGB_EINVAL, "conv h8: no weight scale");
+    VTGB_REQUIRE((d.lda % 8) == 0 && (d.lda2 % 8) == 0 && (d.ldw % 64) == 0 && d.conv_KH <= 7 && d.conv_KW <= 7, VTGB_EUNSUPPORTED, "conv h8: operand alignment");
+    {
+        const int64_t hw = (int64_t)d.conv_H * d.conv_W, span = (512 / hw + 2) * hw, ld = d.lda > d.lda2 ? d.lda : d.lda2;
+        VTGB_REQUIRE(span < (1 << 24) && span * ld * 2 < 0x7FFFFF00ll && (int64_t)256 * d.ldw * 2 < 0x7FFFFF00ll, VTGB_EUNSUPPORTED, "conv h8: tile footprint beyond the 32-bit descriptor offsets");
+    }
+    VTGB_REQUIRE(d.o_map.seg_rows == 0 && d.r_map.seg_rows == 0 && d.out_scale == 0.f, VTGB_EUNSUPPORTED, "conv h8: identity row maps only");
+    switch (d.epi) {
+        case EPI_SPLIT:
+            VTGB_REQUIRE((d.N & 1) == 0 && (d.ldo & 3) == 0 && (d.split_lo & 3) == 0 && d.split_lo > 0, VTGB_EINVAL, "conv h8: pair store needs 4-aligned rows and split_lo");
+            if (d.h8_out_bf16) {
+                VTGB_REQUIRE(d.N > 192 && (d.N & 3) == 0, VTGB_EUNSUPPORTED, "conv h8: bf16-pair output on the 256-wide tile only");
+                return launch_h8<EPI_SPLIT, 4, 4, 0>(d, s);
+            }
+            if (d.N <= 128) return launch_h8<EPI_SPLIT, 2, 4, 1>(d, s);
+            if (d.N <= 192 && (d.N & 7) == 0) return launch_h8<EPI_SPLIT, 4, 3, 1>(d, s);
+            return launch_h8<EPI_SPLIT, 4, 4, 1>(d, s);
+        case EPI_X3ZR:
+            VTGB_REQUIRE(d.N == 256 && d.resid && d.aux && d.out2 && ((d.ldr | d.ldaux | d.ldo | d.ldo2 | d.split_lo) & 3) == 0 && d.act == 0 && !d.bias, VTGB_EINVAL,
+                         "conv h8: the z | r gate epilogue needs a 256-channel convolution with its start map, h and both outputs");
+            return launch_h8<EPI_X3ZR, 4, 4, 1>(d, s);
+        case EPI_X3Q:
+            VTGB_REQUIRE(d.N == 128 && d.resid && d.aux && ((d.ldr | d.ldaux | d.ldo | d.split_lo) & 3) == 0 && d.act == 0 && !d.bias, VTGB_EINVAL,
+                         "conv h8: the GRU update epilogue needs a 128-channel convolution with its start map and z");
+            return launch_h8<EPI_X3Q, 2, 4, 1>(d, s);
+    }
+    vtgb_set_error("conv h8: unsupported epilogue %d", d.epi);
+    return VTGB_EINVAL;
+}

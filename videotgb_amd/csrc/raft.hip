@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "pair_h8.h"
 
 // ---------------------------------------------------------------------------------------
 // state init: NCHW fp32 -> pixel-major buffers
@@ -128,8 +129,9 @@ template <>
 __device__ __forceinline__ float lk_load<float>(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
-// PAIR (bf16x3 mode, OT = bf16): a pixel's row is [hi(384) | lo(384)], hi = bf16(v), lo = bf16(v - hi)
-template <typename CT, typename OT, bool PAIR = false>
+// PAIR (bf16x3 mode, OT = bf16): a pixel's row is [hi(384) | lo(384)], hi = bf16(v), lo = bf16(v - hi); PAIR == 2 (f16c8 mode): the f16c8
+// pair row of pair_h8.h (fp16 values, then 8 correction bytes per 4 taps)
+template <typename CT, typename OT, int PAIR = 0>
 __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr, const float* __restrict__ flow, OT* __restrict__ out,
                                                                int64_t M, int H8, int W8) {
     constexpr int OW = PAIR ? 768 : 384;   // elements per output row
@@ -228,7 +230,13 @@ __global__ __launch_bounds__(256) void raft_corr_lookup_kernel(const CorrPyr pyr
             const lk_f32x2 c = top + wy * (bot - top);                // both columns interpolated along y (packed)
             float v = c[0] + wx * (c[1] - c[0]);
             if (kk == 5) v = lane < 4 ? v : 0.f;                      // k >= 324: the zero padding of K
-            if constexpr (PAIR) {
+            if constexpr (PAIR == 2) {
+                unsigned short h16; unsigned char lr, lv;
+                h8_split1(v, h16, lr, lv);
+                reinterpret_cast<unsigned short*>(&stage[wave][pi & 1][0])[kk * 64 + lane] = h16;
+                unsigned char* lo8 = reinterpret_cast<unsigned char*>(&stage[wave][pi & 1][384]) + h8_lo_off(kk * 64 + lane);
+                lo8[0] = lr; lo8[4] = lv;
+            } else if constexpr (PAIR == 1) {
                 const float hf = bf16_round(v);
                 stage[wave][pi & 1][kk * 64 + lane] = (OT)hf;
                 stage[wave][pi & 1][384 + kk * 64 + lane] = (OT)(v - hf);
@@ -688,10 +696,10 @@ extern "C" void vtgb_debug_set_gru_fused(int v) { g_gru_fused = v; }
 extern "C" void vtgb_debug_set_lk_fused(int v) { g_lk_fused = v; }
 #endif
 
-int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s);   // raft_x3.hip: VTGB_BF16X3
+int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s);   // raft_x3.hip: VTGB_BF16X3, VTGB_F16C8
 static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     VTGB_REQUIRE(a, VTGB_EINVAL, "raft_update: NULL args");
-    if (a->dtype == VTGB_BF16X3) return raft_x3_impl(a, ws, s);
+    if (a->dtype == VTGB_BF16X3 || a->dtype == VTGB_F16C8) return raft_x3_impl(a, ws, s);
     VTGB_REQUIRE(a->dtype == VTGB_BF16 || a->dtype == VTGB_F32, VTGB_EINVAL, "raft_update: bad dtype %d", a->dtype);
     VTGB_REQUIRE(a->n_pairs > 0 && a->H8 >= 8 && a->W8 >= 8 && a->iters > 0, VTGB_EINVAL, "raft_update: bad dims n=%d H8=%d W8=%d iters=%d",
                  a->n_pairs, a->H8, a->W8, a->iters);
@@ -891,9 +899,10 @@ static int raft_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t 
 }
 
 // ---- launchers shared with the bf16x3 orchestration (raft_x3.hip)
-int raft_launch_lookup_pair(const CorrPyr& pyr, const float* flow, void* out_pair, int64_t M, int H8, int W8, hipStream_t s) {
+int raft_launch_lookup_pair(const CorrPyr& pyr, const float* flow, void* out_pair, int64_t M, int H8, int W8, int h8, hipStream_t s) {
     const dim3 lk_grid((unsigned)((M + 4 * CL_PIX - 1) / (4 * CL_PIX)));
-    hipLaunchKernelGGL((raft_corr_lookup_kernel<float, bf16_t, true>), lk_grid, dim3(256), 0, s, pyr, flow, (bf16_t*)out_pair, M, H8, W8);
+    if (h8) hipLaunchKernelGGL((raft_corr_lookup_kernel<float, bf16_t, 2>), lk_grid, dim3(256), 0, s, pyr, flow, (bf16_t*)out_pair, M, H8, W8);
+    else hipLaunchKernelGGL((raft_corr_lookup_kernel<float, bf16_t, 1>), lk_grid, dim3(256), 0, s, pyr, flow, (bf16_t*)out_pair, M, H8, W8);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }

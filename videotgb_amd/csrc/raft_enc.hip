@@ -234,7 +234,7 @@ static GemmDesc enc_conv(int dt, int Mo, int N, int Ho, int Wo, int K, int Cin, 
     return d;
 }
 int launch_x3_pair_pass(const float* x, int64_t ldx, const float* stats, int HW, const void* resid, int64_t ldr, int r_lo, void* out, int64_t ldo, int o_lo,
-                        int C, int Cpad, int relu_in, int relu_out, int64_t M, hipStream_t s);   // raft_x3.hip
+                        int C, int Cpad, int relu_in, int relu_out, int64_t M, hipStream_t s, int h8 = 0);   // raft_x3.hip
 
 static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t s) {
     VTGB_REQUIRE(a, VTGB_EINVAL, "raft_encoder: NULL args");

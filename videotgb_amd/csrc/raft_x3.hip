@@ -13,8 +13,13 @@
 #include <string.h>
 
 #include "common.h"
+#include "pair_h8.h"
 
-int raft_launch_lookup_pair(const CorrPyr& pyr, const float* flow, void* out_pair, int64_t M, int H8, int W8, hipStream_t s);
+// VTGB_F16C8 (round 6): the same orchestration with the update block's large convolutions over f16c8 pairs (pair_h8.h, gemm_h8.hip: fp16 main
+// product + two fp8 correction products at twice the rate -- 2/3 of the bf16x3 form's matrix work at the same accuracy class); the small ones
+// (convf2, FlowHead.conv2, mask.2, the once-per-call start maps) and the encoders / correlation volume stay bf16x3.  `h8` below selects the format of
+// the buffers h, r h, motion | flow, corr taps, c1, [cor | flo]; inp, convf1's output and the flow / mask heads' hidden maps stay bf16 pairs.
+int raft_launch_lookup_pair(const CorrPyr& pyr, const float* flow, void* out_pair, int64_t M, int H8, int W8, int h8, hipStream_t s);
 int raft_launch_flow_head2(const float* P2, const float* bias, float* flow, int n_pairs, int H8, int W8, hipStream_t s);
 int raft_launch_upsample(const float* flow, const float* mask, float* flow_up, int n_pairs, int H8, int W8, hipStream_t s);
 
@@ -41,6 +46,7 @@ struct PairPass {
     bf16_t* out; int64_t ldo; int o_lo;
     int C, Cpad, relu_in, relu_out;
     int64_t M;
+    int h8;                                     // out as an f16c8 pair (pair_h8.h) instead of a bf16 pair
 };
 __global__ __launch_bounds__(256) void x3_pair_pass_kernel(const PairPass p) {
     const int g = p.Cpad >> 2;
@@ -76,28 +82,50 @@ __global__ __launch_bounds__(256) void x3_pair_pass_kernel(const PairPass p) {
             for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
         }
     }
+    bf16_t* o = p.out + m * p.ldo + c;
+    if (p.h8) {
+        h8_u32x2 hu, lu;
+        h8_split4(v, hu, lu);
+        *reinterpret_cast<h8_u32x2*>(o) = hu;
+        *reinterpret_cast<h8_u32x2*>(o + p.o_lo) = lu;
+        return;
+    }
     bf16x4 hi, lo;
     pair_split4(v, hi, lo);
-    bf16_t* o = p.out + m * p.ldo + c;
     *reinterpret_cast<bf16x4*>(o) = hi;
     *reinterpret_cast<bf16x4*>(o + p.o_lo) = lo;
 }
 int launch_x3_pair_pass(const float* x, int64_t ldx, const float* stats, int HW, const void* resid, int64_t ldr, int r_lo, void* out, int64_t ldo, int o_lo,
-                        int C, int Cpad, int relu_in, int relu_out, int64_t M, hipStream_t s) {
+                        int C, int Cpad, int relu_in, int relu_out, int64_t M, hipStream_t s, int h8) {
     VTGB_REQUIRE((C & 3) == 0 && (Cpad & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && (o_lo & 3) == 0 && (ldr & 3) == 0 && (r_lo & 3) == 0, VTGB_EINVAL,
                  "pair pass: 4-aligned rows");
-    PairPass p{x, ldx, stats, HW, (const bf16_t*)resid, ldr, r_lo, (bf16_t*)out, ldo, o_lo, C, Cpad, relu_in, relu_out, M};
+    PairPass p{x, ldx, stats, HW, (const bf16_t*)resid, ldr, r_lo, (bf16_t*)out, ldo, o_lo, C, Cpad, relu_in, relu_out, M, h8};
     const int64_t n = M * (Cpad >> 2);
     hipLaunchKernelGGL(x3_pair_pass_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }
 
+// the flow as columns 126, 127 of the motion buffer X [M, 256 16-bit units] (update.py:97), in the buffer's pair format
+__device__ __forceinline__ void x3_put_flow(bf16_t* __restrict__ X, int64_t m, int i, float f, int h8) {
+    if (h8) {
+        unsigned short hi; unsigned char lr, lv;
+        h8_split1(f, hi, lr, lv);
+        reinterpret_cast<unsigned short*>(X)[m * 256 + 126 + i] = hi;
+        unsigned char* lo = reinterpret_cast<unsigned char*>(X) + m * 512 + 256 + h8_lo_off(126 + i);
+        lo[0] = lr; lo[4] = lv;
+    } else {
+        const float fh = bf16_round(f);
+        X[m * 256 + 126 + i] = (bf16_t)fh;
+        X[m * 256 + 254 + i] = (bf16_t)(f - fh);
+    }
+}
+
 // ---- state init (xraft.py:126-132): h = tanh(cnet[:, :128]) -> hb pair [M, 256]; inp = relu(cnet[:, 128:]) -> INP pair [M, 256];
 // flow = flow_init or 0 -> flow fp32 and columns 126, 127 (| + 128) of the motion buffer X [M, 256].  4 channels per thread.
 __global__ __launch_bounds__(256) void x3_init_kernel(const float* __restrict__ net, const float* __restrict__ inp, const float* __restrict__ cnet,
                                                       bf16_t* __restrict__ hb, bf16_t* __restrict__ INP, bf16_t* __restrict__ X, float* __restrict__ flow,
-                                                      const float* __restrict__ flow_init, int64_t M, int HW) {
+                                                      const float* __restrict__ flow_init, int64_t M, int HW, int h8) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M * 32) return;
     const int64_t m = i >> 5;
@@ -114,9 +142,16 @@ __global__ __launch_bounds__(256) void x3_init_kernel(const float* __restrict__ 
         for (int e = 0; e < 4; e++) { hv[e] = net[(n * 128 + c + e) * HW + pp]; iv[e] = inp[(n * 128 + c + e) * HW + pp]; }
     }
     bf16x4 hi, lo;
-    pair_split4(hv, hi, lo);
-    *reinterpret_cast<bf16x4*>(hb + m * 256 + c) = hi;
-    *reinterpret_cast<bf16x4*>(hb + m * 256 + 128 + c) = lo;
+    if (h8) {
+        h8_u32x2 hu, lu;
+        h8_split4(hv, hu, lu);
+        *reinterpret_cast<h8_u32x2*>(hb + m * 256 + c) = hu;
+        *reinterpret_cast<h8_u32x2*>(hb + m * 256 + 128 + c) = lu;
+    } else {
+        pair_split4(hv, hi, lo);
+        *reinterpret_cast<bf16x4*>(hb + m * 256 + c) = hi;
+        *reinterpret_cast<bf16x4*>(hb + m * 256 + 128 + c) = lo;
+    }
     pair_split4(iv, hi, lo);
     *reinterpret_cast<bf16x4*>(INP + m * 256 + c) = hi;
     *reinterpret_cast<bf16x4*>(INP + m * 256 + 128 + c) = lo;
@@ -129,9 +164,8 @@ __global__ __launch_bounds__(256) void x3_init_kernel(const float* __restrict__ 
         }
         flow[m * 2] = f0;
         flow[m * 2 + 1] = f1;
-        const float h0 = bf16_round(f0), h1 = bf16_round(f1);
-        X[m * 256 + 126] = (bf16_t)h0; X[m * 256 + 127] = (bf16_t)h1;
-        X[m * 256 + 254] = (bf16_t)(f0 - h0); X[m * 256 + 255] = (bf16_t)(f1 - h1);
+        x3_put_flow(X, m, 0, f0, h8);
+        x3_put_flow(X, m, 1, f1, h8);
     }
 }
 
@@ -143,7 +177,7 @@ __global__ __launch_bounds__(256) void x3_init_kernel(const float* __restrict__ 
 constexpr int CF1_PX = 64;
 typedef float x3_f32x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void x3_convf1_kernel(const float* __restrict__ flow, const float* __restrict__ wt, const float* __restrict__ b,
-                                                        bf16_t* __restrict__ f1, bf16_t* __restrict__ X, int64_t M, int H8, int W8) {
+                                                        bf16_t* __restrict__ f1, bf16_t* __restrict__ X, int64_t M, int H8, int W8, int h8) {
     __shared__ __attribute__((aligned(16))) float win[98][CF1_PX];
     const int tid = threadIdx.x, HW = H8 * W8;
     const int64_t m0 = (int64_t)blockIdx.x * CF1_PX;
@@ -196,11 +230,7 @@ __global__ __launch_bounds__(256) void x3_convf1_kernel(const float* __restrict_
     }
     if (tid < 2 * CF1_PX) {
         const int64_t m = m0 + (tid >> 1);
-        if (m < M) {
-            const float f = flow[m * 2 + (tid & 1)], fh = bf16_round(f);
-            X[m * 256 + 126 + (tid & 1)] = (bf16_t)fh;
-            X[m * 256 + 254 + (tid & 1)] = (bf16_t)(f - fh);
-        }
+        if (m < M) x3_put_flow(X, m, tid & 1, flow[m * 2 + (tid & 1)], h8);
     }
 }
 
@@ -215,6 +245,21 @@ static GemmDesc x3_conv(int M, int N, int H, int W, int KH, int KW, const void* 
     d.conv_H = H; d.conv_W = W; d.conv_KH = KH; d.conv_KW = KW; d.conv_Cin = Cin; d.conv_split = 3 * C1; d.conv_wrap = 2 * C1; d.conv_wrap2 = 2 * C2;
     d.zero_page = zero;
     d.algo_flops = 2.0 * M * (double)N * (KH * KW * (C1 + C2));      // the fp32 convolution this launch stands for (executed: 3 x)
+    return d;
+}
+// the same over f16c8 pairs (pair_h8.h; gemm_h8.hip): K = taps * 2 (C1 + C2) 16-bit units, C2 == 0 or C2 == C1; `scale`: device pointer to the layer's
+// E8M0 scale byte (weights[30][...])
+static GemmDesc h8_conv(int M, int N, int H, int W, int KH, int KW, const void* A, int C1, const void* A2, int C2, const void* Wt, const float* bias, int epi,
+                        int act, void* out, int64_t ldo, int split_lo, const void* zero, const int* scale, int out_bf16 = 0) {
+    GemmDesc d;
+    memset(&d, 0, sizeof(d));
+    const int Cin = 2 * (C1 + C2);
+    d.dtype = VTGB_BF16; d.M = M; d.N = N; d.K = KH * KW * Cin; d.epi = epi; d.act = act;
+    d.A = A; d.lda = 2 * C1; d.A2 = A2; d.lda2 = 2 * C2; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = out; d.ldo = ldo; d.split_lo = split_lo;
+    d.conv_H = H; d.conv_W = W; d.conv_KH = KH; d.conv_KW = KW; d.conv_Cin = Cin; d.conv_split = 2 * C1;
+    d.zero_page = zero;
+    d.h8_run = KH * KW * (C1 / 64); d.h8_scale = scale; d.h8_out_bf16 = out_bf16;
+    d.algo_flops = 2.0 * M * (double)N * (KH * KW * (C1 + C2));      // the fp32 convolution this launch stands for (executed: 2 x, in fp16-MFMA units)
     return d;
 }
 
@@ -245,9 +290,18 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     if (ws.dry) return VTGB_OK;
     VTGB_REQUIRE(ws.ok(), VTGB_EWORKSPACE, "raft_update: workspace %zu < %zu bytes", ws.size, ws.used);
     VTGB_REQUIRE(((a->net && a->inp) || a->cnet_nhwc) && a->weights && a->flow_up, VTGB_EINVAL, "raft_update: NULL operand");
-    VTGB_REQUIRE(!a->corr_f16, VTGB_EINVAL, "raft_update: the bf16x3 mode takes an fp32 correlation pyramid");
+    VTGB_REQUIRE(!a->corr_f16, VTGB_EINVAL, "raft_update: the bf16x3 / f16c8 modes take an fp32 correlation pyramid");
     const void* const* w = a->weights;
-    for (int i = 0; i < VTGB_RAFT_NW; i++) VTGB_REQUIRE(w[i], VTGB_EINVAL, "raft_update: weights[%d] is NULL (the bf16x3 table always carries the inp split)", i);
+    const int h8 = a->dtype == VTGB_F16C8;
+    for (int i = 0; i < VTGB_RAFT_NW + h8; i++) VTGB_REQUIRE(w[i], VTGB_EINVAL, "raft_update: weights[%d] is NULL (the bf16x3 / f16c8 tables always carry the inp split)", i);
+    const int* hs = h8 ? (const int*)w[VTGB_RAFT_NW] : nullptr;      // f16c8: the nine large convolutions' weight-scale bytes (include/vtgb.h)
+    // one large convolution in the mode's operand format
+    auto conv = [&](int N, int KH, int KW, const void* A, int C1, const void* A2, int C2, int wi, int si, const float* bias, int epi, int act, void* out, int64_t ldo,
+                    int split_lo, int out_bf16 = 0) {
+        return h8 ? h8_conv((int)M, N, H8, W8, KH, KW, A, C1, A2, C2, w[wi], bias, epi, act, out, ldo, split_lo, zero, hs + si, out_bf16)
+                  : x3_conv((int)M, N, H8, W8, KH, KW, A, C1, A2, C2, w[wi], bias, epi, act, out, ldo, split_lo, zero);
+    };
+    auto run = [&](const GemmDesc& d) { return h8 ? launch_conv_h8(d, s) : launch_conv_gemm(d, s); };
     CorrPyr pyr;
     int hl = H8, wl = W8;
     for (int l = 0; l < 4; l++) {
@@ -259,7 +313,7 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     const int Mi = (int)M;
     const dim3 g32((unsigned)((M * 32 + 255) / 256));
     auto F = [](const void* p) { return (const float*)p; };
-    hipLaunchKernelGGL(x3_init_kernel, g32, dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, hb, INP, X, flow, a->flow_init, M, HW);
+    hipLaunchKernelGGL(x3_init_kernel, g32, dim3(256), 0, s, a->net, a->inp, a->cnet_nhwc, hb, INP, X, flow, a->flow_init, M, HW, h8);
     // the GRU convolutions' contribution of `inp` (input channels 128..255: constant over the refinement iterations) + bias, once per call:
     // the 80 GRU launches contract over [h | motion | flow] = 256 channels instead of 384 (as in the bf16 mode, here as fp32 maps
     // that the gate kernels add)
@@ -273,36 +327,56 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     }
     for (int it = 0; it < a->iters; it++) {
         // ---- BasicMotionEncoder (update.py:88-97)
-        VTGB_TRY(raft_launch_lookup_pair(pyr, flow, corrf, M, H8, W8, s));
-        VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 256, H8, W8, 1, 1, corrf, 384, nullptr, 0, w[0], F(w[1]), VTGB_EPI_SPLIT, 1, c1, 512, 256, zero), s));
-        VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 192, H8, W8, 3, 3, c1, 256, nullptr, 0, w[2], F(w[3]), VTGB_EPI_SPLIT, 1, CF, 512, 256, zero), s));
-        hipLaunchKernelGGL(x3_convf1_kernel, dim3((unsigned)((M + CF1_PX - 1) / CF1_PX)), dim3(256), 0, s, flow, F(w[4]), F(w[5]), f1, X, M, H8, W8);
+        VTGB_TRY(raft_launch_lookup_pair(pyr, flow, corrf, M, H8, W8, h8, s));
+        VTGB_TRY(run(conv(256, 1, 1, corrf, 384, nullptr, 0, 0, 0, F(w[1]), VTGB_EPI_SPLIT, 1, c1, 512, 256)));
+        VTGB_TRY(run(conv(192, 3, 3, c1, 256, nullptr, 0, 2, 1, F(w[3]), VTGB_EPI_SPLIT, 1, CF, 512, 256)));
+        hipLaunchKernelGGL(x3_convf1_kernel, dim3((unsigned)((M + CF1_PX - 1) / CF1_PX)), dim3(256), 0, s, flow, F(w[4]), F(w[5]), f1, X, M, H8, W8, h8);
         VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 64, H8, W8, 3, 3, f1, 128, nullptr, 0, w[6], F(w[7]), VTGB_EPI_STORE_F32, 0, Q, 64, 0, zero), s));
-        VTGB_TRY(launch_x3_pair_pass(Q, 64, nullptr, HW, nullptr, 0, 0, CF + 192, 512, 256, 64, 64, 1, 0, M, s));
-        VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 126, H8, W8, 3, 3, CF, 256, nullptr, 0, w[8], F(w[9]), VTGB_EPI_SPLIT, 1, X, 256, 128, zero), s));
+        VTGB_TRY(launch_x3_pair_pass(Q, 64, nullptr, HW, nullptr, 0, 0, CF + 192, 512, 256, 64, 64, 1, 0, M, s, h8));
+        VTGB_TRY(run(conv(126, 3, 3, CF, 256, nullptr, 0, 8, 2, F(w[9]), VTGB_EPI_SPLIT, 1, X, 256, 128)));
         // ---- SepConvGRU (update.py:50-65): horizontal (1x5) then vertical (5x1); input channels [h(128) | motion(126) | flow(2)], the inp third comes from the start maps
         for (int half = 0; half < 2; half++) {
             const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1, wi = 10 + 4 * half;
             // z | r convolution with the gates in its epilogue: z = sigmoid(. + start map) -> ZR [M, 128] fp32, r * h -> RH pair; then the q
             // convolution over [r h | motion | flow] with the update h' = (1 - z) h + z tanh(. + start map) in ITS epilogue, in place on the h pair
-            GemmDesc zr = x3_conv(Mi, 256, H8, W8, kh, kw, hb, 128, X, 128, w[wi], nullptr, VTGB_EPI_X3ZR, 0, ZR, 128, 128, zero);
+            GemmDesc zr = conv(256, kh, kw, hb, 128, X, 128, wi, 3 + 2 * half, nullptr, VTGB_EPI_X3ZR, 0, ZR, 128, 128);
             zr.resid = ZRI[half]; zr.ldr = 256; zr.aux = hb; zr.ldaux = 256; zr.out2 = RH; zr.ldo2 = 256;
             zr.algo_flops = 2.0 * Mi * 256.0 * (5 * 384);
-            VTGB_TRY(launch_conv_gemm(zr, s));
-            GemmDesc q = x3_conv(Mi, 128, H8, W8, kh, kw, RH, 128, X, 128, w[wi + 2], nullptr, VTGB_EPI_X3Q, 0, hb, 256, 128, zero);
+            VTGB_TRY(run(zr));
+            GemmDesc q = conv(128, kh, kw, RH, 128, X, 128, wi + 2, 4 + 2 * half, nullptr, VTGB_EPI_X3Q, 0, hb, 256, 128);
             q.resid = QI[half]; q.ldr = 128; q.aux = ZR; q.ldaux = 128;
             q.algo_flops = 2.0 * Mi * 128.0 * (5 * 384);
-            VTGB_TRY(launch_conv_gemm(q, s));
+            VTGB_TRY(run(q));
         }
-        // ---- FlowHead (update.py:10-18) and coords1 += delta_flow (xraft.py:145)
-        VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 256, H8, W8, 3, 3, hb, 128, nullptr, 0, w[18], F(w[19]), VTGB_EPI_SPLIT, 1, FH, 512, 256, zero), s));
+        // ---- FlowHead (update.py:10-18) and coords1 += delta_flow (xraft.py:145); the hidden map leaves as a bf16 pair in both modes (conv2 is a bf16x3 launch)
+        VTGB_TRY(run(conv(256, 3, 3, hb, 128, nullptr, 0, 18, 7, F(w[19]), VTGB_EPI_SPLIT, 1, FH, 512, 256, 1)));
         VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 32, H8, W8, 1, 1, FH, 256, nullptr, 0, w[20], nullptr, VTGB_EPI_STORE_F32, 0, P2, 32, 0, zero), s));
         VTGB_TRY(raft_launch_flow_head2(P2, F(w[21]), flow, a->n_pairs, H8, W8, s));
     }
     // ---- mask head of the last iteration (update.py:129-132,143; the 0.25 is folded into [24] / [25]) and convex upsample (xraft.py:88-99)
-    VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 256, H8, W8, 3, 3, hb, 128, nullptr, 0, w[22], F(w[23]), VTGB_EPI_SPLIT, 1, FH, 512, 256, zero), s));
+    VTGB_TRY(run(conv(256, 3, 3, hb, 128, nullptr, 0, 22, 8, F(w[23]), VTGB_EPI_SPLIT, 1, FH, 512, 256, 1)));
     VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 576, H8, W8, 1, 1, FH, 256, nullptr, 0, w[24], F(w[25]), VTGB_EPI_STORE_F32, 0, mask, 576, 0, zero), s));
     VTGB_TRY(raft_launch_upsample(flow, mask, a->flow_up, a->n_pairs, H8, W8, s));
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
+}
+
+// ---- unit-level entry points of the pair formats (include/vtgb.h: vtgb_pair_pack, vtgb_pair_conv)
+extern "C" int vtgb_pair_pack(int32_t fmt, const float* x, void* out, int64_t M, int32_t C, int32_t ld_pair, vtgb_stream_t stream) {
+    VTGB_REQUIRE(x && out && M > 0 && C > 0 && (C & 3) == 0 && ld_pair >= C && (ld_pair & 3) == 0 && (fmt == VTGB_F16C8 || fmt == VTGB_BF16X3), VTGB_EINVAL,
+                 "pair_pack: bad argument (C=%d ld_pair=%d fmt=%d)", C, ld_pair, fmt);
+    return launch_x3_pair_pass(x, C, nullptr, 1, nullptr, 0, 0, out, 2 * (int64_t)ld_pair, ld_pair, C, ld_pair, 0, 0, M, (hipStream_t)stream, fmt == VTGB_F16C8);
+}
+extern "C" int vtgb_pair_conv(const vtgb_pair_conv_args* a, vtgb_stream_t stream) {
+    VTGB_REQUIRE(a && a->a && a->weights && a->scale && a->out && a->M > 0 && a->N > 0 && (a->N & 1) == 0 && a->C1 > 0 && (a->C1 % 64) == 0 && a->ld_out >= a->N &&
+                     (a->ld_out & 3) == 0 && (a->out_fmt == VTGB_F16C8 || a->out_fmt == VTGB_BF16X3) && (a->act == 0 || a->act == 1),
+                 VTGB_EINVAL, "pair_conv: bad argument");
+    static void* zero = nullptr;      // 256 bytes of zeros for the out-of-image taps (allocated once per process)
+    if (!zero) {
+        VTGB_HIP(hipMalloc(&zero, 256));
+        VTGB_HIP(hipMemset(zero, 0, 256));
+    }
+    GemmDesc d = h8_conv(a->M, a->N, a->H, a->W, a->KH, a->KW, a->a, a->C1, a->a2, a->a2 ? a->C1 : 0, a->weights, a->bias, VTGB_EPI_SPLIT, a->act, a->out, 2 * (int64_t)a->ld_out,
+                         a->ld_out, zero, a->scale, a->out_fmt == VTGB_BF16X3);
+    return launch_conv_h8(d, (hipStream_t)stream);
 }

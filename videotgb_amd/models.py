@@ -292,8 +292,9 @@ class Raft(nn.Module):
     def _hip_tables(self):
         if self._table is None:
             sd = {k: v for k, v in self.state_dict().items()}
-            self._table = (ops.RaftWeights(sd, "update_block.", self.code), ops.RaftEncoderWeights(sd, "fnet.", False, self.code),
-                           ops.RaftEncoderWeights(sd, "cnet.", True, self.code))
+            enc = ops.raft_stage_code(self.code)      # (f16c8: the update block's operand format; encoders / correlation at bf16x3)
+            self._table = (ops.RaftWeights(sd, "update_block.", self.code), ops.RaftEncoderWeights(sd, "fnet.", False, enc),
+                           ops.RaftEncoderWeights(sd, "cnet.", True, enc))
         return self._table
 
     @torch.no_grad()
@@ -307,7 +308,7 @@ class Raft(nn.Module):
         fmap = ops.raft_encoder(fw, frames.reshape(b * t, 3, h, w))                           # [b*t, HW, 256]
         cmap = ops.raft_encoder(cw, frames[:, :-1].reshape(b * (t - 1), 3, h, w))             # [n, HW, 256]
         n = b * (t - 1)
-        pyr = ops.raft_corr(fmap, n, h8, w8, t - 1, t, 0, 1, self.code)
+        pyr = ops.raft_corr(fmap, n, h8, w8, t - 1, t, 0, 1, ops.raft_stage_code(self.code))
         # net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:]) (xraft.py:126-127) are taken from the pixel-major cnet output inside
         return ops.raft_update(upd, None, None, pyr, iters, cnet_nhwc=cmap, hw=(h8, w8)).view(b, t - 1, 2, h, w)
 
@@ -325,7 +326,7 @@ class Raft(nn.Module):
         h8, w8 = h // 8, w // 8
         fmap = ops.raft_encoder(fw, torch.cat([image1, image2], 0))                           # fnet([image1, image2]) (:115)
         cmap = ops.raft_encoder(cw, image1)
-        pyr = ops.raft_corr(fmap, n, h8, w8, n, n, 0, n, self.code)
+        pyr = ops.raft_corr(fmap, n, h8, w8, n, n, 0, n, ops.raft_stage_code(self.code))
         if not test_mode:
             return [ops.raft_update(upd, None, None, pyr, i + 1, cnet_nhwc=cmap, hw=(h8, w8), flow_init=flow_init) for i in range(iters)]
         return ops.raft_update(upd, None, None, pyr, iters, cnet_nhwc=cmap, hw=(h8, w8), flow_init=flow_init)

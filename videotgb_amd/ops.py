@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib as L
-from ._lib import BF16, BF16X3, F32
+from ._lib import BF16, BF16X3, F16C8, F32
 
 Tensor = torch.Tensor
 
@@ -44,7 +44,15 @@ def raft_dtype_code(dtype) -> int:
     accuracy on the bf16 matrix cores) and "f32" (fp32 FMAs in the reference's order, the exactness mode)."""
     if dtype in (BF16X3, "bf16x3", "x3"):
         return BF16X3
+    if dtype in (F16C8, "f16c8"):
+        return F16C8
     return dtype_code(dtype)
+
+
+def raft_stage_code(code: int) -> int:
+    """The mode of RAFT's encoders and correlation volume next to an update block at ``code``: the f16c8 operand format exists for the update
+    block's convolutions only (include/vtgb.h) -- its encoders / correlation run at bf16x3."""
+    return BF16X3 if code == F16C8 else code
 
 
 def act_dtype(code: int) -> torch.dtype:
@@ -535,9 +543,84 @@ def split3(w: Tensor, sources: Optional[Sequence[int]] = None) -> Tensor:
     return torch.cat(out, -1)
 
 
+H8_LO_SCALE = 2048.0      # csrc/pair_h8.h
+
+
+def h8_weight_scale(w: Tensor) -> Tuple[float, int]:
+    """(sw, E8M0 byte of 2^-11 / sw): sw = the largest power of two with max |w| sw <= 448 (e4m3's largest finite value)."""
+    import math
+    m = float(w.abs().max())
+    e = 0 if m == 0.0 else math.floor(math.log2(448.0 / m))
+    e = max(min(e, 100), -100)
+    return 2.0 ** e, 127 - 11 - e
+
+
+def h8_conv_pack(w: Tensor, sw: float, sources: Optional[Sequence[int]] = None) -> Tensor:
+    """[co, kh, kw, ci] fp32 -> [co, K] bf16-typed 16-bit units for the f16c8 contraction (csrc/pair_h8.h, gemm_h8.hip): per source of the (virtual)
+    channel concatenation the K order is [fp16(w): taps x C | correction bytes: taps x C], each half 64-channel chunk major / tap minor; the
+    correction bytes of channels 4g .. 4g+3 are (Wh8 x 4, Wl' x 4) -- under the activations' (xl' x 4, xh8 x 4)."""
+    co, kh, kw, ci = w.shape
+    out, c0 = [], 0
+    for c in (sources or [ci]):
+        ws = w[..., c0:c0 + c].float()
+        wh = ws.to(torch.float16)
+        wl = ws - wh.float()
+        h8 = (ws * sw).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)                      # [co, kh, kw, c]
+        l8 = (wl * (sw * H8_LO_SCALE)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        corr = torch.stack([h8.reshape(co, kh, kw, c // 4, 4), l8.reshape(co, kh, kw, c // 4, 4)], -2)      # [.., c/4, {Wh8, Wl'}, 4]
+        corr16 = corr.reshape(co, kh, kw, 2 * c).contiguous().view(torch.int16)                             # [co, kh, kw, c] 16-bit units
+        out += [conv_k_order(wh.view(torch.int16)), conv_k_order(corr16)]
+        c0 += c
+    assert c0 == ci
+    return torch.cat(out, 1).contiguous().view(torch.bfloat16)
+
+
 def _bf16_exact(w: Tensor) -> Tensor:
     """fp32 holding bf16 values -> bf16 (exact)."""
     return w.contiguous().to(torch.bfloat16)
+
+
+def pair_pack(x: Tensor, fmt: int = F16C8, ld_pair: Optional[int] = None) -> Tensor:
+    """x [M, C] fp32 -> pair rows (include/vtgb.h vtgb_pair_pack) as an int16 tensor [M, 2 * ld_pair]."""
+    _need_cuda(x)
+    x = x.contiguous().float()
+    M, Cc = x.shape
+    ld = ld_pair or Cc
+    out = torch.empty(M, 2 * ld, dtype=torch.int16, device=x.device)
+    L.check(L.lib().vtgb_pair_pack(fmt, x.data_ptr(), out.data_ptr(), M, Cc, ld, _stream()))
+    return out
+
+
+def pair_unpack(rows: Tensor, C_: int, fmt: int = F16C8) -> Tensor:
+    """The fp32 values pair rows stand for where they are read back element-wise: f16c8 xh + xl' 2^-11 (csrc/pair_h8.h), bf16x3 hi + lo."""
+    M, two_ld = rows.shape
+    ld = two_ld // 2
+    if fmt == BF16X3:
+        v = rows.view(torch.bfloat16).float()
+        return v[:, :C_] + v[:, ld:ld + C_]
+    hi = rows[:, :C_].contiguous().view(torch.float16).float()
+    lo = rows[:, ld:].contiguous().view(torch.uint8).reshape(M, ld // 4, 2, 4)[:, :, 0].reshape(M, ld)[:, :C_].contiguous()
+    return hi + lo.view(torch.float8_e5m2).float() / H8_LO_SCALE
+
+
+def pair_conv(a: Tensor, w: Tensor, sw: float, H: int, W: int, a2: Optional[Tensor] = None, bias: Optional[Tensor] = None, relu: bool = False,
+              out_fmt: int = F16C8, ld_out: Optional[int] = None) -> Tensor:
+    """One 'same' convolution over f16c8 pair rows (include/vtgb.h vtgb_pair_conv): a [M, 2 C1] int16 pair rows (pair_pack), w [co, kh, kw, ci] fp32 with
+    ci = C1 (x 2 with a2), sw from h8_weight_scale(w) -> pair rows [M, 2 * ld_out] int16."""
+    _need_cuda(a, w)
+    co, kh, kw, ci = w.shape
+    C1 = a.shape[1] // 2
+    assert ci == C1 * (2 if a2 is not None else 1)
+    _, byte = h8_weight_scale(w)
+    packed = h8_conv_pack(w, sw, [C1, C1] if a2 is not None else None)
+    scale = torch.tensor([byte], dtype=torch.int32, device=a.device)
+    ld = ld_out or ((co + 3) // 4 * 4)
+    out = torch.zeros(a.shape[0], 2 * ld, dtype=torch.int16, device=a.device)
+    args = L.PairConvArgs(a.shape[0], co, H, W, kh, kw, C1, a.data_ptr(), _ptr(a2), packed.data_ptr(), scale.data_ptr(), _ptr(None if bias is None else bias.contiguous().float()),
+                          1 if relu else 0, out_fmt, out.data_ptr(), ld)
+    L.check(L.lib().vtgb_pair_conv(C.byref(args), _stream()))
+    torch.cuda.current_stream().synchronize()      # (packed / scale are temporaries of this call)
+    return out
 
 
 class RaftWeights(_WeightTable):
@@ -546,8 +629,8 @@ class RaftWeights(_WeightTable):
     def __init__(self, sd: Dict[str, Tensor], prefix: str = "update_block.", code: int = BF16, hoist_inp: Optional[bool] = None):
         super().__init__(code)
         p = prefix
-        if code == BF16X3:
-            self._init_x3(sd, p)
+        if code in (BF16X3, F16C8):
+            self._init_x3(sd, p, h8=(code == F16C8))
             return
         # bf16 mode: split the loop-invariant `inp` channels (128..255) out of the GRU convolutions (include/vtgb.h [26..29])
         self.hoist_inp = (code == BF16) if hoist_inp is None else (hoist_inp and code == BF16)
@@ -601,12 +684,14 @@ class RaftWeights(_WeightTable):
                 self.add(None); self.add(None)
         self.finish()
 
-    def _init_x3(self, sd: Dict[str, Tensor], p: str) -> None:
+    def _init_x3(self, sd: Dict[str, Tensor], p: str, h8: bool = False) -> None:
         """The bf16x3 table (raft_x3.hip): every MFMA convolution as [C_out, taps, 3 C_in] in the kernels' K order with the channel blocks
-        [Wh | Wh | Wl] per source; convf1 as in the fp32 mode; the mask head's 0.25 (update.py:143) folded into mask.2 (a power of two: exact)."""
+        [Wh | Wh | Wl] per source; convf1 as in the fp32 mode; the mask head's 0.25 (update.py:143) folded into mask.2 (a power of two: exact).
+        ``h8`` (VTGB_F16C8): the nine large convolutions in the f16c8 operand format instead (h8_conv_pack) and entry [30] = their scale bytes."""
         self.hoist_inp = True
+        scales = []
 
-        def conv(name, cin_pad=None, sources=None, scale=1.0, channels=None):
+        def raw(name, cin_pad=None, scale=1.0, channels=None):
             w = sd[p + name + ".weight"].float() * scale
             if channels is not None:
                 w = w[:, channels]
@@ -614,35 +699,53 @@ class RaftWeights(_WeightTable):
             w = w.permute(0, 2, 3, 1)
             if cin_pad and cin_pad != ci:
                 w = torch.nn.functional.pad(w, (0, cin_pad - ci))
-            return _bf16_exact(conv_k_order(split3(w, sources)))
+            return w
+
+        def conv(name, cin_pad=None, sources=None, scale=1.0, channels=None):
+            return _bf16_exact(conv_k_order(split3(raw(name, cin_pad, scale, channels), sources)))
+
+        def big(ws, sources=None):
+            """one large convolution (the rows of `ws` stacked along C_out) in the mode's operand format"""
+            if not h8:
+                return torch.cat([_bf16_exact(conv_k_order(split3(w, sources))) for w in ws], 0).contiguous()
+            sw, byte = h8_weight_scale(torch.cat([w.reshape(-1) for w in ws]))
+            scales.append(byte)
+            return torch.cat([h8_conv_pack(w, sw, sources) for w in ws], 0).contiguous()
+
+        def add_big(name, cin_pad=None):
+            self.tensors.append(big([raw(name, cin_pad)]))
+            self.add(sd[p + name + ".bias"].float())
 
         def add_conv(name, cin_pad=None, scale=1.0):
             self.tensors.append(conv(name, cin_pad, scale=scale))
             self.add(sd[p + name + ".bias"].float() * scale)
 
-        add_conv("encoder.convc1", 384)
-        add_conv("encoder.convc2")
+        add_big("encoder.convc1", 384)
+        add_big("encoder.convc2")
         self.add(sd[p + "encoder.convf1.weight"].float().reshape(128, 98).t().contiguous())
         self.add(sd[p + "encoder.convf1.bias"])
         add_conv("encoder.convf2")
-        add_conv("encoder.conv")
+        add_big("encoder.conv")
         dyn = list(range(0, 128)) + list(range(256, 384))     # [h | motion + flow]: two pair sources of 128 channels
         for sfx in ("1", "2"):
-            self.tensors.append(torch.cat([conv("gru.convz" + sfx, sources=[128, 128], channels=dyn), conv("gru.convr" + sfx, sources=[128, 128], channels=dyn)], 0).contiguous())
+            self.tensors.append(big([raw("gru.convz" + sfx, channels=dyn), raw("gru.convr" + sfx, channels=dyn)], sources=[128, 128]))
             self.add(torch.cat([sd[p + "gru.convz" + sfx + ".bias"], sd[p + "gru.convr" + sfx + ".bias"]], 0))
-            self.tensors.append(conv("gru.convq" + sfx, sources=[128, 128], channels=dyn))
+            self.tensors.append(big([raw("gru.convq" + sfx, channels=dyn)], sources=[128, 128]))
             self.add(sd[p + "gru.convq" + sfx + ".bias"])
-        add_conv("flow_head.conv1")
+        add_big("flow_head.conv1")
         w2 = sd[p + "flow_head.conv2.weight"].float().permute(2, 3, 0, 1).reshape(18, 256)
         w2 = torch.nn.functional.pad(w2, (0, 0, 0, 14)).reshape(32, 1, 1, 256)
         self.tensors.append(_bf16_exact(conv_k_order(split3(w2))))
         self.add(sd[p + "flow_head.conv2.bias"])
-        add_conv("mask.0")
+        add_big("mask.0")
         add_conv("mask.2", scale=0.25)
         inp = list(range(128, 256))                           # the loop-invariant third: start maps, once per call
         for sfx in ("1", "2"):
             self.tensors.append(torch.cat([conv("gru.convz" + sfx, channels=inp), conv("gru.convr" + sfx, channels=inp)], 0).contiguous())
             self.tensors.append(conv("gru.convq" + sfx, channels=inp))
+        if h8:      # [30]: E8M0 bytes of 2^-11 / sw of convc1, convc2, conv, zr1, q1, zr2, q2, flow_head.conv1, mask.0 (include/vtgb.h)
+            assert len(scales) == 9
+            self.tensors.append(torch.tensor(scales, dtype=torch.int32, device=self.tensors[0].device))
         self.finish()
 
 
@@ -793,7 +896,7 @@ def raft_encoder(w: RaftEncoderWeights, images: Tensor, max_images: int = 384) -
     images = images.contiguous().float()
     n, _, H, W = images.shape
     out = torch.empty(n, (H // 8) * (W // 8), 256, dtype=torch.float32, device=images.device)
-    if w.code == F32:
+    if w.code in (F32, BF16X3):      # 4 bytes per channel of every activation (bf16x3: pairs)
         max_images = max(max_images // 2, 1)
     for i0 in range(0, n, max_images):
         chunk = images[i0:i0 + max_images]
