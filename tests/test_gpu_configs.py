@@ -89,9 +89,11 @@ def test_c3_c4_instructblip_vicuna7b_raft_inline(dev, vicuna, T, clips):
     assert torch.equal(idx, idx2) and torch.equal(ids, ids2)
 
 
-def test_c3_with_raft_at_fp32_accuracy(dev, vicuna):
-    """C3 with RAFT in the bf16x3 mode (split-bf16 operands: the reference's fp32 RAFT accuracy on the matrix cores; bench.py's `raft_fp32_accuracy` leg):
-    the whole step runs, is bit-reproducible, and its flows agree with the fp32 FMA mode's to 1e-4 (the bf16 mode: 2.5e-3 on these weights)."""
+@pytest.mark.parametrize("x3", ["f16c8", "bf16x3"])
+def test_c3_with_raft_at_fp32_accuracy(dev, vicuna, x3):
+    """C3 with RAFT in the modes that carry the reference's fp32 RAFT accuracy on the matrix cores -- f16c8 (the module's default and bench.py's headline:
+    update block on fp16 + fp8-correction operands) and bf16x3 (split-bf16 operands everywhere; bench.py's `raft_bf16x3` companion): the whole step runs,
+    is bit-reproducible, and its flows agree with the fp32 FMA mode's to 1e-4 (the bf16 mode: 2.5e-3 on these weights)."""
     import bench
     from videotgb_amd.decode import GreedyDecoder
     m, cfg = vicuna
@@ -99,14 +101,14 @@ def test_c3_with_raft_at_fp32_accuracy(dev, vicuna):
     m.flow_clips_per_call = clips
     d = bench.synth_batch(0, 7, clips, T, "raft", dev, cfg)
     flows = {}
-    for mode in ("f32", "bf16x3", "bf16"):
+    for mode in ("f32", x3, "bf16"):
         m.of_extractor.set_compute_dtype(mode)
         flows[mode] = m.flow(d["flow_frames"]).clone()
     rel = lambda a, b: float(((a - b).double().pow(2).mean().sqrt() / b.double().pow(2).mean().sqrt()).item())
-    e3, e1 = rel(flows["bf16x3"], flows["f32"]), rel(flows["bf16"], flows["f32"])
-    print(f"[C3 flows vs fp32 RAFT] bf16x3 {e3:.3e}, bf16 {e1:.3e}")
+    e3, e1 = rel(flows[x3], flows["f32"]), rel(flows["bf16"], flows["f32"])
+    print(f"[C3 flows vs fp32 RAFT] {x3} {e3:.3e}, bf16 {e1:.3e}")
     assert e3 <= 1e-4 and e3 < e1 / 20
-    m.of_extractor.set_compute_dtype("bf16x3")
+    m.of_extractor.set_compute_dtype(x3)
     dec = GreedyDecoder(m.model.language_model)
     ids, idx = bench.run_step(m, d, clips, 8, 16, None, dec)
     ids2, idx2 = bench.run_step(m, d, clips, 8, 16, None, dec)

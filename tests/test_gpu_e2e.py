@@ -80,14 +80,14 @@ def test_generate_vs_reference(dev, tiny_sd, arch, dtype, fast_decode):
         # HIP-bf16 is at least as close to the reference's fp32 numbers as the reference's bf16 run is, and the two bf16
         # runs agree to 2 x that distance (bounds = 2 x observed ratios; the numbers are printed)
         # Like for like: the reference's bf16 run keeps RAFT in fp32, so the three-way comparison runs the HIP path in the same
-        # split -- which is the module's DEFAULT since round 5 (raft_dtype=None -> "bf16x3": fp32 accuracy on the bf16 MFMA; everything else bf16).  The all-bf16 run above (bf16 RAFT too: a mode the reference does not
+        # split -- which is the module's DEFAULT (raft_dtype=None -> fp32 accuracy on the matrix cores: "f16c8" since round 6, "bf16x3" in round 5; everything else bf16).  The all-bf16 run above (bf16 RAFT too: a mode the reference does not
         # have) is held to the absolute tolerances; its TGB logits additionally carry the bf16 flow's 6e-3 rel-RMS, which has no
         # counterpart in e_ref.
         from test_gpu_stages import rel_rms
         r16 = load_golden(f"tiny_{arch}_e2e_bf16ref")
         assert cand.cpu().tolist() == r16["cand_index"].tolist()
         m2, _ = build(arch, tiny_sd, dev, dtype)
-        assert m2.of_extractor.code == 2                            # VTGB_BF16X3
+        assert m2.of_extractor.code == 3                            # VTGB_F16C8
         _, cand2, st2 = m2.generate(deq(g, "frames_q8").to(dev), deq(g, "flow_frames_q8").to(dev), int(g["nframe"]), te, se,
                                     do_sample=False, temperature=None, max_new_tokens=6, use_cache=False, noise=g["noise"].to(dev),
                                     return_stages=True, fast_decode=fast_decode)

@@ -144,7 +144,7 @@ def test_bench_step_at_124_clips_equals_per_clip_steps(dev):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("dtype,tol", [("bf16", 6e-3), ("bf16x3", 2e-5)])
+@pytest.mark.parametrize("dtype,tol", [("bf16", 6e-3), ("bf16x3", 2e-5), ("f16c8", 2e-5)])
 def test_raft_31_clips_per_call_equals_single_clip_calls(dev, dtype, tol):
     """RAFT at the bench's batch (31 clips = 2 945 frame pairs, 2.31 M coarse pixels per call) vs the same clips one per call.  Not bit-level:
     the InstanceNorm moments of an image are the sum of per-tile partial sums whose cut depends on the image's row offset in the batch (fixed

@@ -42,7 +42,7 @@ def parts(dev):
         tgbs[dt].to(dev)
     rafts = {}
     for wset, rsd in (("default", sd), ("sensitive", synth.raft_sensitive_state_dict(0))):
-        for dt in ("bf16", "bf16x3", "f32"):
+        for dt in ("bf16", "bf16x3", "f16c8", "f32"):
             r = models.Raft(dt)
             r.load_state_dict({k[len("of_extractor."):]: v for k, v in rsd.items() if k.startswith("of_extractor.")}, strict=True)
             rafts[wset, dt] = r.to(dev)
@@ -73,7 +73,7 @@ def test_cand_index_stable_under_bf16_raft(dev, parts, T, per_call, weights):
     cfg, tgbs, rafts = parts
     gen = torch.Generator(device=dev).manual_seed(1000 + T)
     n_clips, N, nframe = 64, 32, 8
-    modes = ("bf16", "bf16x3")
+    modes = ("bf16", "bf16x3", "f16c8")
     keys = [(m, t) for m in modes for t in ("bf16", "f32")]
     moved, differ, total_ep = {k: 0 for k in keys}, {k: 0 for k in keys}, 0
     flow_rms, logit_err, logit_scale = {m: 0.0 for m in modes}, {k: 0.0 for k in keys}, {"bf16": 0.0, "f32": 0.0}
@@ -120,7 +120,7 @@ def test_cand_index_stable_under_bf16_raft(dev, parts, T, per_call, weights):
               f"{moved[m, tdt]}/{total_ep}; clips with a different cand_index {differ[m, tdt]}/{n_clips}")
     print(f"[selection T={T} raft weights={weights} control] the bf16 TGB on the fp32-RAFT flow x (1 + 1e-5 randn): logits max|diff| {floor16:.3e} = "
           f"{floor16 / logit_scale['bf16']:.2e} of their range; span endpoints moved {floor_moved}/{total_ep}")
-    # bf16 RAFT (a mode the reference does not have), TGB as bench.py runs it.  logits: default weights 2e-2 of their range (observed 9e-3);
+    # bf16 RAFT (a REDUCED-PRECISION opt-in the reference does not have; round 6: no longer what bench.py's headline runs), bf16 TGB.  logits: default weights 2e-2 of their range (observed 9e-3);
     # sensitive weights 1e-1 (observed 4.5e-2 ... 5.3e-2: the bf16 flow is 1.45e-2 off there and the flow reaches the logits); at most 2 of
     # 64 clips may differ
     assert logit_err["bf16", "bf16"] <= (2e-2 if weights == "default" else 1e-1) * logit_scale["bf16"]
@@ -131,6 +131,9 @@ def test_cand_index_stable_under_bf16_raft(dev, parts, T, per_call, weights):
     # (~sqrt(perturbation x ulp) per rounding site): the control above -- 1e-5 relative noise on the fp32 flow -- moves the bf16 logits by the same
     # 5e-3 ... 9e-3 of their range, the size of the reference's own bf16-vs-fp32 TGB difference.  That number is a property of
     # the bf16 TGB, not of RAFT: printed, and bounded only by the selection (at most 2 of 64 clips, as for any flow source).
-    assert logit_err["bf16x3", "f32"] <= 1e-3 * logit_scale["f32"]
-    assert differ["bf16x3", "f32"] == 0 and moved["bf16x3", "f32"] == 0
-    assert differ["bf16x3", "bf16"] <= 2
+    # f16c8 (round 6: the update block on fp16 + fp8-correction operands, encoders / correlation at bf16x3 -- the module's default and bench.py's
+    # headline mode) is held to exactly the same hard bounds.
+    for m in ("bf16x3", "f16c8"):
+        assert logit_err[m, "f32"] <= 1e-3 * logit_scale["f32"], m
+        assert differ[m, "f32"] == 0 and moved[m, "f32"] == 0, m
+        assert differ[m, "bf16"] <= 2, m

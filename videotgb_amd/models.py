@@ -263,7 +263,8 @@ class Raft(nn.Module):
     """RAFT-large (xraft.py:51-156) with the reference's parameter names; every forward runs in libvtgb.so:
     vtgb_raft_encoder (fnet, cnet) -> vtgb_raft_corr (all-pairs correlation + pyramid) -> vtgb_raft_update (refinement
     loop, mask head, convex upsample).  ``compute_dtype``: "bf16" = MFMA implicit-GEMM convolutions (a reduced-precision
-    mode the reference does not have), "f32" = fp32 FMAs, the reference's arithmetic (xraft.py:118-119).
+    mode the reference does not have), "f32" = fp32 FMAs, the reference's arithmetic (xraft.py:118-119), "bf16x3" / "f16c8" = the reference's fp32
+    accuracy on the matrix cores (split operands; include/vtgb.h).
     Only the last iteration's upsampled flow is materialised (``test_mode=True``, what every caller on the path uses)."""
 
     def __init__(self, compute_dtype="bf16"):
@@ -420,8 +421,9 @@ class _LSTPBase(nn.Module):
         HF config in ``base_model_path`` sizes the vision tower, Q-Former and language model (random init, the checkpoint
         fills them), the TGB is BERT-base with fusion_layer 6, RAFT is RAFT-large.  ``base_model_path`` may also be a
         ``synth.PathCfg`` (``from_cfg``): then ``language_model`` is the caller's.  Keyword extensions: ``compute_dtype``
-        ("bf16" / "f32") of the HIP stages, ``raft_dtype`` ("bf16x3" by default next to bf16 stages: the reference's fp32 RAFT accuracy; "bf16" = the
-        fast reduced-precision RAFT; "f32" = the fp32 FMA chain), ``lm_dtype`` of the built LLM
+        ("bf16" / "f32") of the HIP stages, ``raft_dtype`` ("f16c8" by default next to bf16 stages: the reference's fp32 RAFT accuracy on the matrix cores -- update
+        block on fp16 + fp8-correction operands, encoders / correlation on split-bf16 operands; "bf16x3" = split-bf16 operands everywhere (round 5's default,
+        same accuracy class, 1.2 x slower); "bf16" = the fast REDUCED-PRECISION RAFT; "f32" = the fp32 FMA chain), ``lm_dtype`` of the built LLM
         (default: bf16 with compute_dtype "bf16", else fp32), ``tgb_cfg`` to size the TGB differently from BERT-base (tests)."""
         super().__init__()
         hf_config = None
@@ -440,8 +442,9 @@ class _LSTPBase(nn.Module):
         self.model = PathModel(cfg, language_model, compute_dtype, hf_config=hf_config)
         self.temporal_encoder = TemporalEncoder(cfg.tgb, compute_dtype)
         # RAFT's mode.  The reference keeps RAFT in fp32 under EVERY Lightning precision (xraft.py:58,113-118: mixed_precision = False), so the
-        # default follows that contract: "bf16x3" (fp32 accuracy on the bf16 matrix cores) next to bf16 stages, "f32" next to fp32 stages.
-        # ``raft_dtype="bf16"`` opts into the faster reduced-precision RAFT the reference does not have (bench.py's headline does, and says so).
+        # default follows that contract: "f16c8" (fp32 accuracy on the matrix cores: tests/test_gpu_raft.py, test_gpu_selection.py hold it to the
+        # bf16x3 mode's bounds) next to bf16 stages, "f32" next to fp32 stages.  ``raft_dtype="bf16"`` opts into the faster reduced-precision RAFT the
+        # reference does not have (bench.py reports it as the `raft_bf16_fast` companion, never as the headline).
         self.of_extractor = Raft(raft_dtype or self._default_raft_dtype(compute_dtype))
         self._raft_follows = raft_dtype is None
         self.device = device
@@ -456,7 +459,7 @@ class _LSTPBase(nn.Module):
 
     @staticmethod
     def _default_raft_dtype(compute_dtype):
-        return "bf16x3" if ops.dtype_code(compute_dtype) == ops.BF16 else "f32"
+        return "f16c8" if ops.dtype_code(compute_dtype) == ops.BF16 else "f32"
 
     @classmethod
     def from_cfg(cls, cfg: synth.PathCfg, device="cuda", language_model: Optional[nn.Module] = None, compute_dtype="bf16", raft_dtype=None):
