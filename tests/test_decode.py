@@ -304,3 +304,105 @@ def test_rope_cache_prefill_kernel_matches_hf_rotary_bit_for_bit(dtype):
     assert torch.equal(got[:, :, : 2 * nh], ref_qk) and torch.equal(got[:, :, 2 * nh:], qkv[:, :, 2 * nh:])
     assert torch.equal(kc[:, :, :S], ref_qk[:, :, nh:].transpose(1, 2)) and torch.equal(vc[:, :, :S], qkv[:, :, 2 * nh:].transpose(1, 2))
     assert not kc[:, :, S:].any() and not vc[:, :, S:].any()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# round 6: the reference's own eval call (eval/inference.py:98-109: do_sample=True, temperature=0.2, stopping_criteria=[KeywordsStoppingCriteria])
+# on the graph decoder
+class _Tok:
+    """A tokenizer of the shape KeywordsStoppingCriteria uses (eval/utils/builder_utils.py:320-346): one id per word `t<id>`, BOS = 1."""
+    bos_token_id = 1
+    name_or_path = "vicuna-test"
+
+    def __call__(self, text):
+        return type("E", (), {"input_ids": [1] + [int(w[1:]) for w in text.split()]})()
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [" ".join(f"t{int(t)}" for t in row.tolist() if not (skip_special_tokens and int(t) <= 2)) for row in ids]
+
+
+def _hf_sample_reference(lm, emb, n, temperature, top_k, top_p, u):
+    """HF's sampling arithmetic restated step by step on full re-forwards (GenerationMixin._sample: temperature, top-k, top-p warpers, then a draw
+    from softmax) with the draw taken by inverse CDF at u[step, row] over the tokens in descending-probability order."""
+    ids = torch.zeros(emb.shape[0], 0, dtype=torch.long, device=emb.device)
+    x = emb
+    for s in range(n):
+        logits = lm(inputs_embeds=x).logits[:, -1].float() / temperature
+        k = min(top_k, logits.shape[-1]) if top_k else logits.shape[-1]
+        vals, idx = logits.topk(k, -1)
+        p = torch.softmax(vals, -1)
+        if top_p < 1.0:
+            keep = (p.cumsum(-1) - p) < top_p
+            p = torch.where(keep, p, torch.zeros_like(p))
+            p = p / p.sum(-1, keepdim=True)
+        j = (p.cumsum(-1) < u[s][:, None]).sum(-1).clamp(max=k - 1)
+        nxt = idx.gather(-1, j[:, None])
+        ids = torch.cat([ids, nxt], 1)
+        x = torch.cat([x, lm.get_input_embeddings()(nxt)], 1)
+    return ids
+
+
+def _check_sampling(device, use_graph):
+    from videotgb_amd.decode import GreedyDecoder
+    lm = _model(device)
+    g = torch.Generator().manual_seed(2)
+    emb = (torch.randn(3, 8, 32, generator=g) * 0.5).to(device)
+    am = torch.ones(3, 8, dtype=torch.long, device=device)
+    dec = GreedyDecoder(lm)
+    greedy = lm.generate(inputs_embeds=emb, attention_mask=am, do_sample=False, max_new_tokens=8, min_new_tokens=8, use_cache=True)
+    # temperature -> 0: the sampler's distribution collapses onto the greedy token, whatever the noise
+    cold = dec.generate(emb, 8, use_graph=use_graph, do_sample=True, temperature=1e-6, top_k=50)
+    assert cold.tolist() == greedy.tolist()
+    # injected noise: the ids are those of HF's warpers + an inverse-CDF draw at the same uniform numbers
+    u = torch.rand(8, 3, generator=g).to(device)
+    for temperature, top_k, top_p in ((0.7, 50, 1.0), (1.3, 5, 1.0), (1.0, 0, 0.8)):
+        want = _hf_sample_reference(lm, emb, 8, temperature, top_k, top_p, u)
+        got = dec.generate(emb, 8, use_graph=use_graph, do_sample=True, temperature=temperature, top_k=top_k, top_p=top_p, sample_noise=u)
+        assert got.tolist() == want.tolist(), (temperature, top_k, top_p)
+    hot = dec.generate(emb, 8, use_graph=use_graph, do_sample=True, temperature=1.5, top_k=0, sample_noise=u)
+    assert hot.tolist() != greedy.tolist()                            # (a hot sampler does leave the greedy path)
+    with pytest.raises(ValueError):
+        dec.generate(emb, 4, use_graph=use_graph, do_sample=True, temperature=0.0)
+
+
+def _check_keyword_stopping(device, use_graph):
+    """Against HF generate with the SAME KeywordsStoppingCriteria object: the token-suffix test (two-token keyword met mid-sequence), the text test
+    (a keyword whose own tokenisation never occurs but whose text does), both with EOS handling on, and no hit at all."""
+    from videotgb_amd.builder_utils import KeywordsStoppingCriteria
+    from videotgb_amd.decode import GreedyDecoder, keyword_stop_plan
+    lm = _model(device)
+    tok = _Tok()
+    g = torch.Generator().manual_seed(5)
+    emb = (torch.randn(1, 7, 32, generator=g) * 0.5).to(device)
+    am = torch.ones(1, 7, dtype=torch.long, device=device)
+    prompt = torch.zeros(1, 3, dtype=torch.long)                      # (start_len = 3: the text prompt's length, as in eval/inference.py:93)
+    free = lm.generate(inputs_embeds=emb, attention_mask=am, do_sample=False, max_new_tokens=24, min_new_tokens=24, use_cache=True)[0].tolist()
+    dec = GreedyDecoder(lm)
+    cases = [f"t{free[9]} t{free[10]}",                                # token test: the ids of steps 9, 10
+             f"t{free[4]}",                                            # one-token keyword
+             "t4711 t4712"]                                            # never met: runs to max_new_tokens
+    for kw in cases:
+        crit = KeywordsStoppingCriteria([kw], tok, prompt)
+        ref = lm.generate(inputs_embeds=emb, attention_mask=am, do_sample=False, max_new_tokens=24, use_cache=True, stopping_criteria=[crit],
+                          eos_token_id=2, pad_token_id=0)
+        out = dec.generate(emb, 24, use_graph=use_graph, eos_token_id=2, pad_token_id=0, **keyword_stop_plan([crit]))
+        assert out.tolist() == ref.tolist(), (kw, out.tolist(), ref.tolist())
+    assert len(lm.generate(inputs_embeds=emb, attention_mask=am, do_sample=False, max_new_tokens=24, use_cache=True,
+                           stopping_criteria=[KeywordsStoppingCriteria([cases[0]], tok, prompt)], eos_token_id=None, pad_token_id=0)[0]) == 11
+
+
+def test_sampling_decoder_cpu():
+    _check_sampling("cpu", False)
+
+
+def test_keyword_stopping_decoder_cpu():
+    _check_keyword_stopping("cpu", False)
+
+
+@pytest.mark.gpu
+def test_sampling_and_keyword_stopping_decoder_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    for use_graph in (True, False):
+        _check_sampling("cuda:0", use_graph)
+        _check_keyword_stopping("cuda:0", use_graph)

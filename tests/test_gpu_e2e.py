@@ -125,3 +125,67 @@ def test_precomputed_flow_and_concat_pool(dev, tiny_sd):
     prefix = m.prefix(sampled, B, nframe, te, "concat")
     assert prefix.shape == ref["prefix"].shape == (B, nframe * 32, cfg.llm_hidden)
     assert (prefix.cpu() - ref["prefix"]).abs().max().item() <= 2e-4 * ref["prefix"].abs().max().item()
+
+
+class _VicunaTok:
+    """What KeywordsStoppingCriteria needs of the Vicuna tokenizer (eval/utils/builder_utils.py:320-346): '</s>' -> [bos, eos]; special tokens are skipped
+    by batch_decode."""
+    bos_token_id, eos_token_id = 1, 2
+    name_or_path = "lmsys/vicuna-7b-v1.1"
+
+    def __call__(self, text):
+        assert text == "</s>"
+        return type("E", (), {"input_ids": [1, 2]})()
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [" ".join(str(int(t)) for t in row.tolist() if not (skip_special_tokens and int(t) <= 2)) for row in ids]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_reference_eval_call_runs_on_the_graph_decoder(dev, tiny_sd, dtype):
+    """The reference's OWN call (eval/inference.py:98-109): ``generate(frames, flow_frames, nframe, text_encoding, sampler_text_encoding, do_sample=True,
+    temperature=..., max_new_tokens=128, use_cache=False, stopping_criteria=[KeywordsStoppingCriteria(['</s>'], tokenizer, input_ids)])`` with NO
+    extra keyword: since round 6 it decodes on libvtgb.so (fast_decode="auto": sampling + keyword stopping inside the graph decoder) -- at
+    temperature -> 0 it returns the greedy ids of HF generate under the same stopping criteria, and the profiler sees no hipBLASLt / rocBLAS kernel."""
+    from torch.profiler import ProfilerActivity, profile
+    from videotgb_amd.builder_utils import KeywordsStoppingCriteria
+    m, cfg = build("instructblip", tiny_sd, dev, dtype)
+    lm = m.model.language_model
+    lm.generation_config.eos_token_id, lm.generation_config.pad_token_id = 2, 0
+    g = load_golden("tiny_instructblip_e2e")
+    te = BE(input_ids=g["prompt_ids"].to(dev), attention_mask=g["prompt_mask"].to(dev), qformer_input_ids=g["qformer_ids"].to(dev),
+            qformer_attention_mask=g["qformer_mask"].to(dev))
+    se = BE(input_ids=g["sampler_ids"].to(dev), attention_mask=g["sampler_mask"].to(dev))
+    frames, flow_frames, nframe = deq(g, "frames_q8").to(dev), deq(g, "flow_frames_q8").to(dev), int(g["nframe"])
+    crit = lambda: [KeywordsStoppingCriteria(["</s>"], _VicunaTok(), te.input_ids)]
+    noise = g["noise"].to(dev)
+    ref, cand_ref = m.generate(frames, flow_frames, nframe, te, se, do_sample=False, temperature=None, max_new_tokens=16, use_cache=False,
+                               stopping_criteria=crit(), noise=noise, fast_decode=False)                       # HF generate, greedy (16 tokens: over 128
+    # tokens of a random-init model a near-tie eventually separates hipBLASLt's summation order from libvtgb.so's; the 128-token comparison below is
+    # against the graph decoder's own greedy path under the same criteria)
+    ref128, _ = m.generate(frames, flow_frames, nframe, te, se, do_sample=False, temperature=None, max_new_tokens=128, use_cache=False,
+                           stopping_criteria=crit(), noise=noise, fast_decode=True)
+    assert m._graph_plan(lm, torch.zeros(1, 4, 8, device=dev), torch.ones(1, 4, device=dev), True, 0.2, crit(), {}) is not None
+    kw = dict(do_sample=True, temperature=1e-9, max_new_tokens=128, use_cache=False)                             # eval/inference.py:103-107, temperature -> 0
+    m.generate(frames, flow_frames, nframe, te, se, stopping_criteria=crit(), noise=noise, **kw)                  # (captures the graph)
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        ids, cand = m.generate(frames, flow_frames, nframe, te, se, stopping_criteria=crit(), noise=noise, **kw)
+        torch.cuda.synchronize()
+    names = {e.key for e in prof.key_averages()}
+    blas = sorted(n for n in names if "Cijk_" in n or "rocblas" in n.lower() or "hipblaslt" in n.lower())
+    assert not blas, blas
+    assert cand.tolist() == cand_ref.tolist()
+    assert ids.tolist() == ref128.tolist(), (ids.tolist(), ref128.tolist())
+    if dtype == "f32":
+        n = min(ids.shape[1], ref.shape[1])
+        assert ids[:, :n].tolist() == ref[:, :n].tolist(), (ids.tolist(), ref.tolist())
+    assert ids.shape[0] == 1 and 1 <= ids.shape[1] <= 128
+    if ids.shape[1] < 128:                                          # stopped: the last token is the keyword's (EOS -> 2 survives the reference's `outputs == 0 -> 2` line)
+        assert int(ids[0, -1]) == 2
+    # the reference's temperature: runs, reproducible under injected noise, and is a different draw under different noise
+    u = torch.rand(128, 1, generator=torch.Generator().manual_seed(0))
+    a, _ = m.generate(frames, flow_frames, nframe, te, se, stopping_criteria=crit(), noise=noise, do_sample=True, temperature=0.2, max_new_tokens=128, use_cache=False, sample_noise=u)
+    b, _ = m.generate(frames, flow_frames, nframe, te, se, stopping_criteria=crit(), noise=noise, do_sample=True, temperature=0.2, max_new_tokens=128, use_cache=False, sample_noise=u)
+    assert a.tolist() == b.tolist()
+    with pytest.raises(TypeError):
+        m.generate(frames, flow_frames, nframe, te, se, noise=noise, fast_decode=True, num_beams=4, **kw)

@@ -45,8 +45,17 @@ def pow2_scale(t, target):
 
 
 def make_conv(scheme, only_update):
+    scheme0 = scheme
+
     def conv(sd, name, x, stride=1, padding=0):
         w, b = sd[name + ".weight"], sd[name + ".bias"]
+        scheme = scheme0
+        if ":" in scheme0:      # per-part map "update=f16c8r,fnet=bf16x3,cnet=bf16[,layer1=...]": the LAST matching key wins
+            scheme = "f32"
+            for kv in scheme0.split(":")[1].split(","):
+                k, v = kv.split("=")
+                if k in name:
+                    scheme = v
         if scheme == "f32" or (only_update and "update_block" not in name) or name.endswith("convf1"):
             return F.conv2d(x, w, b, stride=stride, padding=padding)
         xd, wd = x.double(), w.double()
@@ -105,12 +114,12 @@ def main():
     orig = O._conv
     ref = O.raft_forward(sd, "of_extractor.", frames[:-1], frames[1:], 20)
     print(f"reference: max|flow| = {float(ref.abs().max()):.3f}")
-    for only_update in (True, False):
+    for only_update in ((False,) if any(":" in s for s in schemes) else (True, False)):
         for s in schemes:
             O._conv = make_conv(s, only_update)
             got = O.raft_forward(sd, "of_extractor.", frames[:-1], frames[1:], 20)
             O._conv = orig
-            print(f"{'update block only' if only_update else 'all convolutions  '} {s:9s} flow rel_rms vs fp32 = {rel_rms(got, ref):.3e}   max|diff| = {float((got - ref).abs().max()):.3e}", flush=True)
+            print(f"{'update block only' if only_update else 'all convolutions  '} {s:60s} flow rel_rms vs fp32 = {rel_rms(got, ref):.3e}   max|diff| = {float((got - ref).abs().max()):.3e}", flush=True)
     for k, v in stats.items():
         print(f"  {k:55s} max|x| {v[0]:10.3f}  max|w| {v[1]:8.4f}")
 

@@ -15,9 +15,9 @@ def load(d, counter):
 fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
 res = {}
 for k in fe:
-    if "gemm_bf16" not in k and "attn_bf16" not in k and "conv3x3_c64" not in k and "gru_half_kernel" not in k and "stem7x7" not in k:
+    if "gemm_bf16" not in k and "attn_bf16" not in k and "conv3x3_c64" not in k and "gru_half_kernel" not in k and "stem7x7" not in k and "conv_h8" not in k:
         continue
-    if want == "conv" and ", true, " not in k and "conv3x3_c64" not in k and "gru_half_kernel" not in k and "stem7x7" not in k:
+    if want == "conv" and ", true, " not in k and "conv3x3_c64" not in k and "gru_half_kernel" not in k and "stem7x7" not in k and "conv_h8" not in k:
         continue
     f = sum(fe[k]) / len(fe[k]); w = sum(wr.get(k, [0])) / max(len(wr.get(k, [0])), 1)
     res[k] = {"launches": len(fe[k]), "FETCH_SIZE_KiB_avg": round(f, 1), "WRITE_SIZE_KiB_avg": round(w, 1),

@@ -9,8 +9,11 @@ layers, lm_head, argmax, token/position feedback -- into a hipGraph (torch.cuda.
 so the N-token loop is N graph replays with no host round trip.  At the batch sizes of the
 throughput harness the step is then HBM-bound (13.5 GB of bf16 weights per token for Vicuna-7B).
 
-Scope: Llama-architecture models, greedy, all-ones attention mask (no padding) -- the case of
-every benchmark configuration.  Anything else goes through HF generate (models.LSTP.generate).
+Scope: Llama-architecture models, all-ones attention mask (no padding); greedy, or -- round 6, the reference's own eval call
+(eval/inference.py:98-109: ``do_sample=True, temperature=0.2, stopping_criteria=[KeywordsStoppingCriteria(['</s>'])]``) -- temperature / top-k /
+top-p SAMPLING by inverse CDF over the warped distribution with one uniform number per (step, row) (drawn on the device, or injected:
+``sample_noise``), and keyword STOPPING: the token-suffix half of KeywordsStoppingCriteria (eval/utils/builder_utils.py:333-340) runs inside the
+captured step, its text half on the host once per 16 tokens.  Anything else goes through HF generate (models.LSTP.generate).
 EOS handling is HF's (GenerationMixin._sample with EosTokenCriteria): a per-sequence finished flag
 lives on the device inside the captured step; a finished row emits ``pad_token_id`` from then on, and
 the returned ids end at the step where the last row finished.  ``min_new_tokens`` masks the EOS logit
@@ -191,12 +194,12 @@ class GreedyDecoder:
         """vtgb_gemm takes these projections: any shape at fp32; bf16 needs 8-aligned rows."""
         return dtype == torch.float32 or (self.cfg.hidden_size % 8 == 0 and self.inter % 8 == 0 and (self.nh * self.hd) % 8 == 0)
 
-    def _state(self, B: int, P: int, N: int, device, dtype, eos=None, pad=0, min_new=0):
+    def _state(self, B: int, P: int, N: int, device, dtype, eos=None, pad=0, min_new=0, sample=None, stop=None):
         # The cache length is bucketed (multiples of 64) and the true prompt length is device data (`pos`): an eval loop over real
         # questions with varying P reuses a handful of graphs instead of capturing one -- and allocating 2 x n_layers KV caches --
         # per distinct P.  At most MAX_STATES states are kept (least recently used goes: graph and caches are freed).
         tmax = -(-(P + N) // 64) * 64
-        key = (B, tmax, N, eos, pad, min_new)
+        key = (B, tmax, N, eos, pad, min_new, sample, stop)
         st = self.graphs.pop(key, None)
         if st is not None:
             self.graphs[key] = st                      # most recently used last
@@ -211,7 +214,10 @@ class GreedyDecoder:
                       tok=torch.zeros(B, dtype=torch.long, device=device), pos=torch.zeros(1, dtype=torch.long, device=device),
                       step=torch.zeros(1, dtype=torch.long, device=device), out=torch.zeros(B, N, dtype=torch.long, device=device),
                       ar=torch.arange(tmax, device=device), graph=None, eos=eos, pad=pad, min_new=min_new,
-                      fin=torch.zeros(B, dtype=torch.bool, device=device),
+                      fin=torch.zeros(B, dtype=torch.bool, device=device), sample=sample, stop=stop,
+                      stop_t=[torch.tensor(t, dtype=torch.long, device=device) for t in (stop or ())],      # (device copies made outside any capture)
+                      # sampling: one uniform number per (step, row); stopping: the generated length of every row (N = not finished)
+                      u=torch.zeros(N, B, device=device), len=torch.full((B,), N, dtype=torch.long, device=device),
                       x=torch.zeros(B, self.cfg.hidden_size, device=device, dtype=dtype),
                       h=torch.zeros(B, self.cfg.hidden_size, device=device, dtype=dtype),
                       q=torch.zeros(B, self.nh * self.hd, device=device, dtype=dtype),
@@ -303,23 +309,59 @@ class GreedyDecoder:
             self._emit(st, F.linear(h, self.lm.lm_head.weight))
 
     def _pick(self, st, logits: Tensor, step) -> Tensor:
-        """Greedy token of every row with HF's EOS semantics (device-side, capturable): EOS masked while step < min_new_tokens,
-        finished rows emit pad, a row finishes when it emits EOS."""
+        """Next token of every row with HF's EOS semantics (device-side, capturable): EOS masked while step < min_new_tokens, finished rows emit
+        pad, a row finishes when it emits EOS.  Greedy: argmax.  Sampling (``st["sample"] = (temperature, top_k, top_p)``): HF's warpers
+        (TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper; GenerationMixin._sample) then the inverse CDF of the warped distribution at
+        this step's uniform number -- the distribution of torch.multinomial(softmax(.)), a different random stream (HF's is not reproducible
+        across torch versions either); temperature -> 0 degenerates to the greedy token."""
         eos = st["eos"]
         if eos is not None and st["min_new"] > 0:
             blocked = (step < st["min_new"]) if isinstance(step, Tensor) else torch.tensor([step < st["min_new"]], device=logits.device)
             logits = logits.clone()
             logits[:, eos] = torch.where(blocked, torch.full_like(logits[:, eos], float("-inf")), logits[:, eos])
-        nxt = logits.argmax(-1)
-        if eos is not None:
+        if st.get("sample") is None:
+            nxt = logits.argmax(-1)
+        else:
+            temperature, top_k, top_p = st["sample"]
+            k = min(int(top_k), logits.shape[-1]) if top_k else logits.shape[-1]
+            vals, idx = (logits.float() / temperature).topk(k, dim=-1)                  # sorted, largest first
+            p = torch.softmax(vals, -1)
+            if top_p is not None and top_p < 1.0:                                        # nucleus: the smallest prefix whose mass reaches top_p
+                keep = (p.cumsum(-1) - p) < top_p
+                p = torch.where(keep, p, torch.zeros_like(p))
+                p = p / p.sum(-1, keepdim=True)
+            u = st["u"][step] if not isinstance(step, Tensor) else st["u"].index_select(0, step)[0]
+            j = (p.cumsum(-1) < u[:, None]).sum(-1).clamp_(max=k - 1)
+            nxt = idx.gather(-1, j[:, None])[:, 0]
+        if eos is not None or st.get("stop") is not None:
             nxt = torch.where(st["fin"], torch.full_like(nxt, st["pad"]), nxt)
+        if eos is not None:
             st["fin"].logical_or_(nxt == eos)
         return nxt
+
+    def _after_token(self, st, step):
+        """Bookkeeping behind the token written to out[:, step]: the keyword-suffix test of KeywordsStoppingCriteria (builder_utils.py:337-339:
+        the last len(k) generated ids equal keyword k's ids) and the finished rows' lengths -- on the device, inside the captured step."""
+        stop = st.get("stop")
+        if stop is not None:
+            L = max(len(t) for t in stop)
+            ar = st["ar"][:L]
+            pos = step - (L - 1) + ar                                                    # the last L positions, right-aligned
+            window = st["out"].index_select(1, pos.clamp(min=0))
+            hit = torch.zeros_like(st["fin"])
+            for t, tail in zip(stop, st["stop_t"]):
+                ok = (window[:, L - len(t):] == tail[None]).all(-1) & (pos[L - len(t)] >= 0)
+                hit = hit | ok
+            st["fin"].logical_or_(hit)
+        if st.get("len") is not None and (st["eos"] is not None or stop is not None):
+            n = st["out"].shape[1]
+            st["len"].copy_(torch.where(st["fin"] & (st["len"] == n), (step + 1).expand_as(st["len"]), st["len"]))
 
     def _emit(self, st, logits: Tensor):
         nxt = self._pick(st, logits, st["step"])
         st["tok"].copy_(nxt)
         st["out"].index_copy_(1, st["step"], nxt[:, None])
+        self._after_token(st, st["step"])
         st["pos"].add_(1)
         st["step"].add_(1)
 
@@ -339,9 +381,14 @@ class GreedyDecoder:
 
     @torch.no_grad()
     def generate(self, inputs_embeds: Tensor, max_new_tokens: int, use_graph: bool = True, eos_token_id=None, pad_token_id: int = 0,
-                 min_new_tokens: int = 0) -> Tensor:
-        """inputs_embeds [B, P, H] (no padding) -> greedy ids [B, n <= max_new_tokens] (n < max_new_tokens only when every
-        row has emitted ``eos_token_id``, as HF generate returns them)."""
+                 min_new_tokens: int = 0, do_sample: bool = False, temperature: float = 1.0, top_k: Optional[int] = 50, top_p: Optional[float] = 1.0,
+                 sample_noise: Optional[Tensor] = None, generator: Optional[torch.Generator] = None, stop_ids=None, text_stop=None) -> Tensor:
+        """inputs_embeds [B, P, H] (no padding) -> ids [B, n <= max_new_tokens] (n < max_new_tokens only when every row has finished --
+        emitted ``eos_token_id`` or met a stopping keyword -- as HF generate returns them; finished rows are padded).
+        ``do_sample``: sample from HF's warped distribution (temperature, top_k [HF's default 50], top_p) with ``sample_noise`` [max_new_tokens, B]
+        uniform numbers in [0, 1) (drawn from ``generator`` / the device's default generator when None).  ``stop_ids``: token-id tails that end a
+        row when its last ids equal one of them (KeywordsStoppingCriteria's token test, on the device); ``text_stop(ids [1, n]) -> bool``: its
+        text test, evaluated on the host for every new length once per 16 tokens (batch 1)."""
         B, P, _ = inputs_embeds.shape
         N = max_new_tokens
         dev, dt = inputs_embeds.device, inputs_embeds.dtype
@@ -349,7 +396,22 @@ class GreedyDecoder:
             if len(eos_token_id) != 1:
                 raise NotImplementedError("GreedyDecoder: one eos_token_id")
             eos_token_id = eos_token_id[0]
-        st = self._state(B, P, N, dev, dt, eos_token_id, int(pad_token_id if pad_token_id is not None else (eos_token_id or 0)), int(min_new_tokens or 0))
+        sample = None
+        if do_sample:
+            if temperature is None or not float(temperature) > 0.0:
+                raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float")      # (HF's TemperatureLogitsWarper)
+            sample = (float(temperature), int(top_k) if top_k else 0, float(top_p) if top_p is not None else 1.0)
+        stop = tuple(tuple(int(v) for v in t) for t in stop_ids if len(t)) if stop_ids else None
+        if text_stop is not None and B != 1:
+            raise AssertionError("Only support batch size 1 (yet)")                                          # (the reference's criteria: builder_utils.py:334)
+        st = self._state(B, P, N, dev, dt, eos_token_id, int(pad_token_id if pad_token_id is not None else (eos_token_id or 0)), int(min_new_tokens or 0),
+                         sample, stop or None)
+        if sample is not None:
+            if sample_noise is not None:
+                st["u"].copy_(sample_noise.to(dev).reshape(N, B))
+            else:
+                st["u"].copy_(torch.rand(N, B, device=dev, generator=generator))
+        ending = eos_token_id is not None or stop is not None or text_stop is not None
         # ---- prefill (eager: a handful of large GEMMs)
         x = inputs_embeds
         pidx = st["ar"][:P]
@@ -362,42 +424,66 @@ class GreedyDecoder:
                 x = self._layer(x, w, cos, sin, st["kc"][li], st["vc"][li], pidx, causal)
             last = x[:, -1]
         st["fin"].zero_()
-        if eos_token_id is not None:
+        st["len"].fill_(N)
+        if ending:
             st["out"].fill_(st["pad"])
         first = self._pick(st, self._head(last), 0)
         st["tok"].copy_(first)
         st["out"][:, 0] = first
+        st["step"].fill_(0)
+        self._after_token(st, st["step"])
         st["pos"].fill_(P)
         st["step"].fill_(1)
+        checked, cut = 0, None        # text test: lengths [1, checked] have been tested; cut = the length at which it first held
         if N > 1:
             if use_graph and st["graph"] is None:
                 # warm up on a side stream (handles, workspaces), then capture one step
-                keep = (st["tok"].clone(), st["pos"].clone(), st["step"].clone(), st["out"].clone(), st["fin"].clone())
+                names = ("tok", "pos", "step", "out", "fin", "len")
+                keep = [st[k].clone() for k in names]
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
                     self._decode_step(st)
                 torch.cuda.current_stream().wait_stream(s)
-                st["tok"].copy_(keep[0]); st["pos"].copy_(keep[1]); st["step"].copy_(keep[2]); st["out"].copy_(keep[3]); st["fin"].copy_(keep[4])
+                for k, v in zip(names, keep):
+                    st[k].copy_(v)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._decode_step(st)
                 st["graph"] = g
-                st["tok"].copy_(keep[0]); st["pos"].copy_(keep[1]); st["step"].copy_(keep[2]); st["out"].copy_(keep[3]); st["fin"].copy_(keep[4])
+                for k, v in zip(names, keep):
+                    st[k].copy_(v)
             for i in range(N - 1):
-                if eos_token_id is not None and i % 16 == 0 and bool(st["fin"].all()):
-                    break          # every row has finished (one host read per 16 tokens)
+                if ending and i % 16 == 0:        # one host read per 16 tokens
+                    if text_stop is not None:
+                        cut, checked = self._text_scan(st, text_stop, checked, i + 1)
+                        if cut is not None:
+                            break
+                    if bool(st["fin"].all()):
+                        break                      # every row has finished
                 if use_graph:
                     st["graph"].replay()
                 else:
                     self._decode_step(st)
         out = st["out"].clone()
-        if eos_token_id is not None:
-            # HF stops at the step where the last row finished: keep the columns up to (and including) the last first-EOS
-            is_eos = out == eos_token_id
-            first_eos = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((B,), N, device=dev))
-            out = out[:, : int(first_eos.max().item())]
+        if text_stop is not None and cut is None:
+            cut, checked = self._text_scan(st, text_stop, checked, int(st["step"].item()))
+        if ending:
+            # HF stops at the step where the last row finished: keep the columns up to (and including) that token
+            n = int(st["len"].max().item())
+            if cut is not None:
+                n = min(n, cut)
+            out = out[:, :n]
         return out
+
+    @staticmethod
+    def _text_scan(st, text_stop, checked: int, upto: int):
+        """The criteria's TEXT test for the lengths checked + 1 .. upto (host; the first length at which it holds, or None)."""
+        ids = st["out"][:, :upto].cpu()
+        for n in range(checked + 1, upto + 1):
+            if text_stop(ids[:, :n]):
+                return n, n
+        return None, upto
 
 
 class T5GreedyDecoder:
@@ -555,6 +641,7 @@ class T5GreedyDecoder:
 
     _pick = GreedyDecoder._pick
     _emit = GreedyDecoder._emit
+    _after_token = GreedyDecoder._after_token      # (no keyword stopping / length state here: a no-op)
 
     def _norm(self, x: Tensor, w: Tensor) -> Tensor:
         # T5LayerNorm.forward: fp32 variance, no mean subtraction, no bias; cast to the weight's dtype when it is half / bf16
@@ -695,6 +782,23 @@ class T5GreedyDecoder:
             first_eos = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((B,), N, device=dev))
             out = out[:, : int(first_eos.max().item())]
         return torch.cat([torch.full((B, 1), self.start, dtype=torch.long, device=dev), out], dim=1)
+
+
+def keyword_stop_plan(criteria) -> dict:
+    """``stop_ids`` / ``text_stop`` of GreedyDecoder.generate for a list of KeywordsStoppingCriteria objects (eval/utils/builder_utils.py:320-346; any object
+    with ``keyword_ids``, ``keywords``, ``tokenizer``, ``start_len``, ``max_keyword_len``): the id tails of the token test, and the text test as a
+    host callback on the generated ids.  (With ``inputs_embeds`` HF's ``output_ids`` holds only generated tokens, so the criteria's
+    ``output_ids.shape[1] - start_len`` can be negative; the window arithmetic below is the criteria's own, line 335.)"""
+    crit = list(criteria)
+
+    def text_stop(ids):
+        for c in crit:
+            off = min(ids.shape[1] - c.start_len, c.max_keyword_len)
+            text = c.tokenizer.batch_decode(ids[:, -off:], skip_special_tokens=True)[0]
+            if any(k in text for k in c.keywords):
+                return True
+        return False
+    return dict(stop_ids=[[int(v) for v in t.tolist()] for c in crit for t in c.keyword_ids], text_stop=text_stop)
 
 
 def make_decoder(lm):

@@ -535,15 +535,52 @@ class _LSTPBase(nn.Module):
         qo = qo[:, : query_tokens.size(1), :]
         return self.model.language_projection.pool(qo, [nframe] * batch_size, pool)
 
+    @staticmethod
+    def _graph_plan(lm, inputs_embeds, attention_mask, do_sample, temperature, stopping_criteria, kw):
+        """The keyword arguments of ``decode.*Decoder.generate`` for this request, or None when it is outside what the graph decoders reproduce
+        (then HF ``generate`` runs it): a Llama / T5 language model on the device, no padding, one beam, neutral penalties; greedy, or (Llama)
+        sampling with temperature / top_k / top_p; ``stopping_criteria`` None or KeywordsStoppingCriteria objects (eval/utils/builder_utils.py:320-346:
+        recognised by their ``keyword_ids`` / ``keywords`` / ``tokenizer`` attributes)."""
+        mt = getattr(lm.config, "model_type", "")
+        if not inputs_embeds.is_cuda or not ("llama" in mt or mt == "t5") or not bool((attention_mask != 0).all()):
+            return None
+        gc = getattr(lm, "generation_config", None)     # HF generate's defaults come from the generation config
+        plan = dict(eos_token_id=kw.pop("eos_token_id", getattr(gc, "eos_token_id", None)), pad_token_id=kw.pop("pad_token_id", getattr(gc, "pad_token_id", None)),
+                    min_new_tokens=kw.pop("min_new_tokens", 0))
+        if kw.pop("num_beams", 1) != 1 or kw.pop("repetition_penalty", 1.0) not in (None, 1.0) or kw.pop("length_penalty", 1.0) not in (None, 1.0):
+            return None
+        top_k, top_p = kw.pop("top_k", getattr(gc, "top_k", 50)), kw.pop("top_p", getattr(gc, "top_p", 1.0))
+        noise, gen = kw.pop("sample_noise", None), kw.pop("generator", None)
+        if kw:
+            return None
+        crit = list(stopping_criteria) if stopping_criteria is not None else []
+        if any(not all(hasattr(c, a) for a in ("keyword_ids", "keywords", "tokenizer")) for c in crit):
+            return None
+        if mt == "t5":
+            return plan if not do_sample and not crit else None
+        if do_sample:
+            plan.update(do_sample=True, temperature=temperature, top_k=top_k, top_p=top_p, sample_noise=noise, generator=gen)
+        if crit:
+            if inputs_embeds.shape[0] != 1:
+                raise AssertionError("Only support batch size 1 (yet)")      # (the reference's criteria)
+            from .decode import keyword_stop_plan
+            plan.update(keyword_stop_plan(crit))
+        return plan
+
     # ---- the reference entry point ---------------------------------------------------------------
     @torch.no_grad()
     def generate(self, frames, flow_frames, nframe, text_encoding, sampler_text_encoding, do_sample=True, temperature=0.2,
                  max_new_tokens=1024, use_cache=True, stopping_criteria=None, of: Optional[Tensor] = None,
-                 noise: Optional[Tensor] = None, pool: str = "mean", return_stages: bool = False, fast_decode: bool = False,
+                 noise: Optional[Tensor] = None, pool: str = "mean", return_stages: bool = False, fast_decode="auto",
                  **gen_kwargs):
         """eval/utils/model.py:48-235 (LSTP) / :267-445 (LSTP_blip2).  Extensions: ``of`` supplies a
         precomputed flow (the batch["of"] contract of the LightningModules), ``noise`` injects the
-        Gumbel noise, ``pool`` selects mean (eval) or concat (LightningModules) pooling."""
+        Gumbel noise, ``pool`` selects mean (eval) or concat (LightningModules) pooling.
+        ``fast_decode``: "auto" (default) decodes on libvtgb.so's kernels (videotgb_amd.decode: hipGraph-replayed steps over the same HF weights)
+        whenever the request is one that decoder reproduces -- which includes the reference's own eval call (eval/inference.py:98-109: sampling at
+        temperature 0.2, ``use_cache=False`` [no effect on the ids], ``KeywordsStoppingCriteria``) -- and through HF ``generate`` otherwise; True
+        insists (TypeError outside the envelope); False always takes HF ``generate``.  ``sample_noise`` [max_new_tokens, B] injects the sampler's
+        uniform numbers (tests)."""
         sampler_ids = sampler_text_encoding["input_ids"]
         batch_size = sampler_ids.shape[0]
         pixel_values = frames
@@ -563,18 +600,15 @@ class _LSTPBase(nn.Module):
         attention_mask = torch.cat([lm_mask, text_encoding["attention_mask"]], dim=1)
         inputs_embeds = self.model.get_input_embeddings()(text_encoding["input_ids"])
         inputs_embeds = torch.cat([lm_inputs, inputs_embeds.to(lm_dtype)], dim=1)
-        if fast_decode and not do_sample and stopping_criteria is None and bool((attention_mask != 0).all()):
-            # greedy, unpadded: hipGraph-replayed decode of the same HF weights (videotgb_amd/decode.py)
+        plan = None if fast_decode is False else self._graph_plan(lm, inputs_embeds, attention_mask, do_sample, temperature, stopping_criteria, dict(gen_kwargs))
+        if fast_decode is True and plan is None:      # (nothing is dropped silently -- and nothing is decoded first)
+            raise TypeError(f"generate(fast_decode=True): outside the graph decoder's envelope (do_sample={do_sample}, stopping_criteria="
+                            f"{type(stopping_criteria).__name__}, kwargs {sorted(gen_kwargs)}); call with fast_decode=False or \"auto\"")
+        if plan is not None:
             from .decode import make_decoder, weights_key
             if getattr(self, "_decoder", None) is None or self._decoder.lm is not lm or self._decoder.key != weights_key(lm):
                 self._decoder = make_decoder(lm)      # Llama (causal) or T5 (seq2seq, LSTP_blip2)
-            gc = getattr(lm, "generation_config", None)     # HF generate's defaults (eos / pad from the generation config)
-            eos = gen_kwargs.pop("eos_token_id", getattr(gc, "eos_token_id", None))
-            pad = gen_kwargs.pop("pad_token_id", getattr(gc, "pad_token_id", None))
-            min_new = gen_kwargs.pop("min_new_tokens", 0)
-            if gen_kwargs:      # (nothing is dropped silently -- and nothing is decoded first: what the graph decoder does not implement must go through HF generate)
-                raise TypeError(f"generate(fast_decode=True) does not take {sorted(gen_kwargs)}; call with fast_decode=False")
-            outputs = self._decoder.generate(inputs_embeds, max_new_tokens, eos_token_id=eos, pad_token_id=pad, min_new_tokens=min_new)
+            outputs = self._decoder.generate(inputs_embeds, max_new_tokens, **plan)
         else:
             outputs = lm.generate(inputs_embeds=inputs_embeds, attention_mask=attention_mask, do_sample=do_sample,
                                   temperature=temperature, max_new_tokens=max_new_tokens, use_cache=use_cache,
