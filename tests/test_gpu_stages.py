@@ -274,3 +274,13 @@ def test_frame_stager_overlapped_uploads_equal_the_direct_path(dev):
         assert torch.equal(bf, rf) and torch.equal(bff, rff)
         if i + 2 < len(clips):
             tickets.append(st.stage(clips[i + 2]))                             # reuses the slot of clip i
+    #  a slot whose clip has not been consumed is not overwritten, and a ticket whose clip is gone is refused
+    st2 = video.FrameStager(dev, max_frames=40, height=90, width=160, slots=2)
+    ta, tb = st2.stage(clips[0]), st2.stage(clips[1])
+    with pytest.raises(RuntimeError, match="still holds a staged clip"):
+        st2.stage(clips[2])
+    st2.frames(ta)
+    tc = st2.stage(clips[2])                                                   # slot of clip 0, now free
+    with pytest.raises(RuntimeError, match="stale ticket"):
+        st2.frames(ta)
+    assert torch.equal(st2.frames(tc)[1], video.get_frames(torch.from_numpy(clips[2]).to(dev))[1]) and st2.frames(tb) is not None

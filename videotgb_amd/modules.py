@@ -322,7 +322,8 @@ class _LSTPLightningBase(_Base):
             attention_mask = torch.cat([mask, batch["question_attention_mask"]], dim=1)
             inputs_embeddings = torch.cat([lm_inputs, emb], dim=1)
         outputs = None
-        if getattr(self, "fast_decode", False):      # opt-in: hipGraph-replayed greedy decode of the same HF weights (decode.graph_generate)
+        if getattr(self, "fast_decode", True):       # (round 6: on by default) hipGraph-replayed decode of the same HF weights whenever generate_configs is a
+            # configuration decode.graph_generate reproduces exactly (greedy, one beam, no padding, Llama / T5); None -> HF generate below
             from .decode import graph_generate
             outputs = graph_generate(self, lm, inputs_embeddings, attention_mask, self.generate_configs)
         if outputs is None:

@@ -100,7 +100,8 @@ class FrameStager:
         t0 = st.stage(decoded_clip_0)                                          # async H2D; returns a ticket
         t1 = st.stage(decoded_clip_1)                                          # overlaps clip 0's compute
         frames, flow_frames = st.frames(t0)                                    # == builder_utils.get_frames(...) of the reference
-    A slot is reused once the clip staged ``slots`` calls earlier has been consumed by ``frames()`` (stream-ordered: an event guards it)."""
+    A slot is reused once the clip staged ``slots`` calls earlier has been consumed by ``frames()`` (stream-ordered: an event guards it); staging into a
+    slot whose clip has not been consumed raises, and so does a ticket whose clip is gone."""
 
     def __init__(self, device="cuda", max_frames: int = 256, height: int = 360, width: int = 640, slots: int = 2):
         self.device = torch.device(device)
@@ -111,11 +112,18 @@ class FrameStager:
         self.dev = [torch.empty(self.shape, dtype=torch.uint8, device=self.device) for _ in range(slots)]
         self.uploaded = [torch.cuda.Event() for _ in range(slots)]
         self.consumed = [None] * slots
+        self.state = ["free"] * slots          # free -> staged (stage) -> consumed (frames) -> staged ...
+        self.gen = [0] * slots                 # generation of the clip a slot holds: a ticket of an overwritten clip is refused
         self.copy = torch.cuda.Stream(device=self.device)
         self.n = 0
 
-    def stage(self, decoded) -> Tuple[int, int]:
+    def stage(self, decoded) -> Tuple[int, int, int]:
         i = self.n % len(self.host)
+        if self.state[i] == "staged":
+            # (the slot's earlier clip has not been handed out by frames() yet -- overwriting the pinned buffer would race its upload and
+            # silently give that ticket the newer clip's pixels)
+            raise RuntimeError(f"FrameStager: slot {i} still holds a staged clip that frames() has not consumed ({len(self.host)} slots: call "
+                               f"frames() for the oldest ticket first, or construct with more slots)")
         self.n += 1
         if self.consumed[i] is not None:
             self.consumed[i].synchronize()                      # the clip that used this slot has been preprocessed (host buffer AND device buffer free)
@@ -123,15 +131,20 @@ class FrameStager:
         with torch.cuda.stream(self.copy):
             self.dev[i][:t].copy_(self.host[i][:t], non_blocking=True)
             self.uploaded[i].record(self.copy)
-        return i, t
+        self.state[i] = "staged"
+        self.gen[i] += 1
+        return i, t, self.gen[i]
 
     @torch.no_grad()
-    def frames(self, ticket: Tuple[int, int], target_size: int = 224, n_cand: int = 32) -> Tuple[Tensor, Tensor]:
-        i, t = ticket
+    def frames(self, ticket, target_size: int = 224, n_cand: int = 32) -> Tuple[Tensor, Tensor]:
+        i, t = ticket[0], ticket[1]
+        if len(ticket) > 2 and (ticket[2] != self.gen[i] or self.state[i] != "staged"):
+            raise RuntimeError(f"FrameStager: stale ticket for slot {i} (its clip has been consumed or overwritten)")
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(self.uploaded[i])
         out = get_frames(self.dev[i][:t], target_size, n_cand)
         ev = torch.cuda.Event()
         ev.record(cur)
         self.consumed[i] = ev
+        self.state[i] = "consumed"
         return out
