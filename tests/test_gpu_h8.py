@@ -69,3 +69,23 @@ def test_pair_conv_vs_fp64(dev, N, KH, KW, C1, two, obf, H, W, n):
     err16 = ((F.conv2d(x16, w.to(torch.float16).double(), b.double(), padding=(KH // 2, KW // 2)).relu() - ref).abs() / bound).max().item()
     print(f"[pair conv N={N} {KH}x{KW} C1={C1} two={two}] max err / sum|x||w| = {err:.3e} (2^-14 = {2.0 ** -14:.3e}); fp16-only: {err16:.3e}")
     assert err <= 2.0 ** -14 and err16 > 4 * err
+
+
+@pytest.mark.parametrize("N,KH,KW,C1,two,obf", [(256, 3, 3, 128, False, True), (256, 1, 5, 128, True, False), (192, 3, 3, 256, False, False)])
+def test_pair_conv_wide_and_narrow_tiles_agree_bit_for_bit(dev, N, KH, KW, C1, two, obf):
+    """launch_conv_h8 gives a 256-channel convolution the 256-wide tile on large batches and two 128-wide n-tiles on few m-tiles (a single clip);
+    the contraction order of an output element is the same in both, so 400 images in one call (1 225 m-tiles: wide) and the first two of them alone
+    (7 m-tiles: narrow) must agree bit for bit -- which also carries the fp64 check of the small cases above over to the wide instantiations."""
+    from videotgb_amd import ops
+    g = torch.Generator(device=dev).manual_seed(N + KW)
+    n, H, W = 400, 28, 28
+    x = torch.randn(n * H * W, C1, generator=g, device=dev).abs() * 3
+    a = ops.pair_pack(x)
+    a2 = ops.pair_pack(torch.randn(n * H * W, C1, generator=g, device=dev)) if two else None
+    wk = torch.randn(N, KH, KW, C1 * (2 if two else 1), generator=g, device=dev) * 0.05
+    sw, _ = ops.h8_weight_scale(wk)
+    ofmt = ops.BF16X3 if obf else ops.F16C8
+    full = ops.pair_conv(a, wk, sw, H, W, a2=a2, relu=True, out_fmt=ofmt)
+    m2 = 2 * H * W
+    part = ops.pair_conv(a[:m2].contiguous(), wk, sw, H, W, a2=None if a2 is None else a2[:m2].contiguous(), relu=True, out_fmt=ofmt)
+    assert torch.equal(full[:m2], part) and full.abs().max() > 0

@@ -506,19 +506,28 @@ int launch_conv_h8(const GemmDesc& d_in, hipStream_t s) {
         VTGB_REQUIRE(span < (1 << 24) && span * ld * 2 < 0x7FFFFF00ll && (int64_t)256 * d.ldw * 2 < 0x7FFFFF00ll, VTGB_EUNSUPPORTED, "conv h8: tile footprint beyond the 32-bit descriptor offsets");
     }
     VTGB_REQUIRE(d.o_map.seg_rows == 0 && d.r_map.seg_rows == 0 && d.out_scale == 0.f, VTGB_EUNSUPPORTED, "conv h8: identity row maps only");
+    // 256-wide outputs on FEW m-tiles (a single clip: 291 m-tiles = 1.14 rounds of 256 CUs, paid as 2 on the 256-wide tile): two 128-wide n-tiles per
+    // m-tile instead -- 582 tiles = 2.27 rounds of half the work each (paid as 1.5).  Cost model in units of one 256 x 128 tile's work; the 128-wide
+    // tile is ~10 % dearer per column at the bench batch (z | r 3.57 vs 3.21 ms, flow head 2.84 vs 2.55: same-box A/B, round 6), so large batches keep the
+    // 256-wide tile.
+    const int cus = cu_count(), m_tiles = (d.M + 255) / 256;
+    const bool narrow = ((2 * m_tiles + cus - 1) / cus) * 1.1 < ((m_tiles + cus - 1) / cus) * 2.0;
     switch (d.epi) {
         case EPI_SPLIT:
             VTGB_REQUIRE((d.N & 1) == 0 && (d.ldo & 3) == 0 && (d.split_lo & 3) == 0 && d.split_lo > 0, VTGB_EINVAL, "conv h8: pair store needs 4-aligned rows and split_lo");
             if (d.h8_out_bf16) {
-                VTGB_REQUIRE(d.N > 192 && (d.N & 3) == 0, VTGB_EUNSUPPORTED, "conv h8: bf16-pair output on the 256-wide tile only");
+                VTGB_REQUIRE((d.N & 3) == 0, VTGB_EUNSUPPORTED, "conv h8: bf16-pair output needs N %% 4 == 0");
+                if (d.N <= 128 || (narrow && d.N > 192)) return launch_h8<EPI_SPLIT, 2, 4, 0>(d, s);
                 return launch_h8<EPI_SPLIT, 4, 4, 0>(d, s);
             }
             if (d.N <= 128) return launch_h8<EPI_SPLIT, 2, 4, 1>(d, s);
             if (d.N <= 192 && (d.N & 7) == 0) return launch_h8<EPI_SPLIT, 4, 3, 1>(d, s);
+            if (narrow) return launch_h8<EPI_SPLIT, 2, 4, 1>(d, s);
             return launch_h8<EPI_SPLIT, 4, 4, 1>(d, s);
         case EPI_X3ZR:
             VTGB_REQUIRE(d.N == 256 && d.resid && d.aux && d.out2 && ((d.ldr | d.ldaux | d.ldo | d.ldo2 | d.split_lo) & 3) == 0 && d.act == 0 && !d.bias, VTGB_EINVAL,
                          "conv h8: the z | r gate epilogue needs a 256-channel convolution with its start map, h and both outputs");
+            if (narrow) return launch_h8<EPI_X3ZR, 2, 4, 1>(d, s);      // (n-tile 0 = the z columns, n-tile 1 = the r columns)
             return launch_h8<EPI_X3ZR, 4, 4, 1>(d, s);
         case EPI_X3Q:
             VTGB_REQUIRE(d.N == 128 && d.resid && d.aux && ((d.ldr | d.ldaux | d.ldo | d.split_lo) & 3) == 0 && d.act == 0 && !d.bias, VTGB_EINVAL,
