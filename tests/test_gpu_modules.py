@@ -109,6 +109,7 @@ def test_lightning_module_twin_eval_forward(dev, tmp_path, tag):
     noise = g[f"{tag}_noise"].to(dev) if f"{tag}_noise" in g else None
     cap = []
     h = m.model.language_model.lm_head.register_forward_hook(lambda mod, i, o: cap.append(o))
+    m.fast_decode = False                                        # (HF generate: the hook below captures ITS first-step logits)
     ids, st = m.eval_forward(batch, noise=noise, return_stages=True)
     h.remove()
     assert st["frame_idx"].cpu().tolist() == g[f"{tag}_frame_idx"].tolist()
@@ -119,6 +120,9 @@ def test_lightning_module_twin_eval_forward(dev, tmp_path, tag):
     close(f"{tag} language_model_inputs", st["language_model_inputs"], g[f"{tag}_prefix"])
     close(f"{tag} first-step logits", cap[0][:, -1], g[f"{tag}_first_logits"])
     assert ids.cpu().tolist() == g[f"{tag}_ids"].tolist()
+    m.fast_decode = True                                         # (round 6: the twins' default) the graph decoder emits the same ids
+    ids2 = m.eval_forward(batch, noise=noise)
+    assert ids2.cpu().tolist() == g[f"{tag}_ids"].tolist()
     # Lightning-facing methods
     preds, labels = m.eval_model_step(batch)
     assert len(preds) == B and labels == [""] * B

@@ -169,18 +169,30 @@ __global__ __launch_bounds__(256) void x3_init_kernel(const float* __restrict__ 
     }
 }
 
-// ---- convf1 (update.py:81,92: 7x7, 2 -> 128, ReLU) as fp32 FMAs (weights [98][128], k = c * 49 + ky * 7 + kx), pair out; the flow
-// itself goes to columns 126, 127 of the motion buffer X (update.py:97).  A workgroup takes 64 consecutive pixels: their 98-tap windows
-// are staged tap-major in LDS (zero padded), thread (channel co, half) keeps its channel's 98 weights in registers and walks 32 pixels
-// four at a time -- one broadcast 16-byte LDS read and two packed FMAs per tap.  (The first form -- two pixels per workgroup, every
-// weight re-read from L2 per pixel -- took 3.8 ms per iteration of 40.)
-constexpr int CF1_PX = 64;
-typedef float x3_f32x2 __attribute__((ext_vector_type(2)));
+// ---- convf1 (update.py:81,92: 7x7, 2 -> 128, ReLU) in exact fp32 on the fp32-input matrix instruction (weights [98][128], k = c * 49 + ky * 7 + kx),
+// pair out; the flow itself goes to columns 126, 127 of the motion buffer X (update.py:97).  A workgroup takes 64 consecutive pixels: their 98-tap
+// windows are staged tap-major in LDS (zero padded; rows padded to 65 floats so that the four k rows of a fragment read fall into different banks),
+// then D[channel][pixel] = W^T[128][100] . win[100][64] (K = 98 padded to 100) on v_mfma_f32_16x16x4_f32 -- bit for bit a k-ordered fmaf chain
+// (cdna guide: 'FP32-input MFMA'), i.e. the arithmetic of the vector-FMA form it replaces (round 5: 49 register-pair weights per thread, packed
+// FMAs with op_sel broadcasts, 1.06 ms per launch = 55 TFLOP/s; the first form of all, two pixels per workgroup, took 3.8 ms).  Wave w holds the
+// weights of channels 32 w .. 32 w + 31 as 50 registers (one float per k-step and 16-channel block), reads each window value once per 16-channel
+// pair of blocks (100 ds_read_b32 for 200 MFMAs), and stores four consecutive channels of a pixel per lane as 8-byte pair halves.
+constexpr int CF1_PX = 64, CF1_LDW = 65, CF1_KS = 25;
 __global__ __launch_bounds__(256) void x3_convf1_kernel(const float* __restrict__ flow, const float* __restrict__ wt, const float* __restrict__ b,
                                                         bf16_t* __restrict__ f1, bf16_t* __restrict__ X, int64_t M, int H8, int W8, int h8) {
-    __shared__ __attribute__((aligned(16))) float win[98][CF1_PX];
+    __shared__ float win[4 * CF1_KS][CF1_LDW];
     const int tid = threadIdx.x, HW = H8 * W8;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
     const int64_t m0 = (int64_t)blockIdx.x * CF1_PX;
+    // this wave's weights, A[row = channel][k]: lane holds k = 4 s + fg of channel 32 wave + 16 i + fr (k >= 98: zero)
+    float wa[CF1_KS][2];
+#pragma unroll
+    for (int s_ = 0; s_ < CF1_KS; s_++) {
+        const int k = 4 * s_ + fg;
+#pragma unroll
+        for (int i = 0; i < 2; i++) wa[s_][i] = k < 98 ? wt[k * 128 + wave * 32 + i * 16 + fr] : 0.f;
+    }
     {
         // thread -> (pixel, 25 taps): pixel = tid & 63 (consecutive lanes = consecutive pixels: coalesced-ish 8-byte gathers)
         const int px = tid & 63, part = tid >> 6;
@@ -194,38 +206,41 @@ __global__ __launch_bounds__(256) void x3_convf1_kernel(const float* __restrict_
             win[t][px] = v.x;
             win[49 + t][px] = v.y;
         }
+        if (tid < 2 * CF1_PX) win[98 + (tid >> 6)][tid & 63] = 0.f;      // the two padding rows of K
     }
-    const int co = tid & 127, half = tid >> 7;
-    // the channel's weights as 49 register PAIRS (taps 2j, 2j + 1): the packed FMA takes the pixel pair from one source and BROADCASTS one
-    // half of the weight pair through op_sel (written as inline asm: left to the compiler, {w, w} was materialised per tap -- 470
-    // registers, one wave per SIMD, 4.0 ms per launch)
-    x3_f32x2 w2[49];
+    f32x4 acc[2][4];
 #pragma unroll
-    for (int j = 0; j < 49; j++) w2[j] = x3_f32x2{wt[(2 * j) * 128 + co], wt[(2 * j + 1) * 128 + co]};
-    const float bias = b[co];
+    for (int i = 0; i < 2; i++) {
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(b + wave * 32 + i * 16 + fg * 4);      // (the lane's four rows of block i)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = bi;
+    }
     __syncthreads();
-    for (int g = 0; g < 8; g++) {
-        const int p0 = half * 32 + g * 4;
-        if (m0 + p0 >= M) break;
-        x3_f32x2 a01 = {bias, bias}, a23 = {bias, bias};
 #pragma unroll
-        for (int j = 0; j < 49; j++) {
-            const f32x4 va = *reinterpret_cast<const f32x4*>(&win[2 * j][p0]), vb = *reinterpret_cast<const f32x4*>(&win[2 * j + 1][p0]);
-            const x3_f32x2 va01 = {va[0], va[1]}, va23 = {va[2], va[3]}, vb01 = {vb[0], vb[1]}, vb23 = {vb[2], vb[3]};
-            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a01) : "v"(va01), "v"(w2[j]));
-            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a23) : "v"(va23), "v"(w2[j]));
-            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a01) : "v"(vb01), "v"(w2[j]));
-            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a23) : "v"(vb23), "v"(w2[j]));
-        }
-        const float r[4] = {a01[0], a01[1], a23[0], a23[1]};
+    for (int s_ = 0; s_ < CF1_KS; s_++) {
+        float xb[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int64_t m = m0 + p0 + e;
-            if (m < M) {
-                const float v = fmaxf(r[e], 0.f), hf = bf16_round(v);
-                f1[m * 256 + co] = (bf16_t)hf;
-                f1[m * 256 + 128 + co] = (bf16_t)(v - hf);
-            }
+        for (int j = 0; j < 4; j++) xb[j] = win[4 * s_ + fg][j * 16 + fr];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s_][i], xb[j], acc[i][j], 0, 0, 0);
+    }
+    // D: column = lane & 15 = pixel j * 16 + fr, rows = 4 fg + e = channels 32 wave + 16 i + 4 fg + e
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int64_t m = m0 + j * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            f32x4 v = acc[i][j];
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+            bf16x4 hi, lo;
+            pair_split4(v, hi, lo);
+            bf16_t* o = f1 + m * 256 + wave * 32 + i * 16 + fg * 4;
+            *reinterpret_cast<bf16x4*>(o) = hi;
+            *reinterpret_cast<bf16x4*>(o + 128) = lo;
         }
     }
     if (tid < 2 * CF1_PX) {
