@@ -184,8 +184,9 @@ __global__ __launch_bounds__(256) void x3_convf1_kernel(const float* __restrict_
     const int tid = threadIdx.x, HW = H8 * W8;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
-    const int64_t m0 = (int64_t)blockIdx.x * CF1_PX;
-    // this wave's weights, A[row = channel][k]: lane holds k = 4 s + fg of channel 32 wave + 16 i + fr (k >= 98: zero)
+    const int64_t n_tiles = (M + CF1_PX - 1) / CF1_PX;
+    // this wave's weights, A[row = channel][k]: lane holds k = 4 s + fg of channel 32 wave + 16 i + fr (k >= 98: zero) -- loaded ONCE per workgroup:
+    // the workgroups are persistent (as one workgroup per 64 pixels each re-read its 50 KB of weights in front of 3 us of MFMAs)
     float wa[CF1_KS][2];
 #pragma unroll
     for (int s_ = 0; s_ < CF1_KS; s_++) {
@@ -193,28 +194,48 @@ __global__ __launch_bounds__(256) void x3_convf1_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < 2; i++) wa[s_][i] = k < 98 ? wt[k * 128 + wave * 32 + i * 16 + fr] : 0.f;
     }
+    f32x4 bias4[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) bias4[i] = *reinterpret_cast<const f32x4*>(b + wave * 32 + i * 16 + fg * 4);      // (the lane's four rows of block i)
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t m0 = tile * CF1_PX;
     {
-        // thread -> (pixel, 25 taps): pixel = tid & 63 (consecutive lanes = consecutive pixels: coalesced-ish 8-byte gathers)
+        // thread -> (pixel, 13 taps): pixel = tid & 63 (consecutive lanes = consecutive pixels: coalesced-ish 8-byte gathers).  All 13 loads are issued
+        // before the first LDS write (through a buffer descriptor of the flow field: a tap outside the image gets an out-of-range offset and reads
+        // zeros -- as a loop with conditional loads hipcc waited out every gather on its own); one 64-bit modulo per workgroup, not per thread
         const int px = tid & 63, part = tid >> 6;
         const int64_t m = m0 + px;
         const bool live = m < M;
-        const int pix = live ? (int)(m % HW) : 0, y0 = pix / W8, x0 = pix - y0 * W8;
-        for (int t = part; t < 49; t += 4) {
-            const int ky = t / 7, kx = t - ky * 7, y = y0 + ky - 3, x = x0 + kx - 3;
-            float2 v = make_float2(0.f, 0.f);
-            if (live && (unsigned)y < (unsigned)H8 && (unsigned)x < (unsigned)W8) v = *reinterpret_cast<const float2*>(flow + (m + (ky - 3) * W8 + (kx - 3)) * 2);
-            win[t][px] = v.x;
-            win[49 + t][px] = v.y;
+        const int p0 = __builtin_amdgcn_readfirstlane((int)(m0 % HW));
+        int pix = p0 + px;
+        pix = pix >= HW ? pix - HW : pix;                                  // (CF1_PX <= HW)
+        const int y0 = pix / W8, x0 = pix - y0 * W8;
+        const auto frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow), 0, (int)(M * 8), 0x00020000);
+        typedef unsigned cf1_u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned))));
+        cf1_u32x2 v[13];
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            const int t = part + 4 * i, tt = t < 49 ? t : 48;
+            const int ky = tt / 7, kx = tt - ky * 7, y = y0 + ky - 3, x = x0 + kx - 3;
+            const bool ok = live && t < 49 && (unsigned)y < (unsigned)H8 && (unsigned)x < (unsigned)W8;
+            const unsigned off = ok ? (unsigned)((int)m + (ky - 3) * W8 + (kx - 3)) * 8u : 0xFFFFFFF0u;
+            v[i] = __builtin_amdgcn_raw_buffer_load_b64(frs, off, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            const int t = part + 4 * i;
+            if (t < 49) {
+                win[t][px] = __uint_as_float(v[i][0]);
+                win[49 + t][px] = __uint_as_float(v[i][1]);
+            }
         }
         if (tid < 2 * CF1_PX) win[98 + (tid >> 6)][tid & 63] = 0.f;      // the two padding rows of K
     }
     f32x4 acc[2][4];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const f32x4 bi = *reinterpret_cast<const f32x4*>(b + wave * 32 + i * 16 + fg * 4);      // (the lane's four rows of block i)
+    for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = bi;
-    }
+        for (int j = 0; j < 4; j++) acc[i][j] = bias4[i];
     __syncthreads();
 #pragma unroll
     for (int s_ = 0; s_ < CF1_KS; s_++) {
@@ -246,6 +267,8 @@ __global__ __launch_bounds__(256) void x3_convf1_kernel(const float* __restrict_
     if (tid < 2 * CF1_PX) {
         const int64_t m = m0 + (tid >> 1);
         if (m < M) x3_put_flow(X, m, tid & 1, flow[m * 2 + (tid & 1)], h8);
+    }
+    __syncthreads();      // the windows are re-filled by the next tile
     }
 }
 
@@ -345,7 +368,10 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
         VTGB_TRY(raft_launch_lookup_pair(pyr, flow, corrf, M, H8, W8, h8, s));
         VTGB_TRY(run(conv(256, 1, 1, corrf, 384, nullptr, 0, 0, 0, F(w[1]), VTGB_EPI_SPLIT, 1, c1, 512, 256)));
         VTGB_TRY(run(conv(192, 3, 3, c1, 256, nullptr, 0, 2, 1, F(w[3]), VTGB_EPI_SPLIT, 1, CF, 512, 256)));
-        hipLaunchKernelGGL(x3_convf1_kernel, dim3((unsigned)((M + CF1_PX - 1) / CF1_PX)), dim3(256), 0, s, flow, F(w[4]), F(w[5]), f1, X, M, H8, W8, h8);
+        {
+            const int64_t nt = (M + CF1_PX - 1) / CF1_PX, cap = (int64_t)cu_count() * 6;      // persistent: six workgroups per CU (26 KB of LDS each)
+            hipLaunchKernelGGL(x3_convf1_kernel, dim3((unsigned)(nt < cap ? nt : cap)), dim3(256), 0, s, flow, F(w[4]), F(w[5]), f1, X, M, H8, W8, h8);
+        }
         VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 64, H8, W8, 3, 3, f1, 128, nullptr, 0, w[6], F(w[7]), VTGB_EPI_STORE_F32, 0, Q, 64, 0, zero), s));
         VTGB_TRY(launch_x3_pair_pass(Q, 64, nullptr, HW, nullptr, 0, 0, CF + 192, 512, 256, 64, 64, 1, 0, M, s, h8));
         VTGB_TRY(run(conv(126, 3, 3, CF, 256, nullptr, 0, 8, 2, F(w[9]), VTGB_EPI_SPLIT, 1, X, 256, 128)));
