@@ -161,7 +161,8 @@ int vtgb_shifted_ce_backward(const vtgb_shifted_ce_args* a, vtgb_stream_t stream
  *   +3 self_attn.qkv.bias +4 self_attn.projection.weight `dtype` +5 .bias
  *   +6 layer_norm2.weight +7 layer_norm2.bias +8 mlp.fc1.weight `dtype` +9 .bias
  *   +10 mlp.fc2.weight `dtype` +11 .bias
- *   +12 .. +17 optional, VTGB_BF16 only (all six or none; NULL = the LayerNorms run as their own passes): the two LayerNorms FOLDED into the
+ *   +12 .. +17 optional, VTGB_BF16 only (all six of EVERY layer or none -- a partially filled block is VTGB_EINVAL since version 600; none = the
+ *   LayerNorms run as their own passes; with them present +2 and +8 are not read and may be NULL): the two LayerNorms FOLDED into the
  *   GEMMs that follow them -- LN(x) W^T + b = rstd (x W'^T - mean cs) + c with
  *   +12 W'_qkv = bf16(qkv.weight * layer_norm1.weight[None, :]) [3h, h]   +13 cs = row sums of W'_qkv (of the bf16 values), fp32 [3h]
  *   +14 c = qkv.weight @ layer_norm1.bias + qkv.bias, fp32 [3h]           +15 / +16 / +17 the same for mlp.fc1 with layer_norm2 [mlp]:

@@ -54,6 +54,19 @@ def test_vit_tiny_vs_reference_vectors(dev, tiny_sd, dtype):
     check("vit tiny act", outa, g["last_hidden_state"], dtype)
     with pytest.raises(ValueError, match="pixel_values"):
         ops.vit_forward(w, None)
+    if dtype == "bf16":
+        #  the folded-LayerNorm table: the unfolded qkv / fc1 weights are not uploaded, the unfolded table gives the same result class, and
+        # a PARTIALLY filled folded block is refused instead of silently falling back
+        import ctypes as C
+        assert w.tensors[6 + 2] is None and w.tensors[6 + 8] is None and w.tensors[6 + 12] is not None
+        wu = ops.VitWeights(to_dev(sd, dev), "model.vision_model.", ops.BF16, cfg.vit.heads, cfg.vit.eps, fold_ln=False)
+        assert wu.tensors[6 + 2] is not None and wu.tensors[6 + 12] is None
+        check("vit tiny unfolded", ops.vit_forward(wu, deq(g, "pixel_q8").to(dev), True, False)[0], g["last_hidden_state"], dtype)
+        keep = w.array[6 + 13]
+        w.array[6 + 13] = None
+        with pytest.raises(ValueError, match="folded-LayerNorm"):
+            ops.vit_forward(w, deq(g, "pixel_q8").to(dev))
+        w.array[6 + 13] = keep
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

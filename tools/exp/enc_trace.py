@@ -14,7 +14,7 @@ for k in list(sd):
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 384
 fr = torch.randint(0, 256, (n, 3, 224, 224), device=dev).float()
 for name, bn in (("fnet.", False), ("cnet.", True)):
-    w = ops.RaftEncoderWeights(sd, name, bn, ops.BF16)
+    w = ops.RaftEncoderWeights(sd, name, bn, ops.raft_dtype_code(os.environ.get("RAFT_DTYPE", "bf16")))
     for _ in range(2): ops.raft_encoder(w, fr)
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CUDA]) as prof:

@@ -138,10 +138,16 @@ static int vit_impl(const vtgb_vit_args* a, Workspace& ws, hipStream_t s) {
     VTGB_REQUIRE(a->pixel_values && a->weights && (a->out_f32 || a->out_act), VTGB_EINVAL, "vit: You have to specify pixel_values");
     const void* const* w = a->weights;
     // bf16: the LayerNorms folded into the qkv / fc1 GEMMs when the table carries the folded weights (+12 .. +17 of every layer)
-    bool fold = dt == VTGB_BF16 && a->layers > 0 && (D % 4) == 0;
+    // (all six folded slots of every layer or none -- a partially filled block is an error, not a silent fall back; with them present the
+    // unfolded qkv / fc1 weights at +2 / +8 are not read and may be NULL: 1.1 GB of HBM at EVA-ViT-g)
+    int n_fold = 0;
+    for (int l = 0; l < a->layers; l++)
+        for (int k = 12; k < VTGB_VIT_NW_LAYER; k++) n_fold += w[VTGB_VIT_NW_GLOBAL + VTGB_VIT_NW_LAYER * l + k] != nullptr;
+    VTGB_REQUIRE(n_fold == 0 || n_fold == 6 * a->layers, VTGB_EINVAL, "vit: %d of %d folded-LayerNorm table entries are set (all six per layer, or none)", n_fold, 6 * a->layers);
+    const bool fold = dt == VTGB_BF16 && a->layers > 0 && (D % 4) == 0 && n_fold > 0;
     for (int i = 0; i < VTGB_VIT_NW_GLOBAL + VTGB_VIT_NW_LAYER * a->layers; i++) {
         const int li = i < VTGB_VIT_NW_GLOBAL ? -1 : (i - VTGB_VIT_NW_GLOBAL) % VTGB_VIT_NW_LAYER;
-        if (li >= 12) { fold = fold && w[i] != nullptr; continue; }
+        if (li >= 12 || (fold && (li == 2 || li == 8))) continue;
         VTGB_REQUIRE(w[i], VTGB_EINVAL, "vit: weights[%d] is NULL", i);
     }
 

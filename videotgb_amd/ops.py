@@ -304,11 +304,12 @@ class VitWeights(_WeightTable):
         self.layers = 0
         while f"{p}encoder.layers.{self.layers}.self_attn.qkv.weight" in sd:
             lp = f"{p}encoder.layers.{self.layers}."
+            folded = code == BF16 and fold_ln      # (then the unfolded qkv / fc1 weights are never read: not uploaded -- ADVICE r5)
             self.add(sd[lp + "layer_norm1.weight"]); self.add(sd[lp + "layer_norm1.bias"])
-            self.add(sd[lp + "self_attn.qkv.weight"], True); self.add(sd[lp + "self_attn.qkv.bias"])
+            self.add(None if folded else sd[lp + "self_attn.qkv.weight"], True); self.add(sd[lp + "self_attn.qkv.bias"])
             self.add(sd[lp + "self_attn.projection.weight"], True); self.add(sd[lp + "self_attn.projection.bias"])
             self.add(sd[lp + "layer_norm2.weight"]); self.add(sd[lp + "layer_norm2.bias"])
-            self.add(sd[lp + "mlp.fc1.weight"], True); self.add(sd[lp + "mlp.fc1.bias"])
+            self.add(None if folded else sd[lp + "mlp.fc1.weight"], True); self.add(sd[lp + "mlp.fc1.bias"])
             self.add(sd[lp + "mlp.fc2.weight"], True); self.add(sd[lp + "mlp.fc2.bias"])
             # bf16 mode: the two LayerNorms folded into the GEMMs that follow them (include/vtgb.h: +12 .. +17)
             for lnn, lin in (("layer_norm1", "self_attn.qkv"), ("layer_norm2", "mlp.fc1")):
