@@ -46,7 +46,7 @@ typedef struct ihipStream_t* vtgb_stream_t; /* == hipStream_t */
 #define VTGB_F32 0
 #define VTGB_BF16 1
 #define VTGB_BF16X3 2 /* RAFT entry points only: split-bf16 operands (hi | lo pairs, three bf16 MFMA products per fp32 product) */
-#define VTGB_F16C8 3  /* vtgb_raft_update only: fp16 main product + two OCP-fp8 correction products (fp32 accuracy class at 2/3 of VTGB_BF16X3's matrix work) */
+#define VTGB_F16C8 3  /* vtgb_raft_update / vtgb_raft_encoder only: fp16 main product + two OCP-fp8 correction products (fp32 accuracy class at 2/3 of VTGB_BF16X3's matrix work) */
 
 int vtgb_version(void);
 const char* vtgb_last_error(void);
@@ -343,7 +343,9 @@ int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream);
  * [10] .. [17] the GRU convolutions over [h(128) | motion(126) | flow(2)] and [26] .. [29] their `inp` parts (always present: the loop-invariant
  * third is computed once per call into fp32 start maps), [24] / [25] mask.2 with its 0.25 folded in; vtgb_raft_encoder: [0] the stem
  * [64, 4 (tY), 3 x 64] scaled by 2/255, the 1x1 head [256, 3 x 128].
- * VTGB_F16C8 (version 600; vtgb_raft_update only -- the encoders and the correlation volume of that mode run at VTGB_BF16X3): the nine large
+ * VTGB_F16C8 (version 600; vtgb_raft_update and vtgb_raft_encoder -- the correlation volume of that mode runs at VTGB_BF16X3; vtgb_raft_encoder at
+ * VTGB_F16C8 is the VTGB_BF16X3 encoder with the four convolutions of layer1 [entries 2, 4, 8, 10: layer1.{0,1}.conv{1,2}] on these operands and
+ * weights[40] = DEVICE int32 [4], their scale bytes; its later stages, whose outputs feed the correlation directly, stay split-bf16): the nine large
  * convolutions of the update block ([0] convc1, [2] convc2, [8] conv, [10] / [12] / [14] / [16] the GRU's, [18] flow_head.conv1, [22] mask.0) take
  * their operands as  x . w ~ xh . Wh  (fp16 x fp16)  +  2^-11/sw (xl' . Wh8 + xh8 . Wl')  (OCP fp8 on the block-scaled matrix instruction, twice the
  * fp16 rate), xh = fp16(x), xl' = e5m2((x - xh) 2^11), xh8 = e5m2(x), Wh = fp16(w), Wh8 = e4m3(w sw), Wl' = e4m3((w - Wh) sw 2^11), sw a power of two

@@ -20,6 +20,9 @@
 #include "common.h"
 #include "gemm_dev.h"
 #include "pair_h8.h"
+#ifndef H8_VAR
+#define H8_VAR 0      // (timing experiments: tools/exp/build_variant.sh NAME gemm_h8.hip -DH8_VAR=n)
+#endif
 
 constexpr int H_BK = 64;
 constexpr int H_AOP = 256 * H_BK * 2;   // 32 KiB activation slot (256 rows x 128 bytes)
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
     _Pragma("unroll") for (int i = (i0); i < (i1); i++)                                                  \
         _Pragma("unroll") for (int j = (j0); j < (j1); j++) { H_MF8(i, j) }
 #define H_SCHED_IL(PIECES, NMF)                                                                          \
-    if constexpr ((PIECES) > 0 && (NMF) % (PIECES) == 0) {                                               \
+    if constexpr ((H8_VAR & 2) == 0 && (PIECES) > 0 && (NMF) % (PIECES) == 0) {                                               \
         _Pragma("unroll") for (int g_ = 0; g_ < (PIECES); g_++) {                                        \
             __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                                           \
             __builtin_amdgcn_sched_group_barrier(0x008, (NMF) / (PIECES), 0);                            \
@@ -216,6 +219,9 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
 #define H_MF_BLOCK(KIND, i0, i1, j0, j1)                                                                 \
     if constexpr ((KIND) == 1) {                                                                         \
         H_MF8_BLOCK(i0, i1, j0, j1)                                                                      \
+    } else if constexpr ((H8_VAR & 1) != 0) {                                                            \
+        _Pragma("unroll") for (int i = (i0); i < (i1); i++)                                              \
+            _Pragma("unroll") for (int j = (j0); j < (j1); j++) { H_MF16(i, j, 0) H_MF16(i, j, 1) }      \
     } else {                                                                                             \
         _Pragma("unroll") for (int i = (i0); i < (i1); i++)                                              \
             _Pragma("unroll") for (int j = (j0); j < (j1); j++) { H_MF16(i, j, 0) }                      \
@@ -228,9 +234,11 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
         const int a_nxt = a_slot == 2 ? 0 : a_slot + 1;                                                  \
         const int a_prv = a_slot == 0 ? 2 : a_slot - 1;                                                  \
         if (DEFER) { H_ISSUE_A(a_prv) }                                                                  \
+        if constexpr ((H8_VAR & 4) != 0) __builtin_amdgcn_s_setprio(1);                                  \
         H_MF_BLOCK(KIND, 0, WH, 0, XH)                                                                   \
         H_MF_BLOCK(KIND, WH, WF, 0, XH)                                                                  \
         H_SCHED_IL(AI, WF * XH * MPB)                                                                    \
+        if constexpr ((H8_VAR & 4) != 0) __builtin_amdgcn_s_setprio(0);                                  \
         __builtin_amdgcn_sched_barrier(0);                                                               \
         if (WAIT4) __builtin_amdgcn_s_waitcnt(0x0070 | AI);                                              \
         else __builtin_amdgcn_s_waitcnt(0x0070);                                                         \
@@ -240,12 +248,21 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
         {                                                                                                \
             const char* an = smem + a_nxt * A_OP;                                                        \
             const char* wn_ = smem_w + ((kt + 1) & 1) * W_OP;                                            \
+            if constexpr ((H8_VAR & 8) != 0) {                                                           \
+                H_MF_BLOCK(KIND, 0, WH, XH, NX)                                                          \
+                _Pragma("unroll") for (int j = 0; j < XH; j++) { H_LX(j, 0, an) H_LX(j, 1, an) }         \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+                H_MF_BLOCK(KIND, WH, WF, XH, NX)                                                         \
+                _Pragma("unroll") for (int i = 0; i < WH; i++) { H_LW(i, 0, wn_) H_LW(i, 1, wn_) }       \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+            } else {                                                                                     \
             _Pragma("unroll") for (int j = 0; j < XH; j++) { H_LX(j, 0, an) H_LX(j, 1, an) }             \
             H_MF_BLOCK(KIND, 0, WH, XH, NX)                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                           \
             _Pragma("unroll") for (int i = 0; i < WH; i++) { H_LW(i, 0, wn_) H_LW(i, 1, wn_) }           \
             H_MF_BLOCK(KIND, WH, WF, XH, NX)                                                             \
             __builtin_amdgcn_sched_barrier(0);                                                           \
+            }                                                                                            \
             _Pragma("unroll") for (int i = WH; i < WF; i++) { H_LW(i, 0, wn_) H_LW(i, 1, wn_) }          \
             _Pragma("unroll") for (int j = XH; j < NX; j++) { H_LX(j, 0, an) H_LX(j, 1, an) }            \
         }                                                                                                \
@@ -275,7 +292,8 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
         H_PHASE_BARRIER()                      // every wave's LDS reads and DMAs of this tile are done: the ring is free
 
         // ================= the next tile: its setup replaces this tile's DMA state, its first k-tile is issued by the epilogue
-        const int em0 = m0, en0 = n0;
+        const int em0 = m0, en0 = n0, emt = mt;
+        (void)emt;
         const bool eactive = wave_active;
         (void)eactive;
         const int b2 = next_valid(b + (int)gridDim.x, mt, nt);
@@ -355,6 +373,72 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
                         } else {
                             __builtin_amdgcn_raw_buffer_store_b32(lu[0], o_rs, o_part + lo_b + so, 0, 0);
                         }
+                    }
+                }
+            }
+        }
+        if constexpr (EPI == EPI_STORE_F32) {
+            // fp32 outputs (the encoders' layer1: the InstanceNorm / skip pass behind it needs the unrounded sums) through the staging region as whole
+            // 256-byte row segments, with gemm_pp.hip's per-tile column moments (GemmDesc::col_stats: stored per m-tile, added in tile order by
+            // launch_stats_finish_tiles -- no atomics)
+            constexpr int PR = SB / 256 < WROWS ? SB / 256 : WROWS, NP = WROWS / PR;
+            const int rl = lane_e >> 4, cl = lane_e & 15;
+            const bool do_stats = p.col_stats != nullptr;
+            const int img_a = do_stats ? em0 / p.stats_rows : 0;
+            const int m_b = do_stats ? (img_a + 1) * p.stats_rows : 0x7fffffff;
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, qa = sa, sb = sa, qb = sa;
+            const int n = en0 + wn * 64 + cl * 4;
+            const auto o_rs = tile_rsrc(p.out, p.ldo, 4);
+            const unsigned o_lane = n < p.N ? (unsigned)((wm * WROWS + rl) * (int)p.ldo + n) * 4u : OOB;
+            prefetch();
+#pragma unroll
+            for (int ps = 0; ps < NP; ps++) {
+#pragma unroll
+                for (int jj = 0; jj < PR / 16; jj++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int row = jj * 16 + (lane_e & 15), chunk = i * 4 + (lane_e >> 4);
+                        *reinterpret_cast<f32x4*>(stage + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][ps * (PR / 16) + jj];
+                    }
+#pragma unroll
+                for (int rr = 0; rr < PR / 4; rr++) {
+                    const int row = rr * 4 + rl;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 256 + ((cl ^ (row & 15)) << 4));
+                    H_STORE128(__builtin_bit_cast(u32x4_t, v), o_rs, o_lane, (ps * PR + rr * 4) * (int)p.ldo * 4);
+                    if (do_stats) {
+                        const int m = em0 + wm * WROWS + ps * PR + rr * 4 + rl;
+                        if (m < p.M && n < p.N && eactive) {
+                            if (m < m_b) { sa += v; qa += v * v; }
+                            else { sb += v; qb += v * v; }
+                        }
+                    }
+                }
+            }
+            if (do_stats) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    sa[e] += __shfl_xor(sa[e], 16); sa[e] += __shfl_xor(sa[e], 32);
+                    qa[e] += __shfl_xor(qa[e], 16); qa[e] += __shfl_xor(qa[e], 32);
+                    sb[e] += __shfl_xor(sb[e], 16); sb[e] += __shfl_xor(sb[e], 32);
+                    qb[e] += __shfl_xor(qb[e], 16); qb[e] += __shfl_xor(qb[e], 32);
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);      // (my staging reads are done before the region is reused)
+                if (rl == 0) {
+                    f32x4* const pr = reinterpret_cast<f32x4*>(stage);
+                    pr[cl] = sa; pr[16 + cl] = qa; pr[32 + cl] = sb; pr[48 + cl] = qb;    // (a row-inactive wave parks zeros)
+                }
+                H_PHASE_BARRIER()
+                if (tid < 64 * NWN) {
+                    const int wn_ = tid >> 6, c = tid & 63, nc = en0 + wn_ * 64 + c;
+                    if (nc < p.N) {
+                        float t[4] = {0.f, 0.f, 0.f, 0.f};
+                        for (int wm_ = 0; wm_ < MW; wm_++) {
+                            if (em0 + wm_ * WROWS >= p.M) break;
+                            const float* pr = reinterpret_cast<const float*>(smem + A_OP + (wn_ * MW + wm_) * SB);
+#pragma unroll
+                            for (int e = 0; e < 4; e++) t[e] += pr[e * 64 + c];
+                        }
+                        *reinterpret_cast<float4*>(p.col_stats + ((int64_t)emt * p.N + nc) * 4) = make_float4(t[0], t[1], t[2], t[3]);
                     }
                 }
             }
@@ -477,7 +561,8 @@ static int launch_h8(const GemmDesc& d, hipStream_t s) {
     return VTGB_OK;
 }
 
-// Convolution over f16c8 operands (GemmDesc::h8_run > 0).  epi: EPI_SPLIT (pair store; d.h8_out_bf16: as a bf16 pair), EPI_X3ZR, EPI_X3Q.
+// Convolution over f16c8 operands (GemmDesc::h8_run > 0).  epi: EPI_SPLIT (pair store; d.h8_out_bf16: as a bf16 pair), EPI_X3ZR, EPI_X3Q, EPI_STORE_F32
+// (N <= 64: fp32 rows + optional per-tile column moments).
 int launch_conv_h8(const GemmDesc& d_in, hipStream_t s) {
     GemmDesc d = d_in;
     VTGB_REQUIRE(d.conv_KH > 0 && d.conv_H > 0 && d.conv_W > 0 && d.A && d.W && d.out && d.M > 0 && d.N > 0 && d.zero_page, VTGB_EINVAL, "conv h8: bad argument");
@@ -520,10 +605,15 @@ int launch_conv_h8(const GemmDesc& d_in, hipStream_t s) {
                 if (d.N <= 128 || (narrow && d.N > 192)) return launch_h8<EPI_SPLIT, 2, 4, 0>(d, s);
                 return launch_h8<EPI_SPLIT, 4, 4, 0>(d, s);
             }
+            if (d.N <= 64) return launch_h8<EPI_SPLIT, 1, 4, 1>(d, s);      // 256 x 64 tile: eight waves of 32 rows
             if (d.N <= 128) return launch_h8<EPI_SPLIT, 2, 4, 1>(d, s);
             if (d.N <= 192 && (d.N & 7) == 0) return launch_h8<EPI_SPLIT, 4, 3, 1>(d, s);
             if (narrow) return launch_h8<EPI_SPLIT, 2, 4, 1>(d, s);
             return launch_h8<EPI_SPLIT, 4, 4, 1>(d, s);
+        case EPI_STORE_F32:
+            VTGB_REQUIRE(d.N <= 64 && (d.N & 3) == 0 && (d.ldo & 3) == 0 && d.act == 0 && (!d.col_stats || d.stats_rows >= 256), VTGB_EUNSUPPORTED,
+                         "conv h8: fp32 outputs on the 64-wide tile only (the encoders' layer1)");
+            return launch_h8<EPI_STORE_F32, 1, 4, 1>(d, s);
         case EPI_X3ZR:
             VTGB_REQUIRE(d.N == 256 && d.resid && d.aux && d.out2 && ((d.ldr | d.ldaux | d.ldo | d.ldo2 | d.split_lo) & 3) == 0 && d.act == 0 && !d.bias, VTGB_EINVAL,
                          "conv h8: the z | r gate epilogue needs a 256-channel convolution with its start map, h and both outputs");

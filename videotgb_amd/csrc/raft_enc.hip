@@ -234,15 +234,20 @@ static GemmDesc enc_conv(int dt, int Mo, int N, int Ho, int Wo, int K, int Cin, 
     return d;
 }
 int launch_x3_pair_pass(const float* x, int64_t ldx, const float* stats, int HW, const void* resid, int64_t ldr, int r_lo, void* out, int64_t ldo, int o_lo,
-                        int C, int Cpad, int relu_in, int relu_out, int64_t M, hipStream_t s, int h8 = 0);   // raft_x3.hip
+                        int C, int Cpad, int relu_in, int relu_out, int64_t M, hipStream_t s, int h8 = 0, int resid_h8 = 0);   // raft_x3.hip
 
 static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t s) {
     VTGB_REQUIRE(a, VTGB_EINVAL, "raft_encoder: NULL args");
     VTGB_REQUIRE(a->n_images > 0 && a->H >= 64 && a->W >= 64 && (a->H % 8) == 0 && (a->W % 8) == 0 && (a->norm == 0 || a->norm == 1), VTGB_EINVAL,
                  "raft_encoder: bad dims n=%d H=%d W=%d", a->n_images, a->H, a->W);
-    VTGB_REQUIRE(a->dtype == VTGB_BF16 || a->dtype == VTGB_F32 || a->dtype == VTGB_BF16X3, VTGB_EINVAL, "raft_encoder: bad dtype %d", a->dtype);
-    const int n = a->n_images, dt = a->dtype;
-    const bool x3 = dt == VTGB_BF16X3;                 // activations as bf16 pairs: 4 bytes per channel
+    VTGB_REQUIRE(a->dtype == VTGB_BF16 || a->dtype == VTGB_F32 || a->dtype == VTGB_BF16X3 || a->dtype == VTGB_F16C8, VTGB_EINVAL, "raft_encoder: bad dtype %d", a->dtype);
+    // VTGB_F16C8 (round 6): the bf16x3 encoder with layer1 -- the four 3x3 / 64 -> 64 convolutions at half resolution, 54 % of the encoder's FLOPs -- on
+    // f16c8 operands (gemm_h8.hip's 256 x 64 tile: 2 k-tiles per channel chunk and tap instead of 3; tools/exp/f16c8_emul.py: flows 1.30e-4 vs 1.26e-4 from
+    // fp32 with layer1 of BOTH encoders in this form; fnet's later stages, whose outputs feed the correlation directly, stay bf16x3).  weights[40] =
+    // device int32 [4]: the scale bytes of layer1.{0,1}.conv{1,2}
+    const bool h8l1 = a->dtype == VTGB_F16C8;
+    const int n = a->n_images, dt = h8l1 ? VTGB_BF16X3 : a->dtype;
+    const bool x3 = dt == VTGB_BF16X3;                 // activations as pairs: 4 bytes per channel
     const size_t es = x3 ? 4 : dtype_size(dt);
     const int H2 = a->H / 2, W2 = a->W / 2, H4 = a->H / 4, W4 = a->W / 4, H8 = a->H / 8, W8 = a->W / 8;
     const int64_t M2 = (int64_t)n * H2 * W2, M4 = (int64_t)n * H4 * W4, M8 = (int64_t)n * H8 * W8;
@@ -272,14 +277,14 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
 
     // `fused`: the convolution that produced x has already accumulated the moments (stats zeroed before it)
     auto norm = [&](const float* x, int64_t M, int HW, int C, int Cpad, int ldx, const void* resid, void* out, int relu_in, int relu_out,
-                    float* st, bool fused) -> int {
+                    float* st, bool fused, int out_h8 = 0, int resid_h8 = 0) -> int {
         if (inorm && !fused) {
             const int splits = HW >= 4096 ? 16 : HW >= 1024 ? 4 : 1;
             hipLaunchKernelGGL(inorm_stats_kernel, dim3(n, splits), dim3(256), 0, s, x, spart, HW, C, ldx);
             VTGB_TRY(launch_stats_finish_parts(spart, st, n, splits, C, s));
         }
         if (x3)
-            return launch_x3_pair_pass(x, ldx, inorm ? st : nullptr, HW, resid, 2 * Cpad, Cpad, out, 2 * Cpad, Cpad, C, Cpad, relu_in, relu_out, M, s);
+            return launch_x3_pair_pass(x, ldx, inorm ? st : nullptr, HW, resid, 2 * Cpad, Cpad, out, 2 * Cpad, Cpad, C, Cpad, relu_in, relu_out, M, s, out_h8, resid_h8);
         VTGB_REQUIRE(Cpad == 64 || Cpad == 128, VTGB_EUNSUPPORTED, "raft_encoder: normalisation pass over %d padded channels", Cpad);
         const int ppb = 256 / (Cpad / 4);
         VTGB_REQUIRE(M / HW <= 65535, VTGB_EUNSUPPORTED, "raft_encoder: %lld images per call exceed the normalisation pass's grid (chunk the images)", (long long)(M / HW));
@@ -333,7 +338,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
             if (x3) d.algo_flops = 2.0 * (double)M2 * 64 * 147;
             if (!inorm && !x3) { d.epi = VTGB_EPI_STORE; d.act = 1; d.out = act0; }        // relu(bn1(conv1(x))) straight to bf16
             VTGB_TRY(conv_stats(d, stats));
-            if (inorm || x3) VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, sf != nullptr));
+            if (inorm || x3) VTGB_TRY(norm(cf, M2, H2 * W2, 64, 64, 64, nullptr, act0, 1, 0, stats, sf != nullptr, h8l1));      // (f16c8: layer1 reads f16c8 pairs)
         }
     }
     // ---- six residual blocks
@@ -387,6 +392,30 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
                 outb = x;                                                                                       // the block input is dead from here on
             }
             VTGB_TRY(conv_bn(Mo, g, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), 1, res, 1, outb));             // relu(x + relu(bn2(conv2(y))))
+        } else if (h8l1 && b < 2) {
+            // layer1 at VTGB_F16C8: both convolutions over f16c8 pairs with fp32 outputs (+ the InstanceNorm moments for fnet); the block's input / skip operand
+            // is an f16c8 pair, the second block's output a bf16 pair again (layer2 is a bf16x3 launch)
+            VTGB_REQUIRE(w[40], VTGB_EINVAL, "raft_encoder: weights[40] (layer1's scale bytes) is NULL at VTGB_F16C8");
+            auto conv_h8 = [&](const void* A, const void* Wt, const float* bias, float* col_stats, int si) -> int {
+                GemmDesc d;
+                memset(&d, 0, sizeof(d));
+                d.dtype = VTGB_BF16; d.M = (int)Mo; d.N = 64; d.K = 9 * 128; d.epi = VTGB_EPI_STORE_F32;
+                d.A = A; d.lda = 128; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = cf; d.ldo = 64;
+                d.conv_H = g.Ho; d.conv_W = g.Wo; d.conv_KH = 3; d.conv_KW = 3; d.conv_Cin = 128; d.conv_split = 128; d.zero_page = zero;
+                d.col_stats = col_stats; d.stats_rows = HWo;
+                d.h8_run = 9; d.h8_scale = (const int*)w[40] + si;
+                d.algo_flops = 2.0 * Mo * 64.0 * (9 * 64);
+                VTGB_TRY(launch_conv_h8(d, s));
+                if (col_stats) VTGB_TRY(launch_stats_finish_tiles(col_stats, stats, n, HWo, 64, Mo, s));
+                return VTGB_OK;
+            };
+            float* sf = stats_for(stats, HWo, 64);
+            VTGB_TRY(conv_h8(x, bw[0], F(bw[1]), sf, 2 * b));
+            VTGB_TRY(norm(cf, Mo, HWo, 64, 64, 64, nullptr, t1, 1, 0, stats, sf != nullptr, 1));                           // y = relu(norm1(conv1(x)))
+            sf = stats_for(stats, HWo, 64);
+            VTGB_TRY(conv_h8(t1, bw[2], F(bw[3]), sf, 2 * b + 1));
+            outb = t1;
+            VTGB_TRY(norm(cf, Mo, HWo, 64, 64, 64, x, outb, 1, 1, stats, sf != nullptr, b == 0, 1));                       // relu(x + relu(norm2(conv2(y))))
         } else if (x3 && !inorm && g.Cpad == 128) {
             // cnet at bf16x3, 128-channel stages: no statistics are needed, so conv1 (+ ReLU) and the downsample branch leave the convolution as pairs
             // (EPI_SPLIT; the packed weights carry C_pad output rows, the padded ones zero); conv2 needs the skip operand: fp32 + the pair pass

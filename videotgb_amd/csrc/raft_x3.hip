@@ -47,6 +47,7 @@ struct PairPass {
     int C, Cpad, relu_in, relu_out;
     int64_t M;
     int h8;                                     // out as an f16c8 pair (pair_h8.h) instead of a bf16 pair
+    int resid_h8;                               // resid is an f16c8 pair
 };
 __global__ __launch_bounds__(256) void x3_pair_pass_kernel(const PairPass p) {
     const int g = p.Cpad >> 2;
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(256) void x3_pair_pass_kernel(const PairPass p) {
         }
         if (p.resid) {
             const bf16_t* r = p.resid + m * p.ldr + c;
-            v += pair_join4(*reinterpret_cast<const bf16x4*>(r), *reinterpret_cast<const bf16x4*>(r + p.r_lo));
+            if (p.resid_h8) v += h8_join4(*reinterpret_cast<const h8_u32x2*>(r), *reinterpret_cast<const h8_u32x2*>(r + p.r_lo));
+            else v += pair_join4(*reinterpret_cast<const bf16x4*>(r), *reinterpret_cast<const bf16x4*>(r + p.r_lo));
         }
         if (p.relu_out) {
 #pragma unroll
@@ -96,10 +98,10 @@ __global__ __launch_bounds__(256) void x3_pair_pass_kernel(const PairPass p) {
     *reinterpret_cast<bf16x4*>(o + p.o_lo) = lo;
 }
 int launch_x3_pair_pass(const float* x, int64_t ldx, const float* stats, int HW, const void* resid, int64_t ldr, int r_lo, void* out, int64_t ldo, int o_lo,
-                        int C, int Cpad, int relu_in, int relu_out, int64_t M, hipStream_t s, int h8) {
+                        int C, int Cpad, int relu_in, int relu_out, int64_t M, hipStream_t s, int h8, int resid_h8) {
     VTGB_REQUIRE((C & 3) == 0 && (Cpad & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && (o_lo & 3) == 0 && (ldr & 3) == 0 && (r_lo & 3) == 0, VTGB_EINVAL,
                  "pair pass: 4-aligned rows");
-    PairPass p{x, ldx, stats, HW, (const bf16_t*)resid, ldr, r_lo, (bf16_t*)out, ldo, o_lo, C, Cpad, relu_in, relu_out, M, h8};
+    PairPass p{x, ldx, stats, HW, (const bf16_t*)resid, ldr, r_lo, (bf16_t*)out, ldo, o_lo, C, Cpad, relu_in, relu_out, M, h8, resid_h8};
     const int64_t n = M * (Cpad >> 2);
     hipLaunchKernelGGL(x3_pair_pass_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
     VTGB_HIP(hipGetLastError());
@@ -373,7 +375,7 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
             hipLaunchKernelGGL(x3_convf1_kernel, dim3((unsigned)(nt < cap ? nt : cap)), dim3(256), 0, s, flow, F(w[4]), F(w[5]), f1, X, M, H8, W8, h8);
         }
         VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 64, H8, W8, 3, 3, f1, 128, nullptr, 0, w[6], F(w[7]), VTGB_EPI_STORE_F32, 0, Q, 64, 0, zero), s));
-        VTGB_TRY(launch_x3_pair_pass(Q, 64, nullptr, HW, nullptr, 0, 0, CF + 192, 512, 256, 64, 64, 1, 0, M, s, h8));
+        VTGB_TRY(launch_x3_pair_pass(Q, 64, nullptr, HW, nullptr, 0, 0, CF + 192, 512, 256, 64, 64, 1, 0, M, s, h8, 0));
         VTGB_TRY(run(conv(126, 3, 3, CF, 256, nullptr, 0, 8, 2, F(w[9]), VTGB_EPI_SPLIT, 1, X, 256, 128)));
         // ---- SepConvGRU (update.py:50-65): horizontal (1x5) then vertical (5x1); input channels [h(128) | motion(126) | flow(2)], the inp third comes from the start maps
         for (int half = 0; half < 2; half++) {
@@ -406,7 +408,7 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
 extern "C" int vtgb_pair_pack(int32_t fmt, const float* x, void* out, int64_t M, int32_t C, int32_t ld_pair, vtgb_stream_t stream) {
     VTGB_REQUIRE(x && out && M > 0 && C > 0 && (C & 3) == 0 && ld_pair >= C && (ld_pair & 3) == 0 && (fmt == VTGB_F16C8 || fmt == VTGB_BF16X3), VTGB_EINVAL,
                  "pair_pack: bad argument (C=%d ld_pair=%d fmt=%d)", C, ld_pair, fmt);
-    return launch_x3_pair_pass(x, C, nullptr, 1, nullptr, 0, 0, out, 2 * (int64_t)ld_pair, ld_pair, C, ld_pair, 0, 0, M, (hipStream_t)stream, fmt == VTGB_F16C8);
+    return launch_x3_pair_pass(x, C, nullptr, 1, nullptr, 0, 0, out, 2 * (int64_t)ld_pair, ld_pair, C, ld_pair, 0, 0, M, (hipStream_t)stream, fmt == VTGB_F16C8, 0);
 }
 extern "C" int vtgb_pair_conv(const vtgb_pair_conv_args* a, vtgb_stream_t stream) {
     VTGB_REQUIRE(a && a->a && a->weights && a->scale && a->out && a->M > 0 && a->N > 0 && (a->N & 1) == 0 && a->C1 > 0 && (a->C1 % 64) == 0 && a->ld_out >= a->N &&

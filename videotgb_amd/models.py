@@ -293,9 +293,9 @@ class Raft(nn.Module):
     def _hip_tables(self):
         if self._table is None:
             sd = {k: v for k, v in self.state_dict().items()}
-            enc = ops.raft_stage_code(self.code)      # (f16c8: the update block's operand format; encoders / correlation at bf16x3)
-            self._table = (ops.RaftWeights(sd, "update_block.", self.code), ops.RaftEncoderWeights(sd, "fnet.", False, enc),
-                           ops.RaftEncoderWeights(sd, "cnet.", True, enc))
+            # (f16c8: the update block and the encoders' layer1 on fp16 + fp8-correction operands, the other encoder stages and the correlation at bf16x3)
+            self._table = (ops.RaftWeights(sd, "update_block.", self.code), ops.RaftEncoderWeights(sd, "fnet.", False, self.code),
+                           ops.RaftEncoderWeights(sd, "cnet.", True, self.code))
         return self._table
 
     @torch.no_grad()

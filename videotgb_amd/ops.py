@@ -50,8 +50,8 @@ def raft_dtype_code(dtype) -> int:
 
 
 def raft_stage_code(code: int) -> int:
-    """The mode of RAFT's encoders and correlation volume next to an update block at ``code``: the f16c8 operand format exists for the update
-    block's convolutions only (include/vtgb.h) -- its encoders / correlation run at bf16x3."""
+    """The mode of RAFT's correlation volume next to an update block at ``code``: at f16c8 the correlation (and every encoder stage but layer1,
+    include/vtgb.h) runs at bf16x3."""
     return BF16X3 if code == F16C8 else code
 
 
@@ -267,7 +267,7 @@ class _WeightTable:
     def add(self, t: Optional[Tensor], gemm_weight: bool = False, cols_pad: Optional[int] = None, force_f32: bool = False):
         if t is None:
             self.tensors.append(None)
-        elif gemm_weight and not force_f32 and self.code == BF16X3:
+        elif gemm_weight and not force_f32 and self.code in (BF16X3, F16C8):
             self.tensors.append(_bf16_exact(t.reshape(t.shape[0], -1).float()))      # (already split3: bf16 values)
         elif gemm_weight and not force_f32:
             self.tensors.append(pack_weight(t, self.code, cols_pad))
@@ -833,13 +833,18 @@ class RaftEncoderWeights(_WeightTable):
                 b = (b - sd[p + bn + ".running_mean"].float()) * g + sd[p + bn + ".bias"].float()
             return w, b
 
-        x3 = code == BF16X3
+        x3 = code in (BF16X3, F16C8)
+        h8_scales = []      # VTGB_F16C8: layer1's four convolutions on f16c8 operands (csrc/raft_enc.hip), entry [40] = their scale bytes
 
-        def packed(w, cin_pad, cout_pad=None):
+        def packed(w, cin_pad, cout_pad=None, h8=False):
             co, ci, kh, kw = w.shape
             w = w.permute(0, 2, 3, 1)
             if cin_pad != ci:
                 w = torch.nn.functional.pad(w, (0, cin_pad - ci))
+            if h8:
+                sw, byte = h8_weight_scale(w)
+                h8_scales.append(byte)
+                return h8_conv_pack(w, sw)
             w = conv_k_order(split3(w) if x3 else w)
             if batch_norm and cout_pad and cout_pad != co:        # cnet stores activations straight from the GEMM: padded channels = 0
                 w = torch.nn.functional.pad(w, (0, 0, 0, cout_pad - co))
@@ -875,10 +880,15 @@ class RaftEncoderWeights(_WeightTable):
         for li, c, cpad in (("layer1", 64, 64), ("layer2", 96, 128), ("layer3", 128, 128)):
             for bi in range(2):
                 bp = f"{li}.{bi}."
+                h8 = code == F16C8 and li == "layer1"
                 w1, b1 = folded(bp + "conv1", bp + "norm1")
-                self.add(packed(w1, cin_pad, cpad), True); self.add(pbias(b1, cpad))
                 w2, b2 = folded(bp + "conv2", bp + "norm2")
-                self.add(packed(w2, cpad, cpad), True); self.add(pbias(b2, cpad))
+                if h8:      # (raw 16-bit patterns: appended as they are)
+                    self.tensors.append(packed(w1, cin_pad, cpad, True)); self.add(pbias(b1, cpad))
+                    self.tensors.append(packed(w2, cpad, cpad, True)); self.add(pbias(b2, cpad))
+                else:
+                    self.add(packed(w1, cin_pad, cpad), True); self.add(pbias(b1, cpad))
+                    self.add(packed(w2, cpad, cpad), True); self.add(pbias(b2, cpad))
                 if (p + bp + "downsample.0.weight") in sd:
                     wd, bd = folded(bp + "downsample.0", bp + "norm3")
                     self.add(packed(wd, cin_pad, cpad), True); self.add(pbias(bd, cpad))
@@ -888,6 +898,9 @@ class RaftEncoderWeights(_WeightTable):
         wh = sd[p + "conv2.weight"].float().reshape(256, 128)
         self.add(conv_k_order(split3(wh.reshape(256, 1, 1, 128))) if x3 else wh.contiguous(), True)
         self.add(sd[p + "conv2.bias"])
+        if code == F16C8:
+            assert len(self.tensors) == 40 and len(h8_scales) == 4
+            self.tensors.append(torch.tensor(h8_scales, dtype=torch.int32, device=self.tensors[0].device))
         self.finish()
 
 
@@ -897,7 +910,7 @@ def raft_encoder(w: RaftEncoderWeights, images: Tensor, max_images: int = 384) -
     images = images.contiguous().float()
     n, _, H, W = images.shape
     out = torch.empty(n, (H // 8) * (W // 8), 256, dtype=torch.float32, device=images.device)
-    if w.code in (F32, BF16X3):      # 4 bytes per channel of every activation (bf16x3: pairs)
+    if w.code in (F32, BF16X3, F16C8):      # 4 bytes per channel of every activation (bf16x3 / f16c8: pairs)
         max_images = max(max_images // 2, 1)
     for i0 in range(0, n, max_images):
         chunk = images[i0:i0 + max_images]
