@@ -345,7 +345,26 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
             const unsigned o_part = (inw && n < p.N && n + 3 >= p.N) ? o_off : OOB;      // (N % 4 == 2: two columns)
             const bool cut = (p.N & 3) != 0;
             const unsigned lo_b = (unsigned)p.split_lo * 2u;
+            // 64-wide tile (the context encoder's layer1, BatchNorm folded): the ResidualBlock's tail relu(x + relu(conv)) in the epilogue -- resid_bf16 = the
+            // block input as an f16c8 pair (row stride ldrb, second half at + split_lo), post_relu; its rows are requested in front of the next tile's pieces
+            constexpr bool RES = NWN == 1;
+            const bool resd = RES && p.resid_bf16 != nullptr;
+            u32x2_t rh[RES ? PR / 4 : 1], rl8[RES ? PR / 4 : 1];
+            if constexpr (RES) {
+                if (resd) {
+                    const auto r_rs = tile_rsrc(p.resid_bf16, p.ldrb, 2);
+                    const unsigned r_lane = (inw && n + 3 < p.N) ? (unsigned)((wm * WROWS + rl) * (int)p.ldrb + n) * 2u : OOB;
+#pragma unroll
+                    for (int rr = 0; rr < PR / 4; rr++) {
+                        rh[rr] = __builtin_amdgcn_raw_buffer_load_b64(r_rs, r_lane, rr * 4 * (int)p.ldrb * 2, 0);
+                        rl8[rr] = __builtin_amdgcn_raw_buffer_load_b64(r_rs, r_lane + lo_b, rr * 4 * (int)p.ldrb * 2, 0);
+                    }
+                }
+            }
             prefetch();
+            if constexpr (RES) {
+                if (resd) { H_WAIT_OPERANDS() }
+            }
 #pragma unroll
             for (int ps = 0; ps < NP; ps++) {
 #pragma unroll
@@ -360,6 +379,12 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
                     const int row = rr * 4 + rl;
                     f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 256 + ((cl ^ (row & 15)) << 4));
                     if (p.act) apply_act4(v, p.act);
+                    if constexpr (RES) {
+                        if (resd) {      // (NP == 1 on this tile: the one pass's rows)
+                            v += h8_join4(rh[rr], rl8[rr]);
+                            if (p.post_relu) apply_act4(v, 1);
+                        }
+                    }
                     u32x2_t hu, lu;
                     encode(v, hu, lu);
                     const unsigned so = (unsigned)((ps * PR + rr * 4) * (int)p.ldo * 2);
@@ -600,8 +625,10 @@ int launch_conv_h8(const GemmDesc& d_in, hipStream_t s) {
     switch (d.epi) {
         case EPI_SPLIT:
             VTGB_REQUIRE((d.N & 1) == 0 && (d.ldo & 3) == 0 && (d.split_lo & 3) == 0 && d.split_lo > 0, VTGB_EINVAL, "conv h8: pair store needs 4-aligned rows and split_lo");
+            VTGB_REQUIRE(!d.resid_bf16 || (d.N <= 64 && (d.ldrb & 3) == 0), VTGB_EUNSUPPORTED, "conv h8: the residual tail exists on the 64-wide tile only");
             if (d.h8_out_bf16) {
                 VTGB_REQUIRE((d.N & 3) == 0, VTGB_EUNSUPPORTED, "conv h8: bf16-pair output needs N %% 4 == 0");
+                if (d.N <= 64) return launch_h8<EPI_SPLIT, 1, 4, 0>(d, s);
                 if (d.N <= 128 || (narrow && d.N > 192)) return launch_h8<EPI_SPLIT, 2, 4, 0>(d, s);
                 return launch_h8<EPI_SPLIT, 4, 4, 0>(d, s);
             }

@@ -409,6 +409,24 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
                 if (col_stats) VTGB_TRY(launch_stats_finish_tiles(col_stats, stats, n, HWo, 64, Mo, s));
                 return VTGB_OK;
             };
+            if (!inorm) {
+                // cnet (BatchNorm folded: no statistics): ReLU, the skip connection and the pair store live in the convolutions' epilogues -- no fp32 round
+                // trip, no pair pass (the bf16 mode's arrangement, here on f16c8 pairs)
+                auto conv_pair = [&](const void* A, const void* Wt, const float* bias, int si, const void* resid, void* out, int out_bf16) -> int {
+                    GemmDesc d;
+                    memset(&d, 0, sizeof(d));
+                    d.dtype = VTGB_BF16; d.M = (int)Mo; d.N = 64; d.K = 9 * 128; d.epi = VTGB_EPI_SPLIT; d.act = 1;
+                    d.A = A; d.lda = 128; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = out; d.ldo = 128; d.split_lo = 64;
+                    d.conv_H = g.Ho; d.conv_W = g.Wo; d.conv_KH = 3; d.conv_KW = 3; d.conv_Cin = 128; d.conv_split = 128; d.zero_page = zero;
+                    d.resid_bf16 = resid; d.ldrb = 128; d.post_relu = resid != nullptr;
+                    d.h8_run = 9; d.h8_scale = (const int*)w[40] + si; d.h8_out_bf16 = out_bf16;
+                    d.algo_flops = 2.0 * Mo * 64.0 * (9 * 64);
+                    return launch_conv_h8(d, s);
+                };
+                VTGB_TRY(conv_pair(x, bw[0], F(bw[1]), 2 * b, nullptr, t1, 0));                                             // y = relu(bn1(conv1(x)))
+                outb = t2;                                                                                                  // conv2 reads t1 and x: a third buffer
+                VTGB_TRY(conv_pair(t1, bw[2], F(bw[3]), 2 * b + 1, x, outb, b == 1));                                       // relu(x + relu(bn2(conv2(y))))
+            } else {
             float* sf = stats_for(stats, HWo, 64);
             VTGB_TRY(conv_h8(x, bw[0], F(bw[1]), sf, 2 * b));
             VTGB_TRY(norm(cf, Mo, HWo, 64, 64, 64, nullptr, t1, 1, 0, stats, sf != nullptr, 1));                           // y = relu(norm1(conv1(x)))
@@ -416,6 +434,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
             VTGB_TRY(conv_h8(t1, bw[2], F(bw[3]), sf, 2 * b + 1));
             outb = t1;
             VTGB_TRY(norm(cf, Mo, HWo, 64, 64, 64, x, outb, 1, 1, stats, sf != nullptr, b == 0, 1));                       // relu(x + relu(norm2(conv2(y))))
+            }
         } else if (x3 && !inorm && g.Cpad == 128) {
             // cnet at bf16x3, 128-channel stages: no statistics are needed, so conv1 (+ ReLU) and the downsample branch leave the convolution as pairs
             // (EPI_SPLIT; the packed weights carry C_pad output rows, the padded ones zero); conv2 needs the skip operand: fp32 + the pair pass
