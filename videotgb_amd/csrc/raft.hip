@@ -431,6 +431,254 @@ __global__ __launch_bounds__(512, 2) void raft_lookup_convc1_kernel(const CorrPy
 }
 
 // ---------------------------------------------------------------------------------------
+// The same fusion at VTGB_F16C8 (round 6; raft_x3.hip): lookup -> the operand tile as f16c8 pair rows in LDS ([64][392] fp16 values + [64][784 B]
+// correction bytes: taps 4g .. 4g+3 as (xl' x 4, xh8 x 4), csrc/pair_h8.h) -> wave w multiplies it with its 32 channels' weights -- 11 fp16 k-steps of 32
+// (v_mfma_f32_16x16x32_f16) and 6 fp8 k-tiles of 128 bytes (v_mfma_scale_f32_16x16x128_f8f6f4, K = 324 zero-padded to 384), both streamed from L2 in
+// MFMA fragment order (packed once per call from the table's [256][fp16 x 384 | correction bytes x 768]) -> bias, ReLU -> the f16c8 pair rows of c1 leave
+// through LDS as whole 1 KiB rows.  The tile is 113 KB: ONE workgroup per CU (the bf16 form runs two, one's lookup beside the other's MFMAs); what is saved
+// is the 1.5 KB-per-pixel tap tensor's write + read and a launch.
+// ---------------------------------------------------------------------------------------
+constexpr int LH_KS16 = 11, LH_KT8 = 6, LH_LDA8 = 784, LH_LDO = 1040;      // fp16 k-steps, fp8 k-tiles, correction-row pitch (bytes), output-row pitch (bytes)
+constexpr int LH_A16_BYTES = LC_PX * LC_LDA * 2, LH_A8_BYTES = LC_PX * LH_LDA8;
+constexpr int LH_LDS = LH_A16_BYTES + LH_A8_BYTES + LC_WAVES * 4 * 104 * 4;
+constexpr size_t LH_WPK_BYTES = (size_t)LC_WAVES * (LH_KS16 * 2 * 1024 + LH_KT8 * 2 * 2048);
+static_assert(LC_PX * LH_LDO <= LH_A16_BYTES + LH_A8_BYTES, "the output tile reuses the operand tile");
+typedef int lh_i32x4 __attribute__((ext_vector_type(4)));
+typedef int lh_i32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lh_f16x8 __attribute__((ext_vector_type(8)));
+
+// w: [256][768 16-bit units] = per output channel fp16 values of the 384 taps, then 768 correction bytes (ops.h8_conv_pack of a 1x1 convolution).
+// packed (16-byte units): wave w: [ks < 11][i < 2][lane] fp16 fragments (taps ks * 32 + (lane >> 4) * 8 ..), then [t < 6][i < 2][half < 2][lane] the
+// two 16-byte pieces of the fp8 fragment (bytes t * 128 + half * 64 + (lane >> 4) * 16 ..) of channel w * 32 + i * 16 + (lane & 15)
+__global__ __launch_bounds__(256) void raft_lkc1_h8_pack_w_kernel(const bf16_t* __restrict__ w, lh_i32x4* __restrict__ packed) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    constexpr int PER_WAVE = LH_KS16 * 2 * 64 + LH_KT8 * 2 * 2 * 64;
+    if (idx >= LC_WAVES * PER_WAVE) return;
+    const int wv = idx / PER_WAVE, r = idx - wv * PER_WAVE, lane = r & 63;
+    const char* row;
+    int off;
+    if (r < LH_KS16 * 2 * 64) {
+        const int i = (r >> 6) & 1, ks = r >> 7;
+        row = reinterpret_cast<const char*>(w + (int64_t)(wv * 32 + i * 16 + (lane & 15)) * 768);
+        off = (ks * 32 + (lane >> 4) * 8) * 2;
+    } else {
+        const int q = (r - LH_KS16 * 2 * 64) >> 6, half = q & 1, i = (q >> 1) & 1, t = q >> 2;
+        row = reinterpret_cast<const char*>(w + (int64_t)(wv * 32 + i * 16 + (lane & 15)) * 768) + 768;
+        off = t * 128 + half * 64 + (lane >> 4) * 16;
+    }
+    packed[idx] = *reinterpret_cast<const lh_i32x4*>(row + off);
+}
+
+template <typename CT>
+__global__ __launch_bounds__(512, 2) void raft_lookup_convc1_h8_kernel(const CorrPyr pyr, const float* __restrict__ flow, const lh_i32x4* __restrict__ wpk,
+                                                                       const int* __restrict__ scale, const float* __restrict__ bias, bf16_t* __restrict__ c1, int64_t M,
+                                                                       int H8, int W8) {
+    extern __shared__ __attribute__((aligned(16))) char lc_smem[];
+    unsigned short* const At = reinterpret_cast<unsigned short*>(lc_smem);                 // fp16 values [64][LC_LDA]
+    unsigned char* const A8 = reinterpret_cast<unsigned char*>(lc_smem + LH_A16_BYTES);   // correction bytes [64][LH_LDA8]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* const wv = reinterpret_cast<float*>(lc_smem + LH_A16_BYTES + LH_A8_BYTES) + wave * (4 * 104);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int sc_w = *scale;
+    // this wave's fp16 weight fragments of the first three k-steps: in flight during the whole lookup phase
+    const lh_i32x4* wp = wpk + (int64_t)wave * (LH_KS16 * 2 * 64 + LH_KT8 * 2 * 2 * 64) + lane;
+    lh_i32x4 wf[4][2];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) wf[k][i] = wp[(k * 2 + i) * 64];
+    const int wy0 = lane / 10, wx0 = lane - wy0 * 10;
+    const int e1 = lane < 36 ? lane + 64 : 99;
+    const int wy1 = e1 / 10, wx1 = e1 - wy1 * 10;
+    int la[4], lb[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        la[l] = (wy0 * pyr.w[l] + wx0) * (int)sizeof(CT);
+        lb[l] = (wy1 * pyr.w[l] + wx1) * (int)sizeof(CT);
+    }
+    int tap_off[6], frac_off[6];
+#pragma unroll
+    for (int kk = 0; kk < 6; kk++) {
+        const int k = kk * 64 + lane;
+        const int l = k / 81, t = k - l * 81, i = t / 9, j = t - i * 9;
+        tap_off[kk] = k < 324 ? l * 104 + j * 10 + i : 0;
+        frac_off[kk] = (k < 324 ? l : 0) * 104 + 100;
+    }
+    const int HW = H8 * W8;
+    const int64_t m_tile = (int64_t)blockIdx.x * LC_PX, m_first = m_tile + wave * LC_WPX;
+    const int npx = (int)(M - m_first < LC_WPX ? (M - m_first > 0 ? M - m_first : 0) : LC_WPX);
+    if (npx > 0) {
+        const int p_first = (int)(m_first % HW);
+        int sx0, sbase;
+        float sqx, sqy;
+        {
+            const int spi = (lane >> 2) < npx ? (lane >> 2) : npx - 1, sl = lane & 3;
+            int p = p_first + spi;
+            p = p >= HW ? p - HW : p;
+            const float2 f = *reinterpret_cast<const float2*>(flow + (m_first + spi) * 2);
+            const float cx = (float)(p % W8) + f.x, cy = (float)(p / W8) + f.y;
+            const float sc = 1.0f / (float)(1 << sl);
+            const float xs = cx * sc, ys = cy * sc, x0f = floorf(xs), y0f = floorf(ys);
+            const int x0 = (int)fminf(fmaxf(x0f, -32768.f), 32768.f) - 4, y0 = (int)fminf(fmaxf(y0f, -32768.f), 32768.f) - 4;
+            const int wl = sl == 0 ? pyr.w[0] : sl == 1 ? pyr.w[1] : sl == 2 ? pyr.w[2] : pyr.w[3];
+            sx0 = x0;
+            sbase = (y0 * wl + x0) * (int)sizeof(CT);
+            sqx = xs - x0f; sqy = ys - y0f;
+        }
+        CT r[4][8];
+        const CT* lvl0[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) lvl0[l] = reinterpret_cast<const CT*>(pyr.lvl[l]) + m_first * (int64_t)(pyr.h[l] * pyr.w[l]);
+#define LH_FETCH(pi, d)                                                                                 \
+    {                                                                                                   \
+        _Pragma("unroll") for (int l = 0; l < 4; l++) {                                                 \
+            const int hw = pyr.h[l] * pyr.w[l];                                                         \
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<CT*>(lvl0[l] + (unsigned)((pi) * hw)), 0, \
+                                                              hw * (int)sizeof(CT), 0x00020000);        \
+            const int x0 = __builtin_amdgcn_readlane(sx0, (pi) * 4 + l), b0 = __builtin_amdgcn_readlane(sbase, (pi) * 4 + l); \
+            const unsigned oa = (unsigned)(x0 + wx0) < (unsigned)pyr.w[l] ? (unsigned)(b0 + la[l]) : 0xFFFFFFF0u; \
+            const unsigned ob = (unsigned)(x0 + wx1) < (unsigned)pyr.w[l] ? (unsigned)(b0 + lb[l]) : 0xFFFFFFF0u; \
+            r[d][2 * l] = lk_load<CT>(rs, oa);                                                          \
+            r[d][2 * l + 1] = lk_load<CT>(rs, ob);                                                      \
+        }                                                                                               \
+    }
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int pf = d < npx ? d : npx - 1;
+            LH_FETCH(pf, d)
+        }
+        for (int pb = 0; pb < LC_WPX; pb += 4) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const int pi = pb + d;
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                    wv[l * 104 + lane] = (float)r[d][2 * l];
+                    if (lane < 36) wv[l * 104 + lane + 64] = (float)r[d][2 * l + 1];
+                }
+                if ((lane >> 2) == (pi < npx ? pi : npx - 1)) { wv[(lane & 3) * 104 + 100] = sqx; wv[(lane & 3) * 104 + 101] = sqy; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int pf = pi + 4 < npx ? pi + 4 : npx - 1;
+                LH_FETCH(pf, d)
+                const int prow = wave * LC_WPX + pi;
+#pragma unroll
+                for (int kk = 0; kk < 6; kk++) {
+                    const float wx = wv[frac_off[kk]], wy = wv[frac_off[kk] + 1];
+                    const float* q = wv + tap_off[kk];
+                    const lk_f32x2 top = {q[0], q[1]}, bot = {q[10], q[11]};
+                    const lk_f32x2 c = top + wy * (bot - top);
+                    float v = c[0] + wx * (c[1] - c[0]);
+                    if (kk == 5) v = lane < 4 ? v : 0.f;
+                    unsigned short h16; unsigned char lr, lv;
+                    h8_split1(v, h16, lr, lv);
+                    const int k = kk * 64 + lane;
+                    At[prow * LC_LDA + k] = h16;
+                    unsigned char* lo8 = A8 + prow * LH_LDA8 + h8_lo_off(k);
+                    lo8[0] = lr; lo8[4] = lv;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+#undef LH_FETCH
+    }
+    __syncthreads();
+    // ---- [64 pixels][384 taps] x this wave's [32 channels]^T: 11 fp16 k-steps, then 6 fp8 k-tiles (their fragments follow the fp16 ones in the stream)
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + wave * 32 + i * 16 + fg * 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = b;
+    }
+    const lh_i32x4* wp8 = wp + LH_KS16 * 2 * 64;
+    lh_i32x4 w8[2][2][2];      // ring of two fp8 k-tiles: [slot][i][half]
+#pragma unroll
+    for (int ks = 0; ks < LH_KS16; ks++) {
+        if (ks + 3 < LH_KS16) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) wf[(ks + 3) & 3][i] = wp[((ks + 3) * 2 + i) * 64];
+        } else if (ks + 3 - LH_KS16 < 2) {      // the first two fp8 k-tiles, requested under the last fp16 k-steps
+            const int t = ks + 3 - LH_KS16;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) w8[t][i][h] = wp8[((t * 2 + i) * 2 + h) * 64];
+        }
+        lh_i32x4 af[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) af[j] = *reinterpret_cast<const lh_i32x4*>(At + (j * 16 + fr) * LC_LDA + ks * 32 + fg * 8);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(lh_f16x8, wf[ks & 3][i]), __builtin_bit_cast(lh_f16x8, af[j]), acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < LH_KT8; t++) {
+        lh_i32x8 a8[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned char* rp = A8 + (j * 16 + fr) * LH_LDA8 + t * 128 + fg * 16;
+            const lh_i32x4 lo = *reinterpret_cast<const lh_i32x4*>(rp), hi = *reinterpret_cast<const lh_i32x4*>(rp + 64);
+            a8[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        lh_i32x8 wv8[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) wv8[i] = __builtin_shufflevector(w8[t & 1][i][0], w8[t & 1][i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv8[i], a8[j], acc[i][j], 0, 1, 0, sc_w, 0, 127);
+        if (t + 2 < LH_KT8) {
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) w8[t & 1][i][h] = wp8[(((t + 2) * 2 + i) * 2 + h) * 64];
+        }
+    }
+    __syncthreads();                                                  // every wave has read the operand tile: it becomes the output tile
+    char* const Ot = lc_smem;                                          // [64][LH_LDO]: fp16 x 256 | correction bytes x 512
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            f32x4 v = acc[i][j];
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+            h8_u32x2 hu, lu;
+            h8_split4(v, hu, lu);
+            const int ch = wave * 32 + i * 16 + fg * 4;
+            char* o = Ot + (j * 16 + fr) * LH_LDO;
+            *reinterpret_cast<h8_u32x2*>(o + ch * 2) = hu;
+            *reinterpret_cast<h8_u32x2*>(o + 512 + ch * 2) = lu;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int idx = it * 512 + threadIdx.x, px = idx >> 6, c = idx & 63;
+        if (m_tile + px < M)
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(c1 + (m_tile + px) * 512) + c * 16) = *reinterpret_cast<const uint4*>(Ot + px * LH_LDO + c * 16);
+    }
+}
+
+int raft_lkc1_h8_pack(const void* w, void* packed, hipStream_t s) {
+    const int n = LC_WAVES * (LH_KS16 * 2 * 64 + LH_KT8 * 2 * 2 * 64);
+    hipLaunchKernelGGL(raft_lkc1_h8_pack_w_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)w, (lh_i32x4*)packed);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+size_t raft_lkc1_h8_pack_bytes() { return LH_WPK_BYTES; }
+int raft_launch_lookup_convc1_h8(const CorrPyr& pyr, const float* flow, const void* wpk, const int* scale, const float* bias, void* c1, int64_t M, int H8, int W8,
+                                 hipStream_t s) {
+    static DeviceOnce attr;
+    VTGB_FUNC_LDS_ONCE(attr, raft_lookup_convc1_h8_kernel<float>, LH_LDS);
+    hipLaunchKernelGGL(raft_lookup_convc1_h8_kernel<float>, dim3((unsigned)((M + LC_PX - 1) / LC_PX)), dim3(512), LH_LDS, s, pyr, flow, (const lh_i32x4*)wpk, scale, bias,
+                       (bf16_t*)c1, M, H8, W8);
+    VTGB_HIP(hipGetLastError());
+    return VTGB_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // convf1: 7x7 convolution of the 2-channel flow -> 128 channels + ReLU (update.py:82,92) on the matrix cores.
 // K = 49 taps x {x_hi, y_hi, x_lo, y_lo}: the fp32 flow enters as a bf16 head plus a bf16 remainder (exact to
 // ~2^-17) against bf16 weights (each weight appears for the head and the remainder), 196 padded to 224 = 7

@@ -20,6 +20,11 @@
 // (convf2, FlowHead.conv2, mask.2, the once-per-call start maps) and the encoders / correlation volume stay bf16x3.  `h8` below selects the format of
 // the buffers h, r h, motion | flow, corr taps, c1, [cor | flo]; inp, convf1's output and the flow / mask heads' hidden maps stay bf16 pairs.
 int raft_launch_lookup_pair(const CorrPyr& pyr, const float* flow, void* out_pair, int64_t M, int H8, int W8, int h8, hipStream_t s);
+// f16c8: lookup + convc1 as one launch (raft.hip: the taps of a pixel never leave the CU)
+int raft_lkc1_h8_pack(const void* w, void* packed, hipStream_t s);
+size_t raft_lkc1_h8_pack_bytes();
+int raft_launch_lookup_convc1_h8(const CorrPyr& pyr, const float* flow, const void* wpk, const int* scale, const float* bias, void* c1, int64_t M, int H8, int W8,
+                                 hipStream_t s);
 int raft_launch_flow_head2(const float* P2, const float* bias, float* flow, int n_pairs, int H8, int W8, hipStream_t s);
 int raft_launch_upsample(const float* flow, const float* mask, float* flow_up, int n_pairs, int H8, int W8, hipStream_t s);
 
@@ -327,6 +332,7 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     float* mask = (float*)ws.take(M * 576 * 4);
     float* P2 = mask;   // [M, 32] per-tap partial products of FlowHead.conv2 (the mask buffer is idle until the last iteration)
     void* zero = ws.take(256);
+    void* w1pk = ws.take(raft_lkc1_h8_pack_bytes());      // f16c8: convc1's weights in the fused lookup kernel's fragment order
     if (ws.dry) return VTGB_OK;
     VTGB_REQUIRE(ws.ok(), VTGB_EWORKSPACE, "raft_update: workspace %zu < %zu bytes", ws.size, ws.used);
     VTGB_REQUIRE(((a->net && a->inp) || a->cnet_nhwc) && a->weights && a->flow_up, VTGB_EINVAL, "raft_update: NULL operand");
@@ -365,10 +371,15 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
         VTGB_TRY(launch_conv_gemm(mz, s));
         VTGB_TRY(launch_conv_gemm(mq, s));
     }
+    if (h8) VTGB_TRY(raft_lkc1_h8_pack(w[0], w1pk, s));
     for (int it = 0; it < a->iters; it++) {
         // ---- BasicMotionEncoder (update.py:88-97)
-        VTGB_TRY(raft_launch_lookup_pair(pyr, flow, corrf, M, H8, W8, h8, s));
-        VTGB_TRY(run(conv(256, 1, 1, corrf, 384, nullptr, 0, 0, 0, F(w[1]), VTGB_EPI_SPLIT, 1, c1, 512, 256)));
+        if (h8) {      // lookup + convc1 (1x1, 324 -> 256, ReLU) as one launch: the 1.5 KB-per-pixel tap tensor is never written
+            VTGB_TRY(raft_launch_lookup_convc1_h8(pyr, flow, w1pk, hs, F(w[1]), c1, M, H8, W8, s));
+        } else {
+            VTGB_TRY(raft_launch_lookup_pair(pyr, flow, corrf, M, H8, W8, h8, s));
+            VTGB_TRY(run(conv(256, 1, 1, corrf, 384, nullptr, 0, 0, 0, F(w[1]), VTGB_EPI_SPLIT, 1, c1, 512, 256)));
+        }
         VTGB_TRY(run(conv(192, 3, 3, c1, 256, nullptr, 0, 2, 1, F(w[3]), VTGB_EPI_SPLIT, 1, CF, 512, 256)));
         {
             const int64_t nt = (M + CF1_PX - 1) / CF1_PX, cap = (int64_t)cu_count() * 6;      // persistent: six workgroups per CU (26 KB of LDS each)
