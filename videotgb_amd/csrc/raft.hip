@@ -507,7 +507,13 @@ __global__ __launch_bounds__(512, 2) void raft_lookup_convc1_h8_kernel(const Cor
     const int HW = H8 * W8;
     const int64_t m_tile = (int64_t)blockIdx.x * LC_PX, m_first = m_tile + wave * LC_WPX;
     const int npx = (int)(M - m_first < LC_WPX ? (M - m_first > 0 ? M - m_first : 0) : LC_WPX);
-    if (npx > 0) {
+#ifndef LH_ABL
+#define LH_ABL 0        // timing-only ablation builds (tools/exp/build_variant.sh NAME raft.hip -DLH_ABL=n): 1 no lookup phase, 2 no MFMA loops, 4 no output.
+#endif                  // Measured (2.62 ms whole): no lookup 0.99, no MFMA loops 1.84, no output 2.42, neither lookup nor MFMA 0.40 -- the phases ADD (one workgroup
+                        // per CU: 113 KB of LDS); the lookup phase is 1.6 ms here against 0.87 in the bf16 kernel, whose second workgroup hides the gathers'
+                        // latency.  A vector form of the deposit (fp32 staging row, one four-value split and two 8-byte writes per group) changed nothing
+                        // (2.71 vs 2.62 ms): the deposit is not what the phase waits for.
+    if (npx > 0 && !(LH_ABL & 1)) {
         const int p_first = (int)(m_first % HW);
         int sx0, sbase;
         float sqx, sqy;
@@ -593,7 +599,7 @@ __global__ __launch_bounds__(512, 2) void raft_lookup_convc1_h8_kernel(const Cor
     const lh_i32x4* wp8 = wp + LH_KS16 * 2 * 64;
     lh_i32x4 w8[2][2][2];      // ring of two fp8 k-tiles: [slot][i][half]
 #pragma unroll
-    for (int ks = 0; ks < LH_KS16; ks++) {
+    for (int ks = 0; ks < ((LH_ABL & 2) ? 0 : LH_KS16); ks++) {
         if (ks + 3 < LH_KS16) {
 #pragma unroll
             for (int i = 0; i < 2; i++) wf[(ks + 3) & 3][i] = wp[((ks + 3) * 2 + i) * 64];
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void raft_lookup_convc1_h8_kernel(const Cor
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(lh_f16x8, wf[ks & 3][i]), __builtin_bit_cast(lh_f16x8, af[j]), acc[i][j], 0, 0, 0);
     }
 #pragma unroll
-    for (int t = 0; t < LH_KT8; t++) {
+    for (int t = 0; t < ((LH_ABL & 2) ? 0 : LH_KT8); t++) {
         lh_i32x8 a8[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -656,7 +662,7 @@ __global__ __launch_bounds__(512, 2) void raft_lookup_convc1_h8_kernel(const Cor
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const int idx = it * 512 + threadIdx.x, px = idx >> 6, c = idx & 63;
-        if (m_tile + px < M)
+        if (m_tile + px < M && (!(LH_ABL & 4) || bias[0] == 12345.f))
             *reinterpret_cast<uint4*>(reinterpret_cast<char*>(c1 + (m_tile + px) * 512) + c * 16) = *reinterpret_cast<const uint4*>(Ot + px * LH_LDO + c * 16);
     }
 }
