@@ -320,7 +320,8 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     bf16_t* INP = (bf16_t*)ws.take(M * 256 * 2);       // inp (128): read by the start-map convolutions only
     float* ZRI[2] = {(float*)ws.take(M * 256 * 4), (float*)ws.take(M * 256 * 4)};   // per GRU half: bias + the convolution of `inp` (z | r), loop invariant
     float* QI[2] = {(float*)ws.take(M * 128 * 4), (float*)ws.take(M * 128 * 4)};    // ... (q)
-    bf16_t* corrf = (bf16_t*)ws.take(M * 768 * 2);     // 324 taps, zero-padded to 384
+    const int h8 = a->dtype == VTGB_F16C8;
+    bf16_t* corrf = h8 ? nullptr : (bf16_t*)ws.take(M * 768 * 2);     // 324 taps, zero-padded to 384 (f16c8: the taps never leave the fused lookup kernel)
     bf16_t* c1 = (bf16_t*)ws.take(M * 512 * 2);
     bf16_t* CF = (bf16_t*)ws.take(M * 512 * 2);        // [cor(192) | flo(64)]
     bf16_t* f1 = (bf16_t*)ws.take(M * 256 * 2);
@@ -338,7 +339,6 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     VTGB_REQUIRE(((a->net && a->inp) || a->cnet_nhwc) && a->weights && a->flow_up, VTGB_EINVAL, "raft_update: NULL operand");
     VTGB_REQUIRE(!a->corr_f16, VTGB_EINVAL, "raft_update: the bf16x3 / f16c8 modes take an fp32 correlation pyramid");
     const void* const* w = a->weights;
-    const int h8 = a->dtype == VTGB_F16C8;
     for (int i = 0; i < VTGB_RAFT_NW + h8; i++) VTGB_REQUIRE(w[i], VTGB_EINVAL, "raft_update: weights[%d] is NULL (the bf16x3 / f16c8 tables always carry the inp split)", i);
     const int* hs = h8 ? (const int*)w[VTGB_RAFT_NW] : nullptr;      // f16c8: the nine large convolutions' weight-scale bytes (include/vtgb.h)
     // one large convolution in the mode's operand format
