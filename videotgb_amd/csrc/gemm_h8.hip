@@ -21,7 +21,9 @@
 #include "gemm_dev.h"
 #include "pair_h8.h"
 #ifndef H8_VAR
-#define H8_VAR 0      // (timing experiments: tools/exp/build_variant.sh NAME gemm_h8.hip -DH8_VAR=n)
+#define H8_VAR 0      // (timing experiments: tools/exp/build_variant.sh NAME gemm_h8.hip -DH8_VAR=n.  1 / 2 / 4 / 8: schedule variants of the k-loop, all within +-2 %
+                      // of the default; 16: WRONG RESULTS -- the GRU epilogues without their start-map loads: z | r 3.26 -> 3.06 ms, q 1.94 -> 1.81: the upper
+                      // bound of what fragment-order start maps loaded into the accumulators at tile start could save, ~0.35 ms per iteration if half of it)
 #endif
 
 constexpr int H_BK = 64;
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
 #define H_X3_LOAD(sp)                                                                                                  \
     _Pragma("unroll") for (int rr = 0; rr < 4; rr++) {                                                                 \
         const int r0_ = (sp) * 16 + rr * 4;                                                                            \
-        mq[rr] = __builtin_amdgcn_raw_buffer_load_b128(m_rs, m_lane, r0_ * (int)p.ldr * 4, 0);                          \
+        if constexpr ((H8_VAR & 16) == 0) mq[rr] = __builtin_amdgcn_raw_buffer_load_b128(m_rs, m_lane, r0_ * (int)p.ldr * 4, 0); else mq[rr] = u32x4_t{0u, 0u, 0u, 0u};   \
         if (!ZR) zq[rr] = __builtin_amdgcn_raw_buffer_load_b128(z_rs, z_lane, r0_ * ld_z * 4, 0);                        \
         if (!ZR || is_r) {                                                                                             \
             hh[rr] = __builtin_amdgcn_raw_buffer_load_b64(h_rs, h_lane, r0_ * ld_h * 2, 0);                             \
