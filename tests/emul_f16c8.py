@@ -1,7 +1,9 @@
-"""CPU emulation of candidate split-operand schemes for RAFT's convolutions (no GPU): which operand formats keep the flows of the
+"""TEST INFRASTRUCTURE (uses the oracle as the checker; not collected by pytest, not product).  CPU emulation of candidate split-operand schemes for RAFT's convolutions (no GPU): which operand formats keep the flows of the
 input-sensitive weight set at 224 x 224 / 20 iterations within the bf16x3 mode's bound of the fp32 oracle?
 
-    python tools/exp/f16c8_emul.py [scheme ...]      schemes: bf16, bf16x3, f16, f16x2, f16c8, f16c8fix
+    python tests/emul_f16c8.py [scheme ...]      schemes: bf16, bf16x3, f16, f16x2, f16c8, f16c8r (what the device does: e5m2 activations, no
+                                                 data-dependent scale), or a per-part map "m:update=f16c8r,fnet=bf16x3,cnet=bf16x3,layer1=f16c8r"
+                                                 (the LAST key contained in a convolution's name wins; the product's configuration is that one)
 
 bf16x3 : x ~ hi + lo (bf16), w ~ Wh + Wl (bf16): hi.Wh + lo.Wh + hi.Wl                  (the round-5 mode)
 f16c8  : x ~ xh (fp16) + xl, main product xh.Wh in fp16; the two corrections xl.Wh and xh.Wl with BOTH operands in OCP e4m3 (power-of-two
@@ -12,7 +14,7 @@ import sys
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from oracle import vtgb_oracle as O          # noqa: E402
 from videotgb_amd import synth               # noqa: E402
 

@@ -5,7 +5,7 @@
 //            +  2^-11/sw ( xl' . Wh8  +  xh8 . Wl' )    OCP fp8 on v_mfma_scale_f32_16x16x128_f8f6f4, twice the fp16 rate
 // with  xl' = e5m2((x - xh) 2^11),  xh8 = e5m2(x),  Wh8 = e4m3(w sw),  Wl' = e4m3((w - Wh) sw 2^11),  sw = a power of two per layer (pack time).
 // The two corrections are 2^-11 of the product, so the 3-4 significant bits of their operands leave an error of ~2^-16 of the product -- the
-// level of the bf16x3 mode's pairs (tools/exp/f16c8_emul.py: flows 4.4e-5 vs 1.3e-5 rel-RMS from fp32 RAFT with the update block in this form,
+// level of the bf16x3 mode's pairs (tests/emul_f16c8.py: flows 4.4e-5 vs 1.3e-5 rel-RMS from fp32 RAFT with the update block in this form,
 // 1.26e-4 vs 1.18e-4 with the encoders at bf16x3 in both), for 2/3 of its matrix-core time and 2/3 of its operand traffic.  e5m2 has fp16's
 // exponent range, so the activations need NO data-dependent scale: |x| <= 57344 (values beyond saturate) down to 2^-14 keep their bits.
 //

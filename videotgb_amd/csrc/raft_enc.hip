@@ -242,7 +242,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
                  "raft_encoder: bad dims n=%d H=%d W=%d", a->n_images, a->H, a->W);
     VTGB_REQUIRE(a->dtype == VTGB_BF16 || a->dtype == VTGB_F32 || a->dtype == VTGB_BF16X3 || a->dtype == VTGB_F16C8, VTGB_EINVAL, "raft_encoder: bad dtype %d", a->dtype);
     // VTGB_F16C8 (round 6): the bf16x3 encoder with layer1 -- the four 3x3 / 64 -> 64 convolutions at half resolution, 54 % of the encoder's FLOPs -- on
-    // f16c8 operands (gemm_h8.hip's 256 x 64 tile: 2 k-tiles per channel chunk and tap instead of 3; tools/exp/f16c8_emul.py: flows 1.30e-4 vs 1.26e-4 from
+    // f16c8 operands (gemm_h8.hip's 256 x 64 tile: 2 k-tiles per channel chunk and tap instead of 3; tests/emul_f16c8.py: flows 1.30e-4 vs 1.26e-4 from
     // fp32 with layer1 of BOTH encoders in this form; fnet's later stages, whose outputs feed the correlation directly, stay bf16x3).  weights[40] =
     // device int32 [4]: the scale bytes of layer1.{0,1}.conv{1,2}
     const bool h8l1 = a->dtype == VTGB_F16C8;
