@@ -212,9 +212,11 @@ struct GemmDesc {
     // channels] = 2 C 16-bit units (conv_Cin / conv_split / lda count those), K = taps x conv_Cin runs per source `h8_run` fp16 k-tiles then
     // `h8_run` fp8 k-tiles (h8_run = taps x C / 64).  h8_scale: DEVICE pointer to the E8M0 byte (as an int) of 2^-11 / sw, sw = the layer's
     // power-of-two weight scale (ops.py h8_pack).  h8_out_bf16 (EPI_SPLIT): the output pair is written as a bf16 pair [hi | lo] instead.
+    // split_f16c8 (the bf16 kernels' EPI_SPLIT, gemm_pp.hip): a bf16x3 convolution writes its output as an f16c8 pair (its consumer is an h8 launch).
     int h8_run;
     const int* h8_scale;
     int h8_out_bf16;
+    int split_f16c8;
 };
 int launch_conv_h8(const GemmDesc& d, hipStream_t s);   // gemm_h8.hip
 int launch_ln_fold_stats(const float* part, int nblk, int D, float eps, float* stats, int64_t M, hipStream_t s);

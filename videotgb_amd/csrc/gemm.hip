@@ -1235,6 +1235,7 @@ int launch_conv_f32(const GemmDesc& d, hipStream_t s);   // conv_f32.hip: the ex
 static int launch_split(const GemmDesc& d, hipStream_t s) {
     VTGB_REQUIRE(d.conv_KH > 0 && pp_supported(d), VTGB_EUNSUPPORTED, "conv gemm: pair store needs a convolution with N %% 2 == 0, 4-aligned rows and split_lo (N=%d ldo=%lld split_lo=%d)",
                  d.N, (long long)d.ldo, d.split_lo);
+    VTGB_REQUIRE(!d.split_f16c8 || (d.N & 3) == 0, VTGB_EUNSUPPORTED, "conv gemm: an f16c8 pair store needs N %% 4 == 0 (N=%d)", d.N);
     if (d.N <= 128) return launch_large_pp<EPI_SPLIT, true, 2>(d, s);
     if (d.N <= 192 && (d.N & 7) == 0) return launch_large_pp<EPI_SPLIT, true, 4, 3>(d, s);
     return launch_large_pp<EPI_SPLIT, true, 4>(d, s);
@@ -1286,6 +1287,7 @@ int launch_conv_gemm(const GemmDesc& d_in, hipStream_t s) {
     if (d.col_stats)
         VTGB_REQUIRE(d.epi == EPI_STORE_F32 && d.stats_rows >= L_BM && (d.N % 4) == 0 && (d.ldo % 4) == 0 && d.act == 0 && d.out_scale == 0.f,
                      VTGB_EINVAL, "conv gemm: column statistics need fp32 whole-row stores and images of >= 256 rows");
+    VTGB_REQUIRE(!d.split_f16c8 || d.epi == EPI_SPLIT, VTGB_EINVAL, "conv gemm: split_f16c8 belongs to the pair store");
     switch (d.epi) {
         case EPI_STORE: return conv ? launch_large_forced<EPI_STORE, true>(d, s) : launch_large_forced<EPI_STORE, false>(d, s);
         case EPI_STORE_F32: return conv ? launch_large_forced<EPI_STORE_F32, true>(d, s) : launch_large_forced<EPI_STORE_F32, false>(d, s);

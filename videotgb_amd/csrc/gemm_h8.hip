@@ -589,7 +589,7 @@ static int launch_h8(const GemmDesc& d, hipStream_t s) {
 }
 
 // Convolution over f16c8 operands (GemmDesc::h8_run > 0).  epi: EPI_SPLIT (pair store; d.h8_out_bf16: as a bf16 pair), EPI_X3ZR, EPI_X3Q, EPI_STORE_F32
-// (N <= 64: fp32 rows + optional per-tile column moments).
+// (N <= 128: fp32 rows + optional per-tile column moments).
 int launch_conv_h8(const GemmDesc& d_in, hipStream_t s) {
     GemmDesc d = d_in;
     VTGB_REQUIRE(d.conv_KH > 0 && d.conv_H > 0 && d.conv_W > 0 && d.A && d.W && d.out && d.M > 0 && d.N > 0 && d.zero_page, VTGB_EINVAL, "conv h8: bad argument");
@@ -640,9 +640,10 @@ int launch_conv_h8(const GemmDesc& d_in, hipStream_t s) {
             if (narrow) return launch_h8<EPI_SPLIT, 2, 4, 1>(d, s);
             return launch_h8<EPI_SPLIT, 4, 4, 1>(d, s);
         case EPI_STORE_F32:
-            VTGB_REQUIRE(d.N <= 64 && (d.N & 3) == 0 && (d.ldo & 3) == 0 && d.act == 0 && (!d.col_stats || d.stats_rows >= 256), VTGB_EUNSUPPORTED,
-                         "conv h8: fp32 outputs on the 64-wide tile only (the encoders' layer1)");
-            return launch_h8<EPI_STORE_F32, 1, 4, 1>(d, s);
+            VTGB_REQUIRE(d.N <= 128 && (d.N & 3) == 0 && (d.ldo & 3) == 0 && d.act == 0 && (!d.col_stats || d.stats_rows >= 256), VTGB_EUNSUPPORTED,
+                         "conv h8: fp32 outputs on the 64- and 128-wide tiles only (the encoders' residual blocks)");
+            if (d.N <= 64) return launch_h8<EPI_STORE_F32, 1, 4, 1>(d, s);
+            return launch_h8<EPI_STORE_F32, 2, 4, 1>(d, s);
         case EPI_X3ZR:
             VTGB_REQUIRE(d.N == 256 && d.resid && d.aux && d.out2 && ((d.ldr | d.ldaux | d.ldo | d.ldo2 | d.split_lo) & 3) == 0 && d.act == 0 && !d.bias, VTGB_EINVAL,
                          "conv h8: the z | r gate epilogue needs a 256-channel convolution with its start map, h and both outputs");

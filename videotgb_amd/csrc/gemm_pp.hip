@@ -22,6 +22,7 @@
 // Requires K % 64 == 0 and descriptor-addressable operands (launch_* in gemm.hip check).
 #include "common.h"
 #include "gemm_dev.h"
+#include "pair_h8.h"
 
 constexpr int P_BK = 64;
 constexpr int P_AOP = 256 * P_BK * 2;   // 32 KiB activation slot (256 rows)
@@ -751,11 +752,16 @@ gelu_erf_fast4(v);
                     const int row = rr * 4 + rl;
                     f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 256 + ((cl ^ (row & 15)) << 4));
                     if (p.act) apply_act4(v, p.act);
-                    const f32x4 hf = {bf16_round(v[0]), bf16_round(v[1]), bf16_round(v[2]), bf16_round(v[3])};
-                    const bf16x4 hi = {(bf16_t)hf[0], (bf16_t)hf[1], (bf16_t)hf[2], (bf16_t)hf[3]};
-                    const bf16x4 lo = {(bf16_t)(v[0] - hf[0]), (bf16_t)(v[1] - hf[1]), (bf16_t)(v[2] - hf[2]), (bf16_t)(v[3] - hf[3])};
                     const unsigned so = (unsigned)((ps * PR + rr * 4) * (int)p.ldo * 2);
-                    const u32x2_t hu = __builtin_bit_cast(u32x2_t, hi), lu = __builtin_bit_cast(u32x2_t, lo);
+                    u32x2_t hu, lu;
+                    if (p.split_f16c8) {      // (wave-uniform: the consumer is an f16c8 launch -- pair_h8.h)
+                        h8_split4(v, hu, lu);
+                    } else {
+                        const f32x4 hf = {bf16_round(v[0]), bf16_round(v[1]), bf16_round(v[2]), bf16_round(v[3])};
+                        const bf16x4 hi = {(bf16_t)hf[0], (bf16_t)hf[1], (bf16_t)hf[2], (bf16_t)hf[3]};
+                        const bf16x4 lo = {(bf16_t)(v[0] - hf[0]), (bf16_t)(v[1] - hf[1]), (bf16_t)(v[2] - hf[2]), (bf16_t)(v[3] - hf[3])};
+                        hu = __builtin_bit_cast(u32x2_t, hi); lu = __builtin_bit_cast(u32x2_t, lo);
+                    }
                     P_STORE64(hu, o_rs, o_lane, so);
                     P_STORE64(lu, o_rs, o_lane + lo_b, so);
                     if (cut) {

@@ -241,10 +241,10 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
     VTGB_REQUIRE(a->n_images > 0 && a->H >= 64 && a->W >= 64 && (a->H % 8) == 0 && (a->W % 8) == 0 && (a->norm == 0 || a->norm == 1), VTGB_EINVAL,
                  "raft_encoder: bad dims n=%d H=%d W=%d", a->n_images, a->H, a->W);
     VTGB_REQUIRE(a->dtype == VTGB_BF16 || a->dtype == VTGB_F32 || a->dtype == VTGB_BF16X3 || a->dtype == VTGB_F16C8, VTGB_EINVAL, "raft_encoder: bad dtype %d", a->dtype);
-    // VTGB_F16C8 (round 6): the bf16x3 encoder with layer1 -- the four 3x3 / 64 -> 64 convolutions at half resolution, 54 % of the encoder's FLOPs -- on
-    // f16c8 operands (gemm_h8.hip's 256 x 64 tile: 2 k-tiles per channel chunk and tap instead of 3; tests/emul_f16c8.py: flows 1.30e-4 vs 1.26e-4 from
-    // fp32 with layer1 of BOTH encoders in this form; fnet's later stages, whose outputs feed the correlation directly, stay bf16x3).  weights[40] =
-    // device int32 [4]: the scale bytes of layer1.{0,1}.conv{1,2}
+    // VTGB_F16C8 (round 6): the bf16x3 encoder with the stride-1 3x3 convolutions of its residual blocks -- 10 of the 12, 87 % of the encoder's FLOPs -- on
+    // f16c8 operands (gemm_h8.hip: 2 k-tiles per channel chunk and tap instead of 3; tests/emul_f16c8.py: flows 1.35e-4 vs 1.26e-4 rel-RMS from fp32 with
+    // ALL of layer1-3 of both encoders in this form).  The stem, the stride-2 convolutions, the 1x1 downsamples and the 1x1 head -- fnet's head feeds the
+    // correlation directly -- stay bf16x3.  weights[40] = device int32 [12]: the scale bytes of block b's conv1 / conv2 at [2 b] / [2 b + 1]
     const bool h8l1 = a->dtype == VTGB_F16C8;
     const int n = a->n_images, dt = h8l1 ? VTGB_BF16X3 : a->dtype;
     const bool x3 = dt == VTGB_BF16X3;                 // activations as pairs: 4 bytes per channel
@@ -392,48 +392,81 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
                 outb = x;                                                                                       // the block input is dead from here on
             }
             VTGB_TRY(conv_bn(Mo, g, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), 1, res, 1, outb));             // relu(x + relu(bn2(conv2(y))))
-        } else if (h8l1 && b < 2) {
-            // layer1 at VTGB_F16C8: both convolutions over f16c8 pairs with fp32 outputs (+ the InstanceNorm moments for fnet); the block's input / skip operand
-            // is an f16c8 pair, the second block's output a bf16 pair again (layer2 is a bf16x3 launch)
-            VTGB_REQUIRE(w[40], VTGB_EINVAL, "raft_encoder: weights[40] (layer1's scale bytes) is NULL at VTGB_F16C8");
+        } else if (h8l1) {
+            // VTGB_F16C8: every stride-1 3x3 convolution of the residual blocks reads f16c8 pairs (gemm_h8.hip: 2 k-tiles per 64-channel chunk and tap
+            // instead of 3); outputs are fp32 (+ the InstanceNorm moments for fnet) or, for cnet's first convolutions, pairs straight from the epilogue.
+            // The stride-2 blocks' conv1 and 1x1 downsample stay bf16x3 launches over the block input as a bf16 pair: they share that input and a
+            // 1x1's K (2 k-tiles) is below the f16c8 k-loop's minimum.  So the pair format alternates: the first block of a layer hands an f16c8 pair to
+            // the stride-1 block behind it, the second a bf16 pair to the bf16x3 launches that follow (the next layer's stride-2 block; the head).
+            VTGB_REQUIRE(w[40], VTGB_EINVAL, "raft_encoder: weights[40] (the f16c8 convolutions' scale bytes) is NULL at VTGB_F16C8");
+            const int C2 = 2 * g.Cpad;      // 16-bit units per pair row
+            const bool s2 = g.stride != 1;
+            // 3x3, stride 1, g.Cpad -> g.C channels over an f16c8 pair -> cf fp32 [Mo, ld Cpad] (+ per-tile moments)
             auto conv_h8 = [&](const void* A, const void* Wt, const float* bias, float* col_stats, int si) -> int {
                 GemmDesc d;
                 memset(&d, 0, sizeof(d));
-                d.dtype = VTGB_BF16; d.M = (int)Mo; d.N = 64; d.K = 9 * 128; d.epi = VTGB_EPI_STORE_F32;
-                d.A = A; d.lda = 128; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = cf; d.ldo = 64;
-                d.conv_H = g.Ho; d.conv_W = g.Wo; d.conv_KH = 3; d.conv_KW = 3; d.conv_Cin = 128; d.conv_split = 128; d.zero_page = zero;
+                d.dtype = VTGB_BF16; d.M = (int)Mo; d.N = g.C; d.K = 9 * C2; d.epi = VTGB_EPI_STORE_F32;
+                d.A = A; d.lda = C2; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = cf; d.ldo = g.Cpad;
+                d.conv_H = g.Ho; d.conv_W = g.Wo; d.conv_KH = 3; d.conv_KW = 3; d.conv_Cin = C2; d.conv_split = C2; d.zero_page = zero;
                 d.col_stats = col_stats; d.stats_rows = HWo;
-                d.h8_run = 9; d.h8_scale = (const int*)w[40] + si;
-                d.algo_flops = 2.0 * Mo * 64.0 * (9 * 64);
+                d.h8_run = 9 * (g.Cpad / 64); d.h8_scale = (const int*)w[40] + si;
+                d.algo_flops = 2.0 * Mo * (double)g.C * (9 * g.C);
                 VTGB_TRY(launch_conv_h8(d, s));
-                if (col_stats) VTGB_TRY(launch_stats_finish_tiles(col_stats, stats, n, HWo, 64, Mo, s));
+                if (col_stats) VTGB_TRY(launch_stats_finish_tiles(col_stats, stats, n, HWo, g.C, Mo, s));
                 return VTGB_OK;
             };
-            if (!inorm) {
-                // cnet (BatchNorm folded: no statistics): ReLU, the skip connection and the pair store live in the convolutions' epilogues -- no fp32 round
-                // trip, no pair pass (the bf16 mode's arrangement, here on f16c8 pairs)
-                auto conv_pair = [&](const void* A, const void* Wt, const float* bias, int si, const void* resid, void* out, int out_bf16) -> int {
-                    GemmDesc d;
-                    memset(&d, 0, sizeof(d));
-                    d.dtype = VTGB_BF16; d.M = (int)Mo; d.N = 64; d.K = 9 * 128; d.epi = VTGB_EPI_SPLIT; d.act = 1;
-                    d.A = A; d.lda = 128; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = out; d.ldo = 128; d.split_lo = 64;
-                    d.conv_H = g.Ho; d.conv_W = g.Wo; d.conv_KH = 3; d.conv_KW = 3; d.conv_Cin = 128; d.conv_split = 128; d.zero_page = zero;
-                    d.resid_bf16 = resid; d.ldrb = 128; d.post_relu = resid != nullptr;
-                    d.h8_run = 9; d.h8_scale = (const int*)w[40] + si; d.h8_out_bf16 = out_bf16;
-                    d.algo_flops = 2.0 * Mo * 64.0 * (9 * 64);
-                    return launch_conv_h8(d, s);
-                };
+            // the same convolution with ReLU (+ on the 64-wide tile the block's tail relu(x + .)) and the pair store in its epilogue (cnet: BatchNorm folded)
+            auto conv_pair = [&](const void* A, const void* Wt, const float* bias, int si, const void* resid, void* out, int out_bf16) -> int {
+                GemmDesc d;
+                memset(&d, 0, sizeof(d));
+                d.dtype = VTGB_BF16; d.M = (int)Mo; d.N = g.Cpad; d.K = 9 * C2; d.epi = VTGB_EPI_SPLIT; d.act = 1;
+                d.A = A; d.lda = C2; d.W = Wt; d.ldw = d.K; d.bias = bias; d.out = out; d.ldo = C2; d.split_lo = g.Cpad;
+                d.conv_H = g.Ho; d.conv_W = g.Wo; d.conv_KH = 3; d.conv_KW = 3; d.conv_Cin = C2; d.conv_split = C2; d.zero_page = zero;
+                d.resid_bf16 = resid; d.ldrb = C2; d.post_relu = resid != nullptr;
+                d.h8_run = 9 * (g.Cpad / 64); d.h8_scale = (const int*)w[40] + si; d.h8_out_bf16 = out_bf16;
+                d.algo_flops = 2.0 * Mo * (double)g.C * (9 * g.C);
+                return launch_conv_h8(d, s);
+            };
+            const int out_h8 = (b & 1) == 0;      // the block's output pair: f16c8 for the stride-1 block behind it, bf16 for a bf16x3 consumer
+            if (!inorm && g.Cpad == 64) {
+                // cnet layer1: no statistics, so ReLU, the skip connection and the pair store live in the convolutions' epilogues -- no fp32 round trip, no pair pass
                 VTGB_TRY(conv_pair(x, bw[0], F(bw[1]), 2 * b, nullptr, t1, 0));                                             // y = relu(bn1(conv1(x)))
                 outb = t2;                                                                                                  // conv2 reads t1 and x: a third buffer
-                VTGB_TRY(conv_pair(t1, bw[2], F(bw[3]), 2 * b + 1, x, outb, b == 1));                                       // relu(x + relu(bn2(conv2(y))))
+                VTGB_TRY(conv_pair(t1, bw[2], F(bw[3]), 2 * b + 1, x, outb, !out_h8));                                      // relu(x + relu(bn2(conv2(y))))
+            } else if (!inorm) {
+                // cnet layer2 / layer3: conv1 (+ ReLU) and the downsample branch leave their convolutions as pairs; conv2 needs the skip operand: fp32 + the pair pass
+                auto split_conv = [&](int K, const void* Wt, const float* bias, int relu, void* out, int f16c8) -> int {
+                    GemmDesc d = enc_conv(dt, (int)Mo, g.Cpad, g.Ho, g.Wo, K, Cin_pad, g.stride, Hi, Wi, x, Wt, bias, nullptr, C2, zero, nullptr);
+                    d.epi = VTGB_EPI_SPLIT; d.act = relu; d.out = out; d.split_lo = g.Cpad; d.split_f16c8 = f16c8;
+                    d.algo_flops = 2.0 * Mo * (double)g.C * (K * K * Cin_pad);
+                    return launch_conv_gemm(d, s);
+                };
+                if (s2) VTGB_TRY(split_conv(3, bw[0], F(bw[1]), 1, t1, 1));                                                 // y = relu(bn1(conv1(x))), bf16x3 -> f16c8 pair
+                else VTGB_TRY(conv_pair(x, bw[0], F(bw[1]), 2 * b, nullptr, t1, 0));
+                VTGB_TRY(conv_h8(t1, bw[2], F(bw[3]), nullptr, 2 * b + 1));
+                const void* res = x;
+                if (s2) {                                                                                                   // x = bn3(downsample(x)): a bf16 pair
+                    VTGB_TRY(split_conv(1, bw[4], F(bw[5]), 0, t2, 0));
+                    res = t2;
+                }
+                outb = t1;
+                VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, res, outb, 1, 1, stats, false, out_h8, !s2));               // relu(x + relu(bn2(conv2(y))))
             } else {
-            float* sf = stats_for(stats, HWo, 64);
-            VTGB_TRY(conv_h8(x, bw[0], F(bw[1]), sf, 2 * b));
-            VTGB_TRY(norm(cf, Mo, HWo, 64, 64, 64, nullptr, t1, 1, 0, stats, sf != nullptr, 1));                           // y = relu(norm1(conv1(x)))
-            sf = stats_for(stats, HWo, 64);
-            VTGB_TRY(conv_h8(t1, bw[2], F(bw[3]), sf, 2 * b + 1));
-            outb = t1;
-            VTGB_TRY(norm(cf, Mo, HWo, 64, 64, 64, x, outb, 1, 1, stats, sf != nullptr, b == 0, 1));                       // relu(x + relu(norm2(conv2(y))))
+                float* sf = stats_for(stats, HWo, g.C);
+                if (s2) VTGB_TRY(conv_stats(enc_conv(dt, (int)Mo, g.C, g.Ho, g.Wo, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), cf, g.Cpad, zero, sf), stats));
+                else VTGB_TRY(conv_h8(x, bw[0], F(bw[1]), sf, 2 * b));
+                VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t1, 1, 0, stats, sf != nullptr, 1));               // y = relu(norm1(conv1(x))), f16c8 pair
+                sf = stats_for(stats, HWo, g.C);
+                VTGB_TRY(conv_h8(t1, bw[2], F(bw[3]), sf, 2 * b + 1));
+                const void* res = x;
+                if (s2) {                                                                                                   // x = norm3(downsample(x)): a bf16 pair
+                    float* sf2 = stats_for(stats2, HWo, g.C);
+                    VTGB_TRY(conv_stats(enc_conv(dt, (int)Mo, g.C, g.Ho, g.Wo, 1, Cin_pad, g.stride, Hi, Wi, x, bw[4], F(bw[5]), cf2, g.Cpad, zero, sf2), stats2));
+                    VTGB_TRY(norm(cf2, Mo, HWo, g.C, g.Cpad, g.Cpad, nullptr, t2, 0, 0, stats2, sf2 != nullptr));
+                    res = t2;
+                }
+                outb = t1;
+                VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, res, outb, 1, 1, stats, sf != nullptr, out_h8, !s2));       // relu(x + relu(norm2(conv2(y))))
             }
         } else if (x3 && !inorm && g.Cpad == 128) {
             // cnet at bf16x3, 128-channel stages: no statistics are needed, so conv1 (+ ReLU) and the downsample branch leave the convolution as pairs

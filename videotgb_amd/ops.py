@@ -834,16 +834,18 @@ class RaftEncoderWeights(_WeightTable):
             return w, b
 
         x3 = code in (BF16X3, F16C8)
-        h8_scales = []      # VTGB_F16C8: layer1's four convolutions on f16c8 operands (csrc/raft_enc.hip), entry [40] = their scale bytes
+        h8_scales = [0] * 12      # VTGB_F16C8: the stride-1 3x3 convolutions on f16c8 operands (csrc/raft_enc.hip), entry [40] = their scale bytes
 
-        def packed(w, cin_pad, cout_pad=None, h8=False):
+        def packed(w, cin_pad, cout_pad=None, h8=None):
             co, ci, kh, kw = w.shape
             w = w.permute(0, 2, 3, 1)
             if cin_pad != ci:
                 w = torch.nn.functional.pad(w, (0, cin_pad - ci))
-            if h8:
+            if h8 is not None:      # (slot of the scale byte: 2 * block + conv)
+                if batch_norm and cout_pad and cout_pad != co:
+                    w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - co))
                 sw, byte = h8_weight_scale(w)
-                h8_scales.append(byte)
+                h8_scales[h8] = byte
                 return h8_conv_pack(w, sw)
             w = conv_k_order(split3(w) if x3 else w)
             if batch_norm and cout_pad and cout_pad != co:        # cnet stores activations straight from the GEMM: padded channels = 0
@@ -877,17 +879,20 @@ class RaftEncoderWeights(_WeightTable):
             wp = conv_k_order(split3(wp.reshape(64, 4, 1, 64)))
         self.add(wp.reshape(64, -1).contiguous(), True); self.add(b)
         cin_pad = 64
-        for li, c, cpad in (("layer1", 64, 64), ("layer2", 96, 128), ("layer3", 128, 128)):
+        for l, (li, c, cpad) in enumerate((("layer1", 64, 64), ("layer2", 96, 128), ("layer3", 128, 128))):
             for bi in range(2):
                 bp = f"{li}.{bi}."
-                h8 = code == F16C8 and li == "layer1"
+                blk = 2 * l + bi
                 w1, b1 = folded(bp + "conv1", bp + "norm1")
                 w2, b2 = folded(bp + "conv2", bp + "norm2")
-                if h8:      # (raw 16-bit patterns: appended as they are)
-                    self.tensors.append(packed(w1, cin_pad, cpad, True)); self.add(pbias(b1, cpad))
-                    self.tensors.append(packed(w2, cpad, cpad, True)); self.add(pbias(b2, cpad))
+                # f16c8: every stride-1 3x3 (raw 16-bit patterns: appended as they are); the stride-2 conv1 of layer2.0 / layer3.0 stays bf16x3
+                if code == F16C8 and (l == 0 or bi == 1):
+                    self.tensors.append(packed(w1, cin_pad, cpad, 2 * blk)); self.add(pbias(b1, cpad))
                 else:
                     self.add(packed(w1, cin_pad, cpad), True); self.add(pbias(b1, cpad))
+                if code == F16C8:
+                    self.tensors.append(packed(w2, cpad, cpad, 2 * blk + 1)); self.add(pbias(b2, cpad))
+                else:
                     self.add(packed(w2, cpad, cpad), True); self.add(pbias(b2, cpad))
                 if (p + bp + "downsample.0.weight") in sd:
                     wd, bd = folded(bp + "downsample.0", bp + "norm3")
@@ -899,7 +904,7 @@ class RaftEncoderWeights(_WeightTable):
         self.add(conv_k_order(split3(wh.reshape(256, 1, 1, 128))) if x3 else wh.contiguous(), True)
         self.add(sd[p + "conv2.bias"])
         if code == F16C8:
-            assert len(self.tensors) == 40 and len(h8_scales) == 4
+            assert len(self.tensors) == 40
             self.tensors.append(torch.tensor(h8_scales, dtype=torch.int32, device=self.tensors[0].device))
         self.finish()
 
