@@ -17,13 +17,19 @@
 //     1a (w lo, x lo)   1b (w hi, x lo)   -- barrier: next k-tile landed --   2a (w lo, x hi) + read x lo'   2b (w hi, x hi) + read w lo'
 //     tail: read w hi', x hi' (they land under the next tile's phase 1a)
 // with no more registers than the two fragment sets of the fp16 loop.
+#include <type_traits>
 #include "common.h"
 #include "gemm_dev.h"
 #include "pair_h8.h"
 #ifndef H8_VAR
 #define H8_VAR 0      // (timing experiments: tools/exp/build_variant.sh NAME gemm_h8.hip -DH8_VAR=n.  1 / 2 / 4 / 8: schedule variants of the k-loop, all within +-2 %
                       // of the default; 16: WRONG RESULTS -- the GRU epilogues without their start-map loads: z | r 3.26 -> 3.06 ms, q 1.94 -> 1.81: the upper
-                      // bound of what fragment-order start maps loaded into the accumulators at tile start could save, ~0.35 ms per iteration if half of it)
+                      // bound of what fragment-order start maps loaded into the accumulators at tile start could save, ~0.35 ms per iteration if half of it;
+                      // 32: NO RESULTS -- the k-loops alone, every epilogue removed)
+#endif
+
+#ifndef H8_DELAY
+#define H8_DELAY 6    // (H8_VAR & 64: s_sleep(127) units, ~3.4 us each, per start phase)
 #endif
 
 constexpr int H_BK = 64;
@@ -35,6 +41,8 @@ typedef _Float16 h8_f16x8 __attribute__((ext_vector_type(8)));
 
 #define H_STORE128(data, rs, lane_off, soff) __builtin_amdgcn_raw_buffer_store_b128(data, rs, (lane_off) + (unsigned)(soff), 0, 0)
 #define H_STORE64(data, rs, lane_off, soff) __builtin_amdgcn_raw_buffer_store_b64(data, rs, (lane_off) + (unsigned)(soff), 0, 0)
+// s_waitcnt immediate for vmcnt(n) alone (gfx9: vmcnt = bits 3:0 and 15:14; expcnt / lgkmcnt left at their maxima)
+constexpr int h8_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 #define H_PHASE_BARRIER() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
 
 // OFMT: what the pair-writing epilogues store -- 1 the f16c8 pair (pair_h8.h), 0 the bf16 pair [hi | lo] of the bf16x3 kernels (FlowHead.conv1 /
@@ -170,6 +178,12 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
 
     int b = next_valid(first_q, mt, nt);
     if (b < 0) return;
+#if (H8_VAR & 64)
+    {   // (timing experiment: four start phases a quarter of a tile apart, so that the CUs' epilogues -- HBM bursts -- do not coincide)
+        const int steps = (((int)blockIdx.x >> 3) & 3) * H8_DELAY;
+        for (int i = 0; i < steps; i++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     H_TILE_SETUP()
     H_ISSUE_A(0)
     H_ISSUE_W(0, 0)
@@ -336,7 +350,15 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
                 hu = __builtin_bit_cast(u32x2_t, hi); lu = __builtin_bit_cast(u32x2_t, lo);
             }
         };
-        if constexpr (EPI == EPI_SPLIT) {
+        constexpr bool NO_EPI = (H8_VAR & 32) != 0;
+        if constexpr (NO_EPI) {      // (timing experiment: the k-loops alone -- the accumulators are kept alive, nothing is stored)
+            prefetch();
+#pragma unroll
+            for (int i = 0; i < WF; i++)
+#pragma unroll
+                for (int j = 0; j < NX; j++) asm volatile("" ::"v"(acc[i][j]));
+        }
+        if constexpr (EPI == EPI_SPLIT && !NO_EPI) {
             constexpr int PR = SB / 256 < WROWS ? SB / 256 : WROWS, NP = WROWS / PR;
             const int rl = lane_e >> 4, cl = lane_e & 15;
             const int n = en0 + wn * WC + cl * 4;
@@ -404,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
                 }
             }
         }
-        if constexpr (EPI == EPI_STORE_F32) {
+        if constexpr (EPI == EPI_STORE_F32 && !NO_EPI) {
             // fp32 outputs (the encoders' layer1: the InstanceNorm / skip pass behind it needs the unrounded sums) through the staging region as whole
             // 256-byte row segments, with gemm_pp.hip's per-tile column moments (GemmDesc::col_stats: stored per m-tile, added in tile order by
             // launch_stats_finish_tiles -- no atomics)
@@ -470,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
                 }
             }
         }
-        if constexpr (EPI == EPI_X3ZR || EPI == EPI_X3Q) {
+        if constexpr ((EPI == EPI_X3ZR || EPI == EPI_X3Q) && !NO_EPI) {
             // SepConvGRU gates in the convolution's epilogue (common.h: VTGB_EPI_X3ZR / X3Q), h / r h / h' as f16c8 pairs
             static_assert(EPI == EPI_SPLIT || OFMT == 1, "the GRU's pairs are f16c8 pairs");
             constexpr bool ZR = EPI == EPI_X3ZR;
@@ -478,7 +500,8 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
             static_assert(EPI == EPI_SPLIT || PR == 32, "two sub-passes of 16 rows per staged pass");
             const int rl = lane_e >> 4, cl = lane_e & 15;
             const int n = en0 + wn * 64 + cl * 4;
-            const bool is_r = ZR && n >= 128;                      // wave-uniform
+            const bool is_r = ZR && en0 + wn * 64 >= 128;          // wave-uniform, and from scalar values only: as `n >= 128` (n holds the lane's column) hipcc predicated
+                                                                   // the r waves' loads under exec masks and its own waits then drained the previous sub-pass's stores
             const int c = is_r ? n - 128 : n;
             const int rowl = wm * WROWS + rl;
             const unsigned lo_b = (unsigned)p.split_lo * 2u;
@@ -490,74 +513,90 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
             const bool ok = n < p.N;
             const unsigned m_lane = ok ? (unsigned)(rowl * (int)p.ldr + n) * 4u : OOB, h_lane = ok ? (unsigned)(rowl * ld_h + c) * 2u : OOB;
             const unsigned z_lane = ok ? (unsigned)(rowl * ld_z + c) * 4u : OOB, o_lane = ok ? (unsigned)(rowl * ld_o + c) * 2u : OOB;
-            u32x4_t mq[4], zq[4];
-            u32x2_t hh[4], hl[4];
+            // One straight-line instance per wave role (IS_R: the r columns of the z | r launch; the q launch has one role): with the role as a run-time
+            // condition inside the loops hipcc's own s_waitcnt at every join assumed the conditional loads away and drained the previous sub-pass's
+            // stores before each sub-pass (vmcnt(3) .. vmcnt(0) in front of the four rows).  Operands are requested TWO sub-passes ahead into
+            // alternating register sets (the k-loop's fragment registers are dead here).
+            auto gru_epilogue = [&](auto role) {
+                constexpr bool IS_R = decltype(role)::value;
+                constexpr bool HL = !ZR || IS_R;           // this role reads h
+                constexpr int NLD = (ZR ? 4 : 8) + (HL ? 8 : 0), NST = (ZR && !IS_R) ? 4 : 8;      // vector-memory operations per sub-pass: loads, stores
+                u32x4_t mq[2][4], zq[2][4];
+                u32x2_t hh[2][4], hl[2][4];
 #define H_X3_LOAD(sp)                                                                                                  \
     _Pragma("unroll") for (int rr = 0; rr < 4; rr++) {                                                                 \
         const int r0_ = (sp) * 16 + rr * 4;                                                                            \
-        if constexpr ((H8_VAR & 16) == 0) mq[rr] = __builtin_amdgcn_raw_buffer_load_b128(m_rs, m_lane, r0_ * (int)p.ldr * 4, 0); else mq[rr] = u32x4_t{0u, 0u, 0u, 0u};   \
-        if (!ZR) zq[rr] = __builtin_amdgcn_raw_buffer_load_b128(z_rs, z_lane, r0_ * ld_z * 4, 0);                        \
-        if (!ZR || is_r) {                                                                                             \
-            hh[rr] = __builtin_amdgcn_raw_buffer_load_b64(h_rs, h_lane, r0_ * ld_h * 2, 0);                             \
-            hl[rr] = __builtin_amdgcn_raw_buffer_load_b64(h_rs, h_lane + lo_b, r0_ * ld_h * 2, 0);                      \
+        const int S_ = (sp) & 1;                                                                                       \
+        if constexpr ((H8_VAR & 16) == 0) mq[S_][rr] = __builtin_amdgcn_raw_buffer_load_b128(m_rs, m_lane, r0_ * (int)p.ldr * 4, 0); else mq[S_][rr] = u32x4_t{0u, 0u, 0u, 0u};   \
+        if constexpr (!ZR) zq[S_][rr] = __builtin_amdgcn_raw_buffer_load_b128(z_rs, z_lane, r0_ * ld_z * 4, 0);         \
+        if constexpr (HL) {                                                                                            \
+            hh[S_][rr] = __builtin_amdgcn_raw_buffer_load_b64(h_rs, h_lane, r0_ * ld_h * 2, 0);                         \
+            hl[S_][rr] = __builtin_amdgcn_raw_buffer_load_b64(h_rs, h_lane + lo_b, r0_ * ld_h * 2, 0);                  \
         }                                                                                                              \
     }
-            H_X3_LOAD(0)
-            prefetch();
+                H_X3_LOAD(0)
+                prefetch();
+                H_X3_LOAD(1)
 #pragma unroll
-            for (int ps = 0; ps < NP; ps++) {
+                for (int ps = 0; ps < NP; ps++) {
 #pragma unroll
-                for (int jj = 0; jj < PR / 16; jj++)
+                    for (int jj = 0; jj < PR / 16; jj++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int row = jj * 16 + (lane_e & 15), chunk = i * 4 + (lane_e >> 4);
-                        *reinterpret_cast<f32x4*>(stage + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][ps * (PR / 16) + jj];
-                    }
-#pragma unroll
-                for (int sub = 0; sub < 2; sub++) {
-                    const int sp = ps * 2 + sub;
-                    if (sp == 0) { H_WAIT_OPERANDS() }
-                    else if (!ZR || is_r) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);     // the previous sub-pass's 8 stores may still fly
-                    else __builtin_amdgcn_s_waitcnt(0x0F70 | 4);                     // (z waves: 4 stores)
-                    f32x4 res[4];
-#pragma unroll
-                    for (int rr = 0; rr < 4; rr++) {
-                        const int row = sub * 16 + rr * 4 + rl;
-                        f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 256 + ((cl ^ (row & 15)) << 4));
-                        v += __builtin_bit_cast(f32x4, mq[rr]);
-                        if constexpr (ZR) {
-#pragma unroll
-                            for (int e = 0; e < 4; e++) v[e] = __frcp_rn(1.0f + __expf(-v[e]));
-                            if (is_r) v *= h8_join4(hh[rr], hl[rr]);
-                        } else {
-                            const f32x4 z = __builtin_bit_cast(f32x4, zq[rr]);
-                            const f32x4 h = h8_join4(hh[rr], hl[rr]);
-#pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                const float q = 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v[e]) + 1.0f);
-                                v[e] = (1.0f - z[e]) * h[e] + z[e] * q;
-                            }
+                        for (int i = 0; i < 4; i++) {
+                            const int row = jj * 16 + (lane_e & 15), chunk = i * 4 + (lane_e >> 4);
+                            *reinterpret_cast<f32x4*>(stage + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][ps * (PR / 16) + jj];
                         }
-                        res[rr] = v;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (sp + 1 < NS) { H_X3_LOAD(sp + 1) }       // the next sub-pass's operands (same registers), before this sub-pass's stores
-                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int rr = 0; rr < 4; rr++) {
-                        const unsigned r0 = (unsigned)(sp * 16 + rr * 4);
-                        if (ZR && !is_r) {
-                            H_STORE128(__builtin_bit_cast(u32x4_t, res[rr]), z_rs, z_lane, r0 * (unsigned)ld_z * 4u);
-                        } else {
-                            u32x2_t hu, lu;
-                            encode(res[rr], hu, lu);
-                            H_STORE64(hu, o_rs, o_lane, r0 * (unsigned)ld_o * 2u);
-                            H_STORE64(lu, o_rs, o_lane + lo_b, r0 * (unsigned)ld_o * 2u);
+                    for (int sub = 0; sub < 2; sub++) {
+                        const int sp = ps * 2 + sub;
+                        constexpr int AHEAD = NLD + NST;      // in flight behind this sub-pass's operands: the next sub-pass's loads, the previous one's stores
+                        if (sp == 0) {
+                            if (has_next) __builtin_amdgcn_s_waitcnt(h8_vmcnt(NPRE + NLD)); else __builtin_amdgcn_s_waitcnt(h8_vmcnt(NLD));
+                        } else if (sp + 1 < NS) __builtin_amdgcn_s_waitcnt(h8_vmcnt(AHEAD));
+                        else __builtin_amdgcn_s_waitcnt(h8_vmcnt(NST));
+                        const int S = sp & 1;
+                        f32x4 res[4];
+#pragma unroll
+                        for (int rr = 0; rr < 4; rr++) {
+                            const int row = sub * 16 + rr * 4 + rl;
+                            f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 256 + ((cl ^ (row & 15)) << 4));
+                            v += __builtin_bit_cast(f32x4, mq[S][rr]);
+                            if constexpr (ZR) {
+#pragma unroll
+                                for (int e = 0; e < 4; e++) v[e] = __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));      // (v_rcp_f32: 1 ulp; __frcp_rn expands to the 10-instruction IEEE division)
+                                if constexpr (IS_R) v *= h8_join4(hh[S][rr], hl[S][rr]);
+                            } else {
+                                const f32x4 z = __builtin_bit_cast(f32x4, zq[S][rr]);
+                                const f32x4 h = h8_join4(hh[S][rr], hl[S][rr]);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const float q = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v[e]) + 1.0f);
+                                    v[e] = (1.0f - z[e]) * h[e] + z[e] * q;
+                                }
+                            }
+                            res[rr] = v;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (sp + 2 < NS) { H_X3_LOAD(sp + 2) }       // into the set this sub-pass has just consumed, before this sub-pass's stores
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int rr = 0; rr < 4; rr++) {
+                            const unsigned r0 = (unsigned)(sp * 16 + rr * 4);
+                            if constexpr (ZR && !IS_R) {
+                                H_STORE128(__builtin_bit_cast(u32x4_t, res[rr]), z_rs, z_lane, r0 * (unsigned)ld_z * 4u);
+                            } else {
+                                u32x2_t hu, lu;
+                                encode(res[rr], hu, lu);
+                                H_STORE64(hu, o_rs, o_lane, r0 * (unsigned)ld_o * 2u);
+                                H_STORE64(lu, o_rs, o_lane + lo_b, r0 * (unsigned)ld_o * 2u);
+                            }
                         }
                     }
                 }
-            }
 #undef H_X3_LOAD
+            };
+            if (is_r) gru_epilogue(std::true_type{});
+            else gru_epilogue(std::false_type{});
         }
         if (!has_next) break;
         b = b2;

@@ -781,7 +781,8 @@ gelu_erf_fast4(v);
             static_assert(PR == 32, "two sub-passes of 16 rows per staged pass");
             const int rl = lane_e >> 4, cl = lane_e & 15;
             const int n = en0 + wn * 64 + cl * 4;
-            const bool is_r = ZR && n >= 128;                      // wave-uniform
+            const bool is_r = ZR && en0 + wn * 64 >= 128;          // wave-uniform, and from scalar values only: as `n >= 128` (n holds the lane's column) hipcc predicated
+                                                                   // the r waves' loads under exec masks and its own waits then drained the previous sub-pass's stores
             const int c = is_r ? n - 128 : n;
             const int rowl = wm * WROWS + rl;
             const unsigned lo_b = (unsigned)p.split_lo * 2u;
