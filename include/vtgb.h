@@ -344,8 +344,10 @@ int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream);
  * third is computed once per call into fp32 start maps), [24] / [25] mask.2 with its 0.25 folded in; vtgb_raft_encoder: [0] the stem
  * [64, 4 (tY), 3 x 64] scaled by 2/255, the 1x1 head [256, 3 x 128].
  * VTGB_F16C8 (version 600; vtgb_raft_update and vtgb_raft_encoder -- the correlation volume of that mode runs at VTGB_BF16X3; vtgb_raft_encoder at
- * VTGB_F16C8 is the VTGB_BF16X3 encoder with the four convolutions of layer1 [entries 2, 4, 8, 10: layer1.{0,1}.conv{1,2}] on these operands and
- * weights[40] = DEVICE int32 [4], their scale bytes; its later stages, whose outputs feed the correlation directly, stay split-bf16): the nine large
+ * VTGB_F16C8 is the VTGB_BF16X3 encoder with the ten stride-1 3x3 convolutions of its residual blocks [both convolutions of layer1.0, layer1.1,
+ * layer2.1, layer3.1 and conv2 of layer2.0, layer3.0: entries 2, 4, 8, 10, 16, 20, 22, 28, 32, 34] on these operands and weights[40] = DEVICE
+ * int32 [12], the scale byte of block b's conv1 / conv2 at [2 b] / [2 b + 1]; the stem, the stride-2 convolutions, the 1x1 downsamples and the 1x1
+ * head stay split-bf16): the nine large
  * convolutions of the update block ([0] convc1, [2] convc2, [8] conv, [10] / [12] / [14] / [16] the GRU's, [18] flow_head.conv1, [22] mask.0) take
  * their operands as  x . w ~ xh . Wh  (fp16 x fp16)  +  2^-11/sw (xl' . Wh8 + xh8 . Wl')  (OCP fp8 on the block-scaled matrix instruction, twice the
  * fp16 rate), xh = fp16(x), xl' = e5m2((x - xh) 2^11), xh8 = e5m2(x), Wh = fp16(w), Wh8 = e4m3(w sw), Wl' = e4m3((w - Wh) sw 2^11), sw a power of two

@@ -369,61 +369,75 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
             const unsigned o_part = (inw && n < p.N && n + 3 >= p.N) ? o_off : OOB;      // (N % 4 == 2: two columns)
             const bool cut = (p.N & 3) != 0;
             const unsigned lo_b = (unsigned)p.split_lo * 2u;
-            // 64-wide tile (the context encoder's layer1, BatchNorm folded): the ResidualBlock's tail relu(x + relu(conv)) in the epilogue -- resid_bf16 = the
-            // block input as an f16c8 pair (row stride ldrb, second half at + split_lo), post_relu; its rows are requested in front of the next tile's pieces
-            constexpr bool RES = NWN == 1;
-            const bool resd = RES && p.resid_bf16 != nullptr;
-            u32x2_t rh[RES ? PR / 4 : 1], rl8[RES ? PR / 4 : 1];
-            if constexpr (RES) {
-                if (resd) {
+            // 64- and 128-wide tiles (the context encoder's residual blocks, BatchNorm folded): the ResidualBlock's tail relu(x + relu(conv)) in the
+            // epilogue -- resid_bf16 = the skip operand as an f16c8 pair (row stride ldrb, second half at + split_lo), post_relu; all its rows are requested
+            // up front around the next tile's first pieces (the k-loop's fragment registers are dead here).  One straight-line instance per case: a
+            // run-time `if (residual)` around the loads made hipcc's own waits at the joins drain the stores of the pass before.
+            constexpr bool RES = NWN <= 2;
+            auto split_epilogue = [&](auto with_resid) {
+                constexpr bool RD = decltype(with_resid)::value;
+                u32x2_t rh[RD ? NP : 1][RD ? PR / 4 : 1], rl8[RD ? NP : 1][RD ? PR / 4 : 1];
+                if constexpr (RD) {
                     const auto r_rs = tile_rsrc(p.resid_bf16, p.ldrb, 2);
                     const unsigned r_lane = (inw && n + 3 < p.N) ? (unsigned)((wm * WROWS + rl) * (int)p.ldrb + n) * 2u : OOB;
 #pragma unroll
-                    for (int rr = 0; rr < PR / 4; rr++) {
-                        rh[rr] = __builtin_amdgcn_raw_buffer_load_b64(r_rs, r_lane, rr * 4 * (int)p.ldrb * 2, 0);
-                        rl8[rr] = __builtin_amdgcn_raw_buffer_load_b64(r_rs, r_lane + lo_b, rr * 4 * (int)p.ldrb * 2, 0);
+                    for (int ps = 0; ps < NP; ps++) {
+#pragma unroll
+                        for (int rr = 0; rr < PR / 4; rr++) {
+                            rh[ps][rr] = __builtin_amdgcn_raw_buffer_load_b64(r_rs, r_lane, (ps * PR + rr * 4) * (int)p.ldrb * 2, 0);
+                            rl8[ps][rr] = __builtin_amdgcn_raw_buffer_load_b64(r_rs, r_lane + lo_b, (ps * PR + rr * 4) * (int)p.ldrb * 2, 0);
+                        }
+                        if (ps == 0) prefetch();
                     }
+                } else {
+                    prefetch();
                 }
-            }
-            prefetch();
-            if constexpr (RES) {
-                if (resd) { H_WAIT_OPERANDS() }
-            }
 #pragma unroll
-            for (int ps = 0; ps < NP; ps++) {
+                for (int ps = 0; ps < NP; ps++) {
 #pragma unroll
-                for (int jj = 0; jj < PR / 16; jj++)
+                    for (int jj = 0; jj < PR / 16; jj++)
 #pragma unroll
-                    for (int i = 0; i < WF; i++) {
-                        const int row = jj * 16 + (lane_e & 15), chunk = i * 4 + (lane_e >> 4);
-                        *reinterpret_cast<f32x4*>(stage + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][ps * (PR / 16) + jj];
+                        for (int i = 0; i < WF; i++) {
+                            const int row = jj * 16 + (lane_e & 15), chunk = i * 4 + (lane_e >> 4);
+                            *reinterpret_cast<f32x4*>(stage + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][ps * (PR / 16) + jj];
+                        }
+                    if constexpr (RD) {      // this pass's skip rows have landed (behind them: the later passes' rows, the next tile's pieces, earlier stores)
+                        constexpr int LATER = (NP - 1) * (PR / 2);
+                        if (ps == 0) {
+                            if (has_next) __builtin_amdgcn_s_waitcnt(h8_vmcnt(NPRE + LATER)); else __builtin_amdgcn_s_waitcnt(h8_vmcnt(LATER));
+                        } else __builtin_amdgcn_s_waitcnt(h8_vmcnt(PR / 2));      // (the last pass: only the previous pass's stores may still fly)
                     }
 #pragma unroll
-                for (int rr = 0; rr < PR / 4; rr++) {
-                    const int row = rr * 4 + rl;
-                    f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 256 + ((cl ^ (row & 15)) << 4));
-                    if (p.act) apply_act4(v, p.act);
-                    if constexpr (RES) {
-                        if (resd) {      // (NP == 1 on this tile: the one pass's rows)
-                            v += h8_join4(rh[rr], rl8[rr]);
+                    for (int rr = 0; rr < PR / 4; rr++) {
+                        const int row = rr * 4 + rl;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 256 + ((cl ^ (row & 15)) << 4));
+                        if (p.act) apply_act4(v, p.act);
+                        if constexpr (RD) {
+                            v += h8_join4(rh[ps][rr], rl8[ps][rr]);
                             if (p.post_relu) apply_act4(v, 1);
                         }
-                    }
-                    u32x2_t hu, lu;
-                    encode(v, hu, lu);
-                    const unsigned so = (unsigned)((ps * PR + rr * 4) * (int)p.ldo * 2);
-                    H_STORE64(hu, o_rs, o_lane, so);
-                    H_STORE64(lu, o_rs, o_lane + lo_b, so);
-                    if (cut) {      // the group that straddles N: its first two columns
-                        __builtin_amdgcn_raw_buffer_store_b32(hu[0], o_rs, o_part + so, 0, 0);
-                        if constexpr (OFMT == 1) {
-                            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(lu[0] & 0xFFFFu), o_rs, o_part + lo_b + so, 0, 0);
-                            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(lu[1] & 0xFFFFu), o_rs, o_part + lo_b + 4u + so, 0, 0);
-                        } else {
-                            __builtin_amdgcn_raw_buffer_store_b32(lu[0], o_rs, o_part + lo_b + so, 0, 0);
+                        u32x2_t hu, lu;
+                        encode(v, hu, lu);
+                        const unsigned so = (unsigned)((ps * PR + rr * 4) * (int)p.ldo * 2);
+                        H_STORE64(hu, o_rs, o_lane, so);
+                        H_STORE64(lu, o_rs, o_lane + lo_b, so);
+                        if (cut) {      // the group that straddles N: its first two columns
+                            __builtin_amdgcn_raw_buffer_store_b32(hu[0], o_rs, o_part + so, 0, 0);
+                            if constexpr (OFMT == 1) {
+                                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(lu[0] & 0xFFFFu), o_rs, o_part + lo_b + so, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(lu[1] & 0xFFFFu), o_rs, o_part + lo_b + 4u + so, 0, 0);
+                            } else {
+                                __builtin_amdgcn_raw_buffer_store_b32(lu[0], o_rs, o_part + lo_b + so, 0, 0);
+                            }
                         }
                     }
                 }
+            };
+            if constexpr (RES) {
+                if (p.resid_bf16 != nullptr) split_epilogue(std::true_type{});
+                else split_epilogue(std::false_type{});
+            } else {
+                split_epilogue(std::false_type{});
             }
         }
         if constexpr (EPI == EPI_STORE_F32 && !NO_EPI) {
@@ -666,7 +680,7 @@ int launch_conv_h8(const GemmDesc& d_in, hipStream_t s) {
     switch (d.epi) {
         case EPI_SPLIT:
             VTGB_REQUIRE((d.N & 1) == 0 && (d.ldo & 3) == 0 && (d.split_lo & 3) == 0 && d.split_lo > 0, VTGB_EINVAL, "conv h8: pair store needs 4-aligned rows and split_lo");
-            VTGB_REQUIRE(!d.resid_bf16 || (d.N <= 64 && (d.ldrb & 3) == 0), VTGB_EUNSUPPORTED, "conv h8: the residual tail exists on the 64-wide tile only");
+            VTGB_REQUIRE(!d.resid_bf16 || (d.N <= 128 && (d.N & 3) == 0 && (d.ldrb & 3) == 0), VTGB_EUNSUPPORTED, "conv h8: the residual tail exists on the 64- and 128-wide tiles only");
             if (d.h8_out_bf16) {
                 VTGB_REQUIRE((d.N & 3) == 0, VTGB_EUNSUPPORTED, "conv h8: bf16-pair output needs N %% 4 == 0");
                 if (d.N <= 64) return launch_h8<EPI_SPLIT, 1, 4, 0>(d, s);

@@ -394,7 +394,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
             VTGB_TRY(conv_bn(Mo, g, 3, g.Cpad, 1, g.Ho, g.Wo, t1, bw[2], F(bw[3]), 1, res, 1, outb));             // relu(x + relu(bn2(conv2(y))))
         } else if (h8l1) {
             // VTGB_F16C8: every stride-1 3x3 convolution of the residual blocks reads f16c8 pairs (gemm_h8.hip: 2 k-tiles per 64-channel chunk and tap
-            // instead of 3); outputs are fp32 (+ the InstanceNorm moments for fnet) or, for cnet's first convolutions, pairs straight from the epilogue.
+            // instead of 3); outputs are fp32 (+ the InstanceNorm moments) for fnet, pairs straight from the epilogue for cnet.
             // The stride-2 blocks' conv1 and 1x1 downsample stay bf16x3 launches over the block input as a bf16 pair: they share that input and a
             // 1x1's K (2 k-tiles) is below the f16c8 k-loop's minimum.  So the pair format alternates: the first block of a layer hands an f16c8 pair to
             // the stride-1 block behind it, the second a bf16 pair to the bf16x3 launches that follow (the next layer's stride-2 block; the head).
@@ -415,7 +415,7 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
                 if (col_stats) VTGB_TRY(launch_stats_finish_tiles(col_stats, stats, n, HWo, g.C, Mo, s));
                 return VTGB_OK;
             };
-            // the same convolution with ReLU (+ on the 64-wide tile the block's tail relu(x + .)) and the pair store in its epilogue (cnet: BatchNorm folded)
+            // the same convolution over g.Cpad output rows with ReLU (+ the block's tail relu(x + .), x an f16c8 pair) and the pair store in its epilogue (cnet)
             auto conv_pair = [&](const void* A, const void* Wt, const float* bias, int si, const void* resid, void* out, int out_bf16) -> int {
                 GemmDesc d;
                 memset(&d, 0, sizeof(d));
@@ -428,29 +428,25 @@ static int enc_impl(const vtgb_raft_encoder_args* a, Workspace& ws, hipStream_t 
                 return launch_conv_h8(d, s);
             };
             const int out_h8 = (b & 1) == 0;      // the block's output pair: f16c8 for the stride-1 block behind it, bf16 for a bf16x3 consumer
-            if (!inorm && g.Cpad == 64) {
-                // cnet layer1: no statistics, so ReLU, the skip connection and the pair store live in the convolutions' epilogues -- no fp32 round trip, no pair pass
-                VTGB_TRY(conv_pair(x, bw[0], F(bw[1]), 2 * b, nullptr, t1, 0));                                             // y = relu(bn1(conv1(x)))
-                outb = t2;                                                                                                  // conv2 reads t1 and x: a third buffer
-                VTGB_TRY(conv_pair(t1, bw[2], F(bw[3]), 2 * b + 1, x, outb, !out_h8));                                      // relu(x + relu(bn2(conv2(y))))
-            } else if (!inorm) {
-                // cnet layer2 / layer3: conv1 (+ ReLU) and the downsample branch leave their convolutions as pairs; conv2 needs the skip operand: fp32 + the pair pass
-                auto split_conv = [&](int K, const void* Wt, const float* bias, int relu, void* out, int f16c8) -> int {
+            if (!inorm) {
+                // cnet: no statistics, so ReLU, the skip connection and the pair store live in the convolutions' epilogues -- no fp32 round trip, no pair pass.
+                // Stride-2 blocks: conv1 and the downsample branch are bf16x3 launches that write f16c8 pairs (GemmDesc::split_f16c8)
+                auto split_conv = [&](int K, const void* Wt, const float* bias, int relu, void* out) -> int {
                     GemmDesc d = enc_conv(dt, (int)Mo, g.Cpad, g.Ho, g.Wo, K, Cin_pad, g.stride, Hi, Wi, x, Wt, bias, nullptr, C2, zero, nullptr);
-                    d.epi = VTGB_EPI_SPLIT; d.act = relu; d.out = out; d.split_lo = g.Cpad; d.split_f16c8 = f16c8;
+                    d.epi = VTGB_EPI_SPLIT; d.act = relu; d.out = out; d.split_lo = g.Cpad; d.split_f16c8 = 1;
                     d.algo_flops = 2.0 * Mo * (double)g.C * (K * K * Cin_pad);
                     return launch_conv_gemm(d, s);
                 };
-                if (s2) VTGB_TRY(split_conv(3, bw[0], F(bw[1]), 1, t1, 1));                                                 // y = relu(bn1(conv1(x))), bf16x3 -> f16c8 pair
+                if (s2) VTGB_TRY(split_conv(3, bw[0], F(bw[1]), 1, t1));                                                    // y = relu(bn1(conv1(x)))
                 else VTGB_TRY(conv_pair(x, bw[0], F(bw[1]), 2 * b, nullptr, t1, 0));
-                VTGB_TRY(conv_h8(t1, bw[2], F(bw[3]), nullptr, 2 * b + 1));
                 const void* res = x;
-                if (s2) {                                                                                                   // x = bn3(downsample(x)): a bf16 pair
-                    VTGB_TRY(split_conv(1, bw[4], F(bw[5]), 0, t2, 0));
+                outb = t2;                                                                                                  // conv2 reads t1 and the skip operand: a third buffer
+                if (s2) {                                                                                                   // x = bn3(downsample(x))
+                    VTGB_TRY(split_conv(1, bw[4], F(bw[5]), 0, t2));
                     res = t2;
+                    outb = x;                                                                                               // the block input is dead from here on
                 }
-                outb = t1;
-                VTGB_TRY(norm(cf, Mo, HWo, g.C, g.Cpad, g.Cpad, res, outb, 1, 1, stats, false, out_h8, !s2));               // relu(x + relu(bn2(conv2(y))))
+                VTGB_TRY(conv_pair(t1, bw[2], F(bw[3]), 2 * b + 1, res, outb, !out_h8));                                    // relu(x + relu(bn2(conv2(y))))
             } else {
                 float* sf = stats_for(stats, HWo, g.C);
                 if (s2) VTGB_TRY(conv_stats(enc_conv(dt, (int)Mo, g.C, g.Ho, g.Wo, 3, Cin_pad, g.stride, Hi, Wi, x, bw[0], F(bw[1]), cf, g.Cpad, zero, sf), stats));

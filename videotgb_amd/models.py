@@ -293,7 +293,7 @@ class Raft(nn.Module):
     def _hip_tables(self):
         if self._table is None:
             sd = {k: v for k, v in self.state_dict().items()}
-            # (f16c8: the update block and the encoders' layer1 on fp16 + fp8-correction operands, the other encoder stages and the correlation at bf16x3)
+            # (f16c8: the update block and the encoders' stride-1 3x3 convolutions on fp16 + fp8-correction operands, the other encoder stages and the correlation at bf16x3)
             self._table = (ops.RaftWeights(sd, "update_block.", self.code), ops.RaftEncoderWeights(sd, "fnet.", False, self.code),
                            ops.RaftEncoderWeights(sd, "cnet.", True, self.code))
         return self._table

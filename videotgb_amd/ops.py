@@ -50,8 +50,8 @@ def raft_dtype_code(dtype) -> int:
 
 
 def raft_stage_code(code: int) -> int:
-    """The mode of RAFT's correlation volume next to an update block at ``code``: at f16c8 the correlation (and every encoder stage but layer1,
-    include/vtgb.h) runs at bf16x3."""
+    """The mode of RAFT's correlation volume next to an update block at ``code``: at f16c8 the correlation (and the encoders' stem, stride-2 / 1x1
+    convolutions and head, include/vtgb.h) runs at bf16x3."""
     return BF16X3 if code == F16C8 else code
 
 
@@ -915,7 +915,11 @@ def raft_encoder(w: RaftEncoderWeights, images: Tensor, max_images: int = 384) -
     images = images.contiguous().float()
     n, _, H, W = images.shape
     out = torch.empty(n, (H // 8) * (W // 8), 256, dtype=torch.float32, device=images.device)
-    if w.code in (F32, BF16X3, F16C8):      # 4 bytes per channel of every activation (bf16x3 / f16c8: pairs)
+    # max_images frames per launch sequence.  Workspace per frame at 224 x 224: 7.2 MB at bf16, 14.4 MB at fp32 / bf16x3 / f16c8 (4 bytes per channel of
+    # every activation: pairs) = 5.5 GB for 384 frames.  Larger chunks are faster (per frame, f16c8 fnet: 39.2 us at 96, 36.8 at 192, 35.3 at 384, 34.7 at
+    # 768 frames -- the small late stages fill the 256 CUs better; a chunk that fits the 256 MB Infinity Cache is NOT: tools/exp/enc_chunk.py), so the
+    # pair modes no longer halve the chunk (round 5 did, for memory; the fp32 exactness mode still does).
+    if w.code == F32:
         max_images = max(max_images // 2, 1)
     for i0 in range(0, n, max_images):
         chunk = images[i0:i0 + max_images]
