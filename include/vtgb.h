@@ -354,8 +354,8 @@ int vtgb_layernorm(const vtgb_layernorm_args* a, vtgb_stream_t stream);
  * per layer: the corrections are 2^-11 of the product, so 3-4 significant bits on each side leave ~2^-16 -- the bf16 pair's level (tests/
  * test_gpu_raft.py holds this mode to the bf16x3 mode's bounds).  Their weights are [C_out, K] 16-bit units with K = per source (fp16 [taps, C] |
  * correction bytes [taps, C / 4 groups of (Wh8 x 4, Wl' x 4)]), each half in the 64-channel-chunk-major K order below (ops.h8_conv_pack);
- * weights[30] = DEVICE int32 [9]: the E8M0 byte of 2^-11 / sw of those nine convolutions in the order above.  Everything else in the table is as
- * at VTGB_BF16X3.  Activations beyond +-57344 saturate (e5m2's range; RAFT's are normalised features, gates and correlations of unit-scale features).
+ * weights[30] = DEVICE int32 [10]: the E8M0 byte of 2^-11 / sw of those nine convolutions in the order above, then of [6] convf2 (3x3, 128 -> 64: an
+ * f16c8 convolution as well, its input -- convf1's output -- an f16c8 pair).  Everything else in the table is as at VTGB_BF16X3.  Activations beyond +-57344 saturate (e5m2's range; RAFT's are normalised features, gates and correlations of unit-scale features).
  * Convolution weights are packed [C_out, K] in `dtype` with K running 64-channel chunk
  * major, tap minor, channel-in-chunk innermost (written [C_out, KH,KW,C_in] below for the shapes only).
  *

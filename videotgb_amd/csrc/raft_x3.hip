@@ -18,7 +18,7 @@
 // VTGB_F16C8 (round 6): the same orchestration with the update block's large convolutions over f16c8 pairs (pair_h8.h, gemm_h8.hip: fp16 main
 // product + two fp8 correction products at twice the rate -- 2/3 of the bf16x3 form's matrix work at the same accuracy class); the small ones
 // (convf2, FlowHead.conv2, mask.2, the once-per-call start maps) and the encoders / correlation volume stay bf16x3.  `h8` below selects the format of
-// the buffers h, r h, motion | flow, corr taps, c1, [cor | flo]; inp, convf1's output and the flow / mask heads' hidden maps stay bf16 pairs.
+// the buffers h, r h, motion | flow, corr taps, c1, [cor | flo], convf1's output; inp and the flow / mask heads' hidden maps stay bf16 pairs.
 int raft_launch_lookup_pair(const CorrPyr& pyr, const float* flow, void* out_pair, int64_t M, int H8, int W8, int h8, hipStream_t s);
 // f16c8: lookup + convc1 as one launch (raft.hip: the taps of a pixel never leave the CU)
 int raft_lkc1_h8_pack(const void* w, void* packed, hipStream_t s);
@@ -264,11 +264,18 @@ __global__ __launch_bounds__(256) void x3_convf1_kernel(const float* __restrict_
             f32x4 v = acc[i][j];
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
-            bf16x4 hi, lo;
-            pair_split4(v, hi, lo);
             bf16_t* o = f1 + m * 256 + wave * 32 + i * 16 + fg * 4;
-            *reinterpret_cast<bf16x4*>(o) = hi;
-            *reinterpret_cast<bf16x4*>(o + 128) = lo;
+            if (h8) {      // (f16c8: convf2 is an h8 launch)
+                h8_u32x2 hu, lu;
+                h8_split4(v, hu, lu);
+                *reinterpret_cast<h8_u32x2*>(o) = hu;
+                *reinterpret_cast<h8_u32x2*>(o + 128) = lu;
+            } else {
+                bf16x4 hi, lo;
+                pair_split4(v, hi, lo);
+                *reinterpret_cast<bf16x4*>(o) = hi;
+                *reinterpret_cast<bf16x4*>(o + 128) = lo;
+            }
         }
     }
     if (tid < 2 * CF1_PX) {
@@ -340,7 +347,7 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
     VTGB_REQUIRE(!a->corr_f16, VTGB_EINVAL, "raft_update: the bf16x3 / f16c8 modes take an fp32 correlation pyramid");
     const void* const* w = a->weights;
     for (int i = 0; i < VTGB_RAFT_NW + h8; i++) VTGB_REQUIRE(w[i], VTGB_EINVAL, "raft_update: weights[%d] is NULL (the bf16x3 / f16c8 tables always carry the inp split)", i);
-    const int* hs = h8 ? (const int*)w[VTGB_RAFT_NW] : nullptr;      // f16c8: the nine large convolutions' weight-scale bytes (include/vtgb.h)
+    const int* hs = h8 ? (const int*)w[VTGB_RAFT_NW] : nullptr;      // f16c8: the ten f16c8 convolutions' weight-scale bytes (include/vtgb.h)
     // one large convolution in the mode's operand format
     auto conv = [&](int N, int KH, int KW, const void* A, int C1, const void* A2, int C2, int wi, int si, const float* bias, int epi, int act, void* out, int64_t ldo,
                     int split_lo, int out_bf16 = 0) {
@@ -385,8 +392,12 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
             const int64_t nt = (M + CF1_PX - 1) / CF1_PX, cap = (int64_t)cu_count() * 6;      // persistent: six workgroups per CU (26 KB of LDS each)
             hipLaunchKernelGGL(x3_convf1_kernel, dim3((unsigned)(nt < cap ? nt : cap)), dim3(256), 0, s, flow, F(w[4]), F(w[5]), f1, X, M, H8, W8, h8);
         }
-        VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 64, H8, W8, 3, 3, f1, 128, nullptr, 0, w[6], F(w[7]), VTGB_EPI_STORE_F32, 0, Q, 64, 0, zero), s));
-        VTGB_TRY(launch_x3_pair_pass(Q, 64, nullptr, HW, nullptr, 0, 0, CF + 192, 512, 256, 64, 64, 1, 0, M, s, h8, 0));
+        if (h8) {      // convf2 (3x3, 128 -> 64, ReLU) straight into the [cor | flo] pair: the 64-wide tile's pair store, no fp32 round trip
+            VTGB_TRY(run(conv(64, 3, 3, f1, 128, nullptr, 0, 6, 9, F(w[7]), VTGB_EPI_SPLIT, 1, CF + 192, 512, 256)));
+        } else {
+            VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 64, H8, W8, 3, 3, f1, 128, nullptr, 0, w[6], F(w[7]), VTGB_EPI_STORE_F32, 0, Q, 64, 0, zero), s));
+            VTGB_TRY(launch_x3_pair_pass(Q, 64, nullptr, HW, nullptr, 0, 0, CF + 192, 512, 256, 64, 64, 1, 0, M, s, 0, 0));
+        }
         VTGB_TRY(run(conv(126, 3, 3, CF, 256, nullptr, 0, 8, 2, F(w[9]), VTGB_EPI_SPLIT, 1, X, 256, 128)));
         // ---- SepConvGRU (update.py:50-65): horizontal (1x5) then vertical (5x1); input channels [h(128) | motion(126) | flow(2)], the inp third comes from the start maps
         for (int half = 0; half < 2; half++) {

@@ -688,7 +688,7 @@ class RaftWeights(_WeightTable):
     def _init_x3(self, sd: Dict[str, Tensor], p: str, h8: bool = False) -> None:
         """The bf16x3 table (raft_x3.hip): every MFMA convolution as [C_out, taps, 3 C_in] in the kernels' K order with the channel blocks
         [Wh | Wh | Wl] per source; convf1 as in the fp32 mode; the mask head's 0.25 (update.py:143) folded into mask.2 (a power of two: exact).
-        ``h8`` (VTGB_F16C8): the nine large convolutions in the f16c8 operand format instead (h8_conv_pack) and entry [30] = their scale bytes."""
+        ``h8`` (VTGB_F16C8): the nine large convolutions and convf2 in the f16c8 operand format instead (h8_conv_pack) and entry [30] = their scale bytes."""
         self.hoist_inp = True
         scales = []
 
@@ -725,7 +725,15 @@ class RaftWeights(_WeightTable):
         add_big("encoder.convc2")
         self.add(sd[p + "encoder.convf1.weight"].float().reshape(128, 98).t().contiguous())
         self.add(sd[p + "encoder.convf1.bias"])
-        add_conv("encoder.convf2")
+        late_scales = []
+        if h8:      # (round 6, later: convf2 joins the f16c8 convolutions; its scale byte is entry [9] of the table's scale vector)
+            wf2 = raw("encoder.convf2")
+            sw, byte = h8_weight_scale(wf2)
+            late_scales.append(byte)
+            self.tensors.append(h8_conv_pack(wf2, sw))
+            self.add(sd[p + "encoder.convf2.bias"].float())
+        else:
+            add_conv("encoder.convf2")
         add_big("encoder.conv")
         dyn = list(range(0, 128)) + list(range(256, 384))     # [h | motion + flow]: two pair sources of 128 channels
         for sfx in ("1", "2"):
@@ -744,9 +752,9 @@ class RaftWeights(_WeightTable):
         for sfx in ("1", "2"):
             self.tensors.append(torch.cat([conv("gru.convz" + sfx, channels=inp), conv("gru.convr" + sfx, channels=inp)], 0).contiguous())
             self.tensors.append(conv("gru.convq" + sfx, channels=inp))
-        if h8:      # [30]: E8M0 bytes of 2^-11 / sw of convc1, convc2, conv, zr1, q1, zr2, q2, flow_head.conv1, mask.0 (include/vtgb.h)
+        if h8:      # [30]: E8M0 bytes of 2^-11 / sw of convc1, convc2, conv, zr1, q1, zr2, q2, flow_head.conv1, mask.0, convf2 (include/vtgb.h)
             assert len(scales) == 9
-            self.tensors.append(torch.tensor(scales, dtype=torch.int32, device=self.tensors[0].device))
+            self.tensors.append(torch.tensor(scales + late_scales, dtype=torch.int32, device=self.tensors[0].device))
         self.finish()
 
 
