@@ -32,6 +32,7 @@
 #define H8_DELAY 6    // (H8_VAR & 64: s_sleep(127) units, ~3.4 us each, per start phase)
 #endif
 
+constexpr int EPI_FTAIL = 8;      // (this file only) EPI_SPLIT's arithmetic with GemmDesc::tail_w: relu(conv) is multiplied by a 256 x 32 fp32 matrix in the epilogue and never stored
 constexpr int H_BK = 64;
 constexpr int H_AOP = 256 * H_BK * 2;   // 32 KiB activation slot (256 rows x 128 bytes)
 
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
     constexpr int NPRE = AI + WI;
     constexpr int WH = WF / 2, XH = NX / 2;        // the quarters of the fragment grid (WF = 3: 1 + 2 weight fragments)
     static_assert(WF == 4 || (WF == 3 && NWN == 4 && EPI == EPI_SPLIT), "48-column wave tiles: the pair-store convolution (convc2) only");
+    static_assert(EPI != EPI_FTAIL || (NWN == 4 && WF == 4), "the flow-head tail lives on the 256-wide tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const smem_w = smem + A_SLOTS * A_OP;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -440,6 +442,54 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
                 split_epilogue(std::false_type{});
             }
         }
+        if constexpr (EPI == EPI_FTAIL && !NO_EPI) {
+            // FlowHead (update.py:10-18): hidden = relu(conv1(h) + b) [256 channels] is followed by a 3x3 convolution to 2 channels = per pixel the 18 per-tap
+            // products hidden . W2[tap][c] (summed over the taps' neighbours by raft_flow_head2_kernel).  Those products are formed HERE, from the
+            // accumulators, on the fp32-input matrix instruction -- D2[out][pixel] += W2t[out][k] v[k][pixel] with the k of a step = the four channels
+            // 16 i + 4 fg + e (fg = 0..3) that the lanes of a 16 x 16 accumulator block hold in element e: a lane's own register IS its B operand -- so the
+            // 1 KB-per-pixel hidden map is neither stored nor re-read, and the product is exact fp32 (the bf16x3 1x1 launch it replaces rounded the map
+            // to a bf16 pair).  tail_w: fp32, packed per (wn, i, lane) as [e][ob] (ops.py flow_tail_pack); the four column waves' partial sums meet in the
+            // staging region, in wave order (deterministic), half a tile at a time (64 KB).
+            const int fr = lane_e & 15, fg4 = lane_e >> 4;
+            f32x4 wa4[4][2];
+            {
+                const f32x4* wp = reinterpret_cast<const f32x4*>(p.tail_w) + ((int64_t)(wn * 4) * 64 + lane_e) * 2;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { wa4[i][0] = wp[i * 128]; wa4[i][1] = wp[i * 128 + 1]; }
+            }
+            prefetch();
+            float* const red = reinterpret_cast<float*>(smem + A_OP);
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const int j = half * 4 + jj;
+                    f32x4 d2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float bv = p.act ? fmaxf(acc[i][j][e], 0.f) : acc[i][j][e];
+                            d2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa4[i][e >> 1][(e & 1) * 2], bv, d2[0], 0, 0, 0);
+                            d2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa4[i][e >> 1][(e & 1) * 2 + 1], bv, d2[1], 0, 0, 0);
+                        }
+                    const int rowh = wm * 64 + jj * 16 + fr;
+#pragma unroll
+                    for (int ob = 0; ob < 2; ob++) *reinterpret_cast<f32x4*>(red + ((wn * 128 + rowh) * 32 + 16 * ob + 4 * fg4)) = d2[ob];
+                }
+                H_PHASE_BARRIER()
+#pragma unroll
+                for (int rep = 0; rep < 2; rep++) {
+                    const int idx = tid + rep * 512, rowh = idx >> 3, oc = idx & 7;
+                    f32x4 sum = *reinterpret_cast<const f32x4*>(red + (rowh * 32 + oc * 4));
+#pragma unroll
+                    for (int w_ = 1; w_ < 4; w_++) sum += *reinterpret_cast<const f32x4*>(red + ((w_ * 128 + rowh) * 32 + oc * 4));
+                    const int64_t grow = (int64_t)em0 + (rowh >> 6) * 128 + half * 64 + (rowh & 63);
+                    if (grow < p.M) *reinterpret_cast<f32x4*>(p.tail_out + grow * p.ldtail + oc * 4) = sum;
+                }
+                if (half == 0) { H_PHASE_BARRIER() }      // (the second half's partial sums overwrite the region; behind it: the loop's own barrier)
+            }
+        }
         if constexpr (EPI == EPI_STORE_F32 && !NO_EPI) {
             // fp32 outputs (the encoders' layer1: the InstanceNorm / skip pass behind it needs the unrounded sums) through the staging region as whole
             // 256-byte row segments, with gemm_pp.hip's per-tile column moments (GemmDesc::col_stats: stored per m-tile, added in tile order by
@@ -681,6 +731,11 @@ int launch_conv_h8(const GemmDesc& d_in, hipStream_t s) {
         case EPI_SPLIT:
             VTGB_REQUIRE((d.N & 1) == 0 && (d.ldo & 3) == 0 && (d.split_lo & 3) == 0 && d.split_lo > 0, VTGB_EINVAL, "conv h8: pair store needs 4-aligned rows and split_lo");
             VTGB_REQUIRE(!d.resid_bf16 || (d.N <= 128 && (d.N & 3) == 0 && (d.ldrb & 3) == 0), VTGB_EUNSUPPORTED, "conv h8: the residual tail exists on the 64- and 128-wide tiles only");
+            if (d.tail_w) {      // FlowHead: the 1x1 tail on the accumulators, nothing else stored
+                VTGB_REQUIRE(d.N == 256 && d.tail_out && (d.ldtail & 3) == 0 && d.ldtail >= 32 && !d.resid_bf16, VTGB_EINVAL,
+                             "conv h8: the fused 1x1 tail needs a 256-channel convolution and a 4-aligned fp32 output of >= 32 columns");
+                return launch_h8<EPI_FTAIL, 4, 4, 1>(d, s);
+            }
             if (d.h8_out_bf16) {
                 VTGB_REQUIRE((d.N & 3) == 0, VTGB_EUNSUPPORTED, "conv h8: bf16-pair output needs N %% 4 == 0");
                 if (d.N <= 64) return launch_h8<EPI_SPLIT, 1, 4, 0>(d, s);

@@ -414,8 +414,14 @@ int raft_x3_impl(const vtgb_raft_update_args* a, Workspace& ws, hipStream_t s) {
             VTGB_TRY(run(q));
         }
         // ---- FlowHead (update.py:10-18) and coords1 += delta_flow (xraft.py:145); the hidden map leaves as a bf16 pair in both modes (conv2 is a bf16x3 launch)
-        VTGB_TRY(run(conv(256, 3, 3, hb, 128, nullptr, 0, 18, 7, F(w[19]), VTGB_EPI_SPLIT, 1, FH, 512, 256, 1)));
-        VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 32, H8, W8, 1, 1, FH, 256, nullptr, 0, w[20], nullptr, VTGB_EPI_STORE_F32, 0, P2, 32, 0, zero), s));
+        if (h8) {      // conv1 with conv2's 18 per-tap products formed in its epilogue (gemm_h8.hip EPI_FTAIL: exact fp32, the hidden map is never stored)
+            GemmDesc fh = conv(256, 3, 3, hb, 128, nullptr, 0, 18, 7, F(w[19]), VTGB_EPI_SPLIT, 1, FH, 512, 256, 1);
+            fh.tail_w = w[20]; fh.tail_out = P2; fh.ldtail = 32;
+            VTGB_TRY(run(fh));
+        } else {
+            VTGB_TRY(run(conv(256, 3, 3, hb, 128, nullptr, 0, 18, 7, F(w[19]), VTGB_EPI_SPLIT, 1, FH, 512, 256, 1)));
+            VTGB_TRY(launch_conv_gemm(x3_conv(Mi, 32, H8, W8, 1, 1, FH, 256, nullptr, 0, w[20], nullptr, VTGB_EPI_STORE_F32, 0, P2, 32, 0, zero), s));
+        }
         VTGB_TRY(raft_launch_flow_head2(P2, F(w[21]), flow, a->n_pairs, H8, W8, s));
     }
     // ---- mask head of the last iteration (update.py:129-132,143; the 0.25 is folded into [24] / [25]) and convex upsample (xraft.py:88-99)

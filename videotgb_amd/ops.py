@@ -576,6 +576,14 @@ def h8_conv_pack(w: Tensor, sw: float, sources: Optional[Sequence[int]] = None) 
     return torch.cat(out, 1).contiguous().view(torch.bfloat16)
 
 
+def flow_tail_pack(w2: Tensor) -> Tensor:
+    """FlowHead.conv2 as the 1x1 tail of conv1's f16c8 launch: w2 [32 (tap * 2 + c, zero-padded), 256] fp32 -> [wn 4][i 4][lane 64][e 4][ob 2] fp32 with
+    the value W2[channel = 64 wn + 16 i + 4 (lane >> 4) + e][out = 16 ob + (lane & 15)] -- eight consecutive floats per (wn, i, lane)."""
+    t = w2.float().t().contiguous()                                    # [256 channels, 32 outs]
+    t = t.reshape(4, 4, 4, 4, 2, 16)                                   # [wn, i, fg, e, ob, fr]
+    return t.permute(0, 1, 2, 5, 3, 4).contiguous().reshape(-1)        # [wn, i, fg, fr, e, ob]
+
+
 def _bf16_exact(w: Tensor) -> Tensor:
     """fp32 holding bf16 values -> bf16 (exact)."""
     return w.contiguous().to(torch.bfloat16)
@@ -744,7 +752,10 @@ class RaftWeights(_WeightTable):
         add_big("flow_head.conv1")
         w2 = sd[p + "flow_head.conv2.weight"].float().permute(2, 3, 0, 1).reshape(18, 256)
         w2 = torch.nn.functional.pad(w2, (0, 0, 0, 14)).reshape(32, 1, 1, 256)
-        self.tensors.append(_bf16_exact(conv_k_order(split3(w2))))
+        if h8:      # (round 6, later) fp32, in the order the flow-head epilogue's lanes read it (csrc/gemm_h8.hip EPI_FTAIL)
+            self.add(flow_tail_pack(w2.reshape(32, 256)))
+        else:
+            self.tensors.append(_bf16_exact(conv_k_order(split3(w2))))
         self.add(sd[p + "flow_head.conv2.bias"])
         add_big("mask.0")
         add_conv("mask.2", scale=0.25)
