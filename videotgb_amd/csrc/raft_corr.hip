@@ -42,6 +42,9 @@ __global__ void cast_f16_kernel(const float* __restrict__ x, half_t* __restrict_
     *reinterpret_cast<half4*>(y + i * 4) = half4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
 }
 
+#ifndef CORR_ABL
+#define CORR_ABL 0      // (timing experiments, WRONG RESULTS: 1 = no level-0 store, 2 = no products and no image-2 stream, 4 = no pooled levels, 8 = the stream without the MFMAs, 16 = the MFMAs without the stream; tools/exp/build_variant.sh)
+#endif
 constexpr int CORR_D = 256;
 constexpr int CORR_F1H_LD = CORR_D + 8;    // half elements per LDS row of the image-1 tile (528 B: 16 rows -> 16 bank groups)
 constexpr int CORR_F1F_LD = CORR_D + 4;    // fp32 variant
@@ -57,7 +60,11 @@ static inline CorrLds corr_lds_tp(int H8, int W8, bool f32, int tp, bool split =
     c.n2 = (H8 / 4) * (W8 / 4);
     c.n3 = (H8 / 8) * (W8 / 8);
     c.tp = tp;
-    c.bytes = (size_t)tp * (c.ldS + c.n1 + c.n2) * 4 + (f32 ? tp * CORR_F1F_LD * 4 : tp * CORR_F1H_LD * 2 * (split ? 2 : 1));
+    // the pooled levels 1, 2 live where the image-1 tile was (its rows are in registers / consumed when the products are done): at bf16x3 that
+    // takes the 16-row slice from 83 KB to 67 KB -- TWO workgroups per CU (round 6: 15.4 -> see DESIGN.md section 4)
+    const size_t f1_bytes = f32 ? (size_t)tp * CORR_F1F_LD * 4 : (size_t)tp * CORR_F1H_LD * 2 * (split ? 2 : 1);
+    const size_t pool_bytes = (size_t)tp * (c.n1 + c.n2) * 4;
+    c.bytes = (size_t)tp * c.ldS * 4 + (f1_bytes > pool_bytes ? f1_bytes : pool_bytes);
     return c;
 }
 static inline CorrLds corr_lds(int H8, int W8, bool f32) {
@@ -66,6 +73,13 @@ static inline CorrLds corr_lds(int H8, int W8, bool f32) {
         if (c32.bytes <= 160 * 1024) return c32;
     }
     return corr_lds_tp(H8, W8, f32, 16);
+}
+
+// bf16x3: 32 image-1 rows per workgroup when the slice fits (135 KB at 28 x 28: one workgroup of 8 waves per CU) -- the launch is bound by the image-2
+// stream out of L2 (ablations, round 6: the stream alone 13.7 ms of 13.7, the MFMAs alone 4.9), which 32 rows halve; else 16 rows (67 KB, two per CU)
+static inline CorrLds corr_lds_x3(int H8, int W8) {
+    const CorrLds c32 = corr_lds_tp(H8, W8, false, 32, true);
+    return c32.bytes <= 160 * 1024 ? c32 : corr_lds_tp(H8, W8, false, 16, true);
 }
 
 // SPLIT (VTGB_BF16X3): the features are bf16 pairs (fh = hi plane, then lo plane), S = f1h.f2h + f1h.f2l + f1l.f2h on the bf16 MFMA with
@@ -78,12 +92,19 @@ __global__ __launch_bounds__(TP * 16) void raft_corr_kernel(const vtgb_raft_corr
     const int H = a.H8, W = a.W8, HW = H * W;
     float* const S = reinterpret_cast<float*>(corr_sm);
     constexpr int NT = TP * 16;      // threads: 4 waves per 16 image-1 rows
-    float* const S1 = S + TP * ldS;
+    char* const f1s = reinterpret_cast<char*>(S + TP * ldS);
+    float* const S1 = reinterpret_cast<float*>(f1s);      // (levels 1, 2 reuse the image-1 tile's bytes: written after the barrier behind the products)
     float* const S2 = S1 + TP * n1;
-    char* const f1s = reinterpret_cast<char*>(S2 + TP * n2);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t n = blockIdx.y;
-    const int p0 = blockIdx.x * TP;
+    // workgroup -> (pair, 16-row tile), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own 4 MB L2, and every
+    // workgroup of a pair streams ALL of image 2 (0.8 MB as a bf16 pair at 28 x 28).  With the pair in blockIdx.y a pair's 49 workgroups sat on all 8 XCDs
+    // and each L2 held slices of ~10 pairs at a time (8 MB): the stream missed L2 (116 GB per 2 945 pairs out of the Infinity Cache / HBM).  Now id = 8 k + x
+    // works on pair 8 (k / tiles) + x: a pair stays on ONE XCD, whose L2 holds the one or two images in flight.
+    const int tiles = (HW + TP - 1) / TP;
+    const int xk = (int)(blockIdx.x >> 3);
+    const int64_t n = (int64_t)(xk / tiles) * 8 + (blockIdx.x & 7);
+    if (n >= a.n_pairs) return;
+    const int p0 = (xk % tiles) * TP;
     const int64_t img = (n / a.pairs_per_clip) * a.frames_per_clip + n % a.pairs_per_clip;
     const int64_t i1 = img + a.first_off, i2 = img + a.second_off;
     // ---- image-1 tile -> LDS (rows past the image: the last row again; their outputs are never stored)
@@ -133,48 +154,63 @@ __global__ __launch_bounds__(TP * 16) void raft_corr_kernel(const vtgb_raft_corr
             for (int p = 0; p < 16; p++) S[p * ldS + q] = acc[p] * a.scale;
         }
     } else if constexpr (SPLIT) {
-        static_assert(!SPLIT || TP == 16, "the split path keeps one 16-row half");
+        constexpr int NH = TP / 16;      // 16-row halves of the tile (32 rows: every wave multiplies each q-tile with both -- half the image-2 stream per output)
         const bf16_t* f2 = reinterpret_cast<const bf16_t*>(fh) + i2 * HW * CORR_D;
         const int64_t plane = (int64_t)a.n_images * HW * CORR_D;
         const bf16_t* f1l = reinterpret_cast<const bf16_t*>(f1s);
         const int fr = lane & 15, fg = lane >> 4;
         constexpr int NW = NT / 64, KS = CORR_D / 32;
-        bf16x8 bh[KS], bl[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            bh[ks] = *reinterpret_cast<const bf16x8*>(f1l + fr * CORR_F1H_LD + ks * 32 + fg * 8);
-            bl[ks] = *reinterpret_cast<const bf16x8*>(f1l + (TP + fr) * CORR_F1H_LD + ks * 32 + fg * 8);
-        }
+        // k order of the contraction (any order serves, both operands use it): k-steps 2 s and 2 s + 1 take, for lane group fg, the two 8-element halves of
+        // the 16 CONTIGUOUS features 64 s + 16 fg .. + 16 -- a lane's two loads of image 2 are adjacent and the four lanes of a row cover one whole
+        // 128-byte line per pair of steps (with 32 s + 8 fg each step touched half of 16 lines and the other halves came from L2 again one step later:
+        // the launch moved ~230 GB through L2 for 12 GB of HBM traffic and was bound by that)
+        auto koff = [&](int ks) { return (ks >> 1) * 64 + fg * 16 + (ks & 1) * 8; };
         const int n_qt = (HW + 15) >> 4;
         bf16x8 ah[2][KS], al[2][KS];
         auto load_a = [&](int qt, bf16x8 (&dh)[KS], bf16x8 (&dl)[KS]) {
+            if ((CORR_ABL & 16) != 0 && qt != wave) return;      // (no image-2 stream: the first q-tile's rows again)
             const int q = min(qt * 16 + fr, HW - 1);
-            const bf16_t* row = f2 + (int64_t)q * CORR_D + fg * 8;
+            const bf16_t* row = f2 + (int64_t)q * CORR_D;
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
-                dh[ks] = *reinterpret_cast<const bf16x8*>(row + ks * 32);
-                dl[ks] = *reinterpret_cast<const bf16x8*>(row + plane + ks * 32);
+                dh[ks] = *reinterpret_cast<const bf16x8*>(row + koff(ks));
+                dl[ks] = *reinterpret_cast<const bf16x8*>(row + plane + koff(ks));
             }
         };
         auto compute = [&](int qt, const bf16x8 (&sh)[KS], const bf16x8 (&sl)[KS]) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc;      // the two small terms on their own accumulator: added last
+            if constexpr ((CORR_ABL & 8) != 0) {      // (no products: the loads are kept alive)
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sl[ks], bh[ks], acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh[ks], bl[ks], acc2, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh[ks], bh[ks], acc, 0, 0, 0);
+                for (int ks = 0; ks < KS; ks++) asm volatile("" ::"v"(sh[ks]), "v"(sl[ks]));
+                return;
             }
-            *reinterpret_cast<f32x4*>(S + fr * ldS + qt * 16 + fg * 4) = (acc + acc2) * a.scale;
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc;      // the two small terms on their own accumulator: added last
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {      // image 1's fragments come from LDS each time (64 registers per half otherwise)
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(f1l + (h * 16 + fr) * CORR_F1H_LD + koff(ks));
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(f1l + (TP + h * 16 + fr) * CORR_F1H_LD + koff(ks));
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sl[ks], bh, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh[ks], bl, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh[ks], bh, acc, 0, 0, 0);
+                }
+                if (qt < n_qt) *reinterpret_cast<f32x4*>(S + (h * 16 + fr) * ldS + qt * 16 + fg * 4) = (acc + acc2) * a.scale;      // (a q-tile past the end: computed, not kept)
+            }
         };
-        int qt = wave;
-        if (qt < n_qt) load_a(qt, ah[0], al[0]);
+        // every load is UNCONDITIONAL (a q-tile past the end reads the last row again: load_a clamps): with `if (next tile exists) load` hipcc's
+        // s_waitcnt at the joins was vmcnt(0) -- each q-tile waited out its own L2 round trip (2.9 us per q-tile and wave; the launch: 12.6 ms)
+        int qt = (CORR_ABL & 2) ? n_qt : wave;
+        load_a(qt, ah[0], al[0]);
         for (; qt < n_qt; qt += 2 * NW) {
-            if (qt + NW < n_qt) load_a(qt + NW, ah[1], al[1]);
+            // (the scheduling barriers keep each group of 16 loads in front of the OTHER buffer's products: left alone, hipcc sinks the loads to their uses)
+            load_a(qt + NW, ah[1], al[1]);
+            __builtin_amdgcn_sched_barrier(0);
             compute(qt, ah[0], al[0]);
-            if (qt + NW < n_qt) {
-                if (qt + 2 * NW < n_qt) load_a(qt + 2 * NW, ah[0], al[0]);
-                compute(qt + NW, ah[1], al[1]);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(qt + 2 * NW, ah[0], al[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(qt + NW, ah[1], al[1]);      // (unconditional as well: a branch here and hipcc unswitches the loop, losing the two-buffer order)
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
         const half_t* f2 = fh + i2 * HW * CORR_D;
@@ -203,25 +239,28 @@ __global__ __launch_bounds__(TP * 16) void raft_corr_kernel(const vtgb_raft_corr
 #pragma unroll
                 for (int ks = 0; ks < CORR_D / 32; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(src[ks], bfrag[h][ks], acc, 0, 0, 0);
                 // D: rows fg * 4 + r = q within the tile, column fr = p
-                *reinterpret_cast<f32x4*>(S + (h * 16 + fr) * ldS + qt * 16 + fg * 4) = acc * a.scale;
+                if (qt < n_qt) *reinterpret_cast<f32x4*>(S + (h * 16 + fr) * ldS + qt * 16 + fg * 4) = acc * a.scale;
             }
         };
-        int qt = wave;
-        if (qt < n_qt) load_a(qt, afrag[0]);
+        int qt = wave;      // (unconditional, clamped loads: see the split path)
+        load_a(qt, afrag[0]);
         for (; qt < n_qt; qt += 2 * NW) {
-            if (qt + NW < n_qt) load_a(qt + NW, afrag[1]);
+            load_a(qt + NW, afrag[1]);
+            __builtin_amdgcn_sched_barrier(0);
             compute(qt, afrag[0]);
-            if (qt + NW < n_qt) {
-                if (qt + 2 * NW < n_qt) load_a(qt + 2 * NW, afrag[0]);
-                compute(qt + NW, afrag[1]);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(qt + 2 * NW, afrag[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(qt + NW, afrag[1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
     // ---- the four levels.  Row p of level l is [n * HW + p0 + p][n_l]: the tile's outputs are one contiguous span.
     const int rows = min(TP, HW - p0);
     OT* const o0 = reinterpret_cast<OT*>(a.levels[0]) + (n * HW + p0) * (int64_t)HW;
-    if ((HW & 7) == 0) {
+    if (CORR_ABL & 1) {
+    } else if ((HW & 7) == 0) {
         // 8 consecutive q per lane: 16-byte (half) / 2 x 16-byte (fp32) stores -- element-wise 2-byte stores made this
         // write-out (3/4 of the kernel's bytes) the longest phase of the kernel
         typedef OT OT8 __attribute__((ext_vector_type(8)));
@@ -237,6 +276,7 @@ __global__ __launch_bounds__(TP * 16) void raft_corr_kernel(const vtgb_raft_corr
             o0[i] = (OT)S[p * ldS + q];
         }
     }
+    if (CORR_ABL & 4) return;
     const int w1 = W / 2, w2 = W / 4, w3 = W / 8, n3 = (H / 8) * w3;
     OT* const o1 = reinterpret_cast<OT*>(a.levels[1]) + (n * HW + p0) * (int64_t)n1;
     for (int i = tid; i < rows * n1; i += NT) {
@@ -273,7 +313,7 @@ static int corr_check(const vtgb_raft_corr_args* a) {
     const int64_t last = ((int64_t)(a->n_pairs - 1) / a->pairs_per_clip) * a->frames_per_clip + (a->n_pairs - 1) % a->pairs_per_clip;
     VTGB_REQUIRE(a->first_off >= 0 && a->second_off >= 0 && last + a->first_off < a->n_images && last + a->second_off < a->n_images, VTGB_EINVAL,
                  "raft_corr: pair -> image map leaves the %d feature maps", a->n_images);
-    const CorrLds c = a->dtype == VTGB_BF16X3 ? corr_lds_tp(a->H8, a->W8, false, 16, true) : corr_lds(a->H8, a->W8, a->dtype == VTGB_F32);
+    const CorrLds c = a->dtype == VTGB_BF16X3 ? corr_lds_x3(a->H8, a->W8) : corr_lds(a->H8, a->W8, a->dtype == VTGB_F32);
     VTGB_REQUIRE(c.bytes <= 160 * 1024, VTGB_EUNSUPPORTED, "raft_corr: %d x %d maps exceed the LDS tile", a->H8, a->W8);
     return VTGB_OK;
 }
@@ -288,17 +328,22 @@ extern "C" int vtgb_raft_corr(const vtgb_raft_corr_args* a, vtgb_stream_t stream
     VTGB_TRY(corr_check(a));
     VTGB_REQUIRE(a->fmap && a->levels[0] && a->levels[1] && a->levels[2] && a->levels[3], VTGB_EINVAL, "raft_corr: NULL operand");
     const bool f32 = a->dtype == VTGB_F32, x3 = a->dtype == VTGB_BF16X3;
-    const CorrLds c = x3 ? corr_lds_tp(a->H8, a->W8, false, 16, true) : corr_lds(a->H8, a->W8, f32);
+    const CorrLds c = x3 ? corr_lds_x3(a->H8, a->W8) : corr_lds(a->H8, a->W8, f32);
     const int HW = a->H8 * a->W8;
-    const dim3 grid((unsigned)((HW + c.tp - 1) / c.tp), (unsigned)a->n_pairs);
+    const dim3 grid((unsigned)(((HW + c.tp - 1) / c.tp) * ((a->n_pairs + 7) / 8) * 8));      // (id -> (pair, tile): see the kernel)
     if (x3) {
         const size_t need = vtgb_raft_corr_workspace_bytes(a);
         VTGB_REQUIRE(a->workspace && a->workspace_bytes >= need, VTGB_EWORKSPACE, "raft_corr: workspace %zu < %zu bytes", a->workspace_bytes, need);
         half_t* fh = reinterpret_cast<half_t*>(a->workspace);      // bf16 hi plane | lo plane
         const int64_t n4 = (int64_t)a->n_images * HW * CORR_D / 4;
         hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a->fmap, reinterpret_cast<bf16_t*>(fh), n4);
-        VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_kernel<false, float, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.bytes));
-        hipLaunchKernelGGL((raft_corr_kernel<false, float, 16, true>), grid, dim3(256), c.bytes, stream, *a, fh, c.ldS, c.n1, c.n2);
+        if (c.tp == 32) {
+            VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_kernel<false, float, 32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.bytes));
+            hipLaunchKernelGGL((raft_corr_kernel<false, float, 32, true>), grid, dim3(512), c.bytes, stream, *a, fh, c.ldS, c.n1, c.n2);
+        } else {
+            VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_kernel<false, float, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.bytes));
+            hipLaunchKernelGGL((raft_corr_kernel<false, float, 16, true>), grid, dim3(256), c.bytes, stream, *a, fh, c.ldS, c.n1, c.n2);
+        }
     } else if (f32) {
         VTGB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raft_corr_kernel<true, float, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.bytes));
         hipLaunchKernelGGL((raft_corr_kernel<true, float, 16>), grid, dim3(256), c.bytes, stream, *a, nullptr, c.ldS, c.n1, c.n2);
