@@ -48,18 +48,23 @@ constexpr int h8_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 
 // OFMT: what the pair-writing epilogues store -- 1 the f16c8 pair (pair_h8.h), 0 the bf16 pair [hi | lo] of the bf16x3 kernels (FlowHead.conv1 /
 // mask.0, whose 1x1 successors stay on the bf16x3 kernels)
-template <int EPI, int NWN, int WF, int OFMT>
-__global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G, const int total_blocks) {
+// WV: waves per workgroup.  8 (the 256-row tile, ONE workgroup per CU) or 4 (a 128-row tile of the same 64 x 64 wave tiles in 80 KB of LDS: TWO workgroups
+// per CU, so that one's epilogue -- memory latency, transcendentals -- runs under the other's k-loop; built for the GRU's q convolution, measured SLOWER
+// there (-DH8_Q4=1, see launch_conv_h8) and not dispatched)
+template <int EPI, int NWN, int WF, int OFMT, int WV = 8>
+__global__ __launch_bounds__(64 * WV, 2) void conv_h8_kernel(const GemmDesc p, const int m_tiles, const int n_tiles, const int G, const int total_blocks) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NX = 2 * NWN;          // activation fragments per wave: wave tile = (16 NX) x (16 WF)
-    constexpr int WROWS = 16 * NX;
-    constexpr int MW = 8 / NWN;
+    constexpr int T_BM = 32 * WV;
+    constexpr int MW = WV / NWN;
+    constexpr int WROWS = T_BM / MW;
+    constexpr int NX = WROWS / 16;       // activation fragments per wave: wave tile = (16 NX) x (16 WF)  (= 2 NWN)
     constexpr int WC = 16 * WF;
-    constexpr int T_BM = 256, T_BN = WC * NWN;
-    constexpr int A_OP = H_AOP, W_OP = T_BN * 128;
-    constexpr int AI = 4, WI = T_BN / 64;
+    constexpr int T_BN = WC * NWN;
+    constexpr int A_OP = T_BM * H_BK * 2, W_OP = T_BN * 128;
+    constexpr int AI = 4, WI = T_BN / (8 * WV);
     constexpr int A_SLOTS = 3;
-    constexpr int SB = (A_SLOTS - 1) * A_OP / 8;   // epilogue staging bytes per wave (A slots 1, 2)
+    constexpr int SB = (A_SLOTS - 1) * A_OP / WV;   // epilogue staging bytes per wave (A slots 1, 2)
+    static_assert(WV == 8 || (WV == 4 && NWN == 2 && WF == 4 && (EPI == EPI_X3Q || EPI == EPI_X3ZR || EPI == EPI_SPLIT)), "4-wave workgroups: the 128 x 128 tile");
     constexpr int NPRE = AI + WI;
     constexpr int WH = WF / 2, XH = NX / 2;        // the quarters of the fragment grid (WF = 3: 1 + 2 weight fragments)
     static_assert(WF == 4 || (WF == 3 && NWN == 4 && EPI == EPI_SPLIT), "48-column wave tiles: the pair-store convolution (convc2) only");
@@ -676,17 +681,18 @@ __global__ __launch_bounds__(512, 2) void conv_h8_kernel(const GemmDesc p, const
 }
 
 // ---------------------------------------------------------------------------------------
-template <int EPI, int NWN, int WF, int OFMT>
+template <int EPI, int NWN, int WF, int OFMT, int WV = 8>
 static int launch_h8(const GemmDesc& d, hipStream_t s) {
-    constexpr int T_BM = 256, T_BN = 16 * WF * NWN;
-    constexpr int LDS = 3 * H_AOP + 2 * T_BN * 128;
+    constexpr int T_BM = 32 * WV, T_BN = 16 * WF * NWN;
+    constexpr int LDS = 3 * T_BM * 128 + 2 * T_BN * 128;
     static DeviceOnce attr;
-    VTGB_FUNC_LDS_ONCE(attr, (conv_h8_kernel<EPI, NWN, WF, OFMT>), LDS);
+    VTGB_FUNC_LDS_ONCE(attr, (conv_h8_kernel<EPI, NWN, WF, OFMT, WV>), LDS);
     const int m_tiles = (d.M + T_BM - 1) / T_BM, n_tiles = (d.N + T_BN - 1) / T_BN, total = m_tiles * n_tiles;
-    const int grid = total < cu_count() ? total : cu_count();
+    const int slots = cu_count() * (WV == 4 ? 2 : 1);      // persistent workgroups: what fits the CUs at once
+    const int grid = total < slots ? total : slots;
     const double exec_flops = 2.0 * d.M * d.N * d.K;      // in fp16-MFMA units: an fp8 k-tile takes the matrix-pipe cycles of an fp16 one
     ProfScope prof(VTGB_PROF_CONV, d.algo_flops > 0 ? d.algo_flops : d.algo_flops < 0 ? 0.0 : exec_flops, s, exec_flops);
-    hipLaunchKernelGGL((conv_h8_kernel<EPI, NWN, WF, OFMT>), dim3(grid), dim3(512), LDS, s, d, m_tiles, n_tiles, 8, total);
+    hipLaunchKernelGGL((conv_h8_kernel<EPI, NWN, WF, OFMT, WV>), dim3(grid), dim3(64 * WV), LDS, s, d, m_tiles, n_tiles, 8, total);
     VTGB_HIP(hipGetLastError());
     return VTGB_OK;
 }
@@ -760,6 +766,11 @@ int launch_conv_h8(const GemmDesc& d_in, hipStream_t s) {
         case EPI_X3Q:
             VTGB_REQUIRE(d.N == 128 && d.resid && d.aux && ((d.ldr | d.ldaux | d.ldo | d.split_lo) & 3) == 0 && d.act == 0 && !d.bias, VTGB_EINVAL,
                          "conv h8: the GRU update epilogue needs a 128-channel convolution with its start map and z");
+#ifndef H8_Q4
+#define H8_Q4 0      // (measured, round 6: 128 x 128 tiles with two workgroups per CU -- 2.13 ms against 1.94 for the 256 x 128 tile, same box: the second
+                     // workgroup hides the epilogue, but half-height tiles read every weight k-tile twice as often and synchronise twice as often)
+#endif
+            if (H8_Q4) return launch_h8<EPI_X3Q, 2, 4, 1, 4>(d, s);
             return launch_h8<EPI_X3Q, 2, 4, 1>(d, s);
     }
     vtgb_set_error("conv h8: unsupported epilogue %d", d.epi);
