@@ -31,7 +31,7 @@ extern "C" {
 
 typedef struct ihipStream_t* vtgb_stream_t; /* == hipStream_t */
 
-#define VTGB_VERSION 600 /* 600: VTGB_F16C8 (vtgb_raft_update: the update block over fp16 + fp8-correction operands, weights[30] = scale bytes).  500: VTGB_BF16X3 (RAFT at fp32 accuracy on the bf16 MFMA), deterministic InstanceNorm moments, vtgb_gemm_skinny defer_reduce +
+#define VTGB_VERSION 601 /* 601: vtgb_pair_conv_ex; vtgb_raft_encoder at VTGB_F16C8: every stride-1 3x3 of the residual blocks on f16c8 operands (weights[40] = int32 [12]); vtgb_raft_update at VTGB_F16C8: convf2 on f16c8 operands (weights[30] = int32 [10]), [20] = FlowHead.conv2 as the fp32 tail of conv1.  600: VTGB_F16C8 (vtgb_raft_update: the update block over fp16 + fp8-correction operands, weights[30] = scale bytes).  500: VTGB_BF16X3 (RAFT at fp32 accuracy on the bf16 MFMA), deterministic InstanceNorm moments, vtgb_gemm_skinny defer_reduce +
                             vtgb_llm_rmsnorm_parts / vtgb_llm_rope_cache_parts.  401: vtgb_gemm_train / vtgb_col_sum_f32 / vtgb_layernorm_train_* / vtgb_gelu_* (the training graph without operand copies or torch
                             elementwise passes); 400 = round 4: vtgb_llm_attention_rows / vtgb_llm_gated_act (the T5 language model of the BLIP-2 flavours on own kernels:
                             eval/utils/model.py:427-437), vtgb_llm_rope_cache with NULL tables = plain cache append; 300 = round 3: stem weight hi|lo layout; vtgb_attention_args.causal; vtgb_gemm_skinny without workspace when unsplit;
@@ -419,6 +419,24 @@ typedef struct {
     int32_t ld_out;                   /* >= N, % 4 == 0 */
 } vtgb_pair_conv_args;
 int vtgb_pair_conv(const vtgb_pair_conv_args* a, vtgb_stream_t stream);
+/* The same convolution with one of the three other epilogues the RAFT launches use (version 601; unit tests of those epilogues): exactly one of
+ *   resid    -- the ResidualBlock tail (extractor.py:56-60): out = relu(resid + act(conv(x) + bias)) as a pair row; resid = f16c8 pair rows [M, 2 * ld_resid
+ *               units]; N <= 128, N % 4 == 0 (cnet's blocks at VTGB_F16C8);
+ *   tail_w   -- FlowHead (update.py:10-18): N == 256; tail_out [M, 32] fp32 = act(conv(x) + bias) . W2, the 18 per-tap products of the following 3x3
+ *               convolution (columns 18 .. 31: zero weights), formed from the accumulators in exact fp32; tail_w = W2 [256, 32] fp32 in the epilogue's lane
+ *               order (ops.flow_tail_pack); `out` is not written;
+ *   out_f32  -- fp32 rows [M, ld_f32] instead of a pair (N <= 128, N % 4 == 0, act == 0: fnet's convolutions in front of an InstanceNorm)
+ * may be non-NULL (all NULL: vtgb_pair_conv). */
+typedef struct {
+    vtgb_pair_conv_args conv;
+    const void* resid;
+    int32_t ld_resid;
+    const float* tail_w;
+    float* tail_out;
+    float* out_f32;
+    int32_t ld_f32;
+} vtgb_pair_conv_ex_args;
+int vtgb_pair_conv_ex(const vtgb_pair_conv_ex_args* a, vtgb_stream_t stream);
 
 /* CorrBlock.__init__ (raft_utils/corr.py:12-27; the all-pairs product :52-60): for every pair the correlation of each
  * pixel of image 1 with every pixel of image 2 over the `dim` = 256 features, divided by sqrt(dim), and its three

@@ -25,7 +25,7 @@ def test_exports_match_header(lib):
     L = lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.vtgb_version() == 600
+    assert L.vtgb_version() == 601
 
 
 def test_struct_sizes_follow_header(lib):

@@ -89,3 +89,83 @@ def test_pair_conv_wide_and_narrow_tiles_agree_bit_for_bit(dev, N, KH, KW, C1, t
     m2 = 2 * H * W
     part = ops.pair_conv(a[:m2].contiguous(), wk, sw, H, W, a2=None if a2 is None else a2[:m2].contiguous(), relu=True, out_fmt=ofmt)
     assert torch.equal(full[:m2], part) and full.abs().max() > 0
+
+
+def _inputs(g, n, Cin, H, W):
+    x = torch.randn(n, Cin, H, W, generator=g) * (torch.rand(n, 1, H, W, generator=g) * 10 + 0.1)
+    return torch.relu(x) + 0.05 * torch.randn(n, Cin, H, W, generator=g)
+
+
+@pytest.mark.parametrize("N,C1,obf,H,W,n", [(64, 64, False, 40, 40, 2), (64, 64, True, 17, 23, 3), (128, 128, False, 28, 28, 3), (128, 128, True, 16, 16, 5),
+                                          (96, 128, False, 28, 28, 2)])
+def test_residual_tail_in_the_epilogue_vs_fp64(dev, N, C1, obf, H, W, n):
+    """The ResidualBlock tail relu(x + relu(conv(y) + b)) (extractor.py:56-60) in the pair-store epilogue of the 64- and 128-wide tiles (cnet's blocks at
+    f16c8; vtgb_pair_conv_ex resid): against fp64 from the SAME rounded operands; N = 96 in 128-channel rows: the padded channels come out as zeros."""
+    from videotgb_amd import ops
+    g = torch.Generator().manual_seed(N * 3 + C1 + H)
+    y = _inputs(g, n, C1, H, W)
+    xs = _inputs(g, n, N, H, W)
+    w = torch.randn(N, C1, 3, 3, generator=g) * 0.05
+    b = torch.randn(N, generator=g)
+    ld = C1
+    skip_rows = ops.pair_pack(xs.permute(0, 2, 3, 1).reshape(-1, N).contiguous().to(dev), ops.F16C8, ld)
+    skip = ops.pair_unpack(skip_rows, N).cpu().view(n, H, W, N).permute(0, 3, 1, 2).double()                 # what the kernel adds: the pair's value
+    ref = (skip + F.conv2d(y.double(), w.double(), b.double(), padding=1).relu()).relu()
+    bound = F.conv2d(y.abs().double(), w.abs().double(), None, padding=1) + b.abs().double().view(1, -1, 1, 1) + skip.abs()
+    a = ops.pair_pack(y.permute(0, 2, 3, 1).reshape(-1, C1).contiguous().to(dev))
+    wk = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    sw, _ = ops.h8_weight_scale(wk)
+    ofmt = ops.BF16X3 if obf else ops.F16C8
+    out = ops.pair_conv(a, wk, sw, H, W, bias=b.to(dev), relu=True, out_fmt=ofmt, ld_out=ld, resid=skip_rows)
+    got = ops.pair_unpack(out, N, ofmt).cpu().view(n, H, W, N).permute(0, 3, 1, 2).double()
+    err = ((got - ref).abs() / bound).max().item()
+    print(f"[residual tail N={N} C1={C1} bf16-pair-out={obf}] max err / bound = {err:.3e}")
+    assert err <= 2.0 ** -14
+    if N < ld:
+        assert not out.cpu()[:, N:ld].any() and not out.cpu()[:, ld + N:].any()
+
+
+@pytest.mark.parametrize("H,W,n", [(28, 28, 3), (9, 13, 7)])
+def test_flow_head_tail_vs_fp64(dev, H, W, n):
+    """FlowHead (update.py:10-18): conv1 (3x3, 128 -> 256, ReLU) with conv2's 18 per-tap products formed in its epilogue on the fp32 matrix instruction
+    (gemm_h8.hip EPI_FTAIL; vtgb_pair_conv_ex tail_w) against fp64: hidden . W2 is EXACT fp32 here, so the error is the convolution's own."""
+    from videotgb_amd import ops
+    g = torch.Generator().manual_seed(H * 31 + n)
+    h = torch.tanh(torch.randn(n, 128, H, W, generator=g))
+    w1 = torch.randn(256, 128, 3, 3, generator=g) * 0.04
+    b1 = torch.randn(256, generator=g) * 0.1
+    w2 = torch.zeros(32, 256)
+    w2[:18] = torch.randn(18, 256, generator=g) * 0.05
+    hidden = F.conv2d(h.double(), w1.double(), b1.double(), padding=1).relu()                       # [n, 256, H, W]
+    ref = torch.einsum("nchw,oc->nhwo", hidden, w2.double()).reshape(-1, 32)
+    hb = F.conv2d(h.abs().double(), w1.abs().double(), None, padding=1) + b1.abs().double().view(1, -1, 1, 1)
+    bound = torch.einsum("nchw,oc->nhwo", hb, w2.abs().double()).reshape(-1, 32)
+    a = ops.pair_pack(h.permute(0, 2, 3, 1).reshape(-1, 128).contiguous().to(dev))
+    wk = w1.permute(0, 2, 3, 1).contiguous().to(dev)
+    sw, _ = ops.h8_weight_scale(wk)
+    got = ops.pair_conv(a, wk, sw, H, W, bias=b1.to(dev), relu=True, tail_w=w2).cpu().double()
+    err = ((got[:, :18] - ref[:, :18]).abs() / bound[:, :18]).max().item()
+    print(f"[flow-head tail {n} x {H} x {W}] max err / bound = {err:.3e}")
+    assert err <= 2.0 ** -14 and not got[:, 18:].any()
+    again = ops.pair_conv(a, wk, sw, H, W, bias=b1.to(dev), relu=True, tail_w=w2).cpu().double()
+    assert torch.equal(got, again)                                                                  # the four column waves' sums meet in a fixed order
+
+
+@pytest.mark.parametrize("N,C1,H,W,n", [(64, 64, 40, 40, 2), (96, 128, 28, 28, 3), (128, 128, 16, 16, 5)])
+def test_fp32_output_tiles_vs_fp64(dev, N, C1, H, W, n):
+    """fp32 rows straight from the accumulators (fnet's convolutions in front of an InstanceNorm: 64- and 128-wide tiles; vtgb_pair_conv_ex out_f32)."""
+    from videotgb_amd import ops
+    g = torch.Generator().manual_seed(N + C1 + W)
+    y = _inputs(g, n, C1, H, W)
+    w = torch.randn(N, C1, 3, 3, generator=g) * 0.05
+    b = torch.randn(N, generator=g)
+    ref = F.conv2d(y.double(), w.double(), b.double(), padding=1)
+    bound = F.conv2d(y.abs().double(), w.abs().double(), None, padding=1) + b.abs().double().view(1, -1, 1, 1)
+    a = ops.pair_pack(y.permute(0, 2, 3, 1).reshape(-1, C1).contiguous().to(dev))
+    wk = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    sw, _ = ops.h8_weight_scale(wk)
+    out = ops.pair_conv(a, wk, sw, H, W, bias=b.to(dev), ld_out=C1, out_f32=True).cpu()
+    got = out[:, :N].view(n, H, W, N).permute(0, 3, 1, 2).double()
+    err = ((got - ref).abs() / bound).max().item()
+    print(f"[fp32 rows N={N} C1={C1}] max err / bound = {err:.3e}")
+    assert err <= 2.0 ** -14

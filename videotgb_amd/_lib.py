@@ -38,7 +38,7 @@ EXPORTS = [
     "vtgb_attn_train_forward", "vtgb_attn_train_backward",
     "vtgb_gemm_train", "vtgb_gemm_train_workspace_bytes", "vtgb_col_sum_parts", "vtgb_col_sum_f32", "vtgb_layernorm_train_partials", "vtgb_layernorm_train_forward", "vtgb_layernorm_train_backward",
     "vtgb_gelu_forward", "vtgb_gelu_backward",
-    "vtgb_pair_pack", "vtgb_pair_conv",
+    "vtgb_pair_pack", "vtgb_pair_conv", "vtgb_pair_conv_ex",
 ]
 COMM_ID_BYTES = 128
 
@@ -132,6 +132,10 @@ class PairConvArgs(C.Structure):
                 ("bias", vp), ("act", i32), ("out_fmt", i32), ("out", vp), ("ld_out", i32)]
 
 
+class PairConvExArgs(C.Structure):
+    _fields_ = [("conv", PairConvArgs), ("resid", vp), ("ld_resid", i32), ("tail_w", vp), ("tail_out", vp), ("out_f32", vp), ("ld_f32", i32)]
+
+
 class RaftCorrArgs(C.Structure):
     _fields_ = [("dtype", i32), ("n_pairs", i32), ("H8", i32), ("W8", i32), ("dim", i32), ("pairs_per_clip", i32), ("frames_per_clip", i32),
                 ("first_off", i32), ("second_off", i32), ("n_images", i32), ("scale", f32), ("fmap", vp), ("levels", vp * 4),
@@ -203,6 +207,8 @@ def lib() -> C.CDLL:
     L.vtgb_pair_pack.restype = C.c_int
     L.vtgb_pair_conv.argtypes = [C.POINTER(PairConvArgs), vp]
     L.vtgb_pair_conv.restype = C.c_int
+    L.vtgb_pair_conv_ex.argtypes = [C.POINTER(PairConvExArgs), vp]
+    L.vtgb_pair_conv_ex.restype = C.c_int
     L.vtgb_raft_update.argtypes = [C.POINTER(RaftUpdateArgs), vp]
     L.vtgb_raft_update.restype = C.c_int
     L.vtgb_raft_update_workspace_bytes.argtypes = [C.POINTER(RaftUpdateArgs)]

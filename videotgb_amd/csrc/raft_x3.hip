@@ -438,7 +438,14 @@ extern "C" int vtgb_pair_pack(int32_t fmt, const float* x, void* out, int64_t M,
                  "pair_pack: bad argument (C=%d ld_pair=%d fmt=%d)", C, ld_pair, fmt);
     return launch_x3_pair_pass(x, C, nullptr, 1, nullptr, 0, 0, out, 2 * (int64_t)ld_pair, ld_pair, C, ld_pair, 0, 0, M, (hipStream_t)stream, fmt == VTGB_F16C8, 0);
 }
-extern "C" int vtgb_pair_conv(const vtgb_pair_conv_args* a, vtgb_stream_t stream) {
+static int pair_conv_impl(const vtgb_pair_conv_args* a, const vtgb_pair_conv_ex_args* x, vtgb_stream_t stream);
+extern "C" int vtgb_pair_conv(const vtgb_pair_conv_args* a, vtgb_stream_t stream) { return pair_conv_impl(a, nullptr, stream); }
+extern "C" int vtgb_pair_conv_ex(const vtgb_pair_conv_ex_args* x, vtgb_stream_t stream) {
+    VTGB_REQUIRE(x, VTGB_EINVAL, "pair_conv_ex: NULL args");
+    VTGB_REQUIRE((x->resid != nullptr) + (x->tail_w != nullptr) + (x->out_f32 != nullptr) <= 1, VTGB_EINVAL, "pair_conv_ex: at most one of resid / tail_w / out_f32");
+    return pair_conv_impl(&x->conv, x, stream);
+}
+static int pair_conv_impl(const vtgb_pair_conv_args* a, const vtgb_pair_conv_ex_args* x, vtgb_stream_t stream) {
     VTGB_REQUIRE(a && a->a && a->weights && a->scale && a->out && a->M > 0 && a->N > 0 && (a->N & 1) == 0 && a->C1 > 0 && (a->C1 % 64) == 0 && a->ld_out >= a->N &&
                      (a->ld_out & 3) == 0 && (a->out_fmt == VTGB_F16C8 || a->out_fmt == VTGB_BF16X3) && (a->act == 0 || a->act == 1),
                  VTGB_EINVAL, "pair_conv: bad argument");
@@ -449,5 +456,17 @@ extern "C" int vtgb_pair_conv(const vtgb_pair_conv_args* a, vtgb_stream_t stream
     }
     GemmDesc d = h8_conv(a->M, a->N, a->H, a->W, a->KH, a->KW, a->a, a->C1, a->a2, a->a2 ? a->C1 : 0, a->weights, a->bias, VTGB_EPI_SPLIT, a->act, a->out, 2 * (int64_t)a->ld_out,
                          a->ld_out, zero, a->scale, a->out_fmt == VTGB_BF16X3);
+    if (x && x->resid) {
+        VTGB_REQUIRE(x->ld_resid >= a->N && (x->ld_resid & 3) == 0 && x->ld_resid == a->ld_out, VTGB_EINVAL, "pair_conv_ex: the skip operand's pair rows have the output's layout");
+        d.resid_bf16 = x->resid; d.ldrb = 2 * (int64_t)x->ld_resid; d.post_relu = 1;
+    }
+    if (x && x->tail_w) {
+        VTGB_REQUIRE(x->tail_out, VTGB_EINVAL, "pair_conv_ex: tail_out is NULL");
+        d.tail_w = x->tail_w; d.tail_out = x->tail_out; d.ldtail = 32;
+    }
+    if (x && x->out_f32) {
+        VTGB_REQUIRE(x->ld_f32 >= a->N && (x->ld_f32 & 3) == 0, VTGB_EINVAL, "pair_conv_ex: fp32 rows need ld_f32 >= N, %% 4 == 0");
+        d.epi = VTGB_EPI_STORE_F32; d.out = x->out_f32; d.ldo = x->ld_f32; d.split_lo = 0;
+    }
     return launch_conv_h8(d, (hipStream_t)stream);
 }

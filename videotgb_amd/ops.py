@@ -613,9 +613,12 @@ def pair_unpack(rows: Tensor, C_: int, fmt: int = F16C8) -> Tensor:
 
 
 def pair_conv(a: Tensor, w: Tensor, sw: float, H: int, W: int, a2: Optional[Tensor] = None, bias: Optional[Tensor] = None, relu: bool = False,
-              out_fmt: int = F16C8, ld_out: Optional[int] = None) -> Tensor:
-    """One 'same' convolution over f16c8 pair rows (include/vtgb.h vtgb_pair_conv): a [M, 2 C1] int16 pair rows (pair_pack), w [co, kh, kw, ci] fp32 with
-    ci = C1 (x 2 with a2), sw from h8_weight_scale(w) -> pair rows [M, 2 * ld_out] int16."""
+              out_fmt: int = F16C8, ld_out: Optional[int] = None, resid: Optional[Tensor] = None, tail_w: Optional[Tensor] = None,
+              out_f32: bool = False) -> Tensor:
+    """One 'same' convolution over f16c8 pair rows (include/vtgb.h vtgb_pair_conv / vtgb_pair_conv_ex): a [M, 2 C1] int16 pair rows (pair_pack),
+    w [co, kh, kw, ci] fp32 with ci = C1 (x 2 with a2), sw from h8_weight_scale(w) -> pair rows [M, 2 * ld_out] int16.  resid (f16c8 pair rows of the
+    output's layout): the ResidualBlock tail relu(resid + act(conv)); tail_w ([32, 256] fp32, co == 256): returns the [M, 32] fp32 products with it
+    instead; out_f32: returns fp32 rows [M, ld_out] instead."""
     _need_cuda(a, w)
     co, kh, kw, ci = w.shape
     C1 = a.shape[1] // 2
@@ -625,11 +628,23 @@ def pair_conv(a: Tensor, w: Tensor, sw: float, H: int, W: int, a2: Optional[Tens
     scale = torch.tensor([byte], dtype=torch.int32, device=a.device)
     ld = ld_out or ((co + 3) // 4 * 4)
     out = torch.zeros(a.shape[0], 2 * ld, dtype=torch.int16, device=a.device)
-    args = L.PairConvArgs(a.shape[0], co, H, W, kh, kw, C1, a.data_ptr(), _ptr(a2), packed.data_ptr(), scale.data_ptr(), _ptr(None if bias is None else bias.contiguous().float()),
+    bias_t = None if bias is None else bias.contiguous().float()
+    args = L.PairConvArgs(a.shape[0], co, H, W, kh, kw, C1, a.data_ptr(), _ptr(a2), packed.data_ptr(), scale.data_ptr(), _ptr(bias_t),
                           1 if relu else 0, out_fmt, out.data_ptr(), ld)
-    L.check(L.lib().vtgb_pair_conv(C.byref(args), _stream()))
-    torch.cuda.current_stream().synchronize()      # (packed / scale are temporaries of this call)
-    return out
+    if resid is None and tail_w is None and not out_f32:
+        L.check(L.lib().vtgb_pair_conv(C.byref(args), _stream()))
+        torch.cuda.current_stream().synchronize()      # (packed / scale are temporaries of this call)
+        return out
+    tail_p = tail_out = f32 = None
+    if tail_w is not None:
+        tail_p = flow_tail_pack(tail_w.to(a.device))
+        tail_out = torch.zeros(a.shape[0], 32, dtype=torch.float32, device=a.device)
+    if out_f32:
+        f32 = torch.zeros(a.shape[0], ld, dtype=torch.float32, device=a.device)
+    ex = L.PairConvExArgs(args, _ptr(resid), ld, _ptr(tail_p), _ptr(tail_out), _ptr(f32), ld)
+    L.check(L.lib().vtgb_pair_conv_ex(C.byref(ex), _stream()))
+    torch.cuda.current_stream().synchronize()
+    return tail_out if tail_w is not None else f32 if out_f32 else out
 
 
 class RaftWeights(_WeightTable):
