@@ -46,7 +46,7 @@ def pmc_traffic(family="gemm"):
     """(bytes, source): mean HBM-side bytes per launch of the dominant kernel family from the COMMITTED PMC passes
     (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE) -- NOT measured in this run (counters need their own
     rocprofv3 --pmc passes): gemm = tools/gemm_pmc.py, the four ViT-g layer shapes at 31 clips; conv = tools/conv_pmc.py,
-    one RAFT pass over the bench's 31-clip RAFT batch.  The newest profiles/rNN_pmc_traffic_<family>.json is used."""
+    one RAFT pass over the bench's RAFT batch (62 clips per call since round 6).  The newest profiles/rNN_pmc_traffic_<family>.json is used."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r??_pmc_traffic_{family}.json")))
     if not files:
@@ -82,15 +82,16 @@ def parse():
                     help="graph: videotgb_amd.decode.GreedyDecoder (one hipGraph replay per token); hf: HF generate, eager")
     ap.add_argument("--raft-dtype", choices=["f16c8", "bf16x3", "bf16", "f32"], default="f16c8",
                     help="arithmetic of RAFT in --flow raft mode.  f16c8 (default, the module's default too): the reference's fp32 RAFT ACCURACY on the "
-                         "matrix cores -- update block on fp16 + fp8-correction operands, encoders / correlation on split-bf16 operands, fp32 accumulation "
+                         "matrix cores -- update block and the encoders' stride-1 3x3 convolutions on fp16 + fp8-correction operands, the rest on split-bf16 operands, fp32 accumulation "
                          "(held to the bf16x3 mode's parity bounds by the -m gpu suite); bf16x3: split-bf16 operands everywhere (round 5's form, the "
                          "`raft_bf16x3` companion); f32: the exactness mode (fp32 FMAs in the reference's order); bf16: a REDUCED-PRECISION opt-in the "
                          "reference does not have (reported as the `raft_bf16_fast` companion of the default run, never as the headline)")
-    ap.add_argument("--raft-clips", type=int, default=31,
-                    help="clips per RAFT call (pairs of that many clips form one batch; 31 clips = 249 ViT m-tiles / 9020 RAFT m-tiles: "
-                         "few idle CUs in the last round of 256-row tiles)")
+    ap.add_argument("--raft-clips", type=int, default=62,
+                    help="clips per RAFT call (pairs of that many clips form one batch).  62 (round 6; rounds 3-5: 31): 18 039 RAFT m-tiles = 70.5 rounds of "
+                         "256 CUs paid as 71 (31 clips: 35.2 paid as 36) -- 21.24 vs 21.58 ms per clip, same box; 57 GB of RAFT workspace + 19 GB of "
+                         "correlation pyramid per call at f16c8 (124 clips in one call: 21.17 ms per clip at 150 GB)")
     ap.add_argument("--overlap", action="store_true",
-                    help="two HIP streams: the prefix stage of batch i+1 over the LLM decode of batch i (round 3: +2 % clips/s -- the persistent "
+                    help="two HIP streams: the prefix stage of batch i+1 over the LLM decode of batch i (round 3: +2 %% clips/s -- the persistent "
                          "convolution launches hold every CU, so the decode only fills their tails; off by default: the headline is K strictly "
                          "sequential steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -534,7 +535,7 @@ def main():
             ex = _lib.prof_executed_flops(2)
             traffic, src = pmc_traffic(family)
             return {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel<EPI,true,NWN> / gemm_bf16_large_kernel<EPI,0,true>: implicit-GEMM convolutions of RAFT",
-                    "traffic": traffic, "traffic_source": (f"{src} (committed rocprofv3 --pmc passes of one RAFT call in this mode at the bench's 31-clip batch; not "
+                    "traffic": traffic, "traffic_source": (f"{src} (committed rocprofv3 --pmc passes of one RAFT call in this mode at the bench's RAFT batch (tools/conv_pmc.py 62); not "
                                                             f"collected in this run)") if src else None,
                     "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "executed_tflops": round(ex / (ms * 1e-3) / 1e12, 2),
@@ -595,7 +596,7 @@ def main():
                                    "bf16x3": "fp32 accuracy class (as f16c8)", "f32": "fp32 exactness mode", "bf16": "REDUCED PRECISION (not like for like)"}[args.raft_dtype] if args.flow == "raft" else None,
                "config": {"workload": f"InstructBLIP-Vicuna-7B + TGB, T={T}->{nframe} of 32 frames, 224x224, greedy {args.max_new_tokens} new tokens "
                                       f"(BASELINE.json configs[2])", "flow": args.flow if args.flow == "precomputed" else (
-                              f"raft inline, all HIP ({ {'bf16': 'REDUCED PRECISION: bf16 MFMA convolutions, fp32 state / accumulation', 'bf16x3': 'bf16x3: split-bf16 operands, fp32 accuracy on the MFMA', 'f16c8': 'f16c8: fp32 accuracy on the matrix cores -- update block on fp16 + fp8-correction operands, encoders / correlation on split-bf16 operands', 'f32': 'fp32 exactness mode'}[args.raft_dtype]}), "
+                              f"raft inline, all HIP ({ {'bf16': 'REDUCED PRECISION: bf16 MFMA convolutions, fp32 state / accumulation', 'bf16x3': 'bf16x3: split-bf16 operands, fp32 accuracy on the MFMA', 'f16c8': 'f16c8: fp32 accuracy on the matrix cores -- update block and the stride-1 3x3 convolutions of the encoders on fp16 + fp8-correction operands, stems / stride-2 / 1x1 convolutions and the correlation on split-bf16 operands', 'f32': 'fp32 exactness mode'}[args.raft_dtype]}), "
                               f"{args.raft_clips} clips per RAFT batch"),
                           "clips_per_gpu_per_step": B, "inputs": "resident in HBM when the timed region starts",
                           "global_batch": B * world, "parallelism": f"clip-parallel x{world} (no data-path collective)",

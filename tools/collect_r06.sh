@@ -12,9 +12,9 @@ if has pmc; then
   # HBM traffic (FETCH_SIZE / WRITE_SIZE, one counter per pass) of the conv family in the f16c8 (headline), bf16x3 and bf16 RAFT modes
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/ph_$c /tmp/px_$c /tmp/pc_$c
-    export RAFT_DTYPE=f16c8;  timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/ph_$c -- python3 $GRAFT_REPO_ROOT/tools/conv_pmc.py 31 > /tmp/ph_$c.log 2>&1
-    export RAFT_DTYPE=bf16x3; timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/px_$c -- python3 $GRAFT_REPO_ROOT/tools/conv_pmc.py 31 > /tmp/px_$c.log 2>&1
-    export RAFT_DTYPE=bf16;   timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/pc_$c -- python3 $GRAFT_REPO_ROOT/tools/conv_pmc.py 31 > /tmp/pc_$c.log 2>&1
+    export RAFT_DTYPE=f16c8;  timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/ph_$c -- python3 $GRAFT_REPO_ROOT/tools/conv_pmc.py 62 > /tmp/ph_$c.log 2>&1
+    export RAFT_DTYPE=bf16x3; timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/px_$c -- python3 $GRAFT_REPO_ROOT/tools/conv_pmc.py 62 > /tmp/px_$c.log 2>&1
+    export RAFT_DTYPE=bf16;   timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/pc_$c -- python3 $GRAFT_REPO_ROOT/tools/conv_pmc.py 62 > /tmp/pc_$c.log 2>&1
     unset RAFT_DTYPE
   done
   python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py /tmp/ph_FETCH_SIZE /tmp/ph_WRITE_SIZE $O/${R}_pmc_traffic_convh8.json conv > /dev/null
@@ -33,7 +33,7 @@ if has trace; then
 fi
 if has mfma; then
   cd $GRAFT_REPO_ROOT
-  export RAFT_DTYPE=f16c8; bash tools/pmc_mfma_conv.sh ${R}h8 > /dev/null 2>&1; unset RAFT_DTYPE
+  export RAFT_DTYPE=f16c8; bash tools/pmc_mfma_conv.sh ${R}h8 62 > /dev/null 2>&1; unset RAFT_DTYPE
   cp $O/${R}h8_pmc_mfma_conv_a.txt $P/${R}_pmc_mfma_convh8_a.txt; cp $O/${R}h8_pmc_mfma_conv_b.txt $P/${R}_pmc_mfma_convh8_b.txt; rm -f $P/${R}h8_pmc_mfma_conv_?.txt
   tail -14 $P/${R}_pmc_mfma_convh8_a.txt
 fi

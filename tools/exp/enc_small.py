@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One encoder call per mode and net at a small size (n frames of S x S), f16c8 vs bf16x3 outputs: usage enc_small.py [n] [S]"""
+"""One encoder call per mode and net at a small size (n frames of S x SW), f16c8 vs bf16x3 outputs: usage enc_small.py [n] [S] [SW]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -11,7 +11,8 @@ for k in list(sd):
         sd[k] = sd[k.replace(".downsample.1.", ".norm3.")]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-fr = torch.randint(0, 256, (n, 3, S, S), device=dev).float()
+SW = int(sys.argv[3]) if len(sys.argv) > 3 else S
+fr = torch.randint(0, 256, (n, 3, S, SW), device=dev).float()
 for name, bn in (("fnet.", False), ("cnet.", True)):
     outs = {}
     for mode in ("bf16x3", "f16c8"):
