@@ -6,6 +6,7 @@ returns fresh tensors on the same device.  Nothing here falls back to torch ops.
 from __future__ import annotations
 
 import ctypes as C
+import logging
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -13,6 +14,19 @@ import torch
 
 from . import _lib as L
 from ._lib import BF16, BF16X3, F16C8, F32
+
+_log = logging.getLogger("videotgb_amd")
+_ws_logged = set()
+
+
+def _log_workspace(what: str, need: int, detail: str) -> None:
+    """the split-operand RAFT modes take several times the scratch memory of the bf16 mode -- say so once per (stage, size class) at INFO
+    level (logging.getLogger('videotgb_amd')), and as a WARNING when a single call asks for more than 64 GB."""
+    key = (what, need >> 30)
+    if key in _ws_logged:
+        return
+    _ws_logged.add(key)
+    _log.log(logging.WARNING if need > (64 << 30) else logging.INFO, "%s: %.2f GB of workspace (%s)", what, need / 2 ** 30, detail)
 
 Tensor = torch.Tensor
 
@@ -809,6 +823,7 @@ def raft_update(w: RaftWeights, net: Optional[Tensor], inp: Optional[Tensor], py
                          (C.c_void_p * 4)(*[t.data_ptr() for t in lv]), C.cast(w.array, C.POINTER(C.c_void_p)), out.data_ptr(), None, 0,
                          1 if half else 0, None if cnet_nhwc is None else cnet_nhwc.data_ptr(), _ptr(flow_init))
     need = L.lib().vtgb_raft_update_workspace_bytes(C.byref(a))
+    _log_workspace("raft_update", need, f"{n} frame pairs of {H8} x {W8} coarse pixels, dtype code {w.code}; lower flow_clips_per_call to shrink it")
     ws = _ws.get(need, dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     L.check(L.lib().vtgb_raft_update(C.byref(a), _stream()))
@@ -960,6 +975,7 @@ def raft_encoder(w: RaftEncoderWeights, images: Tensor, max_images: int = 384) -
         a = L.RaftEncoderArgs(w.code, chunk.shape[0], H, W, 1 if w.batch_norm else 0, chunk.data_ptr(), C.cast(w.array, C.POINTER(C.c_void_p)),
                               out[i0:i0 + max_images].data_ptr(), None, 0)
         need = L.lib().vtgb_raft_encoder_workspace_bytes(C.byref(a))
+        _log_workspace("raft_encoder", need, f"{chunk.shape[0]} frames of {H} x {W} per chunk, dtype code {w.code}; max_images sets the chunk")
         ws = _ws.get(need, images.device)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         L.check(L.lib().vtgb_raft_encoder(C.byref(a), _stream()))
