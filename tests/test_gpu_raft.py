@@ -353,7 +353,7 @@ def test_raft_float_valued_frames(dev, tiny_sd):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
-@pytest.mark.parametrize("h8,w8", [(28, 28), (16, 16), (9, 13)])
+@pytest.mark.parametrize("h8,w8", [(28, 28), (16, 16), (9, 13), (36, 40), (33, 21)])      # (36 x 40: the 16-row slice of the MFMA modes; 33 x 21: HW % 8 != 0)
 def test_corr_pyramid_vs_oracle(dev, h8, w8, dtype):
     """CorrBlock.__init__ (corr.py:12-27, :52-60) in one kernel: all-pairs product / sqrt(dim) + three avg_pool2d, odd sizes
     floored like avg_pool2d; both pair -> image maps (consecutive frames of clips; cat(image1, image2))."""
