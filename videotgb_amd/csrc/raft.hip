@@ -531,7 +531,10 @@ __global__ __launch_bounds__(512, 2) void raft_lookup_convc1_h8_kernel(const Cor
             sbase = (y0 * wl + x0) * (int)sizeof(CT);
             sqx = xs - x0f; sqy = ys - y0f;
         }
-        CT r[4][8];
+#ifndef LH_DEPTH
+#define LH_DEPTH 4      // pixels whose window loads are in flight per wave (of LC_WPX = 8).  -DLH_DEPTH=8 (all of them up front) measured SLOWER: 2.83 vs 2.60 ms, same box
+#endif
+        CT r[LH_DEPTH][8];
         const CT* lvl0[4];
 #pragma unroll
         for (int l = 0; l < 4; l++) lvl0[l] = reinterpret_cast<const CT*>(pyr.lvl[l]) + m_first * (int64_t)(pyr.h[l] * pyr.w[l]);
@@ -549,13 +552,13 @@ __global__ __launch_bounds__(512, 2) void raft_lookup_convc1_h8_kernel(const Cor
         }                                                                                               \
     }
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
+        for (int d = 0; d < LH_DEPTH; d++) {
             const int pf = d < npx ? d : npx - 1;
             LH_FETCH(pf, d)
         }
-        for (int pb = 0; pb < LC_WPX; pb += 4) {
+        for (int pb = 0; pb < LC_WPX; pb += LH_DEPTH) {
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
+            for (int d = 0; d < LH_DEPTH; d++) {
                 const int pi = pb + d;
 #pragma unroll
                 for (int l = 0; l < 4; l++) {
@@ -564,8 +567,10 @@ __global__ __launch_bounds__(512, 2) void raft_lookup_convc1_h8_kernel(const Cor
                 }
                 if ((lane >> 2) == (pi < npx ? pi : npx - 1)) { wv[(lane & 3) * 104 + 100] = sqx; wv[(lane & 3) * 104 + 101] = sqy; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const int pf = pi + 4 < npx ? pi + 4 : npx - 1;
-                LH_FETCH(pf, d)
+                if (LH_DEPTH < LC_WPX) {
+                    const int pf = pi + LH_DEPTH < npx ? pi + LH_DEPTH : npx - 1;
+                    LH_FETCH(pf, d)
+                }
                 const int prow = wave * LC_WPX + pi;
 #pragma unroll
                 for (int kk = 0; kk < 6; kk++) {
